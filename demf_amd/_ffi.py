@@ -1,0 +1,74 @@
+"""ctypes binding of libdemf_hip.so (the C ABI declared in include/demf_hip.h).
+
+The reference reaches its native operators through pybind extensions of
+mmdet3d/mmcv; this is the equivalent thin layer.  cffi is not installed in the
+target image, so the binding is ctypes.  There is no fallback: if the library is
+missing, ``load()`` raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdemf_hip.so")
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_ptr = ctypes.c_void_p
+
+# name -> argtypes, exactly mirroring include/demf_hip.h
+SIGNATURES = {
+    "demf_fps_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "demf_ball_query_f32": [_c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _ptr, _ptr,
+                            _ptr, _ptr],
+    "demf_group_points_fwd": [_c_int] * 5 + [_ptr] * 4,
+    "demf_group_points_bwd": [_c_int] * 5 + [_ptr] * 4,
+    "demf_gather_points_fwd": [_c_int] * 4 + [_ptr] * 4,
+    "demf_gather_points_bwd": [_c_int] * 4 + [_ptr] * 4,
+    "demf_three_nn_f32": [_c_int] * 3 + [_ptr] * 5,
+    "demf_three_interpolate_fwd": [_c_int] * 4 + [_ptr] * 5,
+    "demf_three_interpolate_bwd": [_c_int] * 4 + [_ptr] * 5,
+    "demf_group_concat_cl_fwd": [_c_int] * 8 + [_c_float, _c_int] + [_ptr] * 6,
+    "demf_group_concat_cl_bwd": [_c_int] * 7 + [_ptr] * 4,
+    "demf_gather_rows_cl_fwd": [_c_int] * 4 + [_ptr] * 4,
+    "demf_gather_rows_cl_bwd": [_c_int] * 4 + [_ptr] * 4,
+    "demf_three_interpolate_cl_fwd": [_c_int] * 6 + [_ptr] * 5,
+    "demf_three_interpolate_cl_bwd": [_c_int] * 6 + [_ptr] * 5,
+    "demf_maxpool_ns_fwd": [_c_int] * 3 + [_ptr] * 4,
+    "demf_maxpool_ns_bwd": [_c_int] * 3 + [_ptr] * 4,
+    "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
+    "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
+}
+
+_lib = None
+
+
+def load():
+    """Load libdemf_hip.so; raises if it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). demf_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.demf_version.restype = _c_int
+    lib.demf_version.argtypes = []
+    lib.demf_last_error.restype = ctypes.c_char_p
+    lib.demf_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI drifted
+        fn.restype = _c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an entry point; a non-zero return becomes a RuntimeError with the
+    library's thread-local message (the upstream pybind wrappers raise likewise)."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.demf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")

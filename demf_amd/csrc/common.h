@@ -1,0 +1,86 @@
+// Shared helpers for the gfx950 kernels of libdemf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/demf_hip.h"
+
+namespace demf {
+
+// ---- error plumbing (thread-local text, C ABI return codes) --------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define DEMF_REQUIRE(cond, ...)             \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::demf::set_error(__VA_ARGS__);       \
+      return DEMF_EINVAL;                   \
+    }                                       \
+  } while (0)
+
+// ---- canonical arithmetic -------------------------------------------------
+// Squared distance used by FPS / ball query / three_nn.  The upstream CUDA
+// sources spell it  dx*dx + dy*dy + dz*dz  and are built with nvcc's default
+// -fmad=true; this library (built with -ffp-contract=off) and the CPU oracle
+// both pin the contraction explicitly to
+//     fma(dz, dz, fma(dx, dx, dy*dy))
+// so index outputs are bit-reproducible between the two.  See DESIGN.md.
+__device__ __forceinline__ float dist2(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// ---- wave64 cross-lane helpers (DPP; gfx9 row_bcast forms) ----------------
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                         __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                         0xF, false));
+}
+
+// max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ float row16_allmax(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v, v));   // quad_perm [1,0,3,2]
+  v = fmaxf(v, dpp_f32<0x4E>(v, v));   // quad_perm [2,3,0,1]
+  v = fmaxf(v, dpp_f32<0x141>(v, v));  // row_half_mirror
+  v = fmaxf(v, dpp_f32<0x140>(v, v));  // row_mirror
+  return v;
+}
+
+// max over the whole wave, returned wave-uniform
+__device__ __forceinline__ float wave_allmax(float v) {
+  v = row16_allmax(v);
+  v = fmaxf(v, dpp_f32<0x142, 0xA>(v, v));  // row_bcast:15 -> rows 1,3
+  v = fmaxf(v, dpp_f32<0x143, 0xC>(v, v));  // row_bcast:31 -> rows 2,3
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over aligned groups of G lanes (G in {1,2,4,8,16}); every lane of the
+// group receives the total.
+template <int G>
+__device__ __forceinline__ float group_allsum(float v) {
+  if constexpr (G >= 2) v += dpp_f32<0xB1>(v, v);
+  if constexpr (G >= 4) v += dpp_f32<0x4E>(v, v);
+  if constexpr (G >= 8) v += dpp_f32<0x141>(v, v);
+  if constexpr (G >= 16) v += dpp_f32<0x140>(v, v);
+  return v;
+}
+
+__device__ __forceinline__ int readlane_i(int v, int lane) {
+  return __builtin_amdgcn_readlane(v, lane);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace demf

@@ -1,0 +1,339 @@
+// Neighbour gather / scatter kernels for gfx950.
+//
+// (1) The operator-compatible, channel-major forms (features (B,C,N)) that stand in
+//     for mmdet3d.ops grouping_operation / gather_points - reached from
+//     QueryAndGroup / PointSAModule (class_agnostic_vote_head.py:383,455).
+// (2) Point-major ("channels-last", features (B,N,C)) forms used by the MI355X
+//     modules: a neighbour is one contiguous C*4-byte row, so the gather is a
+//     coalesced float4 row copy instead of C scattered 4-byte reads, and the output
+//     (B,M,ns,ld) is directly the A operand of the shared-MLP GEMM.
+// All of these are pure HBM/L2 byte movers: the roofline is bytes written + bytes
+// gathered over 8 TB/s.
+#include "common.h"
+
+namespace demf {
+
+// ---------------- channel-major (operator ABI) -----------------------------
+// out[b,c,j] = feat[b,c,idx[b,j]]  with j over M*ns; CT channels per thread so the
+// index is read once per CT outputs.
+template <int CT>
+__global__ __launch_bounds__(256) void group_cm_fwd(int C, int N, int J,
+                                                    const float* __restrict__ feat,
+                                                    const int* __restrict__ idx,
+                                                    float* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * CT;
+  if (j >= J) return;
+  const int i = idx[(size_t)b * J + j];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int c = c0 + cc;
+    if (c < C) out[((size_t)b * C + c) * J + j] = feat[((size_t)b * C + c) * N + i];
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void group_cm_bwd(int C, int N, int J,
+                                                    const float* __restrict__ gout,
+                                                    const int* __restrict__ idx,
+                                                    float* __restrict__ gfeat) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = blockIdx.y * CT;
+  if (j >= J) return;
+  const int i = idx[(size_t)b * J + j];
+#pragma unroll
+  for (int cc = 0; cc < CT; ++cc) {
+    const int c = c0 + cc;
+    if (c < C)
+      atomicAdd(&gfeat[((size_t)b * C + c) * N + i], gout[((size_t)b * C + c) * J + j]);
+  }
+}
+
+// ---------------- point-major fused QueryAndGroup --------------------------
+// One wave per output row (b,m,s).  Row layout: [feat(C) | rel_xyz(3) | 0-pad].
+template <bool VEC4>
+__global__ __launch_bounds__(256) void group_concat_cl_fwd_k(
+    int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float inv_r,
+    const float* __restrict__ xyz, const float* __restrict__ center,
+    const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out,
+    long long rows) {
+  const int lane = threadIdx.x & 63;
+  long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (; row < rows; row += stride) {
+    const long long bm = row / ns;            // b*M + m
+    const int b = (int)(bm / M);
+    const int i = idx[row];
+    float* o = out + row * ldo;
+    if (C > 0) {
+      const float* f = feat + ((size_t)b * N + i) * C;
+      if constexpr (VEC4) {
+        for (int c = lane * 4; c < C; c += 256)
+          *reinterpret_cast<float4*>(o + feat_col + c) =
+              *reinterpret_cast<const float4*>(f + c);
+      } else {
+        for (int c = lane; c < C; c += 64) o[feat_col + c] = f[c];
+      }
+    }
+    if (lane < 3) {
+      const float p = xyz[((size_t)b * N + i) * 3 + lane];
+      const float q = center[bm * 3 + lane];
+      o[xyz_col + lane] = (p - q) * inv_r;
+    }
+    // zero every column not covered above
+    for (int c = lane; c < ldo; c += 64) {
+      const bool in_feat = (c >= feat_col && c < feat_col + C);
+      const bool in_xyz = (c >= xyz_col && c < xyz_col + 3);
+      if (!in_feat && !in_xyz) o[c] = 0.f;
+    }
+  }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void group_concat_cl_bwd_k(
+    int N, int M, int ns, int C, int ldo, int feat_col, const float* __restrict__ gout,
+    const int* __restrict__ idx, float* __restrict__ gfeat, long long rows) {
+  const int lane = threadIdx.x & 63;
+  long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (; row < rows; row += stride) {
+    const int b = (int)(row / ((long long)M * ns));
+    const int i = idx[row];
+    const float* g = gout + row * ldo + feat_col;
+    float* f = gfeat + ((size_t)b * N + i) * C;
+    if constexpr (VEC4) {
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(g + c);
+        atomicAdd(f + c + 0, v.x);
+        atomicAdd(f + c + 1, v.y);
+        atomicAdd(f + c + 2, v.z);
+        atomicAdd(f + c + 3, v.w);
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) atomicAdd(f + c, g[c]);
+    }
+  }
+}
+
+// rows gather (B,N,C)[idx (B,M)] -> (B,M,C): G lanes per row, float4 when aligned
+__global__ __launch_bounds__(256) void gather_rows_cl_fwd_k(int N, int M, int C,
+                                                            const float* __restrict__ feat,
+                                                            const int* __restrict__ idx,
+                                                            float* __restrict__ out,
+                                                            long long rows) {
+  const int lane = threadIdx.x & 63;
+  long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (; row < rows; row += stride) {
+    const int b = (int)(row / M);
+    const int i = idx[row];
+    const float* f = feat + ((size_t)b * N + i) * C;
+    float* o = out + row * C;
+    for (int c = lane; c < C; c += 64) o[c] = f[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_cl_bwd_k(int N, int M, int C,
+                                                            const float* __restrict__ gout,
+                                                            const int* __restrict__ idx,
+                                                            float* __restrict__ gfeat,
+                                                            long long rows) {
+  const int lane = threadIdx.x & 63;
+  long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+  for (; row < rows; row += stride) {
+    const int b = (int)(row / M);
+    const int i = idx[row];
+    const float* g = gout + row * C;
+    float* f = gfeat + ((size_t)b * N + i) * C;
+    for (int c = lane; c < C; c += 64) atomicAdd(f + c, g[c]);
+  }
+}
+
+// ---------------- max over the ns neighbours --------------------------------
+// x (R,ns,C) -> out (R,C), arg (R,C).  One thread per (r,c); consecutive threads walk
+// consecutive channels so every read is coalesced.  First maximum wins.
+__global__ __launch_bounds__(256) void maxpool_ns_fwd_k(long long RC, int ns, int C,
+                                                        const float* __restrict__ x,
+                                                        float* __restrict__ out,
+                                                        int* __restrict__ arg) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; t < RC; t += stride) {
+    const long long r = t / C;
+    const int c = (int)(t - r * C);
+    const float* p = x + r * ns * C + c;
+    float best = p[0];
+    int bi = 0;
+    for (int s = 1; s < ns; ++s) {
+      const float v = p[(size_t)s * C];
+      if (v > best) {
+        best = v;
+        bi = s;
+      }
+    }
+    out[t] = best;
+    arg[t] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_ns_bwd_k(long long RC, int ns, int C,
+                                                        const float* __restrict__ gout,
+                                                        const int* __restrict__ arg,
+                                                        float* __restrict__ gx) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; t < RC; t += stride) {
+    const long long r = t / C;
+    const int c = (int)(t - r * C);
+    float* p = gx + r * ns * C + c;
+    const float g = gout[t];
+    const int a = arg[t];
+    for (int s = 0; s < ns; ++s) p[(size_t)s * C] = (s == a) ? g : 0.f;
+  }
+}
+
+static inline int grid_for_rows(long long rows, int rows_per_block) {
+  long long g = (rows + rows_per_block - 1) / rows_per_block;
+  const long long cap = 256LL * 16;
+  return (int)(g < cap ? (g > 0 ? g : 1) : cap);
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+extern "C" int demf_group_points_fwd(int B, int C, int N, int M, int ns,
+                                     const float* features, const int* idx, float* out,
+                                     demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 1, "group_points: bad sizes");
+  if (B == 0 || C == 0 || M == 0) return DEMF_OK;
+  DEMF_REQUIRE(features && idx && out, "group_points: null pointer");
+  const int J = M * ns;
+  dim3 grid(cdiv(J, 256), cdiv(C, 8), B);
+  hipLaunchKernelGGL((group_cm_fwd<8>), grid, dim3(256), 0, (hipStream_t)stream, C, N, J,
+                     features, idx, out);
+  return check_launch("group_points_fwd");
+}
+
+extern "C" int demf_group_points_bwd(int B, int C, int N, int M, int ns,
+                                     const float* grad_out, const int* idx,
+                                     float* grad_features, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && C >= 0 && N >= 1 && M >= 0 && ns >= 1, "group_points: bad sizes");
+  if (B == 0 || C == 0 || M == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && idx && grad_features, "group_points: null pointer");
+  const int J = M * ns;
+  dim3 grid(cdiv(J, 256), cdiv(C, 8), B);
+  hipLaunchKernelGGL((group_cm_bwd<8>), grid, dim3(256), 0, (hipStream_t)stream, C, N, J,
+                     grad_out, idx, grad_features);
+  return check_launch("group_points_bwd");
+}
+
+extern "C" int demf_gather_points_fwd(int B, int C, int N, int M, const float* features,
+                                      const int* idx, float* out, demf_stream_t stream) {
+  return demf_group_points_fwd(B, C, N, M, 1, features, idx, out, stream);
+}
+
+extern "C" int demf_gather_points_bwd(int B, int C, int N, int M, const float* grad_out,
+                                      const int* idx, float* grad_features,
+                                      demf_stream_t stream) {
+  return demf_group_points_bwd(B, C, N, M, 1, grad_out, idx, grad_features, stream);
+}
+
+extern "C" int demf_group_concat_cl_fwd(int B, int N, int M, int ns, int C, int ldo,
+                                        int xyz_col, int feat_col, float radius,
+                                        int normalize_xyz, const float* xyz,
+                                        const float* center, const float* feat,
+                                        const int* idx, float* out, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && C >= 0, "group_concat: bad sizes");
+  DEMF_REQUIRE(xyz_col >= 0 && xyz_col + 3 <= ldo && feat_col >= 0 && feat_col + C <= ldo &&
+                   (C == 0 || xyz_col + 3 <= feat_col || feat_col + C <= xyz_col),
+               "group_concat: column ranges xyz=%d feat=%d C=%d ld=%d", xyz_col, feat_col, C,
+               ldo);
+  if (B == 0 || M == 0) return DEMF_OK;
+  DEMF_REQUIRE(xyz && center && idx && out && (C == 0 || feat), "group_concat: null pointer");
+  const long long rows = (long long)B * M * ns;
+  const float inv_r = normalize_xyz ? 1.0f / radius : 1.0f;
+  const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (feat_col % 4 == 0) &&
+                    (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  const int grid = grid_for_rows(rows, 4);
+  if (vec4)
+    hipLaunchKernelGGL((group_concat_cl_fwd_k<true>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, N, M, ns, C, ldo, xyz_col, feat_col, inv_r, xyz,
+                       center, feat, idx, out, rows);
+  else
+    hipLaunchKernelGGL((group_concat_cl_fwd_k<false>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, N, M, ns, C, ldo, xyz_col, feat_col, inv_r, xyz,
+                       center, feat, idx, out, rows);
+  return check_launch("group_concat_cl_fwd");
+}
+
+extern "C" int demf_group_concat_cl_bwd(int B, int N, int M, int ns, int C, int ldo,
+                                        int feat_col, const float* grad_out, const int* idx,
+                                        float* grad_feat, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && C >= 0 && feat_col >= 0 &&
+                   feat_col + C <= ldo,
+               "group_concat_bwd: bad sizes");
+  if (B == 0 || M == 0 || C == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && idx && grad_feat, "group_concat_bwd: null pointer");
+  const long long rows = (long long)B * M * ns;
+  const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (feat_col % 4 == 0) &&
+                    (((uintptr_t)grad_out) % 16 == 0);
+  const int grid = grid_for_rows(rows, 4);
+  if (vec4)
+    hipLaunchKernelGGL((group_concat_cl_bwd_k<true>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, N, M, ns, C, ldo, feat_col, grad_out, idx,
+                       grad_feat, rows);
+  else
+    hipLaunchKernelGGL((group_concat_cl_bwd_k<false>), dim3(grid), dim3(256), 0,
+                       (hipStream_t)stream, N, M, ns, C, ldo, feat_col, grad_out, idx,
+                       grad_feat, rows);
+  return check_launch("group_concat_cl_bwd");
+}
+
+extern "C" int demf_gather_rows_cl_fwd(int B, int N, int M, int C, const float* feat,
+                                       const int* idx, float* out, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && C >= 0, "gather_rows: bad sizes");
+  if (B == 0 || M == 0 || C == 0) return DEMF_OK;
+  DEMF_REQUIRE(feat && idx && out, "gather_rows: null pointer");
+  const long long rows = (long long)B * M;
+  hipLaunchKernelGGL(gather_rows_cl_fwd_k, dim3(grid_for_rows(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, N, M, C, feat, idx, out, rows);
+  return check_launch("gather_rows_cl_fwd");
+}
+
+extern "C" int demf_gather_rows_cl_bwd(int B, int N, int M, int C, const float* grad_out,
+                                       const int* idx, float* grad_feat,
+                                       demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && C >= 0, "gather_rows: bad sizes");
+  if (B == 0 || M == 0 || C == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && idx && grad_feat, "gather_rows: null pointer");
+  const long long rows = (long long)B * M;
+  hipLaunchKernelGGL(gather_rows_cl_bwd_k, dim3(grid_for_rows(rows, 4)), dim3(256), 0,
+                     (hipStream_t)stream, N, M, C, grad_out, idx, grad_feat, rows);
+  return check_launch("gather_rows_cl_bwd");
+}
+
+extern "C" int demf_maxpool_ns_fwd(int R, int ns, int C, const float* x, float* out,
+                                   int* arg, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && ns >= 1 && C >= 0, "maxpool_ns: bad sizes");
+  if (R == 0 || C == 0) return DEMF_OK;
+  DEMF_REQUIRE(x && out && arg, "maxpool_ns: null pointer");
+  const long long RC = (long long)R * C;
+  hipLaunchKernelGGL(maxpool_ns_fwd_k, dim3(grid_for_rows(RC, 256)), dim3(256), 0,
+                     (hipStream_t)stream, RC, ns, C, x, out, arg);
+  return check_launch("maxpool_ns_fwd");
+}
+
+extern "C" int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out,
+                                   const int* arg, float* grad_x, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && ns >= 1 && C >= 0, "maxpool_ns: bad sizes");
+  if (R == 0 || C == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && arg && grad_x, "maxpool_ns: null pointer");
+  const long long RC = (long long)R * C;
+  hipLaunchKernelGGL(maxpool_ns_bwd_k, dim3(grid_for_rows(RC, 256)), dim3(256), 0,
+                     (hipStream_t)stream, RC, ns, C, grad_out, arg, grad_x);
+  return check_launch("maxpool_ns_bwd");
+}

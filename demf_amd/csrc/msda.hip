@@ -1,0 +1,368 @@
+// Multi-scale deformable attention core (forward + backward) for gfx950.
+//
+// This is the DeMF fusion gather: the 256 vote-cluster queries sample the 4-level
+// image pyramid at learned offsets.  Reference call chain:
+//   DeMFVoteHead.transformer_decoder (class_agnostic_vote_head.py:493)
+//   -> DeMFTransformerDecoderLayer.forward (demf/modeling/layers/transformer.py:73)
+//   -> mmcv MultiScaleDeformableAttention -> MultiScaleDeformableAttnFunction
+//      (ms_deform_attn im2col / col2im CUDA kernels upstream).
+//
+// Mapping for wave64: one (batch, query, head) item is served by G = Dh/4 adjacent
+// lanes, each owning 4 consecutive channels, so a bilinear corner is ONE
+// Dh*4-byte contiguous read split into float4 lanes (Dh=32: 8 lanes x 16 B = a
+// full 128-byte line) and a wave covers 64/G heads of consecutive queries; the
+// (B,Q,H*Dh) output row is written as coalesced float4.  The sampling loop is
+// branch-free (clamped addresses, zeroed corner weights) so all L*P*4 corner loads
+// of an item are in flight together - the kernel is a latency/L2-gather problem,
+// not an ALU one.  Backward reduces grad_loc / grad_weight across the G lanes with
+// DPP adds (no LDS) and scatters grad_value with hardware fp32 atomics.
+#include "common.h"
+
+namespace demf {
+
+struct Corner {
+  int off[4];    // element offsets (without channel) of the 4 corners, clamped
+  float cw[4];   // bilinear weights, zero for out-of-image corners
+  float ok[4];   // 1/0 validity of each corner
+  float lh, lw, hh, hw;
+  bool inside;
+};
+
+__device__ __forceinline__ Corner make_corner(float lx, float ly, int Hl, int Wl,
+                                              int start, int H, int Dh, int h) {
+  Corner c;
+  const float h_im = ly * (float)Hl - 0.5f;
+  const float w_im = lx * (float)Wl - 0.5f;
+  c.inside = (h_im > -1.f) && (w_im > -1.f) && (h_im < (float)Hl) && (w_im < (float)Wl);
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  c.lh = h_im - hf;
+  c.lw = w_im - wf;
+  c.hh = 1.f - c.lh;
+  c.hw = 1.f - c.lw;
+  const bool hl = c.inside && h_low >= 0, hh_ = c.inside && h_high <= Hl - 1;
+  const bool wl = w_low >= 0, wh = w_high <= Wl - 1;
+  c.ok[0] = (hl && wl) ? 1.f : 0.f;
+  c.ok[1] = (hl && wh) ? 1.f : 0.f;
+  c.ok[2] = (hh_ && wl) ? 1.f : 0.f;
+  c.ok[3] = (hh_ && wh) ? 1.f : 0.f;
+  c.cw[0] = c.hh * c.hw * c.ok[0];
+  c.cw[1] = c.hh * c.lw * c.ok[1];
+  c.cw[2] = c.lh * c.hw * c.ok[2];
+  c.cw[3] = c.lh * c.lw * c.ok[3];
+  const int hlc = min(max(h_low, 0), Hl - 1), hhc = min(max(h_high, 0), Hl - 1);
+  const int wlc = min(max(w_low, 0), Wl - 1), whc = min(max(w_high, 0), Wl - 1);
+  const int hd = H * Dh;
+  c.off[0] = (start + hlc * Wl + wlc) * hd + h * Dh;
+  c.off[1] = (start + hlc * Wl + whc) * hd + h * Dh;
+  c.off[2] = (start + hhc * Wl + wlc) * hd + h * Dh;
+  c.off[3] = (start + hhc * Wl + whc) * hd + h * Dh;
+  return c;
+}
+
+__device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
+  a.x = __builtin_fmaf(s, v.x, a.x);
+  a.y = __builtin_fmaf(s, v.y, a.y);
+  a.z = __builtin_fmaf(s, v.z, a.z);
+  a.w = __builtin_fmaf(s, v.w, a.w);
+  return a;
+}
+__device__ __forceinline__ float f4_dot(float4 a, float4 b) {
+  return __builtin_fmaf(a.w, b.w, __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)));
+}
+
+constexpr int MAX_L = 8;
+
+// TL,TP > 0: compile-time levels/points (fully unrolled); 0: runtime loop.
+template <int G, int TL, int TP>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(
+    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attw, float* __restrict__ out,
+    long long items) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long item = t / G;
+  if (item >= items) return;
+  const int sub = (int)(t - item * G);
+  const int h = (int)(item % H);
+  const int b = (int)(item / ((long long)Q * H));
+  const float* vb = value + (size_t)b * S * H * Dh + sub * 4;
+  if constexpr (TL > 0) {
+    L = TL;
+    P = TP;
+  }
+  const int nlp = L * P;
+  const float* lp = loc + item * nlp * 2;
+  const float* wp = attw + item * nlp;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < nlp; ++i) {
+    const int l = i / P;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const int start = (int)lsi[l];
+    const Corner c = make_corner(lp[2 * i], lp[2 * i + 1], Hl, Wl, start, H, Dh, h);
+    const float aw = wp[i];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v = f4_fma(c.cw[k], *reinterpret_cast<const float4*>(vb + c.off[k]), v);
+    acc = f4_fma(aw, v, acc);
+  }
+  *reinterpret_cast<float4*>(out + item * Dh + sub * 4) = acc;
+}
+
+template <int G, int TL, int TP>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(
+    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attw,
+    const float* __restrict__ gout, float* __restrict__ gvalue, float* __restrict__ gloc,
+    float* __restrict__ gattw, long long items) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long item = t / G;
+  const bool live = item < items;
+  if (!live) item = items - 1;  // keep the lane in the DPP reductions
+  const int sub = (int)(t - (t / G) * G);
+  const int h = (int)(item % H);
+  const int b = (int)(item / ((long long)Q * H));
+  const size_t boff = (size_t)b * S * H * Dh + sub * 4;
+  const float* vb = value + boff;
+  float* gvb = gvalue + boff;
+  if constexpr (TL > 0) {
+    L = TL;
+    P = TP;
+  }
+  const int nlp = L * P;
+  const float* lp = loc + item * nlp * 2;
+  const float* wp = attw + item * nlp;
+  const float4 top = *reinterpret_cast<const float4*>(gout + item * Dh + sub * 4);
+#pragma unroll
+  for (int i = 0; i < nlp; ++i) {
+    const int l = i / P;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const int start = (int)lsi[l];
+    const Corner c = make_corner(lp[2 * i], lp[2 * i + 1], Hl, Wl, start, H, Dh, h);
+    const float aw = wp[i];
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v[k] = *reinterpret_cast<const float4*>(vb + c.off[k]);
+      v[k].x *= c.ok[k]; v[k].y *= c.ok[k]; v[k].z *= c.ok[k]; v[k].w *= c.ok[k];
+    }
+    // d(sample)/d(h), d(sample)/d(w), and the sample itself, per channel
+    float4 gh, gw, val;
+#define MSDA_CH(m)                                                                     \
+    gh.m = c.hw * (v[2].m - v[0].m) + c.lw * (v[3].m - v[1].m);                        \
+    gw.m = c.hh * (v[1].m - v[0].m) + c.lh * (v[3].m - v[2].m);                        \
+    val.m = c.hh * c.hw * v[0].m + c.hh * c.lw * v[1].m + c.lh * c.hw * v[2].m +       \
+            c.lh * c.lw * v[3].m;
+    MSDA_CH(x) MSDA_CH(y) MSDA_CH(z) MSDA_CH(w)
+#undef MSDA_CH
+    float g_w = f4_dot(top, val);
+    float g_x = f4_dot(top, gw) * aw * (float)Wl;
+    float g_y = f4_dot(top, gh) * aw * (float)Hl;
+    g_w = group_allsum<G>(g_w);
+    g_x = group_allsum<G>(g_x);
+    g_y = group_allsum<G>(g_y);
+    if (live) {
+      if (sub == 0) {
+        gattw[item * nlp + i] = g_w;
+        gloc[(item * nlp + i) * 2 + 0] = g_x;
+        gloc[(item * nlp + i) * 2 + 1] = g_y;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (c.ok[k] != 0.f) {
+          const float s = c.cw[k] * aw;
+          float* g = gvb + c.off[k];
+          atomicAdd(g + 0, s * top.x);
+          atomicAdd(g + 1, s * top.y);
+          atomicAdd(g + 2, s * top.z);
+          atomicAdd(g + 3, s * top.w);
+        }
+      }
+    }
+  }
+}
+
+// Any Dh (multiple of nothing): one thread per (b,q,h), serial over channels.
+__global__ __launch_bounds__(256) void msda_fwd_generic(
+    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attw, float* __restrict__ out,
+    long long items) {
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= items) return;
+  const int h = (int)(item % H);
+  const int b = (int)(item / ((long long)Q * H));
+  const float* vb = value + (size_t)b * S * H * Dh;
+  const int nlp = L * P;
+  for (int ch = 0; ch < Dh; ++ch) {
+    float acc = 0.f;
+    for (int i = 0; i < nlp; ++i) {
+      const int l = i / P;
+      const Corner c = make_corner(loc[(item * nlp + i) * 2], loc[(item * nlp + i) * 2 + 1],
+                                   (int)shapes[2 * l], (int)shapes[2 * l + 1], (int)lsi[l], H,
+                                   Dh, h);
+      float v = 0.f;
+      for (int k = 0; k < 4; ++k) v = __builtin_fmaf(c.cw[k], vb[c.off[k] + ch], v);
+      acc = __builtin_fmaf(attw[item * nlp + i], v, acc);
+    }
+    out[item * Dh + ch] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void msda_bwd_generic(
+    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attw,
+    const float* __restrict__ gout, float* __restrict__ gvalue, float* __restrict__ gloc,
+    float* __restrict__ gattw, long long items) {
+  const long long item = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= items) return;
+  const int h = (int)(item % H);
+  const int b = (int)(item / ((long long)Q * H));
+  const size_t boff = (size_t)b * S * H * Dh;
+  const int nlp = L * P;
+  for (int i = 0; i < nlp; ++i) {
+    const int l = i / P;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const Corner c = make_corner(loc[(item * nlp + i) * 2], loc[(item * nlp + i) * 2 + 1], Hl,
+                                 Wl, (int)lsi[l], H, Dh, h);
+    const float aw = attw[item * nlp + i];
+    float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+    for (int ch = 0; ch < Dh; ++ch) {
+      const float top = gout[item * Dh + ch];
+      float v[4];
+      for (int k = 0; k < 4; ++k) v[k] = value[boff + c.off[k] + ch] * c.ok[k];
+      const float gh = c.hw * (v[2] - v[0]) + c.lw * (v[3] - v[1]);
+      const float gw = c.hh * (v[1] - v[0]) + c.lh * (v[3] - v[2]);
+      const float val = c.hh * c.hw * v[0] + c.hh * c.lw * v[1] + c.lh * c.hw * v[2] +
+                        c.lh * c.lw * v[3];
+      g_w += top * val;
+      g_x += top * gw;
+      g_y += top * gh;
+      for (int k = 0; k < 4; ++k)
+        if (c.ok[k] != 0.f) atomicAdd(gvalue + boff + c.off[k] + ch, c.cw[k] * aw * top);
+    }
+    gattw[item * nlp + i] = g_w;
+    gloc[(item * nlp + i) * 2 + 0] = g_x * aw * (float)Wl;
+    gloc[(item * nlp + i) * 2 + 1] = g_y * aw * (float)Hl;
+  }
+}
+
+template <int G>
+static void launch_fwd(dim3 grid, hipStream_t s, int S, int H, int Dh, int L, int Q,
+                       int P, const float* value, const int64_t* shapes, const int64_t* lsi,
+                       const float* loc, const float* w, float* out, long long items) {
+  if (L == 4 && P == 2)
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 2>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+                       shapes, lsi, loc, w, out, items);
+  else if (L == 4 && P == 4)
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
+                       value, shapes, lsi, loc, w, out, items);
+  else
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 0, 0>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+                       shapes, lsi, loc, w, out, items);
+}
+
+template <int G>
+static void launch_bwd(dim3 grid, hipStream_t s, int S, int H, int Dh, int L, int Q,
+                       int P, const float* value, const int64_t* shapes, const int64_t* lsi,
+                       const float* loc, const float* w, const float* gout, float* gvalue,
+                       float* gloc, float* gw, long long items) {
+  if (L == 4 && P == 2)
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 2>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+                       shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
+  else if (L == 4 && P == 4)
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
+                       value, shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
+  else
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 0, 0>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+                       shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
+}
+
+static int msda_check(int B, int S, int H, int Dh, int L, int Q, int P) {
+  DEMF_REQUIRE(B >= 0 && S >= 1 && H >= 1 && Dh >= 1 && L >= 1 && L <= MAX_L && Q >= 0 && P >= 1,
+               "msda: bad sizes B=%d S=%d H=%d Dh=%d L=%d Q=%d P=%d", B, S, H, Dh, L, Q, P);
+  DEMF_REQUIRE((long long)S * H * Dh < (1LL << 31), "msda: one scene of value exceeds 2^31 elements");
+  return DEMF_OK;
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
+                                 const float* value, const int64_t* spatial_shapes,
+                                 const int64_t* level_start_index, const float* sampling_loc,
+                                 const float* attn_weight, float* out, demf_stream_t stream) {
+  if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
+  if (B == 0 || Q == 0) return DEMF_OK;
+  DEMF_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+               "msda_fwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long long items = (long long)B * Q * H;
+  const int G = Dh / 4;
+  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) &&
+                    (((uintptr_t)value | (uintptr_t)out) % 16 == 0);
+  if (!fast) {
+    hipLaunchKernelGGL(msda_fwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                       S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                       attn_weight, out, items);
+    return check_launch("msda_fwd_generic");
+  }
+  const dim3 grid((unsigned)((items * G + 255) / 256));
+#define GO(g)                                                                              \
+  launch_fwd<g>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
+                sampling_loc, attn_weight, out, items)
+  switch (G) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    default: GO(16); break;
+  }
+#undef GO
+  return check_launch("msda_fwd");
+}
+
+extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
+                                 const float* value, const int64_t* spatial_shapes,
+                                 const int64_t* level_start_index, const float* sampling_loc,
+                                 const float* attn_weight, const float* grad_out,
+                                 float* grad_value, float* grad_sampling_loc,
+                                 float* grad_attn_weight, demf_stream_t stream) {
+  if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
+  if (B == 0 || Q == 0) return DEMF_OK;
+  DEMF_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight &&
+                   grad_out && grad_value && grad_sampling_loc && grad_attn_weight,
+               "msda_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const long long items = (long long)B * Q * H;
+  const int G = Dh / 4;
+  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) &&
+                    (((uintptr_t)value | (uintptr_t)grad_out) % 16 == 0);
+  if (!fast) {
+    hipLaunchKernelGGL(msda_bwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+                       S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                       attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight,
+                       items);
+    return check_launch("msda_bwd_generic");
+  }
+  const dim3 grid((unsigned)((items * G + 255) / 256));
+#define GO(g)                                                                              \
+  launch_bwd<g>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
+                sampling_loc, attn_weight, grad_out, grad_value, grad_sampling_loc,        \
+                grad_attn_weight, items)
+  switch (G) {
+    case 1: GO(1); break;
+    case 2: GO(2); break;
+    case 4: GO(4); break;
+    case 8: GO(8); break;
+    default: GO(16); break;
+  }
+#undef GO
+  return check_launch("msda_bwd");
+}
