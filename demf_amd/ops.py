@@ -50,7 +50,13 @@ class _FurthestPointSampling(Function):
         B, N, three = points_xyz.shape
         assert three == 3
         idx = torch.empty((B, num_points), dtype=torch.int32, device=points_xyz.device)
-        _ffi.call("demf_fps_f32", B, N, num_points, _p(points_xyz), None, _p(idx), _stream())
+        # the register-resident kernel covers 64 <= N <= 24576; outside it the library
+        # needs the (B,N) running-distance scratch the upstream ABI always carries
+        temp = None
+        if N < 64 or N > 24 * 1024:
+            temp = torch.empty((B, N), dtype=torch.float32, device=points_xyz.device)
+        _ffi.call("demf_fps_f32", B, N, num_points, _p(points_xyz), _p(temp), _p(idx),
+                  _stream())
         ctx.mark_non_differentiable(idx)
         return idx
 
