@@ -28,7 +28,7 @@ SIGNATURES = {
     "demf_three_interpolate_fwd": [_c_int] * 4 + [_ptr] * 5,
     "demf_three_interpolate_bwd": [_c_int] * 4 + [_ptr] * 5,
     "demf_group_concat_cl_fwd": [_c_int] * 8 + [_c_float, _c_int] + [_ptr] * 6,
-    "demf_group_concat_cl_bwd": [_c_int] * 7 + [_ptr] * 4,
+    "demf_group_concat_cl_bwd": [_c_int] * 8 + [_c_float, _c_int] + [_ptr] * 6,
     "demf_gather_rows_cl_fwd": [_c_int] * 4 + [_ptr] * 4,
     "demf_gather_rows_cl_bwd": [_c_int] * 4 + [_ptr] * 4,
     "demf_three_interpolate_cl_fwd": [_c_int] * 6 + [_ptr] * 5,

@@ -93,26 +93,36 @@ __global__ __launch_bounds__(256) void group_concat_cl_fwd_k(
 
 template <bool VEC4>
 __global__ __launch_bounds__(256) void group_concat_cl_bwd_k(
-    int N, int M, int ns, int C, int ldo, int feat_col, const float* __restrict__ gout,
-    const int* __restrict__ idx, float* __restrict__ gfeat, long long rows) {
+    int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float inv_r,
+    const float* __restrict__ gout, const int* __restrict__ idx, float* __restrict__ gfeat,
+    float* __restrict__ gxyz, float* __restrict__ gcenter, long long rows) {
   const int lane = threadIdx.x & 63;
   long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
   for (; row < rows; row += stride) {
-    const int b = (int)(row / ((long long)M * ns));
+    const long long bm = row / ns;
+    const int b = (int)(bm / M);
     const int i = idx[row];
-    const float* g = gout + row * ldo + feat_col;
-    float* f = gfeat + ((size_t)b * N + i) * C;
-    if constexpr (VEC4) {
-      for (int c = lane * 4; c < C; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(g + c);
-        atomicAdd(f + c + 0, v.x);
-        atomicAdd(f + c + 1, v.y);
-        atomicAdd(f + c + 2, v.z);
-        atomicAdd(f + c + 3, v.w);
+    if (gfeat != nullptr && C > 0) {
+      const float* g = gout + row * ldo + feat_col;
+      float* f = gfeat + ((size_t)b * N + i) * C;
+      if constexpr (VEC4) {
+        for (int c = lane * 4; c < C; c += 256) {
+          const float4 v = *reinterpret_cast<const float4*>(g + c);
+          atomicAdd(f + c + 0, v.x);
+          atomicAdd(f + c + 1, v.y);
+          atomicAdd(f + c + 2, v.z);
+          atomicAdd(f + c + 3, v.w);
+        }
+      } else {
+        for (int c = lane; c < C; c += 64) atomicAdd(f + c, g[c]);
       }
-    } else {
-      for (int c = lane; c < C; c += 64) atomicAdd(f + c, g[c]);
+    }
+    // rel = (xyz[idx] - center) * inv_r : d/dxyz = +g*inv_r, d/dcenter = -g*inv_r
+    if (gxyz != nullptr && lane < 3) {
+      const float g = gout[row * ldo + xyz_col + lane] * inv_r;
+      atomicAdd(gxyz + ((size_t)b * N + i) * 3 + lane, g);
+      atomicAdd(gcenter + bm * 3 + lane, -g);
     }
   }
 }
@@ -271,25 +281,31 @@ extern "C" int demf_group_concat_cl_fwd(int B, int N, int M, int ns, int C, int 
 }
 
 extern "C" int demf_group_concat_cl_bwd(int B, int N, int M, int ns, int C, int ldo,
-                                        int feat_col, const float* grad_out, const int* idx,
-                                        float* grad_feat, demf_stream_t stream) {
+                                        int xyz_col, int feat_col, float radius,
+                                        int normalize_xyz, const float* grad_out,
+                                        const int* idx, float* grad_feat, float* grad_xyz,
+                                        float* grad_center, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && C >= 0 && feat_col >= 0 &&
-                   feat_col + C <= ldo,
+                   feat_col + C <= ldo && xyz_col >= 0 && xyz_col + 3 <= ldo,
                "group_concat_bwd: bad sizes");
-  if (B == 0 || M == 0 || C == 0) return DEMF_OK;
-  DEMF_REQUIRE(grad_out && idx && grad_feat, "group_concat_bwd: null pointer");
+  if (B == 0 || M == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && idx, "group_concat_bwd: null pointer");
+  DEMF_REQUIRE((grad_xyz == nullptr) == (grad_center == nullptr),
+               "group_concat_bwd: grad_xyz and grad_center must be given together");
+  if ((grad_feat == nullptr || C == 0) && grad_xyz == nullptr) return DEMF_OK;
   const long long rows = (long long)B * M * ns;
+  const float inv_r = normalize_xyz ? 1.0f / radius : 1.0f;
   const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (feat_col % 4 == 0) &&
                     (((uintptr_t)grad_out) % 16 == 0);
   const int grid = grid_for_rows(rows, 4);
   if (vec4)
     hipLaunchKernelGGL((group_concat_cl_bwd_k<true>), dim3(grid), dim3(256), 0,
-                       (hipStream_t)stream, N, M, ns, C, ldo, feat_col, grad_out, idx,
-                       grad_feat, rows);
+                       (hipStream_t)stream, N, M, ns, C, ldo, xyz_col, feat_col, inv_r,
+                       grad_out, idx, grad_feat, grad_xyz, grad_center, rows);
   else
     hipLaunchKernelGGL((group_concat_cl_bwd_k<false>), dim3(grid), dim3(256), 0,
-                       (hipStream_t)stream, N, M, ns, C, ldo, feat_col, grad_out, idx,
-                       grad_feat, rows);
+                       (hipStream_t)stream, N, M, ns, C, ldo, xyz_col, feat_col, inv_r,
+                       grad_out, idx, grad_feat, grad_xyz, grad_center, rows);
   return check_launch("group_concat_cl_bwd");
 }
 

@@ -1,0 +1,12 @@
+from .coder import DeMFClassAgnosticBBoxCoder
+from .detector import DeMFHotPath, head_kwargs
+from .head import DeMFVoteHead
+from .pointnet2 import PointFPModule, PointNet2SASSG, PointSAModule, build_sa_module
+from .transformer import (DeMFTransformerDecoderLayer, MultiScaleDeformableAttention,
+                          PositionEmbeddingLearned)
+from .vote import BaseConvBboxHead, VoteModule
+
+__all__ = ["DeMFClassAgnosticBBoxCoder", "DeMFHotPath", "head_kwargs", "DeMFVoteHead",
+           "PointFPModule", "PointNet2SASSG", "PointSAModule", "build_sa_module",
+           "DeMFTransformerDecoderLayer", "MultiScaleDeformableAttention",
+           "PositionEmbeddingLearned", "BaseConvBboxHead", "VoteModule"]

@@ -1,0 +1,214 @@
+"""The DeMF fusion decoder layer.
+
+``DeMFTransformerDecoderLayer`` / ``PositionEmbeddingLearned`` mirror
+demf/modeling/layers/transformer.py:18-80.  The mmcv layer it wraps
+(DetrTransformerDecoderLayer = BaseTransformerLayer with operation_order
+('self_attn','norm','cross_attn','norm','ffn','norm'), configs/demf/demf_votenet.py:71-91)
+is restated here with identical sub-module names so reference checkpoints load:
+``layer.attentions.0.attn.*`` (nn.MultiheadAttention), ``layer.attentions.1.{sampling_offsets,
+attention_weights,value_proj,output_proj}``, ``layer.ffns.0.layers.{0.0,1}``, ``layer.norms.{0,1,2}``.
+The deformable sampling itself runs on the gfx950 kernel (ops.MultiScaleDeformableAttnFunction).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops import MultiScaleDeformableAttnFunction
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """transformer.py:18-36 - Conv1d(6->256) BN ReLU Conv1d(256->256) on (B,N,6)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        cin, cpos = cfg["input_channel"], cfg["num_pos_feats"]
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(cin, cpos, kernel_size=1), nn.BatchNorm1d(cpos), nn.ReLU(inplace=True),
+            nn.Conv1d(cpos, cpos, kernel_size=1))
+
+    def forward(self, xyz):
+        xyz = xyz.transpose(1, 2).contiguous()
+        return self.position_embedding_head(xyz)
+
+
+class MultiheadAttention(nn.Module):
+    """mmcv.cnn.bricks.transformer.MultiheadAttention (seq-first).  The deprecated
+    ``dropout`` kwarg of the reference config sets BOTH the attention-weight dropout and
+    the output dropout layer, as upstream does."""
+
+    def __init__(self, embed_dims, num_heads, attn_drop=0.0, proj_drop=0.0, dropout=None, **unused):
+        super().__init__()
+        out_drop = 0.0
+        if dropout is not None:
+            attn_drop, out_drop = dropout, dropout
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.dropout_layer = nn.Dropout(out_drop) if out_drop > 0 else nn.Identity()
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_pos=None,
+                attn_mask=None, key_padding_mask=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if identity is None:
+            identity = query
+        if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
+            key_pos = query_pos
+        if query_pos is not None:
+            query = query + query_pos
+        if key_pos is not None:
+            key = key + key_pos
+        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask,
+                        key_padding_mask=key_padding_mask)[0]
+        return identity + self.dropout_layer(self.proj_drop(out))
+
+
+class MultiScaleDeformableAttention(nn.Module):
+    """mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttention (transformer.py:8-15
+    imports it; built from demf_votenet.py:79-85).  forward signature as upstream."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, **unused):
+        super().__init__()
+        assert embed_dims % num_heads == 0
+        self.im2col_step, self.embed_dims = im2col_step, embed_dims
+        self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
+        self.batch_first = batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.init_weights()
+
+    def init_weights(self):
+        nn.init.constant_(self.sampling_offsets.weight, 0.0)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.num_heads, 1, 1, 2).repeat(
+            1, self.num_levels, self.num_points, 1)
+        for i in range(self.num_points):
+            grid[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = grid.view(-1)
+        nn.init.constant_(self.attention_weights.weight, 0.0)
+        nn.init.constant_(self.attention_weights.bias, 0.0)
+        nn.init.xavier_uniform_(self.value_proj.weight)
+        nn.init.constant_(self.value_proj.bias, 0.0)
+        nn.init.xavier_uniform_(self.output_proj.weight)
+        nn.init.constant_(self.output_proj.bias, 0.0)
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None,
+                key_padding_mask=None, reference_points=None, spatial_shapes=None,
+                level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query = query.permute(1, 0, 2)
+            value = value.permute(1, 0, 2)
+        bs, num_query, _ = query.shape
+        bs, num_value, _ = value.shape
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, self.num_heads, -1)
+        offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels,
+                                                    self.num_points, 2)
+        weights = self.attention_weights(query).view(bs, num_query, self.num_heads,
+                                                     self.num_levels * self.num_points)
+        weights = weights.softmax(-1).view(bs, num_query, self.num_heads, self.num_levels,
+                                           self.num_points)
+        assert reference_points.shape[-1] == 2, "the DeMF path passes 2-d reference points"
+        normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+        locations = reference_points[:, :, None, :, None, :] + \
+            offsets / normalizer[None, None, None, :, None, :]
+        output = MultiScaleDeformableAttnFunction.apply(
+            value.contiguous(), spatial_shapes, level_start_index, locations.contiguous(),
+            weights.contiguous(), self.im2col_step)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity
+
+
+class FFN(nn.Module):
+    """mmcv FFN(embed_dims, feedforward_channels, num_fcs=2, ReLU, ffn_drop, add_identity)."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, ffn_drop=0.0, **unused):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.ReLU(inplace=True),
+                          nn.Dropout(ffn_drop)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        return (x if identity is None else identity) + out
+
+
+class DetrTransformerDecoderLayer(nn.Module):
+    """BaseTransformerLayer for operation_order ('self_attn','norm','cross_attn','norm',
+    'ffn','norm') - the only order the reference config uses (demf_votenet.py:89-90)."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=2, attn_dropout=0.4,
+                 feedforward_channels=1024, ffn_dropout=0.1):
+        super().__init__()
+        self.attentions = nn.ModuleList([
+            MultiheadAttention(embed_dims, num_heads, dropout=attn_dropout),
+            MultiScaleDeformableAttention(embed_dims, num_heads, num_levels, num_points,
+                                          dropout=attn_dropout)])
+        self.ffns = nn.ModuleList([FFN(embed_dims, feedforward_channels, ffn_dropout)])
+        self.norms = nn.ModuleList([nn.LayerNorm(embed_dims) for _ in range(3)])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None,
+                key_padding_mask=None, **kwargs):
+        query = self.attentions[0](query, query, query, None, query_pos=query_pos,
+                                   key_pos=query_pos, **kwargs)
+        query = self.norms[0](query)
+        query = self.attentions[1](query, key, value, None, query_pos=query_pos,
+                                   key_pos=key_pos, key_padding_mask=key_padding_mask, **kwargs)
+        query = self.norms[1](query)
+        query = self.ffns[0](query, None)
+        return self.norms[2](query)
+
+
+class DeMFTransformerDecoderLayer(nn.Module):
+    """transformer.py:39-80.  ``transformerlayers``/``posembed`` are the reference's cfg
+    dicts (only the keys the DeMF config sets are honoured)."""
+
+    def __init__(self, *args, transformerlayers=None, posembed=None, **kwargs):
+        super().__init__()
+        t = dict(transformerlayers or {})
+        attn = t.get("attn_cfgs", [{}, {}])
+        self.layer = DetrTransformerDecoderLayer(
+            embed_dims=attn[1].get("embed_dims", 256), num_heads=attn[1].get("num_heads", 8),
+            num_levels=attn[1].get("num_levels", 4), num_points=attn[1].get("num_points", 4),
+            attn_dropout=attn[1].get("dropout", 0.1),
+            feedforward_channels=t.get("feedforward_channels", 1024),
+            ffn_dropout=t.get("ffn_dropout", 0.0))
+        self.posembed = PositionEmbeddingLearned(posembed)
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MultiScaleDeformableAttention):
+                m.init_weights()
+
+    def forward(self, query, query_pos, *args, reference_points=None, valid_ratios=None, **kwargs):
+        if reference_points.shape[-1] == 4:
+            reference_points_input = reference_points[:, :, None] * \
+                torch.cat([valid_ratios, valid_ratios], -1)[:, None]
+        else:
+            assert reference_points.shape[-1] == 2
+            reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
+        query_pos_embed = self.posembed(query_pos).permute(2, 0, 1)
+        return self.layer(query, *args, query_pos=query_pos_embed,
+                          reference_points=reference_points_input, **kwargs)

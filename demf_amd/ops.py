@@ -279,21 +279,32 @@ class _GroupConcatCL(Function):
                   float(radius), int(bool(normalize_xyz)), _p(xyz), _p(center), _p(feat),
                   _p(idx), _p(out), _stream())
         ctx.save_for_backward(idx)
-        ctx.dims = (B, N, M, ns, C, ldo, feat_col)
+        ctx.dims = (B, N, M, ns, C, ldo, xyz_col, feat_col, float(radius),
+                    int(bool(normalize_xyz)))
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
         (idx,) = ctx.saved_tensors
-        B, N, M, ns, C, ldo, feat_col = ctx.dims
-        gfeat = None
-        if C > 0 and ctx.needs_input_grad[2]:
+        B, N, M, ns, C, ldo, xyz_col, feat_col, radius, norm = ctx.dims
+        want_feat = C > 0 and ctx.needs_input_grad[2]
+        want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        gfeat = gxyz = gcenter = None
+        if want_feat or want_xyz:
             grad_out = grad_out.contiguous()
-            gfeat = torch.zeros((B, N, C), dtype=grad_out.dtype, device=grad_out.device)
-            _ffi.call("demf_group_concat_cl_bwd", B, N, M, ns, C, ldo, feat_col,
-                      _p(grad_out), _p(idx), _p(gfeat), _stream())
-        return None, None, gfeat, None, None, None, None, None, None
+            kw = dict(dtype=grad_out.dtype, device=grad_out.device)
+            if want_feat:
+                gfeat = torch.zeros((B, N, C), **kw)
+            if want_xyz:
+                gxyz = torch.zeros((B, N, 3), **kw)
+                gcenter = torch.zeros((B, M, 3), **kw)
+            _ffi.call("demf_group_concat_cl_bwd", B, N, M, ns, C, ldo, xyz_col, feat_col,
+                      radius, norm, _p(grad_out), _p(idx), _p(gfeat), _p(gxyz), _p(gcenter),
+                      _stream())
+        return (gxyz if ctx.needs_input_grad[0] else None,
+                gcenter if ctx.needs_input_grad[1] else None,
+                gfeat, None, None, None, None, None, None)
 
 
 def group_concat_cl(xyz, center, feat, idx, radius, normalize_xyz, ldo=None, xyz_col=None,

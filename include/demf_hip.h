@@ -109,11 +109,15 @@ int demf_group_concat_cl_fwd(int B, int N, int M, int ns, int C, int ldo,
                              int normalize_xyz, const float* xyz,
                              const float* center, const float* feat, const int* idx,
                              float* out, demf_stream_t stream);
-/* bwd wrt feat only (xyz carries no gradient in the reference path):
- * grad_out (B,M,ns,ldo) -> grad_feat (B,N,C), accumulated.                   */
+/* bwd: grad_out (B,M,ns,ldo) -> grad_feat (B,N,C), grad_xyz (B,N,3), grad_center
+ * (B,M,3), all accumulated.  grad_feat may be NULL; grad_xyz/grad_center may both be
+ * NULL (backbone levels: raw coordinates carry no gradient; the vote aggregation of
+ * class_agnostic_vote_head.py:455 needs them - vote_points are learned).        */
 int demf_group_concat_cl_bwd(int B, int N, int M, int ns, int C, int ldo,
-                             int feat_col, const float* grad_out, const int* idx,
-                             float* grad_feat, demf_stream_t stream);
+                             int xyz_col, int feat_col, float radius,
+                             int normalize_xyz, const float* grad_out, const int* idx,
+                             float* grad_feat, float* grad_xyz, float* grad_center,
+                             demf_stream_t stream);
 
 /* rows gather: feat (B,N,C), idx (B,M) -> out (B,M,C); bwd accumulated.      */
 int demf_gather_rows_cl_fwd(int B, int N, int M, int C, const float* feat,

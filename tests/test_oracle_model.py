@@ -1,0 +1,98 @@
+"""Pins the oracle's restatement of the reference's IN-TREE code (oracle/model.py) against
+golden vectors produced by the real reference files (oracle/pin_reference.py):
+DeMFVoteHead forward / prepare_decoder_inputs / get_targets / loss + backward,
+DeMFTransformerDecoderLayer, PositionEmbeddingLearned, DeMFClassAgnosticBBoxCoder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deps, fixtures
+from oracle.model import Coder, OracleDeMF, PositionEmbeddingLearned
+
+CASES = [("tiny_a", 1, 2, 4), ("tiny_b", 2, 3, 2)]
+
+
+def run_oracle(name, seed, B, n_gt, golden_dir):
+    gold = np.load(os.path.join(golden_dir, f"ref_head_{name}.npz"))
+    cfg = fixtures.tiny_cfg()
+    batch = fixtures.make_scene_batch(B, 1024, fixtures.TINY_PYRAMID, fixtures.TINY_INPUT,
+                                      cfg.head.embed_dims, seed=seed, n_gt=n_gt)
+    model = OracleDeMF(cfg)
+    fixtures.seed_weights(model, seed)
+    model.train()
+    points = torch.from_numpy(batch["points"])
+    feats = [torch.from_numpy(f) for f in batch["img_features"]]
+    gtb = [torch.from_numpy(gold[f"gt_boxes.{b}"]) for b in range(B)]
+    gtl = [torch.from_numpy(gold[f"gt_labels.{b}"]) for b in range(B)]
+    losses, preds, targets = model.forward_train(points, feats, batch["img_metas"], gtb, gtl)
+    return gold, model, losses, preds, targets
+
+
+@pytest.mark.parametrize("name,seed,B,n_gt", CASES)
+def test_head_matches_real_reference(name, seed, B, n_gt, golden_dir):
+    gold, model, losses, preds, targets = run_oracle(name, seed, B, n_gt, golden_dir)
+    for k in ("seed_indices", "aggregated_indices"):
+        np.testing.assert_array_equal(preds[k].numpy(), gold[k])
+    for k in ("seed_points", "vote_points", "vote_offset", "aggregated_points"):
+        np.testing.assert_allclose(preds[k].detach().numpy(), gold[k], rtol=1e-5, atol=1e-6)
+    for i, d in enumerate(preds["decode_res_all"]):
+        for k, v in d.items():
+            np.testing.assert_allclose(v.detach().numpy(), gold[f"decode{i}.{k}"], rtol=1e-4,
+                                       atol=1e-5, err_msg=f"decode{i}.{k}")
+    for k, v in targets.items():
+        g = gold["target." + k]
+        if v.dtype in (torch.long, torch.int32):
+            np.testing.assert_array_equal(v.numpy(), g, err_msg=k)
+        else:
+            np.testing.assert_allclose(v.detach().numpy(), g, rtol=1e-5, atol=1e-6, err_msg=k)
+    for k, v in losses.items():
+        np.testing.assert_allclose(v.item(), gold["loss." + k], rtol=1e-5, err_msg=k)
+    sum(losses.values()).backward()
+    gn = {n: p.grad.double().norm().item() for n, p in model.named_parameters() if p.grad is not None}
+    assert sorted(gn) == list(gold["grad_names"])
+    np.testing.assert_allclose([gn[n] for n in sorted(gn)], gold["grad_norms"], rtol=2e-4, atol=1e-7)
+    small = "pts_bbox_head.decoder.0.layer.attentions.1.attention_weights.bias"
+    np.testing.assert_allclose(dict(model.named_parameters())[small].grad.numpy(),
+                               gold["grad." + small], rtol=1e-4, atol=1e-6)
+
+
+def test_decoder_inputs_match_real_reference(golden_dir):
+    gold, model, _, preds, _ = run_oracle(*CASES[0], golden_dir)
+    cfg = fixtures.tiny_cfg()
+    batch = fixtures.make_scene_batch(2, 1024, fixtures.TINY_PYRAMID, fixtures.TINY_INPUT,
+                                      cfg.head.embed_dims, seed=1, n_gt=4)
+    feats = [torch.from_numpy(f) for f in batch["img_features"]]
+    inp = model.pts_bbox_head.decoder_inputs(preds["aggregated_points"].detach(), feats,
+                                             batch["img_metas"])
+    np.testing.assert_allclose(inp["reference_points"].numpy(), gold["reference_points"],
+                               rtol=1e-5, atol=1e-6)
+    assert 0 < (gold["reference_points"] > 0).mean() and (gold["reference_points"] < 1).any()
+    np.testing.assert_array_equal(inp["valid_ratios"].numpy(), gold["valid_ratios"])
+    np.testing.assert_array_equal(np.packbits(inp["mask_flatten"].numpy(), axis=1),
+                                  gold["mask_flatten"])
+    np.testing.assert_array_equal(inp["spatial_shapes"].numpy(), gold["spatial_shapes"])
+    np.testing.assert_array_equal(inp["level_start_index"].numpy(), gold["level_start_index"])
+    np.testing.assert_array_equal(inp["feat_flatten"][::37, :, ::5].numpy(),
+                                  gold["feat_flatten_probe"])
+
+
+def test_coder_and_posembed_match_real_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ref_glue.npz"))
+    coder = Coder(12)
+    sp = coder.split_pred(torch.from_numpy(g["coder.in.cls"]), torch.from_numpy(g["coder.in.reg"]),
+                          torch.from_numpy(g["coder.in.base"]))
+    for k, v in sp.items():
+        np.testing.assert_array_equal(v.numpy(), g["coder.split." + k], err_msg=k)
+    np.testing.assert_allclose(coder.decode(sp).numpy(), g["coder.decode"], rtol=1e-6)
+    np.testing.assert_array_equal(coder.decode_corners(sp["center"], sp["size"].abs()).numpy(),
+                                  g["coder.corners"])
+    boxes = deps.DepthInstance3DBoxes(torch.from_numpy(g["coder.encode.boxes"]))
+    for n, v in zip(("center", "size", "dir_class", "dir_res", "dir"), coder.encode(boxes)):
+        np.testing.assert_array_equal(v.numpy(), g["coder.encode." + n], err_msg=n)
+    pe = PositionEmbeddingLearned(6, 16)
+    fixtures.seed_weights(pe, 3)
+    pe.train()
+    np.testing.assert_allclose(pe(torch.from_numpy(g["posembed.in"])).detach().numpy(),
+                               g["posembed.out"], rtol=1e-5, atol=1e-6)
