@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void group_cm_bwd(int C, int N, int J,
 // One wave per output row (b,m,s).  Row layout: [feat(C) | rel_xyz(3) | 0-pad].
 template <bool VEC4>
 __global__ __launch_bounds__(256) void group_concat_cl_fwd_k(
-    int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float inv_r,
+    int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float radius,
     const float* __restrict__ xyz, const float* __restrict__ center,
     const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out,
     long long rows) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void group_concat_cl_fwd_k(
     if (lane < 3) {
       const float p = xyz[((size_t)b * N + i) * 3 + lane];
       const float q = center[bm * 3 + lane];
-      o[xyz_col + lane] = (p - q) * inv_r;
+      o[xyz_col + lane] = (p - q) / radius;  // upstream: grouped_xyz /= max_radius
     }
     // zero every column not covered above
     for (int c = lane; c < ldo; c += 64) {
@@ -265,7 +265,7 @@ extern "C" int demf_group_concat_cl_fwd(int B, int N, int M, int ns, int C, int 
   if (B == 0 || M == 0) return DEMF_OK;
   DEMF_REQUIRE(xyz && center && idx && out && (C == 0 || feat), "group_concat: null pointer");
   const long long rows = (long long)B * M * ns;
-  const float inv_r = normalize_xyz ? 1.0f / radius : 1.0f;
+  const float inv_r = normalize_xyz ? radius : 1.0f;  // divisor
   const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (feat_col % 4 == 0) &&
                     (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
   const int grid = grid_for_rows(rows, 4);

@@ -461,7 +461,8 @@ class DepthInstance3DBoxes:
     and coder.py:142-166 touch.  tensor (n,7) = x, y, z_bottom, dx, dy, dz, yaw."""
 
     def __init__(self, tensor, box_dim=7, with_yaw=True):
-        self.tensor = torch.as_tensor(tensor, dtype=torch.float32).reshape(-1, 7)
+        t = torch.as_tensor(tensor)
+        self.tensor = (t if t.is_floating_point() else t.float()).reshape(-1, 7)
 
     def to(self, device):
         return DepthInstance3DBoxes(self.tensor.to(device))

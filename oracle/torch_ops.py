@@ -15,7 +15,7 @@ def _np(t):
 class _FPS(Function):
     @staticmethod
     def forward(ctx, xyz, m):
-        idx = torch.from_numpy(K.fps(_np(xyz), int(m)))
+        idx = torch.from_numpy(K.fps(_np(xyz.float()), int(m)))
         ctx.mark_non_differentiable(idx)
         return idx
 
@@ -31,8 +31,8 @@ def furthest_point_sample(points_xyz, num_points):
 class _BallQuery(Function):
     @staticmethod
     def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
-        idx = torch.from_numpy(K.ball_query(min_radius, max_radius, sample_num, _np(xyz),
-                                            _np(center_xyz)))
+        idx = torch.from_numpy(K.ball_query(min_radius, max_radius, sample_num, _np(xyz.float()),
+                                            _np(center_xyz.float())))
         ctx.mark_non_differentiable(idx)
         return idx
 
@@ -59,11 +59,15 @@ class _Group(Function):
 
 
 def grouping_operation(features, indices):
+    if features.dtype == torch.float64:  # noise-floor runs: exact gather, autograd by torch
+        B, C, N = features.shape
+        flat = indices.reshape(B, 1, -1).expand(-1, C, -1).long()
+        return torch.gather(features, 2, flat).reshape(B, C, *indices.shape[1:])
     return _Group.apply(features, indices)
 
 
 def gather_points(features, indices):
-    return _Group.apply(features, indices.unsqueeze(-1)).squeeze(-1)
+    return grouping_operation(features, indices.unsqueeze(-1)).squeeze(-1)
 
 
 class _ThreeNN(Function):
@@ -80,6 +84,12 @@ class _ThreeNN(Function):
 
 
 def three_nn(target, source):
+    if target.dtype == torch.float64:
+        d, idx = _ThreeNN.apply(target.float(), source.float())
+        B, n, _ = target.shape
+        nb = torch.gather(source.unsqueeze(1).expand(-1, n, -1, -1), 2,
+                          idx.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+        return (nb - target.unsqueeze(2)).pow(2).sum(-1).sqrt(), idx
     return _ThreeNN.apply(target, source)
 
 
@@ -98,6 +108,9 @@ class _Interp(Function):
 
 
 def three_interpolate(features, indices, weight):
+    if features.dtype == torch.float64:
+        g = grouping_operation(features, indices)          # (B,C,n,3)
+        return (g * weight.unsqueeze(1)).sum(-1)
     return _Interp.apply(features, indices, weight)
 
 

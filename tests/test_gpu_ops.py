@@ -136,7 +136,7 @@ def test_group_concat_cl(ops, C, ldo, feat_col, xyz_col):
                               xyz_col=xyz_col, feat_col=feat_col)
     o = out.detach().cpu().numpy()
     gx = ok.group_points_fwd(xyz.transpose(0, 2, 1), idx)  # (B,3,M,ns)
-    rel = ((gx - center.transpose(0, 2, 1)[..., None]) * np.float32(1.0 / r))
+    rel = ((gx - center.transpose(0, 2, 1)[..., None]) / np.float32(r))
     np.testing.assert_array_equal(o[..., xyz_col:xyz_col + 3], rel.transpose(0, 2, 3, 1))
     mask = np.ones(ldo, bool)
     mask[xyz_col:xyz_col + 3] = False
