@@ -6,17 +6,20 @@
 //
 // FPS is a chain of M-1 dependent arg-max rounds: it is bound by the latency of
 // one round, not by HBM.  Design for CDNA4:
-//   * one workgroup per scene, the scene's points and their running min-distance
+//   * one workgroup per scene; the scene's points and their running min-distance
 //     live in VGPRs for the whole kernel (20 000 points = 20 per lane at 1024
-//     threads) - global memory is touched once on entry and once per selected
-//     index on exit;
-//   * the per-round arg-max is a value-only v_max chain (8 VALU per point), the
-//     index is recovered afterwards from ballots of (temp == max) on the scalar
-//     unit, so no per-point select of the index is paid;
-//   * one LDS exchange and ONE barrier per round (slots double-buffered by round
-//     parity); every wave redundantly reduces the 16 wave slots with DPP row
-//     operations and broadcasts the winner's coordinates with v_readlane, so the
-//     next round starts from SGPRs.
+//     threads): global memory is read once on entry and written once on exit;
+//   * per round each lane does 8 VALU per point (3 sub, mul, 2 fma, min, max - the
+//     min/max are raw v_min/v_max, no canonicalisation) and keeps only the VALUE of
+//     its maximum; the wave maximum is 6 in-place v_max_f32_dpp;
+//   * round synchronisation is two raw s_barriers with LDS-only waits (a
+//     __syncthreads() would also drain vmcnt, i.e. wait for global stores):
+//     (1) the 16 wave maxima are exchanged, every wave reduces them redundantly and
+//     learns which wave owns the winner; (2) ONLY that wave searches its registers
+//     for the winner's slot (compare/select chain on an otherwise idle SIMD) and
+//     publishes {index, x, y, z}; everyone picks it up after the second barrier;
+//   * selected indices are buffered in LDS and flushed coalesced (no per-round
+//     global store on the critical path).
 //   * thread t owns points t, t+BS, t+2BS, ... with BS = min(1024, 2^floor(log2 N))
 //     - the same ownership as the upstream block reduction - so "first maximum in
 //     the thread, then lowest thread id" reproduces upstream tie-breaking exactly.
@@ -24,110 +27,208 @@
 
 namespace demf {
 
-struct __attribute__((aligned(32))) FpsSlot {
-  float v;
-  int i;
-  float x, y, z;
-  int pad[3];
-};
+__device__ __forceinline__ float raw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float raw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float raw_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
-#define FPS_CASE(c)                         \
-  case c:                                   \
-    if constexpr (c < PPT) {                \
-      wx = readlane_f(px[c], wl);           \
-      wy = readlane_f(py[c], wl);           \
-      wz = readlane_f(pz[c], wl);           \
-    }                                       \
-    break;
+// in-place wave64 max; lane 63 ends up with the maximum (returned wave-uniform)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return readlane_f(v, 63);
+}
+
+// max over each 16-lane row, every lane of the row gets it
+__device__ __forceinline__ float row16_max_dpp(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+using f2 = float __attribute__((ext_vector_type(2)));
+
+constexpr int FPS_IDX_CHUNK = 2048;  // selected indices buffered in LDS between flushes
+
+#ifdef DEMF_FPS_PROFILE  // tools/ubench/fps_prof.cpp: per-phase shader-cycle accounting (wave 0)
+__device__ long long g_fps_prof[8];
+#define FPS_T(k) const long long t##k = __builtin_readcyclecounter();
+#define FPS_ACC(i, a, b) prof[i] += (b) - (a);
+#else
+#define FPS_T(k)
+#define FPS_ACC(i, a, b)
+#endif
 
 template <int BS, int PPT>
 __global__ __launch_bounds__(BS) void fps_reg_kernel(int N, int M,
                                                      const float* __restrict__ xyz,
                                                      int* __restrict__ idx) {
   constexpr int NW = BS / 64;
-  __shared__ FpsSlot slots[2][16];
+  __shared__ float s_wmax[16];
+  __shared__ __attribute__((aligned(16))) float s_res[4];  // {idx bits, x, y, z}
+  __shared__ int s_idx[FPS_IDX_CHUNK];
   const int b = blockIdx.x;
   xyz += (size_t)b * N * 3;
   idx += (size_t)b * M;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+  // two points per 64-bit register pair: the distance math runs on the packed-fp32 pipe
+  // (v_pk_add/mul/fma_f32, bit-identical to the scalar ops)
+  static_assert(PPT % 2 == 0, "points are processed in pairs");
+  constexpr int PP = PPT / 2;
+  f2 px[PP], py[PP], pz[PP];
+  float tmp[PPT];
 #pragma unroll
   for (int p = 0; p < PPT; ++p) {
     const int k = tid + p * BS;
     const bool ok = k < N;
-    px[p] = ok ? xyz[3 * k + 0] : 0.f;
-    py[p] = ok ? xyz[3 * k + 1] : 0.f;
-    pz[p] = ok ? xyz[3 * k + 2] : 0.f;
+    px[p / 2][p % 2] = ok ? xyz[3 * k + 0] : 0.f;
+    py[p / 2][p % 2] = ok ? xyz[3 * k + 1] : 0.f;
+    pz[p / 2][p % 2] = ok ? xyz[3 * k + 2] : 0.f;
     tmp[p] = ok ? 1e10f : -2.f;  // pad slots can never reach the maximum
   }
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
-  if (tid == 0) idx[0] = 0;
+  if (tid == 0) s_idx[0] = 0;
 
+#ifdef DEMF_FPS_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int j = 1; j < M; ++j) {
+    FPS_T(0)
+    // ---- update running distances, keep only the lane's maximum VALUE
     float best = -1.f;
+    const f2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
 #pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const float d = dist2(px[p] - x1, py[p] - y1, pz[p] - z1);
-      const float t = fminf(d, tmp[p]);
-      tmp[p] = t;
-      best = fmaxf(best, t);
+    for (int i = 0; i < PP; ++i) {
+      const f2 dx = px[i] - X1, dy = py[i] - Y1, dz = pz[i] - Z1;
+      f2 d = dy * dy;                               // dist2(): fma(dz,dz,fma(dx,dx,dy*dy))
+      d = __builtin_elementwise_fma(dx, dx, d);
+      d = __builtin_elementwise_fma(dz, dz, d);
+      tmp[2 * i] = raw_min(d[0], tmp[2 * i]);
+      tmp[2 * i + 1] = raw_min(d[1], tmp[2 * i + 1]);
+      best = raw_max3(best, tmp[2 * i], tmp[2 * i + 1]);
     }
-    const float vmax = wave_allmax(best);
-    // lowest lane holding the maximum, and that lane's lowest slot
-    int wl = 64, wp = 0;
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-      const unsigned long long m = __ballot(tmp[p] == vmax);
-      const int l = m ? __builtin_ctzll(m) : 64;
-      if (l < wl) {
-        wl = l;
-        wp = p;
-      }
-    }
-    wl = __builtin_amdgcn_readfirstlane(wl);
-    wp = __builtin_amdgcn_readfirstlane(wp);
-    float wx = 0.f, wy = 0.f, wz = 0.f;
-    switch (wp) {
-      FPS_CASE(0) FPS_CASE(1) FPS_CASE(2) FPS_CASE(3) FPS_CASE(4) FPS_CASE(5)
-      FPS_CASE(6) FPS_CASE(7) FPS_CASE(8) FPS_CASE(9) FPS_CASE(10) FPS_CASE(11)
-      FPS_CASE(12) FPS_CASE(13) FPS_CASE(14) FPS_CASE(15) FPS_CASE(16) FPS_CASE(17)
-      FPS_CASE(18) FPS_CASE(19) FPS_CASE(20) FPS_CASE(21) FPS_CASE(22) FPS_CASE(23)
-      default: break;
-    }
-    const int wi = wave * 64 + wl + wp * BS;
-    int old;
+    FPS_T(1)
+    const float wmax = wave_max_dpp(best);
+    FPS_T(2)
+
+    // ---- which wave holds the block maximum (lowest wave on ties)
+    float gmax;
+    int wwin;
     if constexpr (NW == 1) {
-      old = wi;
-      x1 = wx;
-      y1 = wy;
-      z1 = wz;
+      gmax = wmax;
+      wwin = 0;
     } else {
-      const int par = j & 1;
-      if (lane == 0) {
-        FpsSlot s;
-        s.v = vmax;
-        s.i = wi;
-        s.x = wx;
-        s.y = wy;
-        s.z = wz;
-        slots[par][wave] = s;
-      }
-      __syncthreads();
-      const FpsSlot s = slots[par][lane & (NW - 1)];
-      const float rmax = row16_allmax(s.v);
-      const unsigned long long m = __ballot(s.v == rmax);
-      const int w = __builtin_ctzll(m);  // lowest wave holding the maximum
-      old = readlane_i(s.i, w);
-      x1 = readlane_f(s.x, w);
-      y1 = readlane_f(s.y, w);
-      z1 = readlane_f(s.z, w);
+      if (lane == 0) s_wmax[wave] = wmax;
+      lds_barrier();
+      const float v = s_wmax[lane & (NW - 1)];
+      gmax = readlane_f(row16_max_dpp(v), 0);
+      wwin = __builtin_ctzll(__ballot(v == gmax));
     }
-    if (tid == 0) idx[j] = old;
+    FPS_T(3)
+
+    // ---- only the winning wave locates the slot and publishes the point
+    if (wave == wwin) {
+      float sx = 0.f, sy = 0.f, sz = 0.f;
+      int sp = 0;
+#pragma unroll
+      for (int p = PPT - 1; p >= 0; --p) {  // descending: the lowest matching slot wins
+        const bool c = tmp[p] == gmax;
+        sx = c ? px[p / 2][p % 2] : sx;
+        sy = c ? py[p / 2][p % 2] : sy;
+        sz = c ? pz[p / 2][p % 2] : sz;
+        sp = c ? p : sp;
+      }
+      const int wl = __builtin_ctzll(__ballot(best == gmax));  // lowest lane = lowest thread
+      const int wi = wave * 64 + wl + readlane_i(sp, wl) * BS;
+      const float wx = readlane_f(sx, wl), wy = readlane_f(sy, wl), wz = readlane_f(sz, wl);
+      if constexpr (NW == 1) {
+        x1 = wx;
+        y1 = wy;
+        z1 = wz;
+        if (lane == 0) s_idx[j & (FPS_IDX_CHUNK - 1)] = wi;
+      } else if (lane == 0) {
+        s_res[0] = __builtin_bit_cast(float, wi);
+        s_res[1] = wx;
+        s_res[2] = wy;
+        s_res[3] = wz;
+        s_idx[j & (FPS_IDX_CHUNK - 1)] = wi;
+      }
+    }
+    FPS_T(4)
+    if constexpr (NW > 1) {
+      lds_barrier();
+      const float4 r = *reinterpret_cast<const float4*>(s_res);
+      x1 = readlane_f(r.y, 0);
+      y1 = readlane_f(r.z, 0);
+      z1 = readlane_f(r.w, 0);
+    }
+    FPS_T(5)
+    FPS_ACC(0, t0, t1) FPS_ACC(1, t1, t2) FPS_ACC(2, t2, t3) FPS_ACC(3, t3, t4) FPS_ACC(4, t4, t5)
+    // ---- flush a full chunk of selected indices (coalesced)
+    if (((j + 1) & (FPS_IDX_CHUNK - 1)) == 0) {
+      if constexpr (NW == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      else lds_barrier();
+      const int base = j + 1 - FPS_IDX_CHUNK;
+      for (int t = tid; t < FPS_IDX_CHUNK; t += BS) idx[base + t] = s_idx[t];
+      if constexpr (NW > 1) lds_barrier();
+    }
   }
+#ifdef DEMF_FPS_PROFILE
+  if (tid == 0 && b == 0)
+    for (int i = 0; i < 8; ++i) g_fps_prof[i] = prof[i];
+#endif
+  // tail flush
+  if constexpr (NW > 1) lds_barrier();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int base = M & ~(FPS_IDX_CHUNK - 1);
+  for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
 }
+
+struct __attribute__((aligned(32))) FpsSlot {
+  float v;
+  int i;
+  int pad[6];
+};
 
 // Fallback for N beyond the register budget (or N < 64): the running distance
 // lives in the caller's `temp` scratch, ownership/tie rule identical.
@@ -206,9 +307,7 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
   const int ppt = cdiv(N, bs);
   bool done = true;
   if (bs == 1024) {
-    if (ppt <= 1) launch_reg<1024, 1>(B, N, M, xyz, idx, s);
-    else if (ppt <= 2) launch_reg<1024, 2>(B, N, M, xyz, idx, s);
-    else if (ppt <= 3) launch_reg<1024, 3>(B, N, M, xyz, idx, s);
+    if (ppt <= 2) launch_reg<1024, 2>(B, N, M, xyz, idx, s);
     else if (ppt <= 4) launch_reg<1024, 4>(B, N, M, xyz, idx, s);
     else if (ppt <= 6) launch_reg<1024, 6>(B, N, M, xyz, idx, s);
     else if (ppt <= 8) launch_reg<1024, 8>(B, N, M, xyz, idx, s);
@@ -218,17 +317,13 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
     else if (ppt <= 24) launch_reg<1024, 24>(B, N, M, xyz, idx, s);
     else done = false;
   } else if (bs == 512) {
-    if (ppt <= 1) launch_reg<512, 1>(B, N, M, xyz, idx, s);
-    else launch_reg<512, 2>(B, N, M, xyz, idx, s);
+    launch_reg<512, 2>(B, N, M, xyz, idx, s);
   } else if (bs == 256) {
-    if (ppt <= 1) launch_reg<256, 1>(B, N, M, xyz, idx, s);
-    else launch_reg<256, 2>(B, N, M, xyz, idx, s);
+    launch_reg<256, 2>(B, N, M, xyz, idx, s);
   } else if (bs == 128) {
-    if (ppt <= 1) launch_reg<128, 1>(B, N, M, xyz, idx, s);
-    else launch_reg<128, 2>(B, N, M, xyz, idx, s);
+    launch_reg<128, 2>(B, N, M, xyz, idx, s);
   } else if (bs == 64) {
-    if (ppt <= 1) launch_reg<64, 1>(B, N, M, xyz, idx, s);
-    else launch_reg<64, 2>(B, N, M, xyz, idx, s);
+    launch_reg<64, 2>(B, N, M, xyz, idx, s);
   } else {
     done = false;
   }
