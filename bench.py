@@ -72,7 +72,10 @@ def cpu_baseline(seconds_budget=20.0):
     on this host: fwd + loss + bwd of ONE full-size scene, repeated within the time budget."""
     from oracle import fixtures
     from oracle.model import OracleDeMF
-    torch.set_num_threads(os.cpu_count() or 1)
+    # a few dozen threads is where torch-CPU + the OpenMP oracle stop scaling on this path
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     cfg = DeMFCfg()
     raw = synthetic.make_scene_batch(1, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, 256, seed=0,
                                      n_gt=8, img_shape=IMG_SHAPE[:2], scale_factor=1.5094)

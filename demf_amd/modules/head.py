@@ -310,7 +310,9 @@ class DeMFVoteHead(nn.Module):
         half = dims[:, None] * 0.5
         inb = (rel[..., 2].abs() <= half[..., 2]) & (lx.abs() < half[..., 0]) & \
               (ly.abs() < half[..., 1]) & valid[:, None, :]
-        cnt = inb.cumsum(-1)
+        # running count of containing boxes: a (G,G) triangular matmul instead of an int64 scan
+        tri = torch.triu(torch.ones(G, G, dtype=p.dtype, device=p.device))
+        cnt = torch.matmul(inb.to(p.dtype), tri).round().long()
         total = cnt[..., -1:]
         votes = -rel                                                          # centre - point
         pick = lambda m: (votes * m.unsqueeze(-1).to(votes.dtype)).sum(2)

@@ -29,8 +29,18 @@ class PositionEmbeddingLearned(nn.Module):
             nn.Conv1d(cpos, cpos, kernel_size=1))
 
     def forward(self, xyz):
-        xyz = xyz.transpose(1, 2).contiguous()
-        return self.position_embedding_head(xyz)
+        """(B,N,cin) -> (B,cpos,N).  The two k=1 Conv1d run as row GEMMs (MIOpen's conv
+        path picks naive kernels for these shapes); parameters stay in the Conv1d/BN1d
+        holders so checkpoints load unchanged."""
+        c0, bn, _, c1 = self.position_embedding_head
+        B, N, cin = xyz.shape
+        x = F.linear(xyz.reshape(B * N, cin), c0.weight.view(c0.out_channels, cin), c0.bias)
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                                bn.training, bn.momentum, bn.eps), inplace=True)
+        x = F.linear(x, c1.weight.view(c1.out_channels, -1), c1.bias)
+        return x.view(B, N, -1).transpose(1, 2)
 
 
 class MultiheadAttention(nn.Module):
