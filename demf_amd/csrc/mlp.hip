@@ -1,0 +1,559 @@
+// Fused shared-MLP kernels for gfx950: 1x1 conv (GEMM) + train-mode BatchNorm + ReLU (+ max
+// over neighbours), forward and backward, on point-major rows.
+//
+// This is the dense half of every PointSAModule the reference builds
+// (demf/modeling/heads/class_agnostic_vote_head.py:383 via build_sa_module; backbone
+// configs/demf/demf_votenet.py:48-62): upstream runs Conv2d -> BN2d -> ReLU as separate
+// kernels over (B,C,M,ns) and materialises every intermediate.  Here a layer is ONE pass:
+//
+//   forward   Y_l = act_{l-1}(Y_{l-1}) @ W_l^T          act(y) = max(0, y*scale + shift)
+//             - the previous layer's BN+ReLU is applied in the A-operand prologue (A is never
+//               materialised), per-channel sum / sum-of-squares of Y_l are reduced in the
+//               epilogue (fp32 per block, fp64 atomics across blocks) -> batch statistics;
+//   tail      out = max_s act_L(Y_L)  fused with the last BN+ReLU;
+//   backward  dY_l = gamma*invstd*(dZ - mean(dZ) - xhat*mean(dZ*xhat)) is formed on the fly in
+//             the prologue of  dA_{l-1} = dY_l @ W_l  and of  dW_l = dY_l^T @ A_{l-1}.
+//
+// All GEMMs are fp32 MFMA (v_mfma_f32_32x32x2_f32, exact fp32, 157 TF peak) and at these
+// skinny shapes (K,N <= 512, rows up to 1M) the kernels are HBM-bound: algorithmic bytes are
+// rows*(K+N)*4 per forward layer.
+//
+// Fragment trick: for C = A(RxK) * Bt(NxK)^T with both operands K-contiguous, a lane loads
+// ONE float4 along K for A (row = lane&31) and one per column tile for Bt (row = lane&31), at
+// k = k0 + 4*(lane>>5) .. +3, and feeds component m to MFMA m: MFMA m then contracts over
+// k in {k0+m, k0+4+m} on both operands consistently - four MFMAs consume the two float4.
+#include "common.h"
+
+namespace demf {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_BK = 32;        // K step staged per iteration
+constexpr int MLP_LD = MLP_BK + 4;  // LDS row stride (floats), +16 B pad
+constexpr int MLP_ROWS = 128;     // rows per block tile (4 waves x 32)
+
+enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
+
+// per-channel vectors of the backward prologue, struct-of-arrays of length n each:
+//   [0] scale  [1] shift  (z = y*scale + shift, ReLU mask)
+//   [2] mean   [3] istd_c2 = invstd * mean(dZ*xhat)   [4] c1 = mean(dZ)   [5] gi = gamma*invstd
+struct MlpArgs {
+  int R, K, N;                 // rows, reduction length, output columns
+  int ldx;                     // row stride of X (floats)
+  int ldy;                     // row stride of Y (floats)
+  const float* X;              // PRO_NONE/BNRELU: input rows; PRO_DY_*: Y_l (pre-BN output)
+  const float* G;              // PRO_DY_DENSE: upstream gradient dA_l (R x K)
+  const float* dP;             // PRO_DY_SPARSE: pooled gradient (R/ns x K)
+  const int* arg;              //                and arg-max slot (R/ns x K)
+  int ns;
+  const float* vec;            // BNRELU: [scale|shift] (2K);  DY: 6 vectors of length K
+  const float* Bt;             // (N x K) row-major
+  float* Y;                    // (R x N) output
+  double* stats;               // optional (2N): column sum, column sum of squares
+};
+
+template <int PRO>
+__device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, int row, int col) {
+  // one float4 of the (transformed) A operand at (row, col..col+3); caller guarantees in-range
+  const float4 x = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + col);
+  if constexpr (PRO == PRO_NONE) {
+    return x;
+  } else if constexpr (PRO == PRO_BNRELU) {
+    const float4 s = *reinterpret_cast<const float4*>(p.vec + col);
+    const float4 t = *reinterpret_cast<const float4*>(p.vec + p.K + col);
+    float4 o;
+    o.x = fmaxf(0.f, __builtin_fmaf(x.x, s.x, t.x));
+    o.y = fmaxf(0.f, __builtin_fmaf(x.y, s.y, t.y));
+    o.z = fmaxf(0.f, __builtin_fmaf(x.z, s.z, t.z));
+    o.w = fmaxf(0.f, __builtin_fmaf(x.w, s.w, t.w));
+    return o;
+  } else {
+    float4 g;
+    if constexpr (PRO == PRO_DY_DENSE) {
+      g = *reinterpret_cast<const float4*>(p.G + (size_t)row * p.K + col);
+    } else {
+      const int rp = row / p.ns, s = row - rp * p.ns;
+      const float4 d = *reinterpret_cast<const float4*>(p.dP + (size_t)rp * p.K + col);
+      const int4 a = *reinterpret_cast<const int4*>(p.arg + (size_t)rp * p.K + col);
+      g.x = a.x == s ? d.x : 0.f;
+      g.y = a.y == s ? d.y : 0.f;
+      g.z = a.z == s ? d.z : 0.f;
+      g.w = a.w == s ? d.w : 0.f;
+    }
+    const int K = p.K;
+    const float4 sc = *reinterpret_cast<const float4*>(p.vec + col);
+    const float4 sh = *reinterpret_cast<const float4*>(p.vec + K + col);
+    const float4 mu = *reinterpret_cast<const float4*>(p.vec + 2 * K + col);
+    const float4 ic = *reinterpret_cast<const float4*>(p.vec + 3 * K + col);
+    const float4 c1 = *reinterpret_cast<const float4*>(p.vec + 4 * K + col);
+    const float4 gi = *reinterpret_cast<const float4*>(p.vec + 5 * K + col);
+    float4 o;
+#define MLP_DY(m)                                                              \
+    {                                                                          \
+      const float dz = __builtin_fmaf(x.m, sc.m, sh.m) > 0.f ? g.m : 0.f;      \
+      o.m = gi.m * (dz - c1.m - (x.m - mu.m) * ic.m);                          \
+    }
+    MLP_DY(x) MLP_DY(y) MLP_DY(z) MLP_DY(w)
+#undef MLP_DY
+    return o;
+  }
+}
+
+// C(R x N) = pro(A)(R x K) @ Bt(N x K)^T ; NT = N/32 column tiles per wave (all of N).
+template <int NT, int PRO, bool STATS>
+__global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_a[4][32 * MLP_LD];
+  __shared__ float s_red[STATS ? 4 * NT * 32 * 2 : 1];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  float* sa = s_a[wave];
+  const int ntiles = (p.R + MLP_ROWS - 1) / MLP_ROWS;
+  float cs1[NT], cs2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * MLP_ROWS + wave * 32;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += MLP_BK) {
+      // stage this wave's 32 x BK slice of A (coalesced 128-B row segments), transformed
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const int c = (lane & 7) * 4;
+        const int row = row0 + r, col = k0 + c;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < p.R && col < p.K) v = mlp_load_a<PRO>(p, row, col);
+        *reinterpret_cast<float4*>(sa + r * MLP_LD + c) = v;
+      }
+#pragma unroll
+      for (int c8 = 0; c8 < MLP_BK / 8; ++c8) {
+        const int kk = k0 + c8 * 8 + 4 * lh;
+        const float4 a4 = *reinterpret_cast<const float4*>(sa + lr * MLP_LD + c8 * 8 + 4 * lh);
+        const bool kin = kk < p.K;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kin && nt * 32 + lr < p.N)
+            b4 = *reinterpret_cast<const float4*>(p.Bt + (size_t)(nt * 32 + lr) * p.K + kk);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[nt][r];
+        if (row < p.R && nt * 32 + lr < p.N) p.Y[(size_t)row * p.ldy + nt * 32 + lr] = v;
+        if constexpr (STATS) {
+          s1 += v;                       // rows >= R are exact zeros (their A rows are zero)
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+      }
+      cs1[nt] += s1;
+      cs2[nt] += s2;
+    }
+  }
+  if constexpr (STATS) {
+    // lanes l and l+32 hold the same column: fold, then the 4 waves, then one fp64 atomic
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      cs1[nt] += __shfl_xor(cs1[nt], 32);
+      cs2[nt] += __shfl_xor(cs2[nt], 32);
+      if (lh == 0) {
+        s_red[(wave * NT + nt) * 64 + lr] = cs1[nt];
+        s_red[(wave * NT + nt) * 64 + 32 + lr] = cs2[nt];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * 64; i += 256) {
+      const float v = s_red[i] + s_red[NT * 64 + i] + s_red[2 * NT * 64 + i] + s_red[3 * NT * 64 + i];
+      const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
+      if (nt * 32 + c < p.N) atomicAdd(p.stats + which * p.N + nt * 32 + c, (double)v);
+    }
+  }
+}
+
+// ---- BN statistics -> per-channel scale/shift (+ running stats, saved mean/invstd) -----------
+__global__ void bn_finalize_kernel(int N, double count, const double* __restrict__ stats,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ ss,
+                                   float* __restrict__ mi) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double mean = stats[c] / count;
+  double var = stats[N + c] / count - mean * mean;  // biased, as BN normalises with
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[c] * invstd);
+  ss[c] = sc;                                        // scale
+  ss[N + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);  // shift
+  mi[c] = (float)mean;
+  mi[N + c] = (float)invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// ---- tail: out[r,c] = max_s max(0, y[r,s,c]*scale+shift), first maximum wins -----------------
+__global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_k(long long RC, int ns, int C,
+                                                            const float* __restrict__ y,
+                                                            const float* __restrict__ ss,
+                                                            float* __restrict__ out,
+                                                            int* __restrict__ arg) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; t < RC; t += stride) {
+    const long long r = t / C;
+    const int c = (int)(t - r * C);
+    const float sc = ss[c], sh = ss[C + c];
+    const float* p = y + r * ns * C + c;
+    float best = fmaxf(0.f, __builtin_fmaf(p[0], sc, sh));
+    int bi = 0;
+    for (int s = 1; s < ns; ++s) {
+      const float v = fmaxf(0.f, __builtin_fmaf(p[(size_t)s * C], sc, sh));
+      if (v > best) {
+        best = v;
+        bi = s;
+      }
+    }
+    out[t] = best;
+    arg[t] = bi;
+  }
+}
+
+// ---- backward reductions: g1 = sum dZ, g2 = sum dZ*xhat per channel ---------------------------
+// dense upstream gradient G (R x N); one block strides over rows, 256 threads = 64 col4 x 4 rows
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
+                                                       const float* __restrict__ G,
+                                                       const float* __restrict__ dP,
+                                                       const int* __restrict__ arg,
+                                                       const float* __restrict__ Y,
+                                                       const float* __restrict__ ss,
+                                                       const float* __restrict__ mi,
+                                                       double* __restrict__ g12) {
+  // thread -> one column, strided rows; columns are the fast index so reads coalesce
+  __shared__ float red[2][256];
+  const int cols_per_pass = N < 256 ? N : 256;
+  const int rows_par = 256 / cols_per_pass;           // row lanes per block pass
+  const int c_in = threadIdx.x % cols_per_pass, r_in = threadIdx.x / cols_per_pass;
+  for (int cb = 0; cb < N; cb += cols_per_pass) {
+    const int c = cb + c_in;
+    float a1 = 0.f, a2 = 0.f;
+    if (r_in < rows_par && c < N) {
+      const float sc = ss[c], sh = ss[N + c], mu = mi[c], is = mi[N + c];
+      if constexpr (SPARSE) {
+        const int Rp = R / ns;
+        for (int rp = blockIdx.x * rows_par + r_in; rp < Rp; rp += gridDim.x * rows_par) {
+          const int s = arg[(size_t)rp * N + c];
+          const float y = Y[((size_t)rp * ns + s) * N + c];
+          const float dz = __builtin_fmaf(y, sc, sh) > 0.f ? dP[(size_t)rp * N + c] : 0.f;
+          a1 += dz;
+          a2 = __builtin_fmaf(dz, (y - mu) * is, a2);
+        }
+      } else {
+        for (int r = blockIdx.x * rows_par + r_in; r < R; r += gridDim.x * rows_par) {
+          const float y = Y[(size_t)r * N + c];
+          const float dz = __builtin_fmaf(y, sc, sh) > 0.f ? G[(size_t)r * N + c] : 0.f;
+          a1 += dz;
+          a2 = __builtin_fmaf(dz, (y - mu) * is, a2);
+        }
+      }
+    }
+    red[0][threadIdx.x] = a1;
+    red[1][threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x < cols_per_pass && cb + threadIdx.x < N) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int j = 0; j < rows_par; ++j) {
+        t1 += red[0][j * cols_per_pass + threadIdx.x];
+        t2 += red[1][j * cols_per_pass + threadIdx.x];
+      }
+      atomicAdd(g12 + cb + threadIdx.x, (double)t1);
+      atomicAdd(g12 + N + cb + threadIdx.x, (double)t2);
+    }
+    __syncthreads();
+  }
+}
+
+// g1,g2 -> the 6 backward vectors + dgamma, dbeta
+__global__ void bn_bwd_vectors_k(int N, double count, const double* __restrict__ g12,
+                                 const float* __restrict__ gamma, const float* __restrict__ ss,
+                                 const float* __restrict__ mi, float* __restrict__ vec,
+                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  const double g1 = g12[c], g2 = g12[N + c];
+  const float is = mi[N + c];
+  vec[c] = ss[c];
+  vec[N + c] = ss[N + c];
+  vec[2 * N + c] = mi[c];
+  vec[3 * N + c] = (float)((double)is * (g2 / count));
+  vec[4 * N + c] = (float)(g1 / count);
+  vec[5 * N + c] = gamma[c] * is;
+  dgamma[c] = (float)g2;
+  dbeta[c] = (float)g1;
+}
+
+// ---- dW(N x K) += dY(R x N)^T @ A(R x K): reduction over rows --------------------------------
+// Block = 4 waves sharing a 32-row slab of dY and A in LDS per step; the NxK output is split into
+// 32x32 MFMA tiles dealt round-robin to the waves (TPW tiles per wave).  Each block reduces its
+// row range in registers and adds the partial with fp32 atomics.
+struct DwArgs {
+  int R, N, K, ldx;
+  const float* Yl;     // (R x N) pre-BN output of this layer
+  const float* G;      // dense upstream gradient or null
+  const float* dP;     // sparse upstream gradient
+  const int* arg;
+  int ns;
+  const float* vec;    // 6 x N backward vectors of this layer
+  const float* Xp;     // (R x K) previous layer's pre-BN output, or the raw input
+  const float* pvec;   // [scale|shift] of the previous layer (2K) or null (raw input)
+  float* dW;           // (N x K), accumulated
+  int n0, k0, NTn, NTk;  // output sub-block handled by this launch: tiles [n0, n0+NTn) x [k0, k0+NTk)
+};
+
+template <int TPW, bool SPARSE>
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int WN = p.NTn * 32, WK = p.NTk * 32;       // columns of dY / A staged per step
+  float* s_dy = smem;                                // [32][WN + 4]
+  float* s_a = smem + 32 * (WN + 4);                 // [32][WK + 4]
+  const int ldn = WN + 4, ldk = WK + 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ntile = p.NTn * p.NTk;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  MlpArgs ay;  // reuse the forward prologue loaders
+  ay.K = p.N; ay.ldx = p.N; ay.X = p.Yl; ay.G = p.G; ay.dP = p.dP; ay.arg = p.arg; ay.ns = p.ns;
+  ay.vec = p.vec;
+  MlpArgs ax;
+  ax.K = p.K; ax.ldx = p.ldx; ax.X = p.Xp; ax.vec = p.pvec;
+
+  const int nslab = (p.R + 31) / 32;
+  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+    const int row0 = slab * 32;
+    __syncthreads();
+    // stage dY[32][WN] (columns n0*32 ..) and A[32][WK]
+    for (int i = threadIdx.x; i < 32 * (WN / 4); i += 256) {
+      const int r = i / (WN / 4), c = (i - r * (WN / 4)) * 4;
+      const int row = row0 + r, col = p.n0 * 32 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < p.R && col < p.N)
+        v = SPARSE ? mlp_load_a<PRO_DY_SPARSE>(ay, row, col) : mlp_load_a<PRO_DY_DENSE>(ay, row, col);
+      *reinterpret_cast<float4*>(s_dy + r * ldn + c) = v;
+    }
+    for (int i = threadIdx.x; i < 32 * (WK / 4); i += 256) {
+      const int r = i / (WK / 4), c = (i - r * (WK / 4)) * 4;
+      const int row = row0 + r, col = p.k0 * 32 + c;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < p.R && col < p.K)
+        v = p.pvec ? mlp_load_a<PRO_BNRELU>(ax, row, col) : mlp_load_a<PRO_NONE>(ax, row, col);
+      *reinterpret_cast<float4*>(s_a + r * ldk + c) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wave + 4 * t;
+      if (tile < ntile) {
+        const int tn = tile / p.NTk, tk = tile - tn * p.NTk;
+        // A-op: dY^T -> lane supplies dY[r = 2m + lh][n = tn*32 + lr]; B-op: A[r][k = tk*32 + lr]
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const float a = s_dy[(2 * m + lh) * ldn + tn * 32 + lr];
+          const float b = s_a[(2 * m + lh) * ldk + tk * 32 + lr];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave + 4 * t;
+    if (tile < ntile) {
+      const int tn = tile / p.NTk, tk = tile - tn * p.NTk;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = (p.k0 + tk) * 32 + lr;
+        if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.K + k, acc[t][r]);
+      }
+    }
+  }
+}
+
+static int mlp_grid(int R) {
+  const int tiles = (R + MLP_ROWS - 1) / MLP_ROWS;
+  const int cap = 256 * 2;
+  return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
+}
+
+template <int PRO, bool STATS>
+static int launch_gemm(const MlpArgs& a, hipStream_t s) {
+  const dim3 grid(mlp_grid(a.R)), block(256);
+  switch ((a.N + 31) / 32) {
+#define CASE(nt) \
+    case nt: hipLaunchKernelGGL((mlp_gemm_kernel<nt, PRO, STATS>), grid, block, 0, s, a); break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    default:
+      set_error("mlp_gemm: N=%d unsupported (1..256 columns per launch)", a.N);
+      return DEMF_EUNSUPPORTED;
+  }
+  return check_launch("mlp_gemm");
+}
+
+static int mlp_check(int R, int K, int N, int ldx) {
+  DEMF_REQUIRE(R >= 0 && K >= 4 && K % 4 == 0 && N >= 1 && N <= 256 && ldx >= K && ldx % 4 == 0,
+               "mlp: bad sizes R=%d K=%d N=%d ldx=%d (K%%4==0, 1<=N<=256)", R, K, N, ldx);
+  return DEMF_OK;
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
+                                 const float* pro_scale_shift, const float* Wt, float* Y,
+                                 double* stats, demf_stream_t stream) {
+  if (int e = mlp_check(R, K, N, ldx)) return e;
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(X && Wt && Y, "mlp_gemm_fwd: null pointer");
+  MlpArgs a{};
+  a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
+  a.Y = Y; a.stats = stats;
+  hipStream_t s = (hipStream_t)stream;
+  if (pro_scale_shift)
+    return stats ? launch_gemm<PRO_BNRELU, true>(a, s) : launch_gemm<PRO_BNRELU, false>(a, s);
+  return stats ? launch_gemm<PRO_NONE, true>(a, s) : launch_gemm<PRO_NONE, false>(a, s);
+}
+
+extern "C" int demf_bn_finalize(int N, long long count, const double* stats, const float* gamma,
+                                const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, float* scale_shift,
+                                float* mean_invstd, demf_stream_t stream) {
+  DEMF_REQUIRE(N >= 1 && count >= 1 && stats && gamma && beta && scale_shift && mean_invstd,
+               "bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                     (double)count, stats, gamma, beta, eps, momentum, running_mean, running_var,
+                     scale_shift, mean_invstd);
+  return check_launch("bn_finalize");
+}
+
+extern "C" int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y,
+                                       const float* scale_shift, float* out, int* arg,
+                                       demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && ns >= 1 && C >= 1, "bnrelu_maxpool: bad sizes");
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(Y && scale_shift && out && arg, "bnrelu_maxpool: null pointer");
+  const long long RC = (long long)R * C;
+  long long g = (RC + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(bnrelu_maxpool_fwd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, RC,
+                     ns, C, Y, scale_shift, out, arg);
+  return check_launch("bnrelu_maxpool_fwd");
+}
+
+extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP,
+                                  const int* arg, const float* Y, const float* scale_shift,
+                                  const float* mean_invstd, double* g12, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && N >= 1, "bn_bwd_reduce: bad sizes R=%d N=%d", R, N);
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
+               "bn_bwd_reduce: null pointer");
+  const int rows_par = N < 256 ? 256 / N : 1;
+  const int rows = G ? R : R / ns;
+  int grid = cdiv(rows, rows_par * 8);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  if (G)
+    hipLaunchKernelGGL((bn_bwd_reduce_k<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12);
+  else
+    hipLaunchKernelGGL((bn_bwd_reduce_k<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12);
+  return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int demf_bn_bwd_vectors(int N, long long count, const double* g12, const float* gamma,
+                                   const float* scale_shift, const float* mean_invstd, float* vec6,
+                                   float* dgamma, float* dbeta, demf_stream_t stream) {
+  DEMF_REQUIRE(N >= 1 && count >= 1 && g12 && gamma && scale_shift && mean_invstd && vec6 &&
+                   dgamma && dbeta,
+               "bn_bwd_vectors: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_vectors_k, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
+                     (double)count, g12, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta);
+  return check_launch("bn_bwd_vectors");
+}
+
+// dX(R x K) = dY(R x N) @ W(N x K), dY formed on the fly.  Wtt = W^T as (K x N) row-major.
+// dX has row stride ldo >= K; K may be any multiple of 4 (handled in chunks of <= 256 columns).
+extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
+                                    const int* arg, int ns, const float* Y, const float* vec6,
+                                    const float* Wtt, float* dX, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 1 && ldo >= K,
+               "mlp_gemm_bwd_dx: bad sizes R=%d N=%d K=%d ldo=%d", R, N, K, ldo);
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(Y && vec6 && Wtt && dX && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dx: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  for (int c0 = 0; c0 < K; c0 += 256) {
+    // here the reduction runs over this layer's N channels and the output has K columns
+    MlpArgs a{};
+    a.R = R; a.K = N; a.N = (K - c0) < 256 ? (K - c0) : 256; a.ldx = N; a.ldy = ldo; a.X = Y;
+    a.G = G; a.dP = dP; a.arg = arg; a.ns = ns; a.vec = vec6; a.Bt = Wtt + (size_t)c0 * N;
+    a.Y = dX + c0; a.stats = nullptr;
+    const int e = G ? launch_gemm<PRO_DY_DENSE, false>(a, s) : launch_gemm<PRO_DY_SPARSE, false>(a, s);
+    if (e) return e;
+  }
+  return DEMF_OK;
+}
+
+extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,
+                                    const int* arg, int ns, const float* Y, const float* vec6,
+                                    const float* Xprev, const float* prev_scale_shift, float* dW,
+                                    demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 4 && K % 4 == 0 && ldx >= K && ldx % 4 == 0,
+               "mlp_gemm_bwd_dw: bad sizes R=%d N=%d K=%d", R, N, K);
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(Y && vec6 && Xprev && dW && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dw: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int TN = cdiv(N, 32), TK = cdiv(K, 32);
+  // output handled in sub-blocks of at most 4x4 tiles (16 tiles = 4 per wave, <= 33 KB LDS)
+  for (int n0 = 0; n0 < TN; n0 += 4)
+    for (int k0 = 0; k0 < TK; k0 += 4) {
+      DwArgs a{};
+      a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
+      a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW;
+      a.n0 = n0; a.k0 = k0; a.NTn = (TN - n0) < 4 ? (TN - n0) : 4; a.NTk = (TK - k0) < 4 ? (TK - k0) : 4;
+      const size_t lds = sizeof(float) * 32 * ((a.NTn * 32 + 4) + (a.NTk * 32 + 4));
+      int grid = cdiv(R, 32 * 4);
+      if (grid > 512) grid = 512;
+      if (grid < 1) grid = 1;
+      if (G)
+        hipLaunchKernelGGL((mlp_dw_kernel<4, false>), dim3(grid), dim3(256), lds, s, a);
+      else
+        hipLaunchKernelGGL((mlp_dw_kernel<4, true>), dim3(grid), dim3(256), lds, s, a);
+    }
+  return check_launch("mlp_gemm_bwd_dw");
+}

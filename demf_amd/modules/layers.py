@@ -2,13 +2,12 @@
 
 The reference stacks mmcv ConvModule(Conv2d/Conv1d k=1 -> BN -> ReLU) on channel-major
 tensors.  Here the same parameters (identical state-dict names: ``conv.weight``,
-``bn.weight`` ...) are applied to (rows, C) matrices so a 1x1 conv is a plain GEMM over
-rows = B*M*ns and BatchNorm statistics run over dim 0 - numerically the same batch
-statistics as BN2d/BN1d over (B, *, spatial).
+``bn.weight`` ...) are applied to (rows, C) matrices by the fused gfx950 kernels of
+csrc/mlp.hip: a 1x1 conv is an fp32-MFMA GEMM over rows = B*M*ns whose epilogue reduces the
+BatchNorm batch statistics (over dim 0 - the same statistics as BN2d/BN1d over
+(B, *, spatial)) and whose prologue applies the previous layer's BN + ReLU.
 """
-import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class ConvBNReLU(nn.Module):
@@ -32,17 +31,22 @@ class ConvBNReLU(nn.Module):
     def weight2d(self):
         return self.conv.weight.view(self.cout, self.cin)
 
-    def forward_rows(self, x, weight=None):
-        """x (rows, cin[+pad]) -> (rows, cout).  ``weight`` overrides the (cout, K) matrix
-        when the caller has permuted / padded the input columns."""
-        w = self.weight2d() if weight is None else weight
-        y = F.linear(x, w, self.conv.bias)
-        bn = self.bn
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+
+def fused_rows(blocks, x, ns=1, first_weight=None):
+    """Run a stack of ConvBNReLU blocks on rows x (R, K) through the fused gfx950 kernels
+    (ops.shared_mlp_pool): GEMM + BN statistics + BN/ReLU, optionally max over ``ns`` rows."""
+    from .. import ops
+    layers = []
+    training = blocks[0].bn.training
+    for i, blk in enumerate(blocks):
+        bn = blk.bn
+        w = first_weight if (i == 0 and first_weight is not None) else blk.weight2d()
+        layers.append((w.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                       blk.conv.bias))
+        if training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
-        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                         bn.training or not bn.track_running_stats, bn.momentum, bn.eps)
-        return F.relu(y, inplace=True) if self.act else y
+    bn0 = blocks[0].bn
+    return ops.shared_mlp_pool(x, ns, layers, training=training, eps=bn0.eps, momentum=bn0.momentum)
 
 
 class RowsMLP(nn.Sequential):
@@ -53,7 +57,6 @@ class RowsMLP(nn.Sequential):
         for i in range(len(channels) - 1):
             self.add_module(f"layer{i}", ConvBNReLU(channels[i], channels[i + 1], dim, bias))
 
-    def forward_rows(self, x, first_weight=None):
-        for i, layer in enumerate(self):
-            x = layer.forward_rows(x, first_weight if i == 0 else None)
-        return x
+    def forward_rows(self, x, first_weight=None, ns=1):
+        """x (R, K) -> (R/ns, C_out): the whole stack (+ max over ns neighbours) fused."""
+        return fused_rows(list(self), x.contiguous(), ns, first_weight)

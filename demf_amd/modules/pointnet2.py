@@ -84,8 +84,8 @@ class PointSAModule(nn.Module):
             if self.use_xyz else ops.gather_rows_cl(
                 feat, idx.view(B, M * self.num_sample)).view(B, M, self.num_sample, C)
         x = grouped.view(B * M * self.num_sample, ld)
-        x = self.mlps[0].forward_rows(x, self._first_weight(ld))
-        x = ops.maxpool_ns(x.view(B * M, self.num_sample, x.shape[1]))
+        # shared MLP + BN + ReLU + max over the ns neighbours: one fused chain (csrc/mlp.hip)
+        x = self.mlps[0].forward_rows(x, self._first_weight(ld), ns=self.num_sample)
         new_features = x.view(B, M, -1).transpose(1, 2)  # (B,C',M) view of point-major
         return new_xyz, new_features, indices
 

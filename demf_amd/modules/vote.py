@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import ConvBNReLU, RowsMLP
+from .layers import ConvBNReLU, RowsMLP, fused_rows
 
 
 class VoteModule(nn.Module):
@@ -31,9 +31,7 @@ class VoteModule(nn.Module):
     def forward(self, seed_points, seed_feats):
         B, N, _ = seed_points.shape
         rows = seed_feats.transpose(1, 2).contiguous().view(B * N, -1)
-        x = rows
-        for layer in self.vote_conv:
-            x = layer.forward_rows(x)
+        x = fused_rows(list(self.vote_conv), rows)
         votes = F.linear(x, self.conv_out.weight.view(self.conv_out.out_channels, -1),
                          self.conv_out.bias)
         offset = votes[:, 0:3].view(B, N, 3)

@@ -15,7 +15,7 @@ from . import _ffi
 __all__ = [
     "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
     "three_nn", "three_interpolate", "MultiScaleDeformableAttnFunction",
-    "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns",
+    "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns", "shared_mlp_pool",
 ]
 
 
@@ -410,3 +410,133 @@ def maxpool_ns(x):
     """x (R,ns,C) -> (R,C): max over the neighbour axis (F.max_pool2d(kernel=[1,ns])
     of the reference's PointSAModule, in point-major layout)."""
     return _MaxPoolNS.apply(x)
+
+
+# --------------------------------------------------------------------------
+# Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
+# --------------------------------------------------------------------------
+class _SharedMLPPool(Function):
+    """x (R, ld) rows -> pooled (R/ns, C_L).  Per layer l the tensors are
+    (W_l (N_l, K_l), gamma_l, beta_l, running_mean_l, running_var_l, conv_bias_l|None);
+    K_0 == ld.  A conv bias in front of a train-mode BN cancels in the output, so it never
+    reaches the kernels; its gradient is returned as exact zeros.
+    Forward never materialises a BN/ReLU output: only the raw conv outputs Y_l are stored
+    (needed for backward), statistics come out of the GEMM epilogue, and the last
+    BN+ReLU is fused with the max over the ``ns`` neighbours (ns == 1: plain activation)."""
+
+    @staticmethod
+    def forward(ctx, x, ns, training, eps, momentum, *tensors):
+        _chk(x, "x")
+        R, ld = x.shape
+        L = len(tensors) // 6
+        assert len(tensors) == 6 * L and R % ns == 0
+        dev = x.device
+        st = _stream()
+        Ys, sss, mis = [], [], []
+        cur, cur_ld, pro = x, ld, None
+        for l in range(L):
+            W, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 5]
+            _chk(W, "weight")
+            N, K = W.shape
+            assert K == cur_ld, f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
+            Y = torch.empty((R, N), dtype=torch.float32, device=dev)
+            ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
+            mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
+            if training:
+                stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+                _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                          _p(stats), st)
+                _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
+                          float(momentum), _p(rmean), _p(rvar), _p(ss), _p(mi), st)
+            else:
+                _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                          None, st)
+                invstd = torch.rsqrt(rvar + eps)
+                ss[:N] = gamma * invstd
+                ss[N:] = beta - rmean * gamma * invstd
+                mi[:N] = rmean
+                mi[N:] = invstd
+            Ys.append(Y)
+            sss.append(ss)
+            mis.append(mi)
+            cur, cur_ld, pro = Y, N, ss
+        C = Ys[-1].shape[1]
+        out = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
+        arg = torch.empty((R // ns, C), dtype=torch.int32, device=dev)
+        _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
+                  _p(arg), st)
+        ctx.save_for_backward(x, arg, *Ys, *sss, *mis, *[tensors[6 * l] for l in range(L)],
+                              *[tensors[6 * l + 1] for l in range(L)])
+        ctx.bias_shapes = [None if tensors[6 * l + 5] is None else tensors[6 * l + 5].shape
+                           for l in range(L)]
+        ctx.meta = (R, ld, ns, L, training)
+        ctx.mark_non_differentiable(arg)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        R, ld, ns, L, training = ctx.meta
+        if not training:
+            raise RuntimeError("shared_mlp_pool backward is only defined in training mode")
+        saved = ctx.saved_tensors
+        x, arg = saved[0], saved[1]
+        Ys, sss, mis = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]
+        Ws, gammas = saved[2 + 3 * L:2 + 4 * L], saved[2 + 4 * L:2 + 5 * L]
+        dev, st = x.device, _stream()
+        dP = grad_out.contiguous()
+        G = None
+        grads = [None] * (6 * L)
+        dx = None
+        for l in range(L - 1, -1, -1):
+            W = Ws[l]
+            N, K = W.shape
+            g12 = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+            _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
+                      _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12), st)
+            vec6 = torch.empty(6 * N, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(N, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(N, dtype=torch.float32, device=dev)
+            _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12), _p(gammas[l]), _p(sss[l]), _p(mis[l]),
+                      _p(vec6), _p(dgamma), _p(dbeta), st)
+            xprev = Ys[l - 1] if l > 0 else x
+            ldx = xprev.shape[1]
+            dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+            sparse = G is None
+            _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
+                      _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(xprev),
+                      _p(sss[l - 1] if l > 0 else None), _p(dW), st)
+            grads[6 * l], grads[6 * l + 1], grads[6 * l + 2] = dW, dgamma, dbeta
+            if ctx.bias_shapes[l] is not None:
+                grads[6 * l + 5] = torch.zeros(ctx.bias_shapes[l], dtype=torch.float32, device=dev)
+            if l > 0 or ctx.needs_input_grad[0]:
+                Wtt = W.t().contiguous()
+                dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+                _ffi.call("demf_mlp_gemm_bwd_dx", R, N, K, K, _p(G), _p(dP if sparse else None),
+                          _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(Wtt), _p(dX), st)
+                if l > 0:
+                    G = dX
+                else:
+                    dx = dX
+        return (dx, None, None, None, None, *grads)
+
+
+def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1):
+    """Fused (conv1x1 -> BN -> ReLU) x L -> max over ``ns`` consecutive rows (ns=1: none).
+    ``layers`` = [(weight (N,K), gamma, beta, running_mean, running_var[, conv_bias]), ...].
+    A conv bias in front of a train-mode BN cancels in the normalised output (and its gradient
+    is identically zero); it only shifts the running mean, which is applied here."""
+    flat = []
+    for layer in layers:
+        W, gamma, beta, rmean, rvar = layer[:5]
+        bias = layer[5] if len(layer) > 5 else None
+        if not training and bias is not None:
+            rmean = rmean - bias.detach()      # eval: BN sees y + bias
+        flat += [W, gamma, beta, rmean, rvar, bias]
+    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, *flat)
+    if training:
+        with torch.no_grad():
+            for layer in layers:
+                if len(layer) > 5 and layer[5] is not None:
+                    layer[3].add_(layer[5], alpha=momentum)
+    return out

@@ -145,6 +145,58 @@ int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out, const int* 
                         demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Fused shared-MLP (1x1 conv + train-mode BatchNorm + ReLU [+ max over
+ * neighbours]) on point-major rows: the dense half of every PointSAModule
+ * (class_agnostic_vote_head.py:383; demf_votenet.py:48-62).  fp32 MFMA.
+ * act(y) = max(0, y*scale + shift) with scale = gamma*invstd, shift = beta - mean*scale.
+ * ------------------------------------------------------------------ */
+
+/* Y (R,N) = pro(X) (R,K; row stride ldx) @ Wt (N,K)^T.  pro = act of the PREVIOUS layer when
+ * pro_scale_shift ([scale(K)|shift(K)]) is non-NULL, identity otherwise.  When stats is
+ * non-NULL the per-column sum and sum of squares of Y are ACCUMULATED into stats[0:N],
+ * stats[N:2N] (fp64).  K%4==0, ldx%4==0, N%32==0, N<=256.                        */
+int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
+                      const float* pro_scale_shift, const float* Wt, float* Y,
+                      double* stats, demf_stream_t stream);
+
+/* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
+ * running statistics (momentum, unbiased variance) when they are non-NULL.      */
+int demf_bn_finalize(int N, long long count, const double* stats, const float* gamma,
+                     const float* beta, float eps, float momentum, float* running_mean,
+                     float* running_var, float* scale_shift, float* mean_invstd,
+                     demf_stream_t stream);
+
+/* out (R,C) = max over s of act(Y (R,ns,C)); arg = first maximising s.           */
+int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y, const float* scale_shift,
+                            float* out, int* arg, demf_stream_t stream);
+
+/* BatchNorm backward reductions of one layer: g12[0:N] += sum dZ, g12[N:2N] += sum dZ*xhat
+ * with dZ = dA * [act'(Y)].  Upstream gradient dA is either dense G (R,N) or, for the pooled
+ * last layer, sparse: dP (R/ns,N) routed to slot arg (R/ns,N).                    */
+int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP, const int* arg,
+                       const float* Y, const float* scale_shift, const float* mean_invstd,
+                       double* g12, demf_stream_t stream);
+
+/* g12 -> the six per-channel vectors the backward GEMM prologues consume (vec6, 6N floats:
+ * scale, shift, mean, invstd*mean(dZ*xhat), mean(dZ), gamma*invstd) + dgamma, dbeta.  */
+int demf_bn_bwd_vectors(int N, long long count, const double* g12, const float* gamma,
+                        const float* scale_shift, const float* mean_invstd, float* vec6,
+                        float* dgamma, float* dbeta, demf_stream_t stream);
+
+/* dX (R,K; row stride ldo) = dY (R,N) @ W (N,K) with dY = BN/ReLU backward of (dA, Y)
+ * formed on the fly.  Wtt = W^T stored (K,N) row-major.  N%4==0.                  */
+int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
+                         const int* arg, int ns, const float* Y, const float* vec6,
+                         const float* Wtt, float* dX, demf_stream_t stream);
+
+/* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
+ * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */
+int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,
+                         const int* arg, int ns, const float* Y, const float* vec6,
+                         const float* Xprev, const float* prev_scale_shift, float* dW,
+                         demf_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * DeMF fusion: multi-scale deformable attention core
  * ------------------------------------------------------------------ */
 

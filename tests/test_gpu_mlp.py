@@ -1,0 +1,89 @@
+"""Fused shared-MLP kernels (csrc/mlp.hip) against a plain PyTorch fp64 reference of the same
+op chain: (linear -> train-mode batch_norm -> relu) x L -> max over ns.  fp32 tolerance 1e-4
+relative to each tensor's scale (forward) / 1e-3 (gradients: long fp32 reductions)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, ns, layers, eps=1e-5):
+    h = x
+    for W, g, b in layers:
+        h = F.relu(F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, eps))
+    R, C = h.shape
+    return h.view(R // ns, ns, C).max(1)[0]
+
+
+CASES = [  # (rows/ns, ns, ld, channels, x_grad)
+    (700, 64, 4, (64, 64, 128), False),       # SA1
+    (520, 32, 132, (128, 128, 256), True),    # SA2
+    (300, 16, 260, (128, 128, 256), True),    # SA3/SA4
+    (260, 16, 260, (256, 256, 256), True),    # vote aggregation
+    (1000, 1, 64, (64, 32), True),            # no pooling (ns = 1), odd tile count
+]
+
+
+@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES)
+def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
+    from demf_amd import ops
+    torch.manual_seed(ld + ns)
+    R = Rp * ns
+    x = torch.randn(R, ld, dtype=torch.float64) * 0.7 + 0.1
+    layers64, k = [], ld
+    for n in chans:
+        layers64.append((torch.randn(n, k, dtype=torch.float64) / np.sqrt(k),
+                         1.0 + 0.2 * torch.randn(n, dtype=torch.float64),
+                         0.1 * torch.randn(n, dtype=torch.float64)))
+        k = n
+    layers64[0][1][0] = -0.7        # a negative BN scale: max/relu ordering must still hold
+    go = torch.randn(Rp, chans[-1], dtype=torch.float64)
+
+    xr = x.clone().requires_grad_(xgrad)
+    lr = [tuple(t.clone().requires_grad_() for t in l) for l in layers64]
+    out_r = _ref(xr, ns, lr)
+    out_r.backward(go)
+
+    xg = x.float().cuda().requires_grad_(xgrad)
+    lg = []
+    for W, g, b in layers64:
+        n = W.shape[0]
+        lg.append((W.float().cuda().requires_grad_(), g.float().cuda().requires_grad_(),
+                   b.float().cuda().requires_grad_(), torch.zeros(n, device="cuda"),
+                   torch.ones(n, device="cuda")))
+    out = ops.shared_mlp_pool(xg, ns, lg, training=True)
+    out.backward(go.float().cuda())
+
+    def close(a, b, tol, name):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), f"{name}: err {err:.3e}"
+
+    close(out, out_r, 1e-4, "out")
+    for i, (gl, rl) in enumerate(zip(lg, lr)):
+        close(gl[0].grad, rl[0].grad, 1e-3, f"dW{i}")
+        close(gl[1].grad, rl[1].grad, 1e-3, f"dgamma{i}")
+        close(gl[2].grad, rl[2].grad, 1e-3, f"dbeta{i}")
+    if xgrad:
+        close(xg.grad, xr.grad, 1e-3, "dx")
+    # running statistics follow nn.BatchNorm semantics (momentum 0.1, unbiased variance)
+    h = x
+    for i, (W, g, b) in enumerate(layers64):
+        y = F.linear(h, W)
+        close(lg[i][3], 0.1 * y.mean(0), 1e-4, f"running_mean{i}")
+        close(lg[i][4], 0.9 + 0.1 * y.var(0, unbiased=True), 1e-4, f"running_var{i}")
+        h = F.relu(F.batch_norm(y, None, None, g, b, True, 0.1, 1e-5))
+
+
+def test_shared_mlp_pool_eval_mode():
+    from demf_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(640, 64, device="cuda")
+    W = torch.randn(128, 64, device="cuda") / 8
+    g, b = torch.rand(128, device="cuda") + 0.5, torch.randn(128, device="cuda") * 0.1
+    rm, rv = torch.randn(128, device="cuda") * 0.1, torch.rand(128, device="cuda") + 0.5
+    out = ops.shared_mlp_pool(x, 16, [(W, g, b, rm.clone(), rv.clone())], training=False)
+    ref = F.relu(F.batch_norm(F.linear(x, W), rm, rv, g, b, False, 0.1, 1e-5)).view(40, 16, 128).max(1)[0]
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
