@@ -79,14 +79,45 @@ class Trainer:
             for b in model.buffers():
                 dist.broadcast(b.data, src=0)
 
-    def step(self, batch):
+    def _fwd_bwd(self, batch):
         self.flat.zero_()
         losses = self.model.forward_train(batch["points"], batch["img_features"],
                                           batch["img_metas"], batch["gt_bboxes_3d"],
                                           batch["gt_labels_3d"])
         total = sum(losses.values())
         total.backward()
+        return total.detach()
+
+    def _update(self):
         self.flat.all_reduce_mean()
         self.flat.clip_(self.max_grad_norm)
         self.opt.step()
-        return total.detach()
+
+    def step(self, batch):
+        total = self._fwd_bwd(batch)
+        self._update()
+        return total
+
+    def capture(self, batch, warmup=3):
+        """Capture forward + loss + backward of ``batch`` (static shapes, device-resident
+        inputs) into one hipGraph; returns ``replay()`` = graph launch + eager all-reduce /
+        clip / AdamW.  The path issues no host sync or host->device copy after warm-up
+        (targets are batched, metas are cached), which is what makes it capturable; the
+        collective and the optimizer stay outside the graph."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self._fwd_bwd(batch)
+
+        def replay():
+            graph.replay()
+            self._update()
+            return loss
+        self._graph = graph
+        return replay

@@ -171,40 +171,57 @@ class DeMFVoteHead(nn.Module):
         valid_W = torch.sum(~mask[:, 0, :], 1)
         return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
 
+    def _meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
+        """Device-side constants derived from the (host) img_metas, cached per metas object:
+        the step then issues no host->device copy and can be captured in a hipGraph."""
+        key = (id(img_metas), tuple(mlvl_shapes), str(dev))
+        cache = self.__dict__.setdefault("_meta_cache", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            comp = [compose_projection(m) for m in img_metas]
+            sizes = [h * w for h, w in mlvl_shapes]
+            cache[key] = dict(
+                M=torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev),
+                ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
+                hw=torch.as_tensor([m["img_shape"][:2] for m in img_metas], device=dev),
+                spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
+                level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
+                                                  dtype=torch.long, device=dev),
+                keep=img_metas)   # keep the keyed object alive so its id stays unique
+        return cache[key]
+
     # ---- :524-547 ------------------------------------------------------------
-    def get_reference_points(self, seeds_3d_batch, img_metas):
+    def get_reference_points(self, seeds_3d_batch, img_metas, mlvl_shapes=()):
         dev, dt = seeds_3d_batch.device, seeds_3d_batch.dtype
-        comp = [compose_projection(m) for m in img_metas]
-        M = torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev)   # (B,4,4)
-        ab = torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev)  # (B,4)
+        mt = self._meta_tensors(img_metas, mlvl_shapes, dev, dt)
+        M, ab = mt["M"], mt["ab"]                                   # (B,4,4), (B,4)
         ones = seeds_3d_batch.new_ones(seeds_3d_batch.shape[:-1] + (1,))
         p = torch.cat([seeds_3d_batch, ones], dim=-1) @ M.transpose(1, 2)
         uv = p[..., :2] / p[..., 2:3]
-        uv = uv * ab[:, None, [0, 2]] + ab[:, None, [1, 3]]
+        uv = uv * ab[:, None, 0::2] + ab[:, None, 1::2]   # (au, av) scale, (bu, bv) offset
         return torch.clamp(uv, 0, 1)
 
     # ---- :549-594 ------------------------------------------------------------
     def prepare_decoder_inputs(self, seeds_3d, mlvl_feats, img_metas):
-        reference_points = self.get_reference_points(seeds_3d, img_metas)
+        spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
+        reference_points = self.get_reference_points(seeds_3d, img_metas, spatial)
         B = mlvl_feats[0].size(0)
         in_h, in_w = img_metas[0]["batch_input_shape"]
         dev = mlvl_feats[0].device
+        mt = self._meta_tensors(img_metas, spatial, dev, seeds_3d.dtype)
         # padding masks: nearest-neighbour resize of the (B,Hpad,Wpad) mask == index lookup
-        hw = torch.as_tensor([m["img_shape"][:2] for m in img_metas], device=dev)  # (B,2)
-        mlvl_masks, spatial = [], []
+        hw = mt["hw"]                                                              # (B,2)
+        mlvl_masks = []
         for feat in mlvl_feats:
             h, w = feat.shape[-2:]
-            spatial.append((h, w))
             ys = torch.floor(torch.arange(h, device=dev, dtype=torch.float32) * (in_h / h)).long()
             xs = torch.floor(torch.arange(w, device=dev, dtype=torch.float32) * (in_w / w)).long()
             mlvl_masks.append((ys[None, :, None] >= hw[:, 0, None, None]) |
                               (xs[None, None, :] >= hw[:, 1, None, None]))
         feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
-        spatial_shapes = torch.as_tensor(spatial, dtype=torch.long, device=dev)
-        sizes = [h * w for h, w in spatial]
-        level_start_index = torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]), dtype=torch.long,
-                                            device=dev)
+        spatial_shapes, level_start_index = mt["spatial_shapes"], mt["level_start_index"]
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
         feat_flatten = feat_flatten.permute(1, 0, 2)
         return feat_flatten, mask_flatten, reference_points, spatial_shapes, \
@@ -230,7 +247,12 @@ class DeMFVoteHead(nn.Module):
                                               bbox_preds["seed_indices"], vote_target_masks,
                                               vote_targets)
         ocw = c["objectness"].get("class_weight")
-        ocw = bbox_preds["obj_scores"].new_tensor(ocw) if ocw is not None else None
+        if ocw is not None:
+            dev = bbox_preds["obj_scores"].device
+            cw = self.__dict__.setdefault("_ocw", {})
+            if str(dev) not in cw:
+                cw[str(dev)] = torch.tensor(ocw, dtype=torch.float32, device=dev)
+            ocw = cw[str(dev)]
         objectness_loss = L.cross_entropy_sum(bbox_preds["obj_scores"].transpose(2, 1),
                                               objectness_targets, objectness_weights, ocw,
                                               c["objectness"].get("loss_weight", 1.0))

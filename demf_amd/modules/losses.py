@@ -30,7 +30,7 @@ def axis_aligned_iou(b1, b2, eps=1e-6):
     rb = torch.min(b1[..., 3:], b2[..., 3:])
     wh = (rb - lt).clamp(min=0)
     overlap = wh[..., 0] * wh[..., 1] * wh[..., 2]
-    union = torch.max(a1 + a2 - overlap, overlap.new_tensor([eps]))
+    union = (a1 + a2 - overlap).clamp(min=eps)   # == torch.max(union, eps), no host constant
     return overlap / union
 
 
