@@ -30,13 +30,12 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 
 constexpr int MLP_BK = 32;        // K step staged per iteration
 constexpr int MLP_LD = MLP_BK + 4;  // LDS row stride (floats), +16 B pad
-constexpr int MLP_ROWS = 128;     // rows per block tile (4 waves x 32)
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
 
-// per-channel vectors of the backward prologue, struct-of-arrays of length n each:
-//   [0] scale  [1] shift  (z = y*scale + shift, ReLU mask)
-//   [2] mean   [3] istd_c2 = invstd * mean(dZ*xhat)   [4] c1 = mean(dZ)   [5] gi = gamma*invstd
+// per-channel vectors of the backward prologue ("vec5"), struct-of-arrays of length n each:
+//   [0] scale  [1] shift  (z = y*scale + shift, ReLU mask)   [2] gi = gamma*invstd
+//   [3] a = -gi*invstd*mean(dZ*xhat)   [4] b = -gi*mean(dZ) - a*mean     (dY = gi*dZ + a*y + b)
 struct MlpArgs {
   int R, K, N;                 // rows, reduction length, output columns
   int ldx;                     // row stride of X (floats)
@@ -46,21 +45,56 @@ struct MlpArgs {
   const float* dP;             // PRO_DY_SPARSE: pooled gradient (R/ns x K)
   const int* arg;              //                and arg-max slot (R/ns x K)
   int ns;
-  const float* vec;            // BNRELU: [scale|shift] (2K);  DY: 6 vectors of length K
+  const float* vec;            // BNRELU: [scale|shift] (2K);  DY: 5 vectors of length K
   const float* Bt;             // (N x K) row-major
   float* Y;                    // (R x N) output
   double* stats;               // optional (2N): column sum, column sum of squares
 };
 
+// Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
+// previous step) and only transformed when they are written to LDS.
 template <int PRO>
-__device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, int row, int col) {
-  // one float4 of the (transformed) A operand at (row, col..col+3); caller guarantees in-range
-  const float4 x = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + col);
+struct MlpRaw {
+  float4 x;                                                    // X / Y_l
+  float4 g;                                                    // DY_DENSE: G ; DY_SPARSE: dP
+  int4 a;                                                      // DY_SPARSE: arg
+  int s;                                                       // DY_SPARSE: row's slot in its group
+};
+template <> struct MlpRaw<PRO_NONE> { float4 x; };
+template <> struct MlpRaw<PRO_BNRELU> { float4 x; };
+template <> struct MlpRaw<PRO_DY_DENSE> { float4 x, g; };
+
+template <int PRO>
+__device__ __forceinline__ void mlp_fetch(const MlpArgs& p, int row, int col, bool ok, MlpRaw<PRO>& r) {
+  r.x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO == PRO_DY_DENSE) r.g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO == PRO_DY_SPARSE) {
+    r.g = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.a = make_int4(-1, -1, -1, -1);
+    r.s = 0;
+  }
+  if (!ok) return;
+  r.x = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + col);
+  if constexpr (PRO == PRO_DY_DENSE) r.g = *reinterpret_cast<const float4*>(p.G + (size_t)row * p.K + col);
+  if constexpr (PRO == PRO_DY_SPARSE) {
+    const int rp = row / p.ns;
+    r.s = row - rp * p.ns;
+    r.g = *reinterpret_cast<const float4*>(p.dP + (size_t)rp * p.K + col);
+    r.a = *reinterpret_cast<const int4*>(p.arg + (size_t)rp * p.K + col);
+  }
+}
+
+// `vec` = the per-channel vectors (global, or the block's LDS copy); `ok` false -> zeros
+template <int PRO>
+__device__ __forceinline__ float4 mlp_xform(const MlpArgs& p, const float* __restrict__ vec, int col,
+                                            bool ok, const MlpRaw<PRO>& r) {
+  const float4 x = r.x;
   if constexpr (PRO == PRO_NONE) {
     return x;
   } else if constexpr (PRO == PRO_BNRELU) {
-    const float4 s = *reinterpret_cast<const float4*>(p.vec + col);
-    const float4 t = *reinterpret_cast<const float4*>(p.vec + p.K + col);
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 s = *reinterpret_cast<const float4*>(vec + col);
+    const float4 t = *reinterpret_cast<const float4*>(vec + p.K + col);
     float4 o;
     o.x = fmaxf(0.f, __builtin_fmaf(x.x, s.x, t.x));
     o.y = fmaxf(0.f, __builtin_fmaf(x.y, s.y, t.y));
@@ -68,30 +102,26 @@ __device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, int row, int col)
     o.w = fmaxf(0.f, __builtin_fmaf(x.w, s.w, t.w));
     return o;
   } else {
-    float4 g;
-    if constexpr (PRO == PRO_DY_DENSE) {
-      g = *reinterpret_cast<const float4*>(p.G + (size_t)row * p.K + col);
-    } else {
-      const int rp = row / p.ns, s = row - rp * p.ns;
-      const float4 d = *reinterpret_cast<const float4*>(p.dP + (size_t)rp * p.K + col);
-      const int4 a = *reinterpret_cast<const int4*>(p.arg + (size_t)rp * p.K + col);
-      g.x = a.x == s ? d.x : 0.f;
-      g.y = a.y == s ? d.y : 0.f;
-      g.z = a.z == s ? d.z : 0.f;
-      g.w = a.w == s ? d.w : 0.f;
+    if (!ok) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g = r.g;
+    if constexpr (PRO == PRO_DY_SPARSE) {
+      g.x = r.a.x == r.s ? g.x : 0.f;
+      g.y = r.a.y == r.s ? g.y : 0.f;
+      g.z = r.a.z == r.s ? g.z : 0.f;
+      g.w = r.a.w == r.s ? g.w : 0.f;
     }
+    // dY = gi*(dZ - c1 - xhat*c2) = gi*dZ + (a*y + b), dZ = g where y*scale+shift > 0
     const int K = p.K;
-    const float4 sc = *reinterpret_cast<const float4*>(p.vec + col);
-    const float4 sh = *reinterpret_cast<const float4*>(p.vec + K + col);
-    const float4 mu = *reinterpret_cast<const float4*>(p.vec + 2 * K + col);
-    const float4 ic = *reinterpret_cast<const float4*>(p.vec + 3 * K + col);
-    const float4 c1 = *reinterpret_cast<const float4*>(p.vec + 4 * K + col);
-    const float4 gi = *reinterpret_cast<const float4*>(p.vec + 5 * K + col);
+    const float4 sc = *reinterpret_cast<const float4*>(vec + col);
+    const float4 sh = *reinterpret_cast<const float4*>(vec + K + col);
+    const float4 gi = *reinterpret_cast<const float4*>(vec + 2 * K + col);
+    const float4 va = *reinterpret_cast<const float4*>(vec + 3 * K + col);
+    const float4 vb = *reinterpret_cast<const float4*>(vec + 4 * K + col);
     float4 o;
-#define MLP_DY(m)                                                              \
-    {                                                                          \
-      const float dz = __builtin_fmaf(x.m, sc.m, sh.m) > 0.f ? g.m : 0.f;      \
-      o.m = gi.m * (dz - c1.m - (x.m - mu.m) * ic.m);                          \
+#define MLP_DY(m)                                                                   \
+    {                                                                               \
+      const float dz = __builtin_fmaf(x.m, sc.m, sh.m) > 0.f ? g.m : 0.f;           \
+      o.m = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, x.m, vb.m));              \
     }
     MLP_DY(x) MLP_DY(y) MLP_DY(z) MLP_DY(w)
 #undef MLP_DY
@@ -99,72 +129,135 @@ __device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, int row, int col)
   }
 }
 
-// C(R x N) = pro(A)(R x K) @ Bt(N x K)^T ; NT = N/32 column tiles per wave (all of N).
-template <int NT, int PRO, bool STATS>
+template <int PRO>
+__device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, const float* __restrict__ vec,
+                                             int row, int col) {
+  MlpRaw<PRO> r;
+  mlp_fetch<PRO>(p, row, col, true, r);
+  return mlp_xform<PRO>(p, vec, col, true, r);
+}
+
+// C(R x N) = pro(A)(R x K) @ Bt(N x K)^T ; NT = ceil(N/32) column tiles per wave (all of N).
+// The (tile, k-step) sequence of a block is flattened so the next 32 x BK slab of A (per wave,
+// prologue applied on arrival) and the next N x BK slab of Bt (shared by the 4 waves) are already
+// in flight while the current ones feed the MFMAs.  A lives in a wave-private LDS region; Bt is
+// staged once per step for the whole block as full 128-byte rows (fragment-shaped loads straight
+// from global would cost 32 cache lines per wave-instruction).
+// RT = 32-row tiles per wave (2 when the accumulators fit: twice the MFMA work per Bt fragment
+// and per barrier).  The prologue's per-channel vectors are copied to LDS once per block.
+constexpr int MLP_MAXK = 512;
+template <int NT, int RT, int PRO, bool STATS>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
-  __shared__ __attribute__((aligned(16))) float s_a[4][32 * MLP_LD];
+  constexpr int WROWS = 32 * RT;          // rows per wave
+  constexpr int BROWS = 4 * WROWS;        // rows per block tile
+  constexpr int NVEC = PRO == PRO_NONE ? 0 : (PRO == PRO_BNRELU ? 2 : 5);
+  __shared__ __attribute__((aligned(16))) float s_a[4][WROWS * MLP_LD];
+  __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * MLP_LD];
+  __shared__ __attribute__((aligned(16))) float s_vec[NVEC ? NVEC * MLP_MAXK : 4];
   __shared__ float s_red[STATS ? 4 * NT * 32 * 2 : 1];
+  if constexpr (NVEC > 0) {
+    // compact copy: vector v of length K lives at s_vec + v*K (same addressing as global)
+    for (int i = threadIdx.x; i < NVEC * p.K; i += 256) s_vec[i] = p.vec[i];
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   float* sa = s_a[wave];
-  const int ntiles = (p.R + MLP_ROWS - 1) / MLP_ROWS;
+  const int ntiles = (p.R + BROWS - 1) / BROWS;
+  const int ksteps = (p.K + MLP_BK - 1) / MLP_BK;
+  const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nsteps = my_tiles * ksteps;
   float cs1[NT], cs2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
+  f32x16 acc[RT][NT];
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row0 = tile * MLP_ROWS + wave * 32;
-    f32x16 acc[NT];
+  const int pr = lane >> 3, pc = (lane & 7) * 4;   // this lane's slot in a 32 x BK slab
+  const int br = threadIdx.x >> 3;                  // Bt slab: row br + 32*i, cols pc..pc+3
+  MlpRaw<PRO> pre[4 * RT];
+  bool pok[4 * RT];
+  float4 preb[NT];
+  auto prefetch = [&](int step) {
+    const int tile = blockIdx.x + (step / ksteps) * gridDim.x;
+    const int k0 = (step % ksteps) * MLP_BK;
+    const int row0 = tile * BROWS + wave * WROWS;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int it = 0; it < 4 * RT; ++it) {
+      const int row = row0 + it * 8 + pr, col = k0 + pc;
+      pok[it] = row < p.R && col < p.K;
+      mlp_fetch<PRO>(p, row, col, pok[it], pre[it]);   // raw: stays in flight until the LDS write
+    }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    for (int i = 0; i < NT; ++i) {
+      const int n = br + 32 * i, col = k0 + pc;
+      preb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < p.N && col < p.K) preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * p.K + col);
+    }
+  };
+  if (nsteps > 0) prefetch(0);
 
-    for (int k0 = 0; k0 < p.K; k0 += MLP_BK) {
-      // stage this wave's 32 x BK slice of A (coalesced 128-B row segments), transformed
+  for (int step = 0; step < nsteps; ++step) {
+    const int ks = step % ksteps;
+    const int k0 = ks * MLP_BK;
+    const int row0 = (blockIdx.x + (step / ksteps) * gridDim.x) * BROWS + wave * WROWS;
+    float* sb = s_b;
+    if (ks == 0) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 8 + (lane >> 3);
-        const int c = (lane & 7) * 4;
-        const int row = row0 + r, col = k0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < p.R && col < p.K) v = mlp_load_a<PRO>(p, row, col);
-        *reinterpret_cast<float4*>(sa + r * MLP_LD + c) = v;
-      }
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int c8 = 0; c8 < MLP_BK / 8; ++c8) {
-        const int kk = k0 + c8 * 8 + 4 * lh;
-        const float4 a4 = *reinterpret_cast<const float4*>(sa + lr * MLP_LD + c8 * 8 + 4 * lh);
-        const bool kin = kk < p.K;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (kin && nt * 32 + lr < p.N)
-            b4 = *reinterpret_cast<const float4*>(p.Bt + (size_t)(nt * 32 + lr) * p.K + kk);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[nt], 0, 0, 0);
+          for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
+    }
+    __syncthreads();                                  // everyone is done reading the old Bt slab
+#pragma unroll
+    for (int it = 0; it < 4 * RT; ++it)
+      *reinterpret_cast<float4*>(sa + (it * 8 + pr) * MLP_LD + pc) =
+          mlp_xform<PRO>(p, s_vec, k0 + pc, pok[it], pre[it]);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+      *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
+    __syncthreads();
+    if (step + 1 < nsteps) prefetch(step + 1);
+    const int kchunks = min(MLP_BK / 8, (p.K - k0 + 7) / 8);
+    for (int c8 = 0; c8 < kchunks; ++c8) {
+      float4 a4[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        a4[rt] = *reinterpret_cast<const float4*>(sa + (rt * 32 + lr) * MLP_LD + c8 * 8 + 4 * lh);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(sb + (nt * 32 + lr) * MLP_LD + c8 * 8 + 4 * lh);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].x, b4.x, acc[rt][nt], 0, 0, 0);
+          acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].y, b4.y, acc[rt][nt], 0, 0, 0);
+          acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].z, b4.z, acc[rt][nt], 0, 0, 0);
+          acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].w, b4.w, acc[rt][nt], 0, 0, 0);
         }
       }
     }
-    // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (ks == ksteps - 1) {
+      // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float s1 = 0.f, s2 = 0.f;
+      for (int nt = 0; nt < NT; ++nt) {
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = acc[nt][r];
-        if (row < p.R && nt * 32 + lr < p.N) p.Y[(size_t)row * p.ldy + nt * 32 + lr] = v;
-        if constexpr (STATS) {
-          s1 += v;                       // rows >= R are exact zeros (their A rows are zero)
-          s2 = __builtin_fmaf(v, v, s2);
-        }
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = acc[rt][nt][r];
+            if (row < p.R && nt * 32 + lr < p.N) p.Y[(size_t)row * p.ldy + nt * 32 + lr] = v;
+            if constexpr (STATS) {
+              s1 += v;                     // rows >= R are exact zeros (their A rows are zero)
+              s2 = __builtin_fmaf(v, v, s2);
+            }
+          }
+        cs1[nt] += s1;
+        cs2[nt] += s2;
       }
-      cs1[nt] += s1;
-      cs2[nt] += s2;
     }
   }
   if constexpr (STATS) {
@@ -293,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
   }
 }
 
-// g1,g2 -> the 6 backward vectors + dgamma, dbeta
+// g1,g2 -> the 5 backward vectors + dgamma, dbeta
 __global__ void bn_bwd_vectors_k(int N, double count, const double* __restrict__ g12,
                                  const float* __restrict__ gamma, const float* __restrict__ ss,
                                  const float* __restrict__ mi, float* __restrict__ vec,
@@ -301,13 +394,14 @@ __global__ void bn_bwd_vectors_k(int N, double count, const double* __restrict__
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   const double g1 = g12[c], g2 = g12[N + c];
-  const float is = mi[N + c];
+  const double mean = mi[c], is = mi[N + c];
+  const double gi = (double)gamma[c] * is;
+  const double a = -gi * is * (g2 / count);
   vec[c] = ss[c];
   vec[N + c] = ss[N + c];
-  vec[2 * N + c] = mi[c];
-  vec[3 * N + c] = (float)((double)is * (g2 / count));
-  vec[4 * N + c] = (float)(g1 / count);
-  vec[5 * N + c] = gamma[c] * is;
+  vec[2 * N + c] = (float)gi;
+  vec[3 * N + c] = (float)a;
+  vec[4 * N + c] = (float)(-gi * (g1 / count) - a * mean);
   dgamma[c] = (float)g2;
   dbeta[c] = (float)g1;
 }
@@ -323,110 +417,161 @@ struct DwArgs {
   const float* dP;     // sparse upstream gradient
   const int* arg;
   int ns;
-  const float* vec;    // 6 x N backward vectors of this layer
+  const float* vec;    // 5 x N backward vectors of this layer
   const float* Xp;     // (R x K) previous layer's pre-BN output, or the raw input
   const float* pvec;   // [scale|shift] of the previous layer (2K) or null (raw input)
   float* dW;           // (N x K), accumulated
   int n0, k0, NTn, NTk;  // output sub-block handled by this launch: tiles [n0, n0+NTn) x [k0, k0+NTk)
 };
 
-template <int TPW, bool SPARSE>
+// Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
+// tiles tn = wn + 2i (i < TN), tk = wk + 2j (j < TK), so per row pair it reads TN + TK LDS
+// values for TN*TK MFMAs.
+template <int TN, int TK, bool SPARSE>
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
+  constexpr int PROY = SPARSE ? PRO_DY_SPARSE : PRO_DY_DENSE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int WN = p.NTn * 32, WK = p.NTk * 32;       // columns of dY / A staged per step
-  float* s_dy = smem;                                // [32][WN + 4]
-  float* s_a = smem + 32 * (WN + 4);                 // [32][WK + 4]
+  // staged widths are padded to the wave grid (2*TN, 2*TK tiles) so idle tiles read zeros
+  const int WN = 2 * TN * 32, WK = 2 * TK * 32;      // columns of dY / A staged per slab
   const int ldn = WN + 4, ldk = WK + 4;
+  float* s_dy = smem;                                // [32][WN + 4]
+  float* s_a = s_dy + 32 * ldn;                      // [32][WK + 4]
+  float* s_vy = s_a + 32 * ldk;                      // 5 x N backward vectors of this layer
+  float* s_vx = s_vy + 5 * p.N;                      // [scale|shift] of the previous layer (2K)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int ntile = p.NTn * p.NTk;
-  f32x16 acc[TPW];
+  const int wn = wave >> 1, wk = wave & 1;
+  for (int i = threadIdx.x; i < 5 * p.N; i += 256) s_vy[i] = p.vec[i];
+  if (p.pvec)
+    for (int i = threadIdx.x; i < 2 * p.K; i += 256) s_vx[i] = p.pvec[i];
+  f32x16 acc[TN][TK];
 #pragma unroll
-  for (int t = 0; t < TPW; ++t)
+  for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  MlpArgs ay;  // reuse the forward prologue loaders
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  MlpArgs ay;  // reuse the GEMM prologue helpers
   ay.K = p.N; ay.ldx = p.N; ay.X = p.Yl; ay.G = p.G; ay.dP = p.dP; ay.arg = p.arg; ay.ns = p.ns;
-  ay.vec = p.vec;
   MlpArgs ax;
-  ax.K = p.K; ax.ldx = p.ldx; ax.X = p.Xp; ax.vec = p.pvec;
+  ax.K = p.K; ax.ldx = p.ldx; ax.X = p.Xp;
 
-  const int nslab = (p.R + 31) / 32;
-  for (int slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+  // per-thread slots of the 32-row slab: float4 index f = threadIdx.x + 256*j
+  const int qn = WN / 4, qk = WK / 4;
+  MlpRaw<PROY> ry[4];
+  MlpRaw<PRO_NONE> ra[4];
+  bool oky[4], oka[4];
+  auto prefetch = [&](int slab) {
     const int row0 = slab * 32;
-    __syncthreads();
-    // stage dY[32][WN] (columns n0*32 ..) and A[32][WK]
-    for (int i = threadIdx.x; i < 32 * (WN / 4); i += 256) {
-      const int r = i / (WN / 4), c = (i - r * (WN / 4)) * 4;
-      const int row = row0 + r, col = p.n0 * 32 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < p.R && col < p.N)
-        v = SPARSE ? mlp_load_a<PRO_DY_SPARSE>(ay, row, col) : mlp_load_a<PRO_DY_DENSE>(ay, row, col);
-      *reinterpret_cast<float4*>(s_dy + r * ldn + c) = v;
-    }
-    for (int i = threadIdx.x; i < 32 * (WK / 4); i += 256) {
-      const int r = i / (WK / 4), c = (i - r * (WK / 4)) * 4;
-      const int row = row0 + r, col = p.k0 * 32 + c;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < p.R && col < p.K)
-        v = p.pvec ? mlp_load_a<PRO_BNRELU>(ax, row, col) : mlp_load_a<PRO_NONE>(ax, row, col);
-      *reinterpret_cast<float4*>(s_a + r * ldk + c) = v;
-    }
-    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tile = wave + 4 * t;
-      if (tile < ntile) {
-        const int tn = tile / p.NTk, tk = tile - tn * p.NTk;
-        // A-op: dY^T -> lane supplies dY[r = 2m + lh][n = tn*32 + lr]; B-op: A[r][k = tk*32 + lr]
+    for (int jj = 0; jj < 4; ++jj) {
+      const int f = threadIdx.x + 256 * jj;
+      const int r = f / qn, c = (f - r * qn) * 4;
+      oky[jj] = f < 32 * qn && row0 + r < p.R && p.n0 * 32 + c < p.N;
+      mlp_fetch<PROY>(ay, row0 + r, p.n0 * 32 + c, oky[jj], ry[jj]);
+      const int r2 = f / qk, c2 = (f - r2 * qk) * 4;
+      oka[jj] = f < 32 * qk && row0 + r2 < p.R && p.k0 * 32 + c2 < p.K;
+      mlp_fetch<PRO_NONE>(ax, row0 + r2, p.k0 * 32 + c2, oka[jj], ra[jj]);
+    }
+  };
+  const int nslab = (p.R + 31) / 32;
+  int slab = blockIdx.x;
+  if (slab < nslab) prefetch(slab);
+  for (; slab < nslab; slab += gridDim.x) {
+    __syncthreads();                                 // previous slab fully consumed (and s_v* ready)
 #pragma unroll
-        for (int m = 0; m < 16; ++m) {
-          const float a = s_dy[(2 * m + lh) * ldn + tn * 32 + lr];
-          const float b = s_a[(2 * m + lh) * ldk + tk * 32 + lr];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    for (int jj = 0; jj < 4; ++jj) {
+      const int f = threadIdx.x + 256 * jj;
+      if (f < 32 * qn) {
+        const int r = f / qn, c = (f - r * qn) * 4;
+        *reinterpret_cast<float4*>(s_dy + r * ldn + c) =
+            mlp_xform<PROY>(ay, s_vy, p.n0 * 32 + c, oky[jj], ry[jj]);
+      }
+      if (f < 32 * qk) {
+        const int r = f / qk, c = (f - r * qk) * 4;
+        float4 v = ra[jj].x;
+        if (p.pvec) {
+          MlpRaw<PRO_BNRELU> rb;
+          rb.x = v;
+          v = mlp_xform<PRO_BNRELU>(ax, s_vx, p.k0 * 32 + c, oka[jj], rb);
+        }
+        *reinterpret_cast<float4*>(s_a + r * ldk + c) = v;
+      }
+    }
+    __syncthreads();
+    if (slab + (int)gridDim.x < nslab) prefetch(slab + gridDim.x);
+    // A-op: dY^T -> lane supplies dY[r = 2m + lh][n = tn*32 + lr]; B-op: A[r][k = tk*32 + lr]
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+      float a[TN], b[TK];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) a[i] = s_dy[(2 * m + lh) * ldn + (wn + 2 * i) * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TK; ++j) b[j] = s_a[(2 * m + lh) * ldk + (wk + 2 * j) * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int tn = wn + 2 * i, tk = wk + 2 * j;
+      if (tn < p.NTn && tk < p.NTk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int k = (p.k0 + tk) * 32 + lr;
+          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
         }
       }
     }
-  }
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int tile = wave + 4 * t;
-    if (tile < ntile) {
-      const int tn = tile / p.NTk, tk = tile - tn * p.NTk;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int k = (p.k0 + tk) * 32 + lr;
-        if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.K + k, acc[t][r]);
-      }
-    }
-  }
 }
 
-static int mlp_grid(int R) {
-  const int tiles = (R + MLP_ROWS - 1) / MLP_ROWS;
+static int mlp_grid(int R, int brows) {
+  const int tiles = (R + brows - 1) / brows;
   const int cap = 256 * 2;
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
 template <int PRO, bool STATS>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
-  const dim3 grid(mlp_grid(a.R)), block(256);
-  switch ((a.N + 31) / 32) {
-#define CASE(nt) \
-    case nt: hipLaunchKernelGGL((mlp_gemm_kernel<nt, PRO, STATS>), grid, block, 0, s, a); break;
-    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
-#undef CASE
-    default:
-      set_error("mlp_gemm: N=%d unsupported (1..256 columns per launch)", a.N);
-      return DEMF_EUNSUPPORTED;
+  const dim3 block(256);
+  // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
+  // in 256 VGPRs: up to 4 column tiles for the forward prologues, up to 2 for the backward ones
+  // (whose raw prefetch is 2-3x wider).  Backward launches are limited to 128 columns.
+  constexpr int RT2_MAX = PRO >= PRO_DY_DENSE ? 2 : 4;
+  constexpr int NT_MAX = PRO >= PRO_DY_DENSE ? 4 : 8;
+  const int nt = (a.N + 31) / 32;
+  if (nt < 1 || nt > NT_MAX) {
+    set_error("mlp_gemm: N=%d unsupported for this prologue (max %d columns per launch)", a.N,
+              NT_MAX * 32);
+    return DEMF_EUNSUPPORTED;
   }
+#define GO(NTv, RTv)                                                                            \
+  hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS>), dim3(mlp_grid(a.R, 128 * RTv)),   \
+                     block, 0, s, a)
+#define CASE(NTv)                                                                               \
+  case NTv:                                                                                     \
+    if constexpr (NTv <= NT_MAX) {                                                              \
+      if constexpr (NTv <= RT2_MAX) GO(NTv, 2); else GO(NTv, 1);                                \
+    }                                                                                           \
+    break;
+  switch (nt) {
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+  }
+#undef CASE
+#undef GO
   return check_launch("mlp_gemm");
 }
 
 static int mlp_check(int R, int K, int N, int ldx) {
-  DEMF_REQUIRE(R >= 0 && K >= 4 && K % 4 == 0 && N >= 1 && N <= 256 && ldx >= K && ldx % 4 == 0,
-               "mlp: bad sizes R=%d K=%d N=%d ldx=%d (K%%4==0, 1<=N<=256)", R, K, N, ldx);
+  DEMF_REQUIRE(R >= 0 && K >= 4 && K % 4 == 0 && K <= MLP_MAXK && N >= 1 && N <= 256 && ldx >= K &&
+                   ldx % 4 == 0,
+               "mlp: bad sizes R=%d K=%d N=%d ldx=%d (K%%4==0, K<=512, 1<=N<=256)", R, K, N, ldx);
   return DEMF_OK;
 }
 
@@ -508,7 +653,7 @@ extern "C" int demf_bn_bwd_vectors(int N, long long count, const double* g12, co
 }
 
 // dX(R x K) = dY(R x N) @ W(N x K), dY formed on the fly.  Wtt = W^T as (K x N) row-major.
-// dX has row stride ldo >= K; K may be any multiple of 4 (handled in chunks of <= 256 columns).
+// dX has row stride ldo >= K; K may be any multiple of 4 (handled in chunks of <= 128 columns).
 extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
                                     const int* arg, int ns, const float* Y, const float* vec6,
                                     const float* Wtt, float* dX, demf_stream_t stream) {
@@ -517,10 +662,10 @@ extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && vec6 && Wtt && dX && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dx: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  for (int c0 = 0; c0 < K; c0 += 256) {
+  for (int c0 = 0; c0 < K; c0 += 128) {
     // here the reduction runs over this layer's N channels and the output has K columns
     MlpArgs a{};
-    a.R = R; a.K = N; a.N = (K - c0) < 256 ? (K - c0) : 256; a.ldx = N; a.ldy = ldo; a.X = Y;
+    a.R = R; a.K = N; a.N = (K - c0) < 128 ? (K - c0) : 128; a.ldx = N; a.ldy = ldo; a.X = Y;
     a.G = G; a.dP = dP; a.arg = arg; a.ns = ns; a.vec = vec6; a.Bt = Wtt + (size_t)c0 * N;
     a.Y = dX + c0; a.stats = nullptr;
     const int e = G ? launch_gemm<PRO_DY_DENSE, false>(a, s) : launch_gemm<PRO_DY_SPARSE, false>(a, s);
@@ -546,14 +691,19 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
       a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
       a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW;
       a.n0 = n0; a.k0 = k0; a.NTn = (TN - n0) < 4 ? (TN - n0) : 4; a.NTk = (TK - k0) < 4 ? (TK - k0) : 4;
-      const size_t lds = sizeof(float) * 32 * ((a.NTn * 32 + 4) + (a.NTk * 32 + 4));
+      const int tn = a.NTn > 2 ? 2 : 1, tk = a.NTk > 2 ? 2 : 1;
+      const size_t lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
       int grid = cdiv(R, 32 * 4);
       if (grid > 512) grid = 512;
       if (grid < 1) grid = 1;
-      if (G)
-        hipLaunchKernelGGL((mlp_dw_kernel<4, false>), dim3(grid), dim3(256), lds, s, a);
-      else
-        hipLaunchKernelGGL((mlp_dw_kernel<4, true>), dim3(grid), dim3(256), lds, s, a);
+#define DW(TNv, TKv)                                                                             \
+      if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), dim3(grid), dim3(256), lds, s, a); \
+      else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true>), dim3(grid), dim3(256), lds, s, a)
+      if (tn == 1 && tk == 1) { DW(1, 1); }
+      else if (tn == 1) { DW(1, 2); }
+      else if (tk == 1) { DW(2, 1); }
+      else { DW(2, 2); }
+#undef DW
     }
   return check_launch("mlp_gemm_bwd_dw");
 }

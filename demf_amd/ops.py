@@ -494,7 +494,7 @@ class _SharedMLPPool(Function):
             g12 = torch.zeros(2 * N, dtype=torch.float64, device=dev)
             _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
                       _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12), st)
-            vec6 = torch.empty(6 * N, dtype=torch.float32, device=dev)
+            vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
             dgamma = torch.empty(N, dtype=torch.float32, device=dev)
             dbeta = torch.empty(N, dtype=torch.float32, device=dev)
             _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12), _p(gammas[l]), _p(sss[l]), _p(mis[l]),

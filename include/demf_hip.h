@@ -177,8 +177,8 @@ int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP, co
                        const float* Y, const float* scale_shift, const float* mean_invstd,
                        double* g12, demf_stream_t stream);
 
-/* g12 -> the six per-channel vectors the backward GEMM prologues consume (vec6, 6N floats:
- * scale, shift, mean, invstd*mean(dZ*xhat), mean(dZ), gamma*invstd) + dgamma, dbeta.  */
+/* g12 -> the five per-channel vectors the backward GEMM prologues consume (vec6: 5N floats:
+ * scale, shift, gi = gamma*invstd, a, b with dY = gi*dZ + a*y + b) + dgamma, dbeta.     */
 int demf_bn_bwd_vectors(int N, long long count, const double* g12, const float* gamma,
                         const float* scale_shift, const float* mean_invstd, float* vec6,
                         float* dgamma, float* dbeta, demf_stream_t stream);
