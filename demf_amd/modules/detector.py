@@ -32,22 +32,60 @@ class DeMFHotPath(nn.Module):
         x = self.pts_backbone(points)
         return x["fp_xyz"][-1], x["fp_features"][-1], x["fp_indices"][-1]
 
-    def forward_head(self, points, img_features, img_metas):
+    def _side_streams(self, device):
+        ss = self.__dict__.setdefault("_streams", {})
+        if str(device) not in ss:
+            ss[str(device)] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        return ss[str(device)]
+
+    def forward_head(self, points, img_features, img_metas, image_inputs=None):
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)                                    # demfnet.py:150
         seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points)
         feat_dict = dict(seed_points=seeds_3d, seed_features=seed_3d_features,
                          seed_indices=seed_indices)
-        img_dict = dict(img_features=img_features, img_metas=img_metas)
+        img_dict = dict(img_features=img_features, img_metas=img_metas, image_inputs=image_inputs)
         return self.pts_bbox_head(feat_dict, self.cfg.head.sample_mod, img_dict)  # :165
 
-    def forward_train(self, points, img_features, img_metas, gt_bboxes_3d, gt_labels_3d):
-        """-> dict of losses (demfnet.py:134-170 with the image pyramid precomputed)."""
+    def forward_train(self, points, img_features, img_metas, gt_bboxes_3d, gt_labels_3d,
+                      overlap=False):
+        """-> dict of losses (demfnet.py:134-170 with the image pyramid precomputed).
+
+        ``overlap=True``: the point stream starts with furthest-point sampling, which keeps 8 of
+        the 256 CUs busy for milliseconds; everything that does not depend on it - flattening /
+        masking / value-projecting the image tokens, and the per-point vote targets - is issued
+        on two side HIP streams.  Measured (profiles/, round 1): inside a captured hipGraph the
+        ROCm 7.2 runtime replays the forked branches serially (no kernel starts inside the FPS
+        launch) and the joins cost ~3 ms of idle, so the default is off until the step is
+        replayed as separate per-stream graphs."""
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)
-        bbox_preds = self.forward_head(points, img_features, img_metas)
-        return self.pts_bbox_head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d,
-                                       None, None, img_metas)                # :167
+        head = self.pts_bbox_head
+        if not (overlap and points.is_cuda):
+            bbox_preds = self.forward_head(points, img_features, img_metas)
+            return head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None, img_metas)
+        main = torch.cuda.current_stream()
+        s_img, s_tgt = self._side_streams(points.device)
+        s_img.wait_stream(main)
+        s_tgt.wait_stream(main)
+        with torch.cuda.stream(s_img):
+            image_inputs = head.prepare_image_inputs(img_features, img_metas)
+        with torch.cuda.stream(s_tgt):
+            vote_pack = head.vote_targets(points, gt_bboxes_3d, gt_labels_3d)
+        seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points)
+        main.wait_stream(s_img)
+        for t in [image_inputs["feat_flatten"], image_inputs["mask_flatten"],
+                  image_inputs["valid_ratios"], *image_inputs["value_projected"]]:
+            t.record_stream(main)
+        feat_dict = dict(seed_points=seeds_3d, seed_features=seed_3d_features,
+                         seed_indices=seed_indices)
+        img_dict = dict(img_features=img_features, img_metas=img_metas, image_inputs=image_inputs)
+        bbox_preds = head(feat_dict, self.cfg.head.sample_mod, img_dict)     # :165
+        main.wait_stream(s_tgt)
+        for t in vote_pack.values():
+            t.record_stream(main)
+        return head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None, img_metas,
+                         vote_pack=vote_pack)                                # :167
 
     def param_groups(self, lr=0.008, weight_decay=0.01):
         """AdamW groups of demf_votenet.py:16-24: 'decoder' params at lr*0.05."""

@@ -138,18 +138,24 @@ class DeMFVoteHead(nn.Module):
         aggregated_points, features, aggregated_indices = self.vote_aggregation(**agg_in)
         results["aggregated_points"] = aggregated_points
         results["aggregated_indices"] = aggregated_indices
-        results["decode_res_all"] = self.transformer_decoder(features, aggregated_points,
-                                                             img_features, img_metas)
+        results["decode_res_all"] = self.transformer_decoder(
+            features, aggregated_points, img_features, img_metas, img_dict.get("image_inputs"))
         return results
 
     # ---- :468-512 ------------------------------------------------------------
-    def transformer_decoder(self, features, aggregated_points, img_features, img_metas):
+    def transformer_decoder(self, features, aggregated_points, img_features, img_metas,
+                            image_inputs=None):
         decode_res_all = []
         cls_p, reg_p = self.conv_preds[0](features)
         decode_res = self.bbox_coder.split_pred(cls_p, reg_p, aggregated_points)
         decode_res_all.append(decode_res)
-        feat_flatten, mask_flatten, reference_points, spatial_shapes, level_start_index, \
-            valid_ratios = self.prepare_decoder_inputs(aggregated_points, img_features, img_metas)
+        if image_inputs is None:
+            image_inputs = self.prepare_image_inputs(img_features, img_metas)
+        feat_flatten, mask_flatten = image_inputs["feat_flatten"], image_inputs["mask_flatten"]
+        spatial_shapes = image_inputs["spatial_shapes"]
+        level_start_index, valid_ratios = image_inputs["level_start_index"], image_inputs["valid_ratios"]
+        reference_points = self.get_reference_points(aggregated_points, img_metas,
+                                                     image_inputs["spatial"])
         query = features.permute(2, 0, 1)
         for i in range(self.num_decoder_layers):
             query_pos = torch.cat([decode_res["center"], decode_res["size"]], dim=-1).detach().clone()
@@ -158,7 +164,8 @@ class DeMFVoteHead(nn.Module):
                                     reference_points=reference_points,
                                     spatial_shapes=spatial_shapes,
                                     level_start_index=level_start_index,
-                                    valid_ratios=valid_ratios)
+                                    valid_ratios=valid_ratios,
+                                    value_projected=image_inputs["value_projected"][i])
             cls_p, reg_p = self.conv_preds[i + 1](query.permute(1, 2, 0))
             decode_res = self.bbox_coder.split_pred(cls_p, reg_p, aggregated_points)
             decode_res_all.append(decode_res)
@@ -203,13 +210,15 @@ class DeMFVoteHead(nn.Module):
         return torch.clamp(uv, 0, 1)
 
     # ---- :549-594 ------------------------------------------------------------
-    def prepare_decoder_inputs(self, seeds_3d, mlvl_feats, img_metas):
+    def prepare_image_inputs(self, mlvl_feats, img_metas):
+        """The part of prepare_decoder_inputs (:556-594) that depends only on the image pyramid:
+        padding masks, flattened tokens, valid ratios - plus the per-layer value projection of
+        the fusion attention.  Independent of the point stream, so the detector runs it on a
+        side stream while furthest-point sampling occupies 8 of the 256 CUs."""
         spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-        reference_points = self.get_reference_points(seeds_3d, img_metas, spatial)
-        B = mlvl_feats[0].size(0)
         in_h, in_w = img_metas[0]["batch_input_shape"]
         dev = mlvl_feats[0].device
-        mt = self._meta_tensors(img_metas, spatial, dev, seeds_3d.dtype)
+        mt = self._meta_tensors(img_metas, spatial, dev, mlvl_feats[0].dtype)
         # padding masks: nearest-neighbour resize of the (B,Hpad,Wpad) mask == index lookup
         hw = mt["hw"]                                                              # (B,2)
         mlvl_masks = []
@@ -221,18 +230,26 @@ class DeMFVoteHead(nn.Module):
                               (xs[None, None, :] >= hw[:, 1, None, None]))
         feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
-        spatial_shapes, level_start_index = mt["spatial_shapes"], mt["level_start_index"]
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
         feat_flatten = feat_flatten.permute(1, 0, 2)
-        return feat_flatten, mask_flatten, reference_points, spatial_shapes, \
-            level_start_index, valid_ratios
+        value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)
+                           for layer in self.decoder]
+        return dict(feat_flatten=feat_flatten, mask_flatten=mask_flatten, spatial=spatial,
+                    spatial_shapes=mt["spatial_shapes"], level_start_index=mt["level_start_index"],
+                    valid_ratios=valid_ratios, value_projected=value_projected)
+
+    def prepare_decoder_inputs(self, seeds_3d, mlvl_feats, img_metas):
+        ii = self.prepare_image_inputs(mlvl_feats, img_metas)
+        reference_points = self.get_reference_points(seeds_3d, img_metas, ii["spatial"])
+        return ii["feat_flatten"], ii["mask_flatten"], reference_points, ii["spatial_shapes"], \
+            ii["level_start_index"], ii["valid_ratios"]
 
     # ---- loss: :596-712 ------------------------------------------------------
     def loss(self, bbox_preds, points, gt_bboxes_3d, gt_labels_3d, pts_semantic_mask=None,
-             pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None):
+             pts_instance_mask=None, img_metas=None, gt_bboxes_ignore=None, vote_pack=None):
         bbox_preds = dict(bbox_preds)
         decode_res_all = bbox_preds.pop("decode_res_all")
-        targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, bbox_preds)
+        targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, bbox_preds, vote_pack)
         losses_all = [self._loss({**bbox_preds, **d}, targets) for d in decode_res_all]
         assert self.num_fusion_layers + 1 == len(losses_all)
         return {k: sum(l[k] for l in losses_all) / (self.num_fusion_layers + 1)
@@ -308,23 +325,21 @@ class DeMFVoteHead(nn.Module):
         return gt, lab, valid
 
     @torch.no_grad()
-    def get_targets(self, points, gt_bboxes_3d, gt_labels_3d, bbox_preds):
-        if isinstance(gt_bboxes_3d, (list, tuple)):
-            dev = bbox_preds["aggregated_points"].device
-            gt, lab, valid = self.pad_gt(gt_bboxes_3d, gt_labels_3d, dev)
-        else:
-            gt, lab, valid = gt_bboxes_3d, gt_labels_3d, bbox_preds.get("gt_valid")
-            if valid is None:
-                valid = torch.ones(gt.shape[:2], dtype=torch.bool, device=gt.device)
+    def vote_targets(self, points, gt_bboxes_3d, gt_labels_3d):
+        """The proposal-independent half of get_targets (:828-858): per-point vote targets from
+        box membership (first / second / last containing box).  Only needs the inputs, so the
+        detector computes it on a side stream.  -> dict incl. the padded GT."""
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)
-        agg = bbox_preds["aggregated_points"]
+        if isinstance(gt_bboxes_3d, (list, tuple)):
+            gt, lab, valid = self.pad_gt(gt_bboxes_3d, gt_labels_3d, points.device)
+        else:
+            gt, lab = gt_bboxes_3d, gt_labels_3d
+            valid = torch.ones(gt.shape[:2], dtype=torch.bool, device=gt.device)
         B, G = gt.shape[:2]
         p = points[..., :3]
         center = torch.cat([gt[..., :2], gt[..., 2:3] + gt[..., 5:6] * 0.5], dim=-1)  # gravity
         dims, yaw = gt[..., 3:6], gt[..., 6]
-
-        # -- vote targets (:828-858) : first / second / last containing box per point
         rel = p[:, :, None, :] - center[:, None, :, :]                        # (B,N,G,3)
         cs, sn = torch.cos(-yaw)[:, None], torch.sin(-yaw)[:, None]
         lx = rel[..., 0] * cs + rel[..., 1] * sn
@@ -345,7 +360,16 @@ class DeMFVoteHead(nn.Module):
         s2 = torch.where(total >= 3, vl, v1)
         has = total > 0
         vote_targets = torch.cat([v1, s1, s2], dim=-1) * has.to(votes.dtype)
-        vote_target_masks = has.squeeze(-1).long()
+        return dict(gt=gt, lab=lab, valid=valid, center=center, dims=dims, yaw=yaw,
+                    vote_targets=vote_targets, vote_target_masks=has.squeeze(-1).long())
+
+    @torch.no_grad()
+    def get_targets(self, points, gt_bboxes_3d, gt_labels_3d, bbox_preds, vote_pack=None):
+        vp = vote_pack if vote_pack is not None else \
+            self.vote_targets(points, gt_bboxes_3d, gt_labels_3d)
+        lab, valid, center, dims, yaw = vp["lab"], vp["valid"], vp["center"], vp["dims"], vp["yaw"]
+        vote_targets, vote_target_masks = vp["vote_targets"], vp["vote_target_masks"]
+        agg = bbox_preds["aggregated_points"]
 
         # -- proposal targets (:877-934)
         dir_class_t, dir_res_t = self.bbox_coder.angle2class(yaw)

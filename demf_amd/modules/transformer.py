@@ -110,9 +110,20 @@ class MultiScaleDeformableAttention(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.constant_(self.output_proj.bias, 0.0)
 
+    def project_value(self, value, key_padding_mask=None):
+        """value (S,B,C) [batch_first: (B,S,C)] -> masked, projected (B,S,H,Dh).  Depends only on
+        the image tokens, so the head can run it ahead of time on a side stream."""
+        if not self.batch_first:
+            value = value.permute(1, 0, 2)
+        bs, num_value, _ = value.shape
+        value = self.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        return value.view(bs, num_value, self.num_heads, -1)
+
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, **kwargs):
+                level_start_index=None, value_projected=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -121,13 +132,9 @@ class MultiScaleDeformableAttention(nn.Module):
             query = query + query_pos
         if not self.batch_first:
             query = query.permute(1, 0, 2)
-            value = value.permute(1, 0, 2)
         bs, num_query, _ = query.shape
-        bs, num_value, _ = value.shape
-        value = self.value_proj(value)
-        if key_padding_mask is not None:
-            value = value.masked_fill(key_padding_mask[..., None], 0.0)
-        value = value.view(bs, num_value, self.num_heads, -1)
+        value = value_projected if value_projected is not None else \
+            self.project_value(value, key_padding_mask)
         offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels,
                                                     self.num_points, 2)
         weights = self.attention_weights(query).view(bs, num_query, self.num_heads,

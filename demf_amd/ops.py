@@ -434,6 +434,10 @@ class _SharedMLPPool(Function):
         st = _stream()
         Ys, sss, mis = [], [], []
         cur, cur_ld, pro = x, ld, None
+        # one zero-filled fp64 workspace for every layer's statistics (one fill, not L)
+        ws = torch.zeros(2 * sum(tensors[6 * l].shape[0] for l in range(L)), dtype=torch.float64,
+                         device=dev) if training else None
+        woff = 0
         for l in range(L):
             W, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 5]
             _chk(W, "weight")
@@ -443,7 +447,8 @@ class _SharedMLPPool(Function):
             ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
             mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
             if training:
-                stats = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+                stats = ws[woff:woff + 2 * N]
+                woff += 2 * N
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           _p(stats), st)
                 _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
@@ -488,10 +493,15 @@ class _SharedMLPPool(Function):
         G = None
         grads = [None] * (6 * L)
         dx = None
+        # zero-filled workspaces for all layers at once: BN reductions (fp64), weight grads (fp32)
+        ws64 = torch.zeros(2 * sum(W.shape[0] for W in Ws), dtype=torch.float64, device=dev)
+        ws32 = torch.zeros(sum(W.numel() for W in Ws), dtype=torch.float32, device=dev)
+        o64 = o32 = 0
         for l in range(L - 1, -1, -1):
             W = Ws[l]
             N, K = W.shape
-            g12 = torch.zeros(2 * N, dtype=torch.float64, device=dev)
+            g12 = ws64[o64:o64 + 2 * N]
+            o64 += 2 * N
             _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
                       _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12), st)
             vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
@@ -501,7 +511,8 @@ class _SharedMLPPool(Function):
                       _p(vec6), _p(dgamma), _p(dbeta), st)
             xprev = Ys[l - 1] if l > 0 else x
             ldx = xprev.shape[1]
-            dW = torch.zeros((N, K), dtype=torch.float32, device=dev)
+            dW = ws32[o32:o32 + N * K].view(N, K)
+            o32 += N * K
             sparse = G is None
             _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
                       _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(xprev),
