@@ -42,6 +42,9 @@ SIGNATURES = {
     "demf_bn_bwd_vectors": [_c_int, ctypes.c_longlong] + [_ptr] * 8,
     "demf_mlp_gemm_bwd_dx": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
     "demf_mlp_gemm_bwd_dw": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 6,
+    "demf_head_loss_fwd": [_c_int] * 3 + [_ptr] * 14,
+    "demf_head_loss_bwd": [_c_int] * 3 + [_ptr] * 17,
+    "demf_vote_loss": [_c_int] * 4 + [_c_float] + [_ptr] * 10,
     "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
 }

@@ -1,0 +1,310 @@
+// Fused DeMF head losses for gfx950.
+//
+// DeMFVoteHead._loss (demf/modeling/heads/class_agnostic_vote_head.py:622-712) evaluates, per
+// decode layer, seven reductions over the B*256 proposals (objectness CE, direction CE,
+// direction-residual / size / centre SmoothL1, semantic CE, axis-aligned IoU) plus the vote
+// loss over the B*1024 seeds (VoteModule.get_loss, called at :641-644) - upstream that is
+// ~100 small kernels forward and more backward, all launch-latency bound.  Here each is ONE
+// kernel forward and ONE backward over the raw prediction rows of the conv head:
+//   cls row (12) = [objectness 2 | semantic 10]
+//   reg row (30) = [centre offset 3 | size 3 | dir class 12 | dir residual (normalised) 12]
+// (the slicing of DeMFClassAgnosticBBoxCoder.split_pred, coder.py:196-240, folded in).
+// Loss definitions restate mmdet CrossEntropyLoss / SmoothL1Loss and mmdet3d
+// AxisAlignedIoULoss with reduction='sum' (configs/demf/demf_votenet.py:116-141).
+#include "common.h"
+
+namespace demf {
+
+struct HeadLossCfg {
+  int R, ncls, nreg, nbins, nsem;          // rows, 12, 30, 12, 10
+  float cw0, cw1;                          // objectness class weights
+  float w_obj, w_dircls, w_dirres, w_size, w_center, w_sem, w_iou;
+  float beta_dirres, beta_size, beta_center;
+};
+
+// order of the 7 outputs: objectness, dir_class, dir_res, size_res, center, semantic, iou
+constexpr int NLOSS = 7;
+
+__device__ __forceinline__ float smooth_l1(float d, float beta) {
+  const float a = fabsf(d);
+  return a < beta ? 0.5f * a * a / beta : a - 0.5f * beta;
+}
+__device__ __forceinline__ float smooth_l1_grad(float d, float beta) {
+  const float a = fabsf(d);
+  return a < beta ? d / beta : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+}
+
+// log-softmax cross entropy over n logits at p; returns loss, optionally writes softmax-onehot
+template <int MAXN>
+__device__ __forceinline__ float ce(const float* p, int n, int t, float* grad /*nullable*/, float gscale) {
+  float m = p[0];
+  for (int i = 1; i < n; ++i) m = fmaxf(m, p[i]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += __expf(p[i] - m);
+  const float lse = m + __logf(s);
+  if (grad)
+    for (int i = 0; i < n; ++i) grad[i] += gscale * (__expf(p[i] - lse) - (i == t ? 1.f : 0.f));
+  return lse - p[t];
+}
+
+struct IoU {
+  float iou, overlap, uni;
+  float lo[3], hi[3];          // intersection bounds
+  bool pos[3];                 // intersection extent > 0 per axis
+  bool clamped;                // union was clamped to eps
+};
+
+__device__ __forceinline__ IoU aa_iou(const float* c, const float* s, const float* ct, const float* st) {
+  IoU r;
+  float a1 = 1.f, a2 = 1.f, ov = 1.f;
+  for (int k = 0; k < 3; ++k) {
+    const float l1 = c[k] - s[k] * 0.5f, h1 = c[k] + s[k] * 0.5f;
+    const float l2 = ct[k] - st[k] * 0.5f, h2 = ct[k] + st[k] * 0.5f;
+    a1 *= (h1 - l1);
+    a2 *= (h2 - l2);
+    r.lo[k] = fmaxf(l1, l2);
+    r.hi[k] = fminf(h1, h2);
+    const float w = r.hi[k] - r.lo[k];
+    r.pos[k] = w > 0.f;
+    ov *= fmaxf(w, 0.f);
+  }
+  r.overlap = ov;
+  const float u = a1 + a2 - ov;
+  r.clamped = u < 1e-6f;
+  r.uni = r.clamped ? 1e-6f : u;
+  r.iou = ov / r.uni;
+  return r;
+}
+
+// one thread per proposal row; block-reduce the 7 partial sums; fp32 atomics into out[7]
+__global__ __launch_bounds__(256) void head_loss_fwd_k(
+    HeadLossCfg c, const float* __restrict__ cls, const float* __restrict__ reg,
+    const float* __restrict__ base, const float* __restrict__ center_t,
+    const float* __restrict__ size_t_, const long long* __restrict__ dircls_t,
+    const float* __restrict__ dirres_t, const long long* __restrict__ sem_t,
+    const long long* __restrict__ obj_t, const float* __restrict__ obj_w,
+    const float* __restrict__ box_w, float* __restrict__ out) {
+  __shared__ float red[NLOSS][256];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  float l[NLOSS] = {0, 0, 0, 0, 0, 0, 0};
+  if (r < c.R) {
+    const float* pc = cls + (size_t)r * c.ncls;
+    const float* pr = reg + (size_t)r * c.nreg;
+    const float bw = box_w[r];
+    const int ot = (int)obj_t[r];
+    l[0] = c.w_obj * obj_w[r] * (ot ? c.cw1 : c.cw0) * ce<2>(pc, 2, ot, nullptr, 0.f);
+    if (bw != 0.f) {   // every box term carries the weight objectness_target / n_pos
+      const int dt = (int)dircls_t[r];
+      float cen[3], siz[3];
+      for (int k = 0; k < 3; ++k) {
+        cen[k] = base[r * 3 + k] + pr[k];
+        siz[k] = pr[3 + k];
+      }
+      l[1] = c.w_dircls * bw * ce<12>(pr + 6, c.nbins, dt, nullptr, 0.f);
+      l[2] = c.w_dirres * bw * smooth_l1(pr[6 + c.nbins + dt] - dirres_t[r], c.beta_dirres);
+      for (int k = 0; k < 3; ++k) {
+        l[3] += c.w_size * bw * smooth_l1(siz[k] - size_t_[r * 3 + k], c.beta_size);
+        l[4] += c.w_center * bw * smooth_l1(cen[k] - center_t[r * 3 + k], c.beta_center);
+      }
+      l[5] = c.w_sem * bw * ce<10>(pc + 2, c.nsem, (int)sem_t[r], nullptr, 0.f);
+      const IoU u = aa_iou(cen, siz, center_t + r * 3, size_t_ + r * 3);
+      l[6] = c.w_iou * bw * (1.f - u.iou);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NLOSS; ++i) red[i][threadIdx.x] = l[i];
+  __syncthreads();
+  for (int sft = 128; sft > 0; sft >>= 1) {
+    if (threadIdx.x < sft)
+#pragma unroll
+      for (int i = 0; i < NLOSS; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + sft];
+    __syncthreads();
+  }
+  if (threadIdx.x < NLOSS) atomicAdd(out + threadIdx.x, red[threadIdx.x][0]);
+}
+
+// gradients wrt cls (R,12), reg (R,30), base (R,3) given the 7 upstream scalars gout[7]
+__global__ __launch_bounds__(256) void head_loss_bwd_k(
+    HeadLossCfg c, const float* __restrict__ cls, const float* __restrict__ reg,
+    const float* __restrict__ base, const float* __restrict__ center_t,
+    const float* __restrict__ size_t_, const long long* __restrict__ dircls_t,
+    const float* __restrict__ dirres_t, const long long* __restrict__ sem_t,
+    const long long* __restrict__ obj_t, const float* __restrict__ obj_w,
+    const float* __restrict__ box_w, const float* __restrict__ gout,
+    float* __restrict__ gcls, float* __restrict__ greg, float* __restrict__ gbase) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.R) return;
+  const float* pc = cls + (size_t)r * c.ncls;
+  const float* pr = reg + (size_t)r * c.nreg;
+  float gc[12], gr[30];
+  for (int i = 0; i < c.ncls; ++i) gc[i] = 0.f;
+  for (int i = 0; i < c.nreg; ++i) gr[i] = 0.f;
+  const float bw = box_w[r];
+  const int ot = (int)obj_t[r];
+  ce<2>(pc, 2, ot, gc, gout[0] * c.w_obj * obj_w[r] * (ot ? c.cw1 : c.cw0));
+  if (bw != 0.f) {
+    const int dt = (int)dircls_t[r];
+    float cen[3], siz[3];
+    for (int k = 0; k < 3; ++k) {
+      cen[k] = base[r * 3 + k] + pr[k];
+      siz[k] = pr[3 + k];
+    }
+    ce<12>(pr + 6, c.nbins, dt, gr + 6, gout[1] * c.w_dircls * bw);
+    gr[6 + c.nbins + dt] += gout[2] * c.w_dirres * bw *
+                            smooth_l1_grad(pr[6 + c.nbins + dt] - dirres_t[r], c.beta_dirres);
+    for (int k = 0; k < 3; ++k) {
+      gr[3 + k] += gout[3] * c.w_size * bw * smooth_l1_grad(siz[k] - size_t_[r * 3 + k], c.beta_size);
+      gr[k] += gout[4] * c.w_center * bw * smooth_l1_grad(cen[k] - center_t[r * 3 + k], c.beta_center);
+    }
+    ce<10>(pc + 2, c.nsem, (int)sem_t[r], gc + 2, gout[5] * c.w_sem * bw);
+    // IoU: loss = 1 - ov/u ; d(ov)/d(.) via the intersection extents, d(a1)/d(size)
+    const IoU u = aa_iou(cen, siz, center_t + r * 3, size_t_ + r * 3);
+    const float gl = -gout[6] * c.w_iou * bw;       // d total / d iou
+    // d iou = (d ov * u - ov * d u) / u^2, d u = d a1 - d ov (unless clamped: d u = 0)
+    const float inv_u = 1.f / u.uni;
+    const float k_ov = gl * (inv_u + (u.clamped ? 0.f : u.overlap * inv_u * inv_u));
+    const float k_a1 = u.clamped ? 0.f : -gl * u.overlap * inv_u * inv_u;
+    float ext[3], sz[3];
+    for (int k = 0; k < 3; ++k) {
+      ext[k] = fmaxf(u.hi[k] - u.lo[k], 0.f);
+      sz[k] = siz[k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      const float other_ov = ext[(k + 1) % 3] * ext[(k + 2) % 3];
+      const float other_a1 = sz[(k + 1) % 3] * sz[(k + 2) % 3];
+      float d_hi_c = 0.f, d_hi_s = 0.f, d_lo_c = 0.f, d_lo_s = 0.f;
+      if (u.pos[k]) {
+        const float l1 = cen[k] - siz[k] * 0.5f, h1 = cen[k] + siz[k] * 0.5f;
+        const float l2 = center_t[r * 3 + k] - size_t_[r * 3 + k] * 0.5f;
+        const float h2 = center_t[r * 3 + k] + size_t_[r * 3 + k] * 0.5f;
+        // torch.min/max backward: on ties the gradient is split evenly between both operands
+        const float wh = h1 < h2 ? 1.f : (h1 == h2 ? 0.5f : 0.f);
+        const float wl = l1 > l2 ? 1.f : (l1 == l2 ? 0.5f : 0.f);
+        d_hi_c = wh; d_hi_s = 0.5f * wh;
+        d_lo_c = wl; d_lo_s = -0.5f * wl;
+      }
+      const float d_ext_c = d_hi_c - d_lo_c, d_ext_s = d_hi_s - d_lo_s;
+      const float g_c = k_ov * other_ov * d_ext_c;
+      const float g_s = k_ov * other_ov * d_ext_s + k_a1 * other_a1;
+      gr[k] += g_c;
+      gr[3 + k] += g_s;
+    }
+  }
+  for (int i = 0; i < c.ncls; ++i) gcls[(size_t)r * c.ncls + i] = gc[i];
+  for (int i = 0; i < c.nreg; ++i) greg[(size_t)r * c.nreg + i] = gr[i];
+  for (int k = 0; k < 3; ++k) gbase[r * 3 + k] = gr[k];   // centre = base + offset
+}
+
+// ---- vote loss: sum over seeds of min_j L1(vote - (gt_vote_j + seed)) * mask/(sum mask) * w --
+__global__ __launch_bounds__(256) void vote_loss_k(
+    int B, int S, int N, int G3 /*3*gt_per_seed*/, float wdst, const float* __restrict__ seed,
+    const float* __restrict__ vote, const long long* __restrict__ seed_idx,
+    const long long* __restrict__ tmask, const float* __restrict__ vtgt,
+    const float* __restrict__ mask_sum, const float* __restrict__ gout /*null: forward*/,
+    float* __restrict__ out, float* __restrict__ gvote) {
+  __shared__ float red[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (i < B * S) {
+    const int b = i / S;
+    const long long k = seed_idx[i];
+    const float w = (float)tmask[(size_t)b * N + k] / (mask_sum[0] + 1e-6f) * wdst;
+    const float* t = vtgt + ((size_t)b * N + k) * G3;
+    float best = 3.0e38f;
+    int bj = 0;
+    for (int j = 0; j < G3 / 3; ++j) {
+      float d = 0.f;
+      for (int c = 0; c < 3; ++c) d += fabsf(vote[i * 3 + c] - (t[j * 3 + c] + seed[i * 3 + c])) * w;
+      if (d < best) {
+        best = d;
+        bj = j;
+      }
+    }
+    l = best;
+    if (gout) {
+      for (int c = 0; c < 3; ++c) {
+        const float d = vote[i * 3 + c] - (t[bj * 3 + c] + seed[i * 3 + c]);
+        gvote[i * 3 + c] = gout[0] * w * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      }
+    }
+  }
+  if (!gout) {
+    red[threadIdx.x] = l;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+  }
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+static HeadLossCfg make_cfg(int R, const float* hp) {
+  HeadLossCfg c;
+  c.R = R; c.ncls = 12; c.nreg = 30; c.nbins = 12; c.nsem = 10;
+  c.cw0 = hp[0]; c.cw1 = hp[1];
+  c.w_obj = hp[2]; c.w_dircls = hp[3]; c.w_dirres = hp[4]; c.w_size = hp[5]; c.w_center = hp[6];
+  c.w_sem = hp[7]; c.w_iou = hp[8];
+  c.beta_dirres = hp[9]; c.beta_size = hp[10]; c.beta_center = hp[11];
+  return c;
+}
+
+extern "C" int demf_head_loss_fwd(int R, int num_dir_bins, int num_classes, const float* hyper12,
+                                  const float* cls, const float* reg, const float* base_xyz,
+                                  const float* center_t, const float* size_t_,
+                                  const int64_t* dir_class_t, const float* dir_res_t,
+                                  const int64_t* sem_t, const int64_t* obj_t, const float* obj_w,
+                                  const float* box_w, float* out7, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && num_dir_bins == 12 && num_classes == 10,
+               "head_loss: only the reference layout (12 direction bins, 10 classes) is built");
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(hyper12 && cls && reg && base_xyz && center_t && size_t_ && dir_class_t && dir_res_t &&
+                   sem_t && obj_t && obj_w && box_w && out7, "head_loss_fwd: null pointer");
+  hipLaunchKernelGGL(head_loss_fwd_k, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+                     make_cfg(R, hyper12), cls, reg, base_xyz, center_t, size_t_,
+                     (const long long*)dir_class_t, dir_res_t, (const long long*)sem_t,
+                     (const long long*)obj_t, obj_w, box_w, out7);
+  return check_launch("head_loss_fwd");
+}
+
+extern "C" int demf_head_loss_bwd(int R, int num_dir_bins, int num_classes, const float* hyper12,
+                                  const float* cls, const float* reg, const float* base_xyz,
+                                  const float* center_t, const float* size_t_,
+                                  const int64_t* dir_class_t, const float* dir_res_t,
+                                  const int64_t* sem_t, const int64_t* obj_t, const float* obj_w,
+                                  const float* box_w, const float* grad_out7, float* grad_cls,
+                                  float* grad_reg, float* grad_base, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && num_dir_bins == 12 && num_classes == 10,
+               "head_loss: only the reference layout (12 direction bins, 10 classes) is built");
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(hyper12 && cls && reg && base_xyz && center_t && size_t_ && dir_class_t && dir_res_t &&
+                   sem_t && obj_t && obj_w && box_w && grad_out7 && grad_cls && grad_reg && grad_base,
+               "head_loss_bwd: null pointer");
+  hipLaunchKernelGGL(head_loss_bwd_k, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream,
+                     make_cfg(R, hyper12), cls, reg, base_xyz, center_t, size_t_,
+                     (const long long*)dir_class_t, dir_res_t, (const long long*)sem_t,
+                     (const long long*)obj_t, obj_w, box_w, grad_out7, grad_cls, grad_reg, grad_base);
+  return check_launch("head_loss_bwd");
+}
+
+extern "C" int demf_vote_loss(int B, int S, int N, int gt_per_seed, float dst_weight,
+                              const float* seed_points, const float* vote_points,
+                              const int64_t* seed_indices, const int64_t* vote_target_masks,
+                              const float* vote_targets, const float* mask_sum,
+                              const float* grad_out, float* out, float* grad_vote,
+                              demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && S >= 0 && N >= 1 && gt_per_seed >= 1, "vote_loss: bad sizes");
+  if (B * S == 0) return DEMF_OK;
+  DEMF_REQUIRE(seed_points && vote_points && seed_indices && vote_target_masks && vote_targets &&
+                   mask_sum && (grad_out ? grad_vote != nullptr : out != nullptr),
+               "vote_loss: null pointer");
+  hipLaunchKernelGGL(vote_loss_k, dim3(cdiv(B * S, 256)), dim3(256), 0, (hipStream_t)stream, B, S, N,
+                     3 * gt_per_seed, dst_weight, seed_points, vote_points,
+                     (const long long*)seed_indices, (const long long*)vote_target_masks,
+                     vote_targets, mask_sum, grad_out, out, grad_vote);
+  return check_launch("vote_loss");
+}

@@ -147,7 +147,7 @@ class DeMFVoteHead(nn.Module):
                             image_inputs=None):
         decode_res_all = []
         cls_p, reg_p = self.conv_preds[0](features)
-        decode_res = self.bbox_coder.split_pred(cls_p, reg_p, aggregated_points)
+        decode_res = self._split(cls_p, reg_p, aggregated_points)
         decode_res_all.append(decode_res)
         if image_inputs is None:
             image_inputs = self.prepare_image_inputs(img_features, img_metas)
@@ -167,9 +167,16 @@ class DeMFVoteHead(nn.Module):
                                     valid_ratios=valid_ratios,
                                     value_projected=image_inputs["value_projected"][i])
             cls_p, reg_p = self.conv_preds[i + 1](query.permute(1, 2, 0))
-            decode_res = self.bbox_coder.split_pred(cls_p, reg_p, aggregated_points)
+            decode_res = self._split(cls_p, reg_p, aggregated_points)
             decode_res_all.append(decode_res)
         return decode_res_all
+
+    def _split(self, cls_p, reg_p, base_xyz):
+        """split_pred + private handles on the raw conv-head rows ((B*Q, 12) / (B*Q, 30) - the
+        point-major storage behind cls_p / reg_p) for the fused loss kernel."""
+        res = self.bbox_coder.split_pred(cls_p, reg_p, base_xyz)
+        res["_rows"] = (cls_p.transpose(1, 2), reg_p.transpose(1, 2), base_xyz)
+        return res
 
     # ---- :514-522 ------------------------------------------------------------
     def get_valid_ratio(self, mask):
@@ -260,6 +267,10 @@ class DeMFVoteHead(nn.Module):
          objectness_targets, objectness_weights, box_loss_weights, distance_targets,
          dir_targets, size_targets, center_targets) = targets
         c = self.loss_cfg
+        rows = bbox_preds.get("_rows")
+        if rows is not None and rows[0].is_cuda and rows[0].shape[-1] == 12 and \
+                rows[1].shape[-1] == 30 and c["semantic"] is not None and c["iou"]:
+            return self._loss_fused(bbox_preds, targets, rows)
         vote_loss = self.vote_module.get_loss(bbox_preds["seed_points"], bbox_preds["vote_points"],
                                               bbox_preds["seed_indices"], vote_target_masks,
                                               vote_targets)
@@ -301,6 +312,36 @@ class DeMFVoteHead(nn.Module):
             losses["iou_loss"] = L.axis_aligned_iou_loss_sum(corners_pred, corners_target,
                                                              box_loss_weights,
                                                              c["iou"].get("loss_weight", 1.0))
+        return losses
+
+    def _loss_fused(self, bbox_preds, targets, rows):
+        """The same eight losses through csrc/loss.hip: one kernel for the seven per-proposal
+        reductions and one for the vote loss (instead of ~100 small kernels each way)."""
+        (vote_targets, vote_target_masks, dir_class_targets, dir_res_targets, mask_targets,
+         objectness_targets, objectness_weights, box_loss_weights, distance_targets,
+         dir_targets, size_targets, center_targets) = targets
+        c = self.loss_cfg
+        cw = c["objectness"].get("class_weight") or [1.0, 1.0]
+        hyper = (cw[0], cw[1], c["objectness"].get("loss_weight", 1.0),
+                 c["dir_class"].get("loss_weight", 1.0), c["dir_res"].get("loss_weight", 1.0),
+                 c["size_res"].get("loss_weight", 1.0), c["center"].get("loss_weight", 1.0),
+                 c["semantic"].get("loss_weight", 1.0), c["iou"].get("loss_weight", 1.0),
+                 c["dir_res"].get("beta", 1.0), c["size_res"].get("beta", 1.0),
+                 c["center"].get("beta", 1.0))
+        cls_rows, reg_rows, base = rows
+        R = cls_rows.shape[0] * cls_rows.shape[1]
+        seven = ops.head_loss(
+            cls_rows.reshape(R, 12), reg_rows.reshape(R, 30), base.reshape(R, 3).contiguous(), hyper,
+            center_targets.reshape(R, 3), size_targets.reshape(R, 3),
+            dir_class_targets.reshape(R), dir_res_targets.reshape(R).contiguous(),
+            mask_targets.reshape(R), objectness_targets.reshape(R),
+            objectness_weights.reshape(R).contiguous(), box_loss_weights.reshape(R).contiguous())
+        losses = dict(vote_loss=ops.vote_loss(bbox_preds["vote_points"], bbox_preds["seed_points"],
+                                              bbox_preds["seed_indices"], vote_target_masks,
+                                              vote_targets, self.gt_per_seed,
+                                              self.vote_module.vote_loss_dst_weight))
+        for i, name in enumerate(ops.HEAD_LOSS_NAMES):
+            losses[name] = seven[i]
         return losses
 
     # ---- targets: :756-941, batched ----------------------------------------------

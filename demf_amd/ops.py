@@ -551,3 +551,95 @@ def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1):
                 if len(layer) > 5 and layer[5] is not None:
                     layer[3].add_(layer[5], alpha=momentum)
     return out
+
+
+# --------------------------------------------------------------------------
+# Fused head losses (DeMFVoteHead._loss on the raw conv-head rows)
+# --------------------------------------------------------------------------
+import ctypes as _ct
+
+HEAD_LOSS_NAMES = ("objectness_loss", "dir_class_loss", "dir_res_loss", "size_res_loss",
+                   "center_loss", "semantic_loss", "iou_loss")
+
+
+class _HeadLoss(Function):
+    @staticmethod
+    def forward(ctx, cls_rows, reg_rows, base, hyper, center_t, size_t, dir_class_t, dir_res_t,
+                sem_t, obj_t, obj_w, box_w):
+        for t, n in ((cls_rows, "cls"), (reg_rows, "reg"), (base, "base"), (center_t, "center_t"),
+                     (size_t, "size_t"), (dir_res_t, "dir_res_t"), (obj_w, "obj_w"), (box_w, "box_w")):
+            _chk(t, n)
+        for t, n in ((dir_class_t, "dir_class_t"), (sem_t, "sem_t"), (obj_t, "obj_t")):
+            _chk(t, n, torch.int64)
+        R = cls_rows.shape[0]
+        assert cls_rows.shape[1] == 12 and reg_rows.shape[1] == 30
+        hp = (_ct.c_float * 12)(*hyper)
+        out = torch.zeros(7, dtype=torch.float32, device=cls_rows.device)
+        _ffi.call("demf_head_loss_fwd", R, 12, 10, hp, _p(cls_rows), _p(reg_rows), _p(base),
+                  _p(center_t), _p(size_t), _p(dir_class_t), _p(dir_res_t), _p(sem_t), _p(obj_t),
+                  _p(obj_w), _p(box_w), _p(out), _stream())
+        ctx.save_for_backward(cls_rows, reg_rows, base, center_t, size_t, dir_class_t, dir_res_t,
+                              sem_t, obj_t, obj_w, box_w)
+        ctx.hyper = tuple(hyper)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        cls_rows, reg_rows, base = ctx.saved_tensors[:3]
+        rest = ctx.saved_tensors[3:]
+        R = cls_rows.shape[0]
+        hp = (_ct.c_float * 12)(*ctx.hyper)
+        gout = grad_out.contiguous()
+        gc, gr, gb = torch.empty_like(cls_rows), torch.empty_like(reg_rows), torch.empty_like(base)
+        _ffi.call("demf_head_loss_bwd", R, 12, 10, hp, _p(cls_rows), _p(reg_rows), _p(base),
+                  *[_p(t) for t in rest], _p(gout), _p(gc), _p(gr), _p(gb), _stream())
+        return (gc, gr, gb) + (None,) * 9
+
+
+def head_loss(cls_rows, reg_rows, base_xyz, hyper12, center_t, size_t, dir_class_t, dir_res_t,
+              sem_t, obj_t, obj_w, box_w):
+    """-> (7,) tensor of reduction='sum' losses in HEAD_LOSS_NAMES order; rows are (B*Q, .)."""
+    return _HeadLoss.apply(cls_rows, reg_rows, base_xyz, hyper12, center_t, size_t, dir_class_t,
+                           dir_res_t, sem_t, obj_t, obj_w, box_w)
+
+
+class _VoteLoss(Function):
+    @staticmethod
+    def forward(ctx, vote_points, seed_points, seed_indices, masks, vote_targets, gt_per_seed,
+                dst_weight):
+        _chk(vote_points, "vote_points")
+        _chk(seed_points, "seed_points")
+        _chk(seed_indices, "seed_indices", torch.int64)
+        _chk(masks, "vote_target_masks", torch.int64)
+        _chk(vote_targets, "vote_targets")
+        B, S, _ = seed_points.shape
+        N = masks.shape[1]
+        msum = torch.gather(masks, 1, seed_indices).sum().to(torch.float32).reshape(1)
+        out = torch.zeros(1, dtype=torch.float32, device=vote_points.device)
+        _ffi.call("demf_vote_loss", B, S, N, int(gt_per_seed), float(dst_weight), _p(seed_points),
+                  _p(vote_points), _p(seed_indices), _p(masks), _p(vote_targets), _p(msum), None,
+                  _p(out), None, _stream())
+        ctx.save_for_backward(vote_points, seed_points, seed_indices, masks, vote_targets, msum)
+        ctx.meta = (B, S, N, int(gt_per_seed), float(dst_weight))
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        vote_points, seed_points, seed_indices, masks, vote_targets, msum = ctx.saved_tensors
+        B, S, N, gps, w = ctx.meta
+        g = grad_out.reshape(1).contiguous()
+        gv = torch.empty_like(vote_points)
+        _ffi.call("demf_vote_loss", B, S, N, gps, w, _p(seed_points), _p(vote_points),
+                  _p(seed_indices), _p(masks), _p(vote_targets), _p(msum), _p(g), None, _p(gv),
+                  _stream())
+        return gv, None, None, None, None, None, None
+
+
+def vote_loss(vote_points, seed_points, seed_indices, vote_target_masks, vote_targets, gt_per_seed,
+              dst_weight):
+    """VoteModule.get_loss (vote_per_seed == 1) as one kernel each way."""
+    return _VoteLoss.apply(vote_points.contiguous(), seed_points.contiguous(), seed_indices.contiguous(),
+                           vote_target_masks.contiguous(), vote_targets.contiguous(), gt_per_seed,
+                           dst_weight)

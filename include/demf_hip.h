@@ -197,6 +197,41 @@ int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const flo
                          demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Fused head losses: DeMFVoteHead._loss (class_agnostic_vote_head.py:622-712)
+ * over the raw conv-head rows  cls (R,12) = [objectness 2 | semantic 10],
+ * reg (R,30) = [centre offset 3 | size 3 | dir class 12 | dir residual 12]
+ * (split_pred of coder.py:196-240 folded in); base_xyz (R,3) = aggregated points.
+ * hyper12 (host floats) = objectness class weights (2), loss weights of objectness /
+ * dir_class / dir_res / size / centre / semantic / iou (7), SmoothL1 betas of dir_res /
+ * size / centre (3)   [configs/demf/demf_votenet.py:116-141].
+ * out7 (accumulated) = the seven reduction='sum' losses in that order.
+ * ------------------------------------------------------------------ */
+int demf_head_loss_fwd(int R, int num_dir_bins, int num_classes, const float* hyper12,
+                       const float* cls, const float* reg, const float* base_xyz,
+                       const float* center_t, const float* size_t_, const int64_t* dir_class_t,
+                       const float* dir_res_t, const int64_t* sem_t, const int64_t* obj_t,
+                       const float* obj_w, const float* box_w, float* out7,
+                       demf_stream_t stream);
+/* gradients wrt cls, reg, base_xyz given the seven upstream scalars grad_out7 (device).  */
+int demf_head_loss_bwd(int R, int num_dir_bins, int num_classes, const float* hyper12,
+                       const float* cls, const float* reg, const float* base_xyz,
+                       const float* center_t, const float* size_t_, const int64_t* dir_class_t,
+                       const float* dir_res_t, const int64_t* sem_t, const int64_t* obj_t,
+                       const float* obj_w, const float* box_w, const float* grad_out7,
+                       float* grad_cls, float* grad_reg, float* grad_base,
+                       demf_stream_t stream);
+
+/* VoteModule.get_loss (called at class_agnostic_vote_head.py:641-644): chamfer-L1 of each
+ * seed's vote against its gt_per_seed target votes, min over targets, weighted by
+ * mask/(mask_sum+1e-6)*dst_weight.  grad_out == NULL: forward (out accumulated);
+ * otherwise backward: grad_vote (B,S,3) written.                                  */
+int demf_vote_loss(int B, int S, int N, int gt_per_seed, float dst_weight,
+                   const float* seed_points, const float* vote_points,
+                   const int64_t* seed_indices, const int64_t* vote_target_masks,
+                   const float* vote_targets, const float* mask_sum, const float* grad_out,
+                   float* out, float* grad_vote, demf_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * DeMF fusion: multi-scale deformable attention core
  * ------------------------------------------------------------------ */
 

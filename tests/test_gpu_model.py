@@ -54,6 +54,8 @@ def test_hot_path_vs_real_reference_goldens(name, seed, B, n_gt, golden_dir):
         np.testing.assert_allclose(preds[k].detach().cpu().numpy(), gold[k], **TOL, err_msg=k)
     for i, d in enumerate(preds["decode_res_all"]):
         for k, v in d.items():
+            if k.startswith("_"):       # private handles for the fused loss kernel
+                continue
             _close_to_gold(v.detach().cpu().numpy(), gold[f"decode{i}.{k}"], f"decode{i}.{k}")
     losses = model.pts_bbox_head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
     for k, v in losses.items():
