@@ -112,6 +112,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="compute the FPS/ball-query pre-pass inside the step instead of pipelining it")
+    ap.add_argument("--cu-mask", action="store_true",
+                    help="pin the FPS pre-pass to its own CUs (hipExtStreamCreateWithCUMask); measured: "
+                         "no effect under hipGraph replay, off by default")
     args = ap.parse_args()
 
     rank, local, world = engine.init_distributed()
@@ -133,7 +138,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = (lambda: trainer.step(batch)) if args.no_graph else trainer.capture(batch)
+    if not args.no_graph and args.cu_mask:
+        # FPS pre-pass of the next batch on B dedicated CUs, the step on the other 256-B
+        main_s, trainer.side_stream = engine.cu_masked_streams(list(range(args.batch)))
+        torch.cuda.set_stream(main_s)
+    step = (lambda: trainer.step(batch)) if args.no_graph else \
+        trainer.capture(batch, prefetch_geometry=not args.no_prefetch)
     for _ in range(args.warmup):
         step()
     sync()
@@ -171,7 +181,8 @@ def main():
                                    "allreduce+AdamW, 8 scenes/GPU x (20000 pts, 800x1120 -> "
                                    "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=2, fp32",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph(fwd+loss+bwd) + eager allreduce/AdamW"},
+                       "launch": "eager" if args.no_graph else "hipGraph(fwd+loss+bwd) + eager allreduce/AdamW; "
+                                 "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
             "roofline": {"kernel": "fps_reg_kernel<1024,20> (20000->2048)", "bound": "hbm",
                          "achieved": algo_bytes / (fps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -17,6 +17,7 @@ _ptr = ctypes.c_void_p
 
 # name -> argtypes, exactly mirroring include/demf_hip.h
 SIGNATURES = {
+    "demf_stream_create_cu_masked": [_ptr, _c_int, _c_int, _ptr],
     "demf_fps_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "demf_ball_query_f32": [_c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _ptr, _ptr,
                             _ptr, _ptr],

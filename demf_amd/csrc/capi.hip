@@ -28,3 +28,34 @@ int check_launch(const char* what) {
 
 extern "C" int demf_version(void) { return DEMF_ABI_VERSION; }
 extern "C" const char* demf_last_error(void) { return demf::g_err; }
+
+// A HIP stream restricted to a subset of the CUs (hipExtStreamCreateWithCUMask).  Used by the
+// training engine to pin the latency-bound FPS pre-pass of the next batch to a few CUs and keep
+// the main stream off them: co-resident FPS waves are the oldest on their SIMDs and win issue
+// arbitration, which otherwise stretches the tail of every main-stream kernel (measured).
+// `cus` lists CU indices; `invert` != 0 selects all CUs EXCEPT those.
+extern "C" int demf_stream_create_cu_masked(const int* cus, int n, int invert, void** out) {
+  DEMF_REQUIRE(cus && n >= 0 && out, "stream_create_cu_masked: bad arguments");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    demf::set_error("stream_create_cu_masked: cannot query the device");
+    return DEMF_ELAUNCH;
+  }
+  const int ncu = prop.multiProcessorCount;
+  const int words = (ncu + 31) / 32;
+  uint32_t mask[16] = {0};
+  DEMF_REQUIRE(words <= 16, "stream_create_cu_masked: %d CUs unsupported", ncu);
+  for (int i = 0; i < n; ++i)
+    if (cus[i] >= 0 && cus[i] < ncu) mask[cus[i] / 32] |= 1u << (cus[i] % 32);
+  if (invert)
+    for (int i = 0; i < ncu; ++i) mask[i / 32] ^= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask);
+  if (e != hipSuccess) {
+    demf::set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return DEMF_ELAUNCH;
+  }
+  *out = (void*)s;
+  return DEMF_OK;
+}

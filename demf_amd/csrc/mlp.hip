@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
 
 static int mlp_grid(int R, int brows) {
   const int tiles = (R + brows - 1) / brows;
-  const int cap = 256 * 2;
+  const int cap = 256 * 2;   // persistent: two 256-thread blocks per CU
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 

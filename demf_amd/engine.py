@@ -35,6 +35,21 @@ def init_distributed():
     return rank, local, world
 
 
+def cu_masked_streams(side_cus):
+    """(main, side) torch streams on disjoint CU sets: ``side`` runs only on ``side_cus``, ``main``
+    on every other CU (hipExtStreamCreateWithCUMask through libdemf_hip.so)."""
+    import ctypes
+    from . import _ffi
+    arr = (ctypes.c_int * len(side_cus))(*side_cus)
+    out = []
+    for invert in (1, 0):
+        h = ctypes.c_void_p()
+        _ffi.call("demf_stream_create_cu_masked", ctypes.cast(arr, ctypes.c_void_p), len(side_cus),
+                  invert, ctypes.cast(ctypes.byref(h), ctypes.c_void_p))
+        out.append(torch.cuda.ExternalStream(h.value))
+    return out[0], out[1]
+
+
 class FlatGrads:
     """All trainable gradients as views of one contiguous buffer; one all-reduce per step."""
 
@@ -91,10 +106,11 @@ class Trainer:
             for b in model.buffers():
                 dist.broadcast(b.data, src=0)
 
-    def _fwd_bwd(self, batch):
+    def _fwd_bwd(self, batch, geometry=None):
+        kw = {} if geometry is None else dict(geometry=geometry)
         losses = self.model.forward_train(batch["points"], batch["img_features"],
                                           batch["img_metas"], batch["gt_bboxes_3d"],
-                                          batch["gt_labels_3d"])
+                                          batch["gt_labels_3d"], **kw)
         total = torch.stack(list(losses.values())).sum()
         self.flat.backward_into(total)
         return total.detach()
@@ -109,26 +125,69 @@ class Trainer:
         self._update()
         return total
 
-    def capture(self, batch, warmup=3):
+    def capture(self, batch, warmup=3, prefetch_geometry=True):
         """Capture forward + loss + backward of ``batch`` (static shapes, device-resident
-        inputs) into one hipGraph; returns ``replay()`` = graph launch + eager all-reduce /
-        clip / AdamW.  The path issues no host sync or host->device copy after warm-up
-        (targets are batched, metas are cached), which is what makes it capturable; the
-        collective and the optimizer stay outside the graph."""
-        side = torch.cuda.Stream()
+        inputs) into one hipGraph; returns ``replay(next_points=None)`` = graph launch + eager
+        all-reduce / clip / AdamW.  The path issues no host sync or host->device copy after
+        warm-up (targets are batched, metas are cached), which is what makes it capturable; the
+        collective and the optimizer stay outside the graph.
+
+        ``prefetch_geometry``: the coordinate-only pre-pass of the NEXT batch (every FPS level,
+        the backbone ball queries, 3-NN - ``DeMFHotPath.index_geometry``) is issued on a side
+        HIP stream before the graph of the current batch is launched, so the latency-bound FPS
+        chain (B workgroups on 256 CUs) runs underneath the current step instead of in front of
+        the next one.  Every step still computes one full pre-pass; the graph reads it from
+        static buffers that are refreshed by a ~6 MB device copy at the step boundary."""
+        side = self.side_stream if getattr(self, "side_stream", None) is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(batch)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        can_prefetch = prefetch_geometry and hasattr(self.model, "index_geometry")
+        static_geo = self.model.index_geometry(batch["points"]) if can_prefetch else None
+        torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            loss = self._fwd_bwd(batch)
+            loss = self._fwd_bwd(batch, static_geo)
 
-        def replay():
+        def flat_tensors(g):
+            out = []
+            for lvl in g["sa"]:
+                out += list(lvl)
+            for lvl in g["fp"]:
+                out += list(lvl)
+            if "sample_indices" in g:
+                out.append(g["sample_indices"])
+            return out
+
+        geo_graph, fresh, static_pts = None, None, None
+        if can_prefetch:
+            # the pre-pass is its own (small) hipGraph, replayed on the side stream: one launch
+            # call instead of ~30, so the main graph is not held up behind host launch latency
+            static_pts = batch["points"].clone()
+            torch.cuda.synchronize()
+            geo_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(geo_graph, stream=side):
+                fresh = flat_tensors(self.model.index_geometry(static_pts))
+            torch.cuda.synchronize()
+        static_flat = flat_tensors(static_geo) if can_prefetch else None
+
+        def replay(next_points=None):
+            main = torch.cuda.current_stream()
+            if can_prefetch and next_points is not None:
+                static_pts.copy_(next_points)
+            if can_prefetch:
+                side.wait_stream(main)            # inputs of the next batch are in place
             graph.replay()
+            if can_prefetch:
+                with torch.cuda.stream(side):
+                    geo_graph.replay()
             self._update()
+            if can_prefetch:
+                main.wait_stream(side)
+                torch._foreach_copy_(static_flat, fresh)
             return loss
         self._graph = graph
         return replay

@@ -9,6 +9,7 @@ checkpoints load with the same keys.
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..config import DeMFCfg, head_kwargs
 from .head import DeMFVoteHead
 from .pointnet2 import PointNet2SASSG
@@ -27,10 +28,24 @@ class DeMFHotPath(nn.Module):
         for layer in self.pts_bbox_head.decoder:
             layer.init_weights()
 
-    def extract_pts_feat(self, points):
+    def extract_pts_feat(self, points, geometry=None):
         """ImVoteNet.extract_pts_feat as reached from demfnet.py:151-152."""
-        x = self.pts_backbone(points)
+        x = self.pts_backbone(points, geometry)
         return x["fp_xyz"][-1], x["fp_features"][-1], x["fp_indices"][-1]
+
+    @torch.no_grad()
+    def index_geometry(self, points):
+        """Coordinate-only pre-pass of the step: the backbone's FPS / ball-query / 3-NN indices and
+        the head's seed FPS (class_agnostic_vote_head.py:429-430; seeds are input points)."""
+        if isinstance(points, (list, tuple)):
+            points = torch.stack(points)
+        geo = self.pts_backbone.index_geometry(points)
+        bb = self.pts_backbone
+        seed_xyz = ([points[..., :3]] + [t[1] for t in geo["sa"]])[bb.num_sa - bb.num_fp]
+        if self.cfg.head.sample_mod == "seed":
+            geo["sample_indices"] = ops.furthest_point_sample(seed_xyz.contiguous(),
+                                                              self.pts_bbox_head.num_proposal)
+        return geo
 
     def _side_streams(self, device):
         ss = self.__dict__.setdefault("_streams", {})
@@ -38,17 +53,18 @@ class DeMFHotPath(nn.Module):
             ss[str(device)] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
         return ss[str(device)]
 
-    def forward_head(self, points, img_features, img_metas, image_inputs=None):
+    def forward_head(self, points, img_features, img_metas, image_inputs=None, geometry=None):
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)                                    # demfnet.py:150
-        seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points)
+        seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points, geometry)
         feat_dict = dict(seed_points=seeds_3d, seed_features=seed_3d_features,
-                         seed_indices=seed_indices)
+                         seed_indices=seed_indices,
+                         sample_indices=None if geometry is None else geometry.get("sample_indices"))
         img_dict = dict(img_features=img_features, img_metas=img_metas, image_inputs=image_inputs)
         return self.pts_bbox_head(feat_dict, self.cfg.head.sample_mod, img_dict)  # :165
 
     def forward_train(self, points, img_features, img_metas, gt_bboxes_3d, gt_labels_3d,
-                      overlap=False):
+                      overlap=False, geometry=None):
         """-> dict of losses (demfnet.py:134-170 with the image pyramid precomputed).
 
         ``overlap=True``: the point stream starts with furthest-point sampling, which keeps 8 of
@@ -62,7 +78,7 @@ class DeMFHotPath(nn.Module):
             points = torch.stack(points)
         head = self.pts_bbox_head
         if not (overlap and points.is_cuda):
-            bbox_preds = self.forward_head(points, img_features, img_metas)
+            bbox_preds = self.forward_head(points, img_features, img_metas, geometry=geometry)
             return head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None, img_metas)
         main = torch.cuda.current_stream()
         s_img, s_tgt = self._side_streams(points.device)

@@ -126,7 +126,9 @@ class DeMFVoteHead(nn.Module):
         if sample_mod == "vote":
             agg_in = dict(points_xyz=vote_points, features=vote_features)
         elif sample_mod == "seed":
-            sample_indices = ops.furthest_point_sample(seed_points, self.num_proposal)
+            sample_indices = feat_dict.get("sample_indices")   # coordinate-only: may be prefetched
+            if sample_indices is None:
+                sample_indices = ops.furthest_point_sample(seed_points, self.num_proposal)
             agg_in = dict(points_xyz=vote_points, features=vote_features, indices=sample_indices)
         elif sample_mod == "random":
             B, num_seed = seed_points.shape[:2]

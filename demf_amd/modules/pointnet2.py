@@ -62,7 +62,16 @@ class PointSAModule(nn.Module):
             parts.append(w.new_zeros(w.shape[0], pad))
         return torch.cat(parts, dim=1) if len(parts) > 1 else w
 
-    def forward(self, points_xyz, features=None, indices=None, target_xyz=None):
+    def index_geometry(self, points_xyz, indices=None):
+        """Everything of this level that depends on coordinates only: D-FPS indices, the sampled
+        centres and the ball-query neighbour lists.  -> (indices, new_xyz, group_idx)"""
+        if indices is None:
+            indices = ops.furthest_point_sample(points_xyz, self.num_point)
+        new_xyz = ops.gather_rows_cl(points_xyz, indices)
+        group_idx = ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
+        return indices, new_xyz, group_idx
+
+    def forward(self, points_xyz, features=None, indices=None, target_xyz=None, group_idx=None):
         B, N, _ = points_xyz.shape
         if indices is not None:
             assert indices.shape[1] == self.num_point
@@ -75,7 +84,8 @@ class PointSAModule(nn.Module):
         M = new_xyz.shape[1]
         feat = _rows(features) if features is not None else None
         C = 0 if feat is None else feat.shape[2]
-        idx = ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
+        idx = group_idx if group_idx is not None else \
+            ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
         assert self.use_xyz or feat is not None
         ld = _pad4(C + 3) if self.use_xyz else C
         grouped = ops.group_concat_cl(points_xyz, new_xyz, feat, idx, self.radius,
@@ -110,11 +120,16 @@ class PointFPModule(nn.Module):
         super().__init__()
         self.mlps = RowsMLP(list(mlp_channels), dim=2, bias=False)
 
-    def forward(self, target, source, target_feats, source_feats):
-        B, n, _ = target.shape
+    @staticmethod
+    def index_geometry(target, source):
+        """3-NN indices and inverse-distance weights (coordinates only)."""
         dist, idx = ops.three_nn(target, source)
         dist_recip = 1.0 / (dist + 1e-8)
-        weight = dist_recip / dist_recip.sum(dim=2, keepdim=True)
+        return idx, (dist_recip / dist_recip.sum(dim=2, keepdim=True)).contiguous()
+
+    def forward(self, target, source, target_feats, source_feats, nn=None):
+        B, n, _ = target.shape
+        idx, weight = nn if nn is not None else self.index_geometry(target, source)
         interp = ops.three_interpolate_cl(_rows(source_feats), idx, weight.contiguous())
         x = torch.cat([interp, _rows(target_feats)], dim=2) if target_feats is not None else interp
         x = self.mlps.forward_rows(x.view(B * n, -1))
@@ -152,14 +167,38 @@ class PointNet2SASSG(nn.Module):
             if i != self.num_fp - 1:
                 fp_src, fp_tgt = ch[-1], skip.pop()
 
-    def forward(self, points):
+    @torch.no_grad()
+    def index_geometry(self, points):
+        """The coordinate-only pre-pass of the whole backbone: per SA level (fps indices, centres,
+        ball-query lists), per FP level (3-NN indices, weights).  It depends on nothing but the
+        input cloud, so a training loop can run it for batch k+1 on a side stream while batch k
+        trains (demf_amd/engine.py) - FPS is a latency-bound chain that occupies only B of the
+        256 CUs."""
+        xyz = points[..., 0:3].contiguous()
+        sa, cur = [], xyz
+        for m in self.SA_modules:
+            idx, new_xyz, gidx = m.index_geometry(cur)
+            sa.append((idx, new_xyz, gidx))
+            cur = new_xyz
+        sa_xyz = [xyz] + [t[1] for t in sa]
+        fp = [PointFPModule.index_geometry(sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i])
+              for i in range(self.num_fp)]
+        return dict(sa=sa, fp=fp)
+
+    def forward(self, points, geometry=None):
         xyz = points[..., 0:3].contiguous()
         features = points[..., 3:].transpose(1, 2) if points.shape[-1] > 3 else None
         B, N = xyz.shape[:2]
         indices = torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()
         sa_xyz, sa_features, sa_indices = [xyz], [features], [indices]
         for i in range(self.num_sa):
-            cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i])
+            if geometry is not None:
+                gi, gxyz, gg = geometry["sa"][i]
+                cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i],
+                                                                 indices=gi, target_xyz=None,
+                                                                 group_idx=gg)
+            else:
+                cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i])
             sa_xyz.append(cur_xyz)
             sa_features.append(cur_feat)
             sa_indices.append(torch.gather(sa_indices[-1], 1, cur_idx.long()))
@@ -168,7 +207,8 @@ class PointNet2SASSG(nn.Module):
             fp_features.append(self.FP_modules[i](sa_xyz[self.num_sa - i - 1],
                                                   sa_xyz[self.num_sa - i],
                                                   sa_features[self.num_sa - i - 1],
-                                                  fp_features[-1]))
+                                                  fp_features[-1],
+                                                  nn=geometry["fp"][i] if geometry is not None else None))
             fp_xyz.append(sa_xyz[self.num_sa - i - 1])
             fp_indices.append(sa_indices[self.num_sa - i - 1])
         return dict(fp_xyz=fp_xyz, fp_features=fp_features, fp_indices=fp_indices,

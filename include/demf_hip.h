@@ -40,6 +40,11 @@ typedef void* demf_stream_t;
 int demf_version(void);
 const char* demf_last_error(void);
 
+/* A stream restricted to the listed CUs (invert != 0: to all CUs except them); used to keep the
+ * pipelined FPS pre-pass and the main training stream on disjoint CUs.  Host-side helper: `cus`
+ * and `out` are HOST pointers; the stream is owned by the caller (hipStreamDestroy).        */
+int demf_stream_create_cu_masked(const int* cus, int n, int invert, void** out);
+
 /* ------------------------------------------------------------------ *
  * PointNet++ set-abstraction operators
  * ------------------------------------------------------------------ */
