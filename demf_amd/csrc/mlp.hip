@@ -164,6 +164,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   float* sa = s_a[wave];
+  // few-row launches split the output columns over blockIdx.y so the chip is still filled
+  const int cofs = blockIdx.y * NT * 32;
   const int ntiles = (p.R + BROWS - 1) / BROWS;
   const int ksteps = (p.K + MLP_BK - 1) / MLP_BK;
   const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int n = br + 32 * i, col = k0 + pc;
+      const int n = cofs + br + 32 * i, col = k0 + pc;
       preb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n < p.N && col < p.K) preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * p.K + col);
     }
@@ -249,7 +251,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           for (int r = 0; r < 16; ++r) {
             const int row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float v = acc[rt][nt][r];
-            if (row < p.R && nt * 32 + lr < p.N) p.Y[(size_t)row * p.ldy + nt * 32 + lr] = v;
+            if (row < p.R && cofs + nt * 32 + lr < p.N)
+              p.Y[(size_t)row * p.ldy + cofs + nt * 32 + lr] = v;
             if constexpr (STATS) {
               s1 += v;                     // rows >= R are exact zeros (their A rows are zero)
               s2 = __builtin_fmaf(v, v, s2);
@@ -275,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     for (int i = threadIdx.x; i < NT * 64; i += 256) {
       const float v = s_red[i] + s_red[NT * 64 + i] + s_red[2 * NT * 64 + i] + s_red[3 * NT * 64 + i];
       const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
-      if (nt * 32 + c < p.N) atomicAdd(p.stats + which * p.N + nt * 32 + c, (double)v);
+      if (cofs + nt * 32 + c < p.N)
+        atomicAdd(p.stats + which * p.N + cofs + nt * 32 + c, (double)v);
     }
   }
 }
@@ -421,7 +425,8 @@ struct DwArgs {
   const float* Xp;     // (R x K) previous layer's pre-BN output, or the raw input
   const float* pvec;   // [scale|shift] of the previous layer (2K) or null (raw input)
   float* dW;           // (N x K), accumulated
-  int n0, k0, NTn, NTk;  // output sub-block handled by this launch: tiles [n0, n0+NTn) x [k0, k0+NTk)
+  int n0, k0, NTn, NTk;  // output sub-block of a block (derived from blockIdx.y inside the kernel)
+  int nsub_k;            // sub-blocks along K
 };
 
 // Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
@@ -430,6 +435,13 @@ struct DwArgs {
 template <int TN, int TK, bool SPARSE>
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
   constexpr int PROY = SPARSE ? PRO_DY_SPARSE : PRO_DY_DENSE;
+  {  // this block's (<= 2TN x 2TK tiles) corner of the N x K output
+    const int TNt = (p.N + 31) / 32, TKt = (p.K + 31) / 32;
+    p.n0 = ((int)blockIdx.y / p.nsub_k) * 2 * TN;
+    p.k0 = ((int)blockIdx.y % p.nsub_k) * 2 * TK;
+    p.NTn = TNt - p.n0 < 2 * TN ? TNt - p.n0 : 2 * TN;
+    p.NTk = TKt - p.k0 < 2 * TK ? TKt - p.k0 : 2 * TK;
+  }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // staged widths are padded to the wave grid (2*TN, 2*TK tiles) so idle tiles read zeros
   const int WN = 2 * TN * 32, WK = 2 * TK * 32;      // columns of dY / A staged per slab
@@ -543,6 +555,8 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
   // in 256 VGPRs: up to 4 column tiles for the forward prologues, up to 2 for the backward ones
   // (whose raw prefetch is 2-3x wider).  Backward launches are limited to 128 columns.
+  // Launches with few rows (FP / vote / head layers: 4-8 k rows) would fill only a few CUs with
+  // full-width tiles, so their columns are split over blockIdx.y (A is re-read; it is tiny).
   constexpr int RT2_MAX = PRO >= PRO_DY_DENSE ? 2 : 4;
   constexpr int NT_MAX = PRO >= PRO_DY_DENSE ? 4 : 8;
   const int nt = (a.N + 31) / 32;
@@ -550,6 +564,21 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     set_error("mlp_gemm: N=%d unsupported for this prologue (max %d columns per launch)", a.N,
               NT_MAX * 32);
     return DEMF_EUNSUPPORTED;
+  }
+  const int tiles1 = (a.R + 127) / 128;
+  if (tiles1 < 192 && nt > 1) {
+    int ysplit = (256 + tiles1 - 1) / tiles1;
+    if (ysplit > nt) ysplit = nt;
+    const int ntl = (nt + ysplit - 1) / ysplit;          // column tiles per block
+    const dim3 grid(tiles1, (nt + ntl - 1) / ntl);
+    switch (ntl) {
+#define SPLIT(NTv)                                                                              \
+      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS>), grid, block, 0, s, a); break;
+      SPLIT(1) SPLIT(2) SPLIT(3) SPLIT(4)
+#undef SPLIT
+      default: break;
+    }
+    if (ntl <= 4) return check_launch("mlp_gemm");
   }
 #define GO(NTv, RTv)                                                                            \
   hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS>), dim3(mlp_grid(a.R, 128 * RTv)),   \
@@ -683,27 +712,29 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && vec6 && Xprev && dW && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dw: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int TN = cdiv(N, 32), TK = cdiv(K, 32);
-  // output handled in sub-blocks of at most 4x4 tiles (16 tiles = 4 per wave, <= 33 KB LDS)
-  for (int n0 = 0; n0 < TN; n0 += 4)
-    for (int k0 = 0; k0 < TK; k0 += 4) {
-      DwArgs a{};
-      a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
-      a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW;
-      a.n0 = n0; a.k0 = k0; a.NTn = (TN - n0) < 4 ? (TN - n0) : 4; a.NTk = (TK - k0) < 4 ? (TK - k0) : 4;
-      const int tn = a.NTn > 2 ? 2 : 1, tk = a.NTk > 2 ? 2 : 1;
-      const size_t lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
-      int grid = cdiv(R, 32 * 4);
-      if (grid > 512) grid = 512;
-      if (grid < 1) grid = 1;
+  const int TNt = cdiv(N, 32), TKt = cdiv(K, 32);
+  // one launch: grid.x strides the 32-row slabs, grid.y enumerates the (<= 4x4-tile) sub-blocks
+  // of the N x K output, so even a 4 k-row layer spreads over the whole chip
+  const int tn = TNt > 2 ? 2 : 1, tk = TKt > 2 ? 2 : 1;
+  DwArgs a{};
+  a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
+  a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW;
+  const int nsub_n = cdiv(TNt, 2 * tn);
+  a.nsub_k = cdiv(TKt, 2 * tk);
+  const int nsub = nsub_n * a.nsub_k;
+  const size_t lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
+  int gx = cdiv(R, 32 * 4);
+  const int cap = 512 / nsub > 16 ? 512 / nsub : 16;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, nsub);
 #define DW(TNv, TKv)                                                                             \
-      if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), dim3(grid), dim3(256), lds, s, a); \
-      else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true>), dim3(grid), dim3(256), lds, s, a)
-      if (tn == 1 && tk == 1) { DW(1, 1); }
-      else if (tn == 1) { DW(1, 2); }
-      else if (tk == 1) { DW(2, 1); }
-      else { DW(2, 2); }
+  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), grid, dim3(256), lds, s, a);       \
+  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true>), grid, dim3(256), lds, s, a)
+  if (tn == 1 && tk == 1) { DW(1, 1); }
+  else if (tn == 1) { DW(1, 2); }
+  else if (tk == 1) { DW(2, 1); }
+  else { DW(2, 2); }
 #undef DW
-    }
   return check_launch("mlp_gemm_bwd_dw");
 }
