@@ -152,6 +152,10 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    # a throughput figure over non-finite arithmetic would be meaningless: refuse to report it
+    if not bool(torch.isfinite(trainer.flat.flat).all()) or \
+            not all(bool(torch.isfinite(p).all()) for p in model.parameters()):
+        raise RuntimeError("non-finite gradients/parameters after the timed steps")
     # dominant-kernel duration: HIP events around the same launches, same inputs, same stream,
     # in an eager pass right after the timed region (a graph replay cannot host per-kernel
     # events); profiles/ holds the rocprofv3 figure for the same kernel inside the replays

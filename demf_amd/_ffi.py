@@ -36,6 +36,7 @@ SIGNATURES = {
     "demf_three_interpolate_cl_bwd": [_c_int] * 6 + [_ptr] * 5,
     "demf_maxpool_ns_fwd": [_c_int] * 3 + [_ptr] * 4,
     "demf_maxpool_ns_bwd": [_c_int] * 3 + [_ptr] * 4,
+    "demf_colsum_f32": [_c_int] * 3 + [_ptr] * 3,
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 5,
     "demf_bnrelu_maxpool_fwd": [_c_int] * 3 + [_ptr] * 5,

@@ -211,6 +211,25 @@ static inline int grid_for_rows(long long rows, int rows_per_block) {
   return (int)(g < cap ? (g > 0 ? g : 1) : cap);
 }
 
+// column sums of a row-major (R, N) matrix (row stride ld): the bias gradient of a linear layer.
+// One block = a chunk of rows x all columns; coalesced over columns, one atomic per column.
+__global__ __launch_bounds__(256) void colsum_k(int R, int N, int ld, int rows_per_block,
+                                                const float* __restrict__ x,
+                                                float* __restrict__ out) {
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float a0 = 0.f, a1 = 0.f;
+    int r = r0;
+    for (; r + 1 < r1; r += 2) {
+      a0 += x[(size_t)r * ld + c];
+      a1 += x[(size_t)(r + 1) * ld + c];
+    }
+    if (r < r1) a0 += x[(size_t)r * ld + c];
+    atomicAdd(out + c, a0 + a1);
+  }
+}
+
 }  // namespace demf
 
 using namespace demf;
@@ -352,4 +371,16 @@ extern "C" int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out,
   hipLaunchKernelGGL(maxpool_ns_bwd_k, dim3(grid_for_rows(RC, 256)), dim3(256), 0,
                      (hipStream_t)stream, RC, ns, C, grad_out, arg, grad_x);
   return check_launch("maxpool_ns_bwd");
+}
+
+extern "C" int demf_colsum_f32(int R, int N, int ld, const float* x, float* out,
+                               demf_stream_t stream) {
+  if (R <= 0 || N <= 0) return DEMF_OK;
+  DEMF_REQUIRE(x && out, "colsum: null pointer");
+  DEMF_REQUIRE(ld >= N, "colsum: ld=%d < N=%d", ld, N);
+  int rpb = R / 512;
+  rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : rpb);
+  hipLaunchKernelGGL(colsum_k, dim3((R + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, R, N,
+                     ld, rpb, x, out);
+  return check_launch("colsum");
 }

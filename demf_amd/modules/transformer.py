@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..ops import MultiScaleDeformableAttnFunction
 
 
@@ -34,12 +35,12 @@ class PositionEmbeddingLearned(nn.Module):
         holders so checkpoints load unchanged."""
         c0, bn, _, c1 = self.position_embedding_head
         B, N, cin = xyz.shape
-        x = F.linear(xyz.reshape(B * N, cin), c0.weight.view(c0.out_channels, cin), c0.bias)
+        x = ops.linear(xyz.reshape(B * N, cin), c0.weight.view(c0.out_channels, cin), c0.bias)
         if bn.training and bn.num_batches_tracked is not None:
             bn.num_batches_tracked.add_(1)
         x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                                 bn.training, bn.momentum, bn.eps), inplace=True)
-        x = F.linear(x, c1.weight.view(c1.out_channels, -1), c1.bias)
+        x = ops.linear(x, c1.weight.view(c1.out_channels, -1), c1.bias)
         return x.view(B, N, -1).transpose(1, 2)
 
 
@@ -67,13 +68,45 @@ class MultiheadAttention(nn.Module):
             identity = query
         if key_pos is None and query_pos is not None and query_pos.shape == key.shape:
             key_pos = query_pos
+        shared_qk = key is query and key_pos is query_pos      # self-attention: one q|k projection
         if query_pos is not None:
             query = query + query_pos
-        if key_pos is not None:
+        if shared_qk:
+            key = query
+        elif key_pos is not None:
             key = key + key_pos
-        out = self.attn(query=query, key=key, value=value, attn_mask=attn_mask,
-                        key_padding_mask=key_padding_mask)[0]
+        out = self._attend(query, key, value, attn_mask, key_padding_mask)
         return identity + self.dropout_layer(self.proj_drop(out))
+
+
+    def _attend(self, query, key, value, attn_mask, key_padding_mask):
+        """torch.nn.MultiheadAttention's math (seq-first, packed in_proj) spelled out on
+        ops.linear; ``self.attn`` stays the parameter holder so state-dict keys are upstream's."""
+        a = self.attn
+        L, B, E = query.shape
+        S, H = key.shape[0], a.num_heads
+        Dh = E // H
+        W, b = a.in_proj_weight, a.in_proj_bias
+        if key is query:
+            qk = ops.linear(query, W[:2 * E], None if b is None else b[:2 * E])
+            q, k = qk[..., :E], qk[..., E:]
+        else:
+            q = ops.linear(query, W[:E], None if b is None else b[:E])
+            k = ops.linear(key, W[E:2 * E], None if b is None else b[E:2 * E])
+        v = ops.linear(value, W[2 * E:], None if b is None else b[2 * E:])
+        q = q.reshape(L, B * H, Dh).transpose(0, 1)
+        k = k.reshape(S, B * H, Dh).transpose(0, 1)
+        v = v.reshape(S, B * H, Dh).transpose(0, 1)
+        scores = torch.bmm(q * (1.0 / math.sqrt(Dh)), k.transpose(1, 2))        # (B*H, L, S)
+        if attn_mask is not None:
+            scores = scores.masked_fill(attn_mask, float("-inf")) if attn_mask.dtype == torch.bool \
+                else scores + attn_mask
+        if key_padding_mask is not None:
+            scores = scores.view(B, H, L, S).masked_fill(key_padding_mask[:, None, None, :],
+                                                         float("-inf")).view(B * H, L, S)
+        attn = F.dropout(scores.softmax(dim=-1), a.dropout, self.training)
+        out = torch.bmm(attn, v).transpose(0, 1).reshape(L, B, E)
+        return ops.linear(out, a.out_proj.weight, a.out_proj.bias)
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -116,7 +149,7 @@ class MultiScaleDeformableAttention(nn.Module):
         if not self.batch_first:
             value = value.permute(1, 0, 2)
         bs, num_value, _ = value.shape
-        value = self.value_proj(value)
+        value = ops.linear(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
             value = value.masked_fill(key_padding_mask[..., None], 0.0)
         return value.view(bs, num_value, self.num_heads, -1)
@@ -135,9 +168,9 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, num_query, _ = query.shape
         value = value_projected if value_projected is not None else \
             self.project_value(value, key_padding_mask)
-        offsets = self.sampling_offsets(query).view(bs, num_query, self.num_heads, self.num_levels,
+        offsets = ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(bs, num_query, self.num_heads, self.num_levels,
                                                     self.num_points, 2)
-        weights = self.attention_weights(query).view(bs, num_query, self.num_heads,
+        weights = ops.linear(query, self.attention_weights.weight, self.attention_weights.bias).view(bs, num_query, self.num_heads,
                                                      self.num_levels * self.num_points)
         weights = weights.softmax(-1).view(bs, num_query, self.num_heads, self.num_levels,
                                            self.num_points)
@@ -148,7 +181,7 @@ class MultiScaleDeformableAttention(nn.Module):
         output = MultiScaleDeformableAttnFunction.apply(
             value.contiguous(), spatial_shapes, level_start_index, locations.contiguous(),
             weights.contiguous(), self.im2col_step)
-        output = self.output_proj(output)
+        output = ops.linear(output, self.output_proj.weight, self.output_proj.bias)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
         return self.dropout(output) + identity
@@ -165,7 +198,9 @@ class FFN(nn.Module):
             nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop))
 
     def forward(self, x, identity=None):
-        out = self.layers(x)
+        (fc0, _, drop0), fc1, drop1 = self.layers
+        h = drop0(F.relu(ops.linear(x, fc0.weight, fc0.bias)))
+        out = drop1(ops.linear(h, fc1.weight, fc1.bias))
         return (x if identity is None else identity) + out
 
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .layers import ConvBNReLU, RowsMLP, fused_rows
 
 
@@ -32,7 +33,7 @@ class VoteModule(nn.Module):
         B, N, _ = seed_points.shape
         rows = seed_feats.transpose(1, 2).contiguous().view(B * N, -1)
         x = fused_rows(list(self.vote_conv), rows)
-        votes = F.linear(x, self.conv_out.weight.view(self.conv_out.out_channels, -1),
+        votes = ops.linear(x, self.conv_out.weight.view(self.conv_out.out_channels, -1),
                          self.conv_out.bias)
         offset = votes[:, 0:3].view(B, N, 3)
         vote_points = (seed_points + offset).contiguous()
@@ -71,6 +72,6 @@ class BaseConvBboxHead(nn.Module):
     def forward(self, feats):
         B, C, N = feats.shape
         x = self.shared_convs.forward_rows(feats.transpose(1, 2).contiguous().view(B * N, C))
-        cls = F.linear(x, self.conv_cls.weight.view(self.conv_cls.out_channels, -1), self.conv_cls.bias)
-        reg = F.linear(x, self.conv_reg.weight.view(self.conv_reg.out_channels, -1), self.conv_reg.bias)
+        cls = ops.linear(x, self.conv_cls.weight.view(self.conv_cls.out_channels, -1), self.conv_cls.bias)
+        reg = ops.linear(x, self.conv_reg.weight.view(self.conv_reg.out_channels, -1), self.conv_reg.bias)
         return cls.view(B, N, -1).transpose(1, 2), reg.view(B, N, -1).transpose(1, 2)

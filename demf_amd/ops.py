@@ -412,6 +412,39 @@ def maxpool_ns(x):
     return _MaxPoolNS.apply(x)
 
 
+class _LinearRows(Function):
+    """y = x W^T + b on rows.  GEMMs through hipBLASLt; the bias gradient through
+    demf_colsum_f32 instead of at::sum (see include/demf_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device)
+            _ffi.call("demf_colsum_f32", g.shape[0], g.shape[1], g.shape[1], _p(g), _p(gb), _stream())
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear(x (..., K), weight (N, K), bias (N)) for device tensors of the hot path."""
+    if not x.is_cuda:
+        raise RuntimeError("x must be a GPU (HIP) tensor: demf_amd operators have no CPU path")
+    lead = x.shape[:-1]
+    y = _LinearRows.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+    return y.view(*lead, weight.shape[0])
+
+
 # --------------------------------------------------------------------------
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------

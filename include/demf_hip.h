@@ -149,6 +149,12 @@ int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out, const int* 
                         float* grad_x /* (R,ns,C), fully written */,
                         demf_stream_t stream);
 
+/* out (N) += column sums of x (R,N; row stride ld).  out arrives zeroed.  The bias gradient of the
+ * path's linear layers (mmcv FFN / MultiheadAttention / MultiScaleDeformableAttention projections,
+ * transformer.py:73; conv_cls / conv_reg, class_agnostic_vote_head.py:398) - replaces
+ * at::sum's two-stage semaphore reduction, which mis-reduces inside hipGraph replays. */
+int demf_colsum_f32(int R, int N, int ld, const float* x, float* out, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Fused shared-MLP (1x1 conv + train-mode BatchNorm + ReLU [+ max over
  * neighbours]) on point-major rows: the dense half of every PointSAModule

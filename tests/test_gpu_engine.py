@@ -56,3 +56,31 @@ def test_steps_reduce_the_loss():
     tr = engine.Trainer(model, lr=1e-4)
     losses = [tr.step(batch).item() for _ in range(12)]
     assert losses[-1] < losses[0] and min(losses[6:]) < losses[0] * 0.999, losses
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_full_size_replays_stay_finite(prefetch):
+    """BASELINE-size step (8 scenes x 20000 points, 18609 image tokens) through
+    Trainer.capture(): every replay - with and without the pipelined coordinate pre-pass -
+    leaves finite gradients, parameters and loss.  Regression test: at::sum's semaphore
+    reduction returned inf/NaN bias gradients inside hipGraph replays; the path
+    now reduces them with demf_colsum_f32."""
+    import bench
+    from demf_amd import engine
+    from demf_amd.config import DeMFCfg
+    from demf_amd.modules import DeMFHotPath
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = DeMFHotPath(DeMFCfg()).to(dev).train()
+    tr = engine.Trainer(model)
+    batch, _ = bench.make_batch(8, seed=1000, device=dev)
+    other, _ = bench.make_batch(8, seed=2000, device=dev)
+    step = tr.capture(batch, prefetch_geometry=prefetch)
+    for it in range(12):
+        # alternate two point clouds so that the refreshed geometry is really consumed
+        nxt = (other if it % 2 == 0 else batch)["points"] if prefetch else None
+        loss = step(nxt) if prefetch else step()
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(loss)), f"replay {it}: loss {float(loss)}"
+        assert bool(torch.isfinite(tr.flat.flat).all()), f"replay {it}: non-finite gradient"
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
