@@ -190,7 +190,11 @@ def main():
             "roofline": {"kernel": "fps_reg_kernel<1024,20> (20000->2048)", "bound": "hbm",
                          "achieved": algo_bytes / (fps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": fps_ms,
+                         # profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, B=8:
+                         # FETCH_SIZE 986.2 KiB x2 (gfx950 half-count correction, calibrated on the
+                         # SA1 dx GEMM) + WRITE_SIZE 64.0 KiB per launch
+                         "traffic": (2 * 986.2 + 64.0) * 1024 if args.batch == 8 else None,
+                         "avg_launch_ms": fps_ms,
                          "note": "latency-bound chain of 2047 dependent rounds; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
