@@ -267,6 +267,18 @@ int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
                       float* grad_value, float* grad_sampling_loc,
                       float* grad_attn_weight, demf_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ * Optimizer step on flat buffers: torch.optim.AdamW + clip_grad_norm_ as the reference's
+ * runner applies them (configs/_base_/schedules/schedule_3x.py:6-7: AdamW lr 0.008, wd 0.01,
+ * grad_clip max_norm 10; configs/demf/demf_votenet.py:16-24: 'decoder' lr_mult 0.05).  One call
+ * per parameter group.  g_eff = grad * grad_scale * min(1, max_norm / (norm*grad_scale + 1e-6))
+ * with norm read from the device scalar grad_norm (NULL: no clipping); grad itself is not
+ * modified.  step is the 1-based step count (bias correction).
+ * ------------------------------------------------------------------ */
+int demf_adamw_f32(long long n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   const float* grad_norm, float max_norm, float grad_scale, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, demf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

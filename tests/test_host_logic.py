@@ -12,6 +12,17 @@ from demf_amd.modules import DeMFHotPath
 from oracle import fixtures
 from oracle.model import OracleDeMF
 
+
+
+@pytest.fixture(autouse=True)
+def _torch_linear_on_cpu(monkeypatch):
+    """The product's ops.linear is device-only (no CPU path); the glue exercised here contains
+    one value projection, which this CPU test runs through torch's own linear instead."""
+    import torch.nn.functional as F
+    from demf_amd import ops
+    monkeypatch.setattr(ops, "linear", F.linear)
+
+
 NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
          "mask_targets", "objectness_targets", "objectness_weights", "box_loss_weights",
          "distance_targets", "dir_targets", "size_targets", "center_targets")
