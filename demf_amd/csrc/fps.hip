@@ -101,6 +101,11 @@ __global__ __launch_bounds__(BS) void fps_reg_kernel(int N, int M,
                                                      const float* __restrict__ xyz,
                                                      int* __restrict__ idx) {
   constexpr int NW = BS / 64;
+  // Claim the CU's whole vector register file (BS/256 waves per SIMD x the per-wave budget):
+  // this latency-bound chain runs for milliseconds on one CU per scene, and any other kernel's
+  // workgroup scheduled next to it becomes the straggler of that kernel.
+  if constexpr (BS == 1024) asm volatile("" ::: "v127");
+  else if constexpr (BS == 512) asm volatile("" ::: "v255");
   __shared__ float s_wmax[16];
   __shared__ __attribute__((aligned(16))) float s_res[4];  // {idx bits, x, y, z}
   __shared__ int s_idx[FPS_IDX_CHUNK];

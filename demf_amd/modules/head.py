@@ -197,10 +197,27 @@ class DeMFVoteHead(nn.Module):
                 cache.clear()
             comp = [compose_projection(m) for m in img_metas]
             sizes = [h * w for h, w in mlvl_shapes]
+            # padding masks (:559-568): nearest-neighbour resize of the (B,Hpad,Wpad) mask is an
+            # index lookup, and the valid ratios (:514-522) count its first column / row - both
+            # functions of the metas alone, so they are built here once per metas object
+            hw = np.asarray([m["img_shape"][:2] for m in img_metas], dtype=np.int64)
+            in_h, in_w = img_metas[0]["batch_input_shape"]
+            masks, ratios = [], []
+            for h, w in mlvl_shapes:
+                ys = np.floor(np.arange(h, dtype=np.float32) * np.float32(in_h / h)).astype(np.int64)
+                xs = np.floor(np.arange(w, dtype=np.float32) * np.float32(in_w / w)).astype(np.int64)
+                m = (ys[None, :, None] >= hw[:, 0, None, None]) | (xs[None, None, :] >= hw[:, 1, None, None])
+                masks.append(m.reshape(len(img_metas), h * w))
+                valid_h = (~m[:, :, 0]).sum(1).astype(np.float32)
+                valid_w = (~m[:, 0, :]).sum(1).astype(np.float32)
+                ratios.append(np.stack([valid_w / np.float32(w), valid_h / np.float32(h)], -1))
+            empty = len(mlvl_shapes) == 0
             cache[key] = dict(
                 M=torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev),
                 ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
-                hw=torch.as_tensor([m["img_shape"][:2] for m in img_metas], device=dev),
+                hw=torch.as_tensor(hw, device=dev),
+                mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
+                valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
                 spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
                 level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
                                                   dtype=torch.long, device=dev),
@@ -225,21 +242,10 @@ class DeMFVoteHead(nn.Module):
         the fusion attention.  Independent of the point stream, so the detector runs it on a
         side stream while furthest-point sampling occupies 8 of the 256 CUs."""
         spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-        in_h, in_w = img_metas[0]["batch_input_shape"]
         dev = mlvl_feats[0].device
         mt = self._meta_tensors(img_metas, spatial, dev, mlvl_feats[0].dtype)
-        # padding masks: nearest-neighbour resize of the (B,Hpad,Wpad) mask == index lookup
-        hw = mt["hw"]                                                              # (B,2)
-        mlvl_masks = []
-        for feat in mlvl_feats:
-            h, w = feat.shape[-2:]
-            ys = torch.floor(torch.arange(h, device=dev, dtype=torch.float32) * (in_h / h)).long()
-            xs = torch.floor(torch.arange(w, device=dev, dtype=torch.float32) * (in_w / w)).long()
-            mlvl_masks.append((ys[None, :, None] >= hw[:, 0, None, None]) |
-                              (xs[None, None, :] >= hw[:, 1, None, None]))
+        mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
         feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
-        mask_flatten = torch.cat([m.flatten(1) for m in mlvl_masks], 1)
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in mlvl_masks], 1)
         feat_flatten = feat_flatten.permute(1, 0, 2)
         value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)
                            for layer in self.decoder]
