@@ -390,6 +390,72 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
   }
 }
 
+// dense G, N % 4 == 0, N <= 1024: a thread owns 4 consecutive channels (float4 loads of G and Y),
+// row lanes fill the rest of the block; 4 rows in flight per thread
+__global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
+                                                              const float* __restrict__ G,
+                                                              const float* __restrict__ Y,
+                                                              const float* __restrict__ ss,
+                                                              const float* __restrict__ mi,
+                                                              double* __restrict__ g12) {
+  __shared__ float4 red[2][256];
+  const int cg = N >> 2;
+  const int rows_par = 256 / cg;
+  const int c4 = threadIdx.x % cg, r_in = threadIdx.x / cg;
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  if (r_in < rows_par) {
+    const float4 sc = reinterpret_cast<const float4*>(ss)[c4];
+    const float4 sh = reinterpret_cast<const float4*>(ss + N)[c4];
+    const float4 mu = reinterpret_cast<const float4*>(mi)[c4];
+    const float4 is = reinterpret_cast<const float4*>(mi + N)[c4];
+    const int step = gridDim.x * rows_par;
+    auto acc = [&](const float4& g, const float4& y) {
+      const float d0 = __builtin_fmaf(y.x, sc.x, sh.x) > 0.f ? g.x : 0.f;
+      const float d1 = __builtin_fmaf(y.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+      const float d2 = __builtin_fmaf(y.z, sc.z, sh.z) > 0.f ? g.z : 0.f;
+      const float d3 = __builtin_fmaf(y.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+      a1.x += d0; a1.y += d1; a1.z += d2; a1.w += d3;
+      a2.x = __builtin_fmaf(d0, (y.x - mu.x) * is.x, a2.x);
+      a2.y = __builtin_fmaf(d1, (y.y - mu.y) * is.y, a2.y);
+      a2.z = __builtin_fmaf(d2, (y.z - mu.z) * is.z, a2.z);
+      a2.w = __builtin_fmaf(d3, (y.w - mu.w) * is.w, a2.w);
+    };
+    int r = blockIdx.x * rows_par + r_in;
+    for (; r + 3 * step < R; r += 4 * step) {
+      float4 g[4], y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)(r + u * step) * N + 4 * c4;
+        g[u] = *reinterpret_cast<const float4*>(G + o);
+        y[u] = *reinterpret_cast<const float4*>(Y + o);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc(g[u], y[u]);
+    }
+    for (; r < R; r += step) {
+      const size_t o = (size_t)r * N + 4 * c4;
+      acc(*reinterpret_cast<const float4*>(G + o), *reinterpret_cast<const float4*>(Y + o));
+    }
+  }
+  red[0][threadIdx.x] = a1;
+  red[1][threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < cg) {
+    float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+    for (int j = 0; j < rows_par; ++j) {
+      const float4 u = red[0][j * cg + threadIdx.x], v = red[1][j * cg + threadIdx.x];
+      t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+      t2.x += v.x; t2.y += v.y; t2.z += v.z; t2.w += v.w;
+    }
+    double* o1 = g12 + 4 * threadIdx.x;
+    double* o2 = g12 + N + 4 * threadIdx.x;
+    atomicAdd(o1, (double)t1.x); atomicAdd(o1 + 1, (double)t1.y);
+    atomicAdd(o1 + 2, (double)t1.z); atomicAdd(o1 + 3, (double)t1.w);
+    atomicAdd(o2, (double)t2.x); atomicAdd(o2 + 1, (double)t2.y);
+    atomicAdd(o2 + 2, (double)t2.z); atomicAdd(o2 + 3, (double)t2.w);
+  }
+}
+
 // g1,g2 -> the 5 backward vectors + dgamma, dbeta
 __global__ void bn_bwd_vectors_k(int N, double count, const double* __restrict__ g12,
                                  const float* __restrict__ gamma, const float* __restrict__ ss,
@@ -543,9 +609,14 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
     }
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 static int mlp_grid(int R, int brows) {
   const int tiles = (R + brows - 1) / brows;
-  const int cap = 256 * 2;   // persistent: two 256-thread blocks per CU
+  const int cap = env_int("DEMF_GEMM_GRID", 256 * 2);   // persistent: two 256-thread blocks per CU
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
@@ -608,6 +679,7 @@ static int mlp_check(int R, int K, int N, int ldx) {
 
 using namespace demf;
 
+
 extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
                                  const float* pro_scale_shift, const float* Wt, float* Y,
                                  double* stats, demf_stream_t stream) {
@@ -656,6 +728,17 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
                "bn_bwd_reduce: null pointer");
+  if (G && N % 4 == 0 && N <= 1024) {
+    const int rp = 256 / (N / 4);
+    // few blocks: every block ends with 2N same-address fp64 atomics, which serialise in L2
+    // (~70 ns each), so 2048 blocks cost ~150 us in the tail alone
+    int grid = cdiv(R, rp * 16);
+    const int cap = env_int("DEMF_BNRED_GRID", 256);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(bn_bwd_reduce_dense4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
+                       Y, scale_shift, mean_invstd, g12);
+    return check_launch("bn_bwd_reduce");
+  }
   const int rows_par = N < 256 ? 256 / N : 1;
   const int rows = G ? R : R / ns;
   int grid = cdiv(rows, rows_par * 8);
@@ -724,7 +807,8 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
   const int nsub = nsub_n * a.nsub_k;
   const size_t lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
   int gx = cdiv(R, 32 * 4);
-  const int cap = 512 / nsub > 16 ? 512 / nsub : 16;
+  const int tot = env_int("DEMF_DW_GRID", 512);
+  const int cap = tot / nsub > 16 ? tot / nsub : 16;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
   const dim3 grid(gx, nsub);

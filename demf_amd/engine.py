@@ -229,11 +229,12 @@ class Trainer:
             if can_prefetch and next_points is not None:
                 static_pts.copy_(next_points)
             if can_prefetch:
+                # the pre-pass goes first: enqueueing the ~900-node step graph takes the host
+                # about a millisecond, which would otherwise delay the start of the FPS chain
                 side.wait_stream(main)            # inputs of the next batch are in place
-            graph.replay()
-            if can_prefetch:
                 with torch.cuda.stream(side):
                     geo_graph.replay()
+            graph.replay()
             self._update()
             if can_prefetch:
                 main.wait_stream(side)
