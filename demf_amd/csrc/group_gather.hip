@@ -212,21 +212,55 @@ static inline int grid_for_rows(long long rows, int rows_per_block) {
 }
 
 // column sums of a row-major (R, N) matrix (row stride ld): the bias gradient of a linear layer.
-// One block = a chunk of rows x all columns; coalesced over columns, one atomic per column.
+// One block = a chunk of rows; a thread owns VEC consecutive columns and keeps 4 rows in flight;
+// row lanes are folded through LDS, then one atomic per column per block.
+template <int VEC>
 __global__ __launch_bounds__(256) void colsum_k(int R, int N, int ld, int rows_per_block,
                                                 const float* __restrict__ x,
                                                 float* __restrict__ out) {
+  __shared__ float red[256 * VEC];
+  const int cg = (N + VEC - 1) / VEC;                 // column groups
+  const int cgp = cg < 256 ? cg : 256;                // column groups per pass
+  const int rows_par = 256 / cgp;
+  const int c_in = threadIdx.x % cgp, r_in = threadIdx.x / cgp;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-  for (int c = threadIdx.x; c < N; c += 256) {
-    float a0 = 0.f, a1 = 0.f;
-    int r = r0;
-    for (; r + 1 < r1; r += 2) {
-      a0 += x[(size_t)r * ld + c];
-      a1 += x[(size_t)(r + 1) * ld + c];
+  for (int cb = 0; cb < cg; cb += cgp) {
+    const int c = (cb + c_in) * VEC;
+    float acc[VEC] = {};
+    if (r_in < rows_par && c < N) {
+      int r = r0 + r_in;
+      if constexpr (VEC == 4) {
+        for (; r + 3 * rows_par < r1; r += 4 * rows_par) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            v[u] = *reinterpret_cast<const float4*>(x + (size_t)(r + u * rows_par) * ld + c);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc[0] += v[u].x; acc[1] += v[u].y; acc[2] += v[u].z; acc[3] += v[u].w;
+          }
+        }
+        for (; r < r1; r += rows_par) {
+          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + c);
+          acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+        }
+      } else {
+        for (; r < r1; r += rows_par) acc[0] += x[(size_t)r * ld + c];
+      }
     }
-    if (r < r1) a0 += x[(size_t)r * ld + c];
-    atomicAdd(out + c, a0 + a1);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) red[threadIdx.x * VEC + v] = acc[v];
+    __syncthreads();
+    if (threadIdx.x < cgp && (cb + threadIdx.x) * VEC < N) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float t = 0.f;
+        for (int j = 0; j < rows_par; ++j) t += red[(j * cgp + threadIdx.x) * VEC + v];
+        if ((cb + threadIdx.x) * VEC + v < N) atomicAdd(out + (cb + threadIdx.x) * VEC + v, t);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -378,9 +412,13 @@ extern "C" int demf_colsum_f32(int R, int N, int ld, const float* x, float* out,
   if (R <= 0 || N <= 0) return DEMF_OK;
   DEMF_REQUIRE(x && out, "colsum: null pointer");
   DEMF_REQUIRE(ld >= N, "colsum: ld=%d < N=%d", ld, N);
-  int rpb = R / 512;
-  rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : rpb);
-  hipLaunchKernelGGL(colsum_k, dim3((R + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, R, N,
-                     ld, rpb, x, out);
+  // at most ~256 blocks: each ends in N same-address atomics, which serialise in L2
+  int rpb = (R + 255) / 256;
+  rpb = rpb < 16 ? 16 : rpb;
+  const dim3 grid((R + rpb - 1) / rpb);
+  if (N % 4 == 0 && ld % 4 == 0 && ((size_t)x & 15) == 0)
+    hipLaunchKernelGGL(colsum_k<4>, grid, dim3(256), 0, (hipStream_t)stream, R, N, ld, rpb, x, out);
+  else
+    hipLaunchKernelGGL(colsum_k<1>, grid, dim3(256), 0, (hipStream_t)stream, R, N, ld, rpb, x, out);
   return check_launch("colsum");
 }

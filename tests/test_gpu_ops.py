@@ -225,3 +225,15 @@ def test_msda_linearity_full_size(ops):
     torch.testing.assert_close(o1, o2, rtol=1e-5, atol=1e-5)
     o3 = f(v, s, i, l, a, 64)
     assert torch.equal(o1, o3)  # forward has no atomics: run-to-run bitwise
+
+
+@pytest.mark.parametrize("R,N", [(1, 4), (37, 30), (2048, 1024), (2048, 12), (20000, 256), (148872, 256), (300, 1028)])
+def test_colsum_matches_fp64_sum(R, N):
+    """demf_colsum_f32 (bias gradient of the linear layers) against a float64 column sum."""
+    from demf_amd import _ffi
+    torch.manual_seed(R + N)
+    x = torch.randn(R, N, device="cuda")
+    out = torch.zeros(N, device="cuda")
+    _ffi.call("demf_colsum_f32", R, N, N, x.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    ref = x.double().sum(0)
+    assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * (R ** 0.5))
