@@ -91,6 +91,44 @@ __global__ __launch_bounds__(256) void group_concat_cl_fwd_k(
   }
 }
 
+// Thin rows (ld <= 8: the first SA level carries one feature channel): one THREAD per output row
+// instead of one wave - 1 M rows of 16 bytes are otherwise 1 M mostly idle waves.
+__global__ __launch_bounds__(256) void group_concat_cl_fwd_thin_k(
+    int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float radius,
+    const float* __restrict__ xyz, const float* __restrict__ center,
+    const float* __restrict__ feat, const int* __restrict__ idx, float* __restrict__ out,
+    long long rows) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += stride) {
+    const long long bm = row / ns;
+    const int b = (int)(bm / M);
+    const int i = idx[row];
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = 0.f;
+    const float* f = feat + ((size_t)b * N + i) * C;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c >= feat_col && c < feat_col + C) v[c] = f[c - feat_col];
+    const float* pp = xyz + ((size_t)b * N + i) * 3;
+    const float* qq = center + bm * 3;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c >= xyz_col && c < xyz_col + 3) v[c] = (pp[c - xyz_col] - qq[c - xyz_col]) / radius;
+    float* o = out + row * ldo;
+    if (ldo == 4) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (ldo == 8) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (c < ldo) o[c] = v[c];
+    }
+  }
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void group_concat_cl_bwd_k(
     int N, int M, int ns, int C, int ldo, int xyz_col, int feat_col, float inv_r,
@@ -321,6 +359,12 @@ extern "C" int demf_group_concat_cl_fwd(int B, int N, int M, int ns, int C, int 
   const float inv_r = normalize_xyz ? radius : 1.0f;  // divisor
   const bool vec4 = (C % 4 == 0) && (ldo % 4 == 0) && (feat_col % 4 == 0) &&
                     (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  if (ldo <= 8 && (ldo % 4 != 0 || ((uintptr_t)out) % 16 == 0)) {
+    hipLaunchKernelGGL(group_concat_cl_fwd_thin_k, dim3(grid_for_rows(rows, 256)), dim3(256), 0,
+                       (hipStream_t)stream, N, M, ns, C, ldo, xyz_col, feat_col, inv_r, xyz,
+                       center, feat, idx, out, rows);
+    return check_launch("group_concat_cl_fwd");
+  }
   const int grid = grid_for_rows(rows, 4);
   if (vec4)
     hipLaunchKernelGGL((group_concat_cl_fwd_k<true>), dim3(grid), dim3(256), 0,

@@ -123,7 +123,8 @@ def test_three_interpolate(ops):
 
 # ---- point-major fused variants vs the channel-major oracle -----------------
 @pytest.mark.parametrize("C,ldo,feat_col,xyz_col", [(128, 132, 0, 128), (1, 4, 3, 0),
-                                                     (0, 4, 0, 0), (5, 11, 4, 0)])
+                                                     (0, 4, 0, 0), (5, 11, 4, 0),
+                                                     (1, 4, 0, 1), (2, 8, 0, 2), (3, 7, 0, 3)])
 def test_group_concat_cl(ops, C, ldo, feat_col, xyz_col):
     rng = np.random.default_rng(3)
     B, N, M, ns, r = 2, 900, 70, 16, 0.4
