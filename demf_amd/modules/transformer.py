@@ -151,7 +151,7 @@ class MultiScaleDeformableAttention(nn.Module):
         bs, num_value, _ = value.shape
         value = ops.linear(value, self.value_proj.weight, self.value_proj.bias)
         if key_padding_mask is not None:
-            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+            value = ops.mask_rows(value, key_padding_mask)
         return value.view(bs, num_value, self.num_heads, -1)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,

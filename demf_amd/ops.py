@@ -412,6 +412,21 @@ def maxpool_ns(x):
     return _MaxPoolNS.apply(x)
 
 
+_IDENTITY_DY = {}
+
+
+def _identity_dy_vectors(n, device):
+    """The 5 per-channel vectors (scale, shift, gi, a, b) that make the dY prologue of
+    demf_mlp_gemm_bwd_dw the identity: mask 0*y+1 > 0, dY = 1*dZ + 0*y + 0."""
+    key = (n, str(device))
+    if key not in _IDENTITY_DY:
+        v = torch.zeros(5, n, dtype=torch.float32, device=device)
+        v[1] = 1.0
+        v[2] = 1.0
+        _IDENTITY_DY[key] = v.reshape(-1).contiguous()
+    return _IDENTITY_DY[key]
+
+
 class _LinearRows(Function):
     """y = x W^T + b on rows.  GEMMs through hipBLASLt; the bias gradient through
     demf_colsum_f32 instead of at::sum (see include/demf_hip.h)."""
@@ -428,12 +443,45 @@ class _LinearRows(Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            R, N, K = g.shape[0], g.shape[1], x.shape[1]
+            if R >= 32768 and N % 4 == 0 and K % 4 == 0 and x.is_contiguous():
+                # long reduction (the value projection: 149 k tokens -> 256x256): the slab-split
+                # dW kernel of the shared-MLP path, run with an identity dY prologue
+                gw = torch.zeros(N, K, dtype=g.dtype, device=g.device)
+                _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, K, _p(g), None, None, 1, _p(g),
+                          _p(_identity_dy_vectors(N, g.device)), _p(x), None, _p(gw), _stream())
+            else:
+                gw = g.t() @ x
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device)
             _ffi.call("demf_colsum_f32", g.shape[0], g.shape[1], g.shape[1], _p(g), _p(gb), _stream())
         return gx, gw, gb
+
+
+class _MaskRows(Function):
+    """x.masked_fill(mask[..., None], 0) for a freshly produced x: in place, forward and backward
+    (one pass each instead of torch's clone + fill; x is 152 MB at the bench size)."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        ctx.mark_dirty(x)
+        return x.masked_fill_(mask.unsqueeze(-1), 0.0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        # g is the value gradient produced by the MSDA backward for this use only
+        return g.masked_fill_(mask.unsqueeze(-1), 0.0), None
+
+
+def mask_rows(x, mask):
+    """Zero the rows of x (..., C) selected by the boolean mask (...) - in place."""
+    return _MaskRows.apply(x, mask)
 
 
 def linear(x, weight, bias=None):
