@@ -165,6 +165,107 @@ __global__ __launch_bounds__(256) void group_concat_cl_bwd_k(
   }
 }
 
+// ---- inverse neighbour lists --------------------------------------------------------------
+// idx (B, E) with values in [0, N) (E = M*ns entries of a ball query) -> CSR by source point:
+// off (B, N+1), rows (B, E) = the entry positions e (= m*ns+s) that reference point j, ascending
+// within a list.  One block per scene; histogram, scan and cursors live in LDS (N <= 16384).
+// Depends on coordinates only, so the training step computes it in the pre-pass.
+constexpr int INV_MAX_N = 16384;
+__global__ __launch_bounds__(1024) void invert_index_k(int N, int E, const int* __restrict__ idx,
+                                                       int* __restrict__ off,
+                                                       int* __restrict__ rows) {
+  extern __shared__ int s_inv[];          // cnt[N] | start[N+1]
+  int* cnt = s_inv;
+  int* start = s_inv + N;
+  __shared__ int s_part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  idx += (size_t)b * E;
+  off += (size_t)b * (N + 1);
+  rows += (size_t)b * E;
+  for (int j = tid; j < N; j += 1024) cnt[j] = 0;
+  __syncthreads();
+  for (int e = tid; e < E; e += 1024) atomicAdd(&cnt[idx[e]], 1);
+  __syncthreads();
+  // exclusive scan of cnt: each thread owns a contiguous chunk
+  const int chunk = (N + 1023) / 1024;
+  const int j0 = tid * chunk, j1 = j0 + chunk < N ? j0 + chunk : N;
+  int local = 0;
+  for (int j = j0; j < j1; ++j) local += cnt[j];
+  s_part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int j = j0; j < j1; ++j) {
+    start[j] = run;
+    off[j] = run;
+    run += cnt[j];
+  }
+  if (tid == 1023) { start[N] = E; off[N] = E; }
+  __syncthreads();
+  for (int j = tid; j < N; j += 1024) cnt[j] = 0;      // reuse as fill cursors
+  __syncthreads();
+  for (int e = tid; e < E; e += 1024) {
+    const int j = idx[e];
+    rows[start[j] + atomicAdd(&cnt[j], 1)] = e;
+  }
+  __syncthreads();
+  // make every list ascending (the fill order above depends on wave scheduling)
+  for (int j = tid; j < N; j += 1024) {
+    int* l = rows + start[j];
+    const int n = cnt[j];
+    for (int a = 1; a < n; ++a) {
+      const int v = l[a];
+      int c = a - 1;
+      while (c >= 0 && l[c] > v) { l[c + 1] = l[c]; --c; }
+      l[c + 1] = v;
+    }
+  }
+}
+
+// grad_feat (B,N,C) = sum over the entries that gathered point j of grad_out rows - the
+// atomic-free transpose of group_concat_cl_fwd's feature copy.  LPR lanes (C/4) own one
+// destination row; 4 source rows in flight; every destination row is written exactly once.
+template <int LPR>
+__global__ __launch_bounds__(256) void group_concat_cl_bwd_gather_k(
+    int N, int E, int C, int ldo, int feat_col, const float* __restrict__ gout,
+    const int* __restrict__ off, const int* __restrict__ rows, float* __restrict__ gfeat,
+    long long points) {
+  const int sub = threadIdx.x % LPR;
+  long long pt = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const long long stride = (long long)gridDim.x * blockDim.x / LPR;
+  for (; pt < points; pt += stride) {
+    const int b = (int)(pt / N), j = (int)(pt - (long long)b * N);
+    const int* o = off + (size_t)b * (N + 1) + j;
+    const int e0 = o[0], e1 = o[1];
+    const int* r = rows + (size_t)b * E;
+    const float* g = gout + (size_t)b * E * ldo + feat_col;
+    for (int c = sub * 4; c < C; c += LPR * 4) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int e = e0;
+      for (; e + 3 < e1; e += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          v[u] = *reinterpret_cast<const float4*>(g + (size_t)r[e + u] * ldo + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
+      }
+      for (; e < e1; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(g + (size_t)r[e] * ldo + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(gfeat + ((size_t)b * N + j) * C + c) = acc;
+    }
+  }
+}
+
 // rows gather (B,N,C)[idx (B,M)] -> (B,M,C): G lanes per row, float4 when aligned
 __global__ __launch_bounds__(256) void gather_rows_cl_fwd_k(int N, int M, int C,
                                                             const float* __restrict__ feat,
@@ -465,4 +566,48 @@ extern "C" int demf_colsum_f32(int R, int N, int ld, const float* x, float* out,
   else
     hipLaunchKernelGGL(colsum_k<1>, grid, dim3(256), 0, (hipStream_t)stream, R, N, ld, rpb, x, out);
   return check_launch("colsum");
+}
+
+extern "C" int demf_invert_index(int B, int N, int E, const int* idx, int* off, int* rows,
+                                 demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && E >= 0, "invert_index: bad sizes B=%d N=%d E=%d", B, N, E);
+  if (N > INV_MAX_N) {
+    set_error("invert_index: N=%d exceeds %d (LDS-resident histogram)", N, INV_MAX_N);
+    return DEMF_EUNSUPPORTED;
+  }
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(idx && off && rows, "invert_index: null pointer");
+  hipLaunchKernelGGL(invert_index_k, dim3(B), dim3(1024), sizeof(int) * (2 * N + 1),
+                     (hipStream_t)stream, N, E, idx, off, rows);
+  return check_launch("invert_index");
+}
+
+extern "C" int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int feat_col,
+                                               const float* grad_out, const int* off,
+                                               const int* rows, float* grad_feat,
+                                               demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && E >= 0 && C >= 4 && C % 4 == 0 && ldo % 4 == 0 &&
+                   feat_col % 4 == 0 && feat_col + C <= ldo,
+               "group_concat_bwd_gather: bad sizes C=%d ldo=%d feat_col=%d", C, ldo, feat_col);
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(grad_out && off && rows && grad_feat, "group_concat_bwd_gather: null pointer");
+  DEMF_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_feat) % 16) == 0,
+               "group_concat_bwd_gather: buffers must be 16-byte aligned");
+  const long long points = (long long)B * N;
+  const int lpr = C >= 256 ? 64 : (C >= 128 ? 32 : 16);
+  const long long threads = points * lpr;
+  long long blocks = (threads + 255) / 256;
+  if (blocks > 256LL * 16) blocks = 256LL * 16;
+  const dim3 grid((unsigned)blocks);
+  hipStream_t s = (hipStream_t)stream;
+  if (lpr == 64)
+    hipLaunchKernelGGL(group_concat_cl_bwd_gather_k<64>, grid, dim3(256), 0, s, N, E, C, ldo,
+                       feat_col, grad_out, off, rows, grad_feat, points);
+  else if (lpr == 32)
+    hipLaunchKernelGGL(group_concat_cl_bwd_gather_k<32>, grid, dim3(256), 0, s, N, E, C, ldo,
+                       feat_col, grad_out, off, rows, grad_feat, points);
+  else
+    hipLaunchKernelGGL(group_concat_cl_bwd_gather_k<16>, grid, dim3(256), 0, s, N, E, C, ldo,
+                       feat_col, grad_out, off, rows, grad_feat, points);
+  return check_launch("group_concat_cl_bwd_gather");
 }

@@ -62,16 +62,20 @@ class PointSAModule(nn.Module):
             parts.append(w.new_zeros(w.shape[0], pad))
         return torch.cat(parts, dim=1) if len(parts) > 1 else w
 
-    def index_geometry(self, points_xyz, indices=None):
+    def index_geometry(self, points_xyz, indices=None, with_inverse=False):
         """Everything of this level that depends on coordinates only: D-FPS indices, the sampled
-        centres and the ball-query neighbour lists.  -> (indices, new_xyz, group_idx)"""
+        centres, the ball-query neighbour lists and (``with_inverse``: levels whose input features
+        carry a gradient) their inverse lists.  -> (indices, new_xyz, group_idx[, inv_off, inv_rows])"""
         if indices is None:
             indices = ops.furthest_point_sample(points_xyz, self.num_point)
         new_xyz = ops.gather_rows_cl(points_xyz, indices)
         group_idx = ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
+        if with_inverse and points_xyz.shape[1] <= 16384:
+            return (indices, new_xyz, group_idx) + ops.invert_index(group_idx, points_xyz.shape[1])
         return indices, new_xyz, group_idx
 
-    def forward(self, points_xyz, features=None, indices=None, target_xyz=None, group_idx=None):
+    def forward(self, points_xyz, features=None, indices=None, target_xyz=None, group_idx=None,
+                group_inv=None):
         B, N, _ = points_xyz.shape
         if indices is not None:
             assert indices.shape[1] == self.num_point
@@ -88,9 +92,13 @@ class PointSAModule(nn.Module):
             ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
         assert self.use_xyz or feat is not None
         ld = _pad4(C + 3) if self.use_xyz else C
+        if group_inv is None and feat is not None and feat.requires_grad and C % 4 == 0 \
+                and N <= 16384:
+            group_inv = ops.invert_index(idx, N)
         grouped = ops.group_concat_cl(points_xyz, new_xyz, feat, idx, self.radius,
                                       self.normalize_xyz, ldo=ld,
-                                      xyz_col=C if self.use_xyz else 0, feat_col=0) \
+                                      xyz_col=C if self.use_xyz else 0, feat_col=0,
+                                      inverse=group_inv) \
             if self.use_xyz else ops.gather_rows_cl(
                 feat, idx.view(B, M * self.num_sample)).view(B, M, self.num_sample, C)
         x = grouped.view(B * M * self.num_sample, ld)
@@ -176,10 +184,10 @@ class PointNet2SASSG(nn.Module):
         256 CUs."""
         xyz = points[..., 0:3].contiguous()
         sa, cur = [], xyz
-        for m in self.SA_modules:
-            idx, new_xyz, gidx = m.index_geometry(cur)
-            sa.append((idx, new_xyz, gidx))
-            cur = new_xyz
+        for i, m in enumerate(self.SA_modules):
+            lvl = m.index_geometry(cur, with_inverse=i > 0)   # level 0 gathers the raw input
+            sa.append(lvl)
+            cur = lvl[1]
         sa_xyz = [xyz] + [t[1] for t in sa]
         fp = [PointFPModule.index_geometry(sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i])
               for i in range(self.num_fp)]
@@ -193,10 +201,10 @@ class PointNet2SASSG(nn.Module):
         sa_xyz, sa_features, sa_indices = [xyz], [features], [indices]
         for i in range(self.num_sa):
             if geometry is not None:
-                gi, gxyz, gg = geometry["sa"][i]
-                cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i],
-                                                                 indices=gi, target_xyz=None,
-                                                                 group_idx=gg)
+                lvl = geometry["sa"][i]
+                cur_xyz, cur_feat, cur_idx = self.SA_modules[i](
+                    sa_xyz[i], sa_features[i], indices=lvl[0], target_xyz=None, group_idx=lvl[2],
+                    group_inv=tuple(lvl[3:5]) if len(lvl) >= 5 else None)
             else:
                 cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i])
             sa_xyz.append(cur_xyz)

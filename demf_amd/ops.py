@@ -264,7 +264,8 @@ class MultiScaleDeformableAttnFunction(Function):
 # --------------------------------------------------------------------------
 class _GroupConcatCL(Function):
     @staticmethod
-    def forward(ctx, xyz, center, feat, idx, radius, normalize_xyz, ldo, xyz_col, feat_col):
+    def forward(ctx, xyz, center, feat, idx, radius, normalize_xyz, ldo, xyz_col, feat_col,
+                inv_off, inv_rows):
         _chk(xyz, "xyz")
         _chk(center, "center")
         _chk(idx, "idx", torch.int32)
@@ -278,7 +279,15 @@ class _GroupConcatCL(Function):
         _ffi.call("demf_group_concat_cl_fwd", B, N, M, ns, C, ldo, xyz_col, feat_col,
                   float(radius), int(bool(normalize_xyz)), _p(xyz), _p(center), _p(feat),
                   _p(idx), _p(out), _stream())
-        ctx.save_for_backward(idx)
+        gather = inv_off is not None and C >= 4 and C % 4 == 0 and ldo % 4 == 0 and feat_col % 4 == 0
+        if gather:
+            _chk(inv_off, "inv_off", torch.int32)
+            _chk(inv_rows, "inv_rows", torch.int32)
+            assert inv_off.shape == (B, N + 1) and inv_rows.shape == (B, M * ns)
+            ctx.save_for_backward(idx, inv_off, inv_rows)
+        else:
+            ctx.save_for_backward(idx)
+        ctx.gather = gather
         ctx.dims = (B, N, M, ns, C, ldo, xyz_col, feat_col, float(radius),
                     int(bool(normalize_xyz)))
         return out
@@ -286,7 +295,7 @@ class _GroupConcatCL(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out):
-        (idx,) = ctx.saved_tensors
+        idx = ctx.saved_tensors[0]
         B, N, M, ns, C, ldo, xyz_col, feat_col, radius, norm = ctx.dims
         want_feat = C > 0 and ctx.needs_input_grad[2]
         want_xyz = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
@@ -294,31 +303,54 @@ class _GroupConcatCL(Function):
         if want_feat or want_xyz:
             grad_out = grad_out.contiguous()
             kw = dict(dtype=grad_out.dtype, device=grad_out.device)
-            if want_feat:
+            if want_feat and ctx.gather:
+                # atomic-free: every source point sums the rows that gathered it
+                _, inv_off, inv_rows = ctx.saved_tensors
+                gfeat = torch.empty((B, N, C), **kw)
+                _ffi.call("demf_group_concat_cl_bwd_gather", B, N, M * ns, C, ldo, feat_col,
+                          _p(grad_out), _p(inv_off), _p(inv_rows), _p(gfeat), _stream())
+            elif want_feat:
                 gfeat = torch.zeros((B, N, C), **kw)
             if want_xyz:
                 gxyz = torch.zeros((B, N, 3), **kw)
                 gcenter = torch.zeros((B, M, 3), **kw)
-            _ffi.call("demf_group_concat_cl_bwd", B, N, M, ns, C, ldo, xyz_col, feat_col,
-                      radius, norm, _p(grad_out), _p(idx), _p(gfeat), _p(gxyz), _p(gcenter),
-                      _stream())
+            scatter_feat = gfeat if not ctx.gather else None
+            if scatter_feat is not None or want_xyz:
+                _ffi.call("demf_group_concat_cl_bwd", B, N, M, ns, C, ldo, xyz_col, feat_col,
+                          radius, norm, _p(grad_out), _p(idx), _p(scatter_feat), _p(gxyz),
+                          _p(gcenter), _stream())
         return (gxyz if ctx.needs_input_grad[0] else None,
                 gcenter if ctx.needs_input_grad[1] else None,
-                gfeat, None, None, None, None, None, None)
+                gfeat, None, None, None, None, None, None, None, None)
+
+
+def invert_index(idx, num_source):
+    """Inverse neighbour lists of idx (B,M,ns) int32 over ``num_source`` points:
+    (off (B,N+1), rows (B,M*ns)) - see demf_invert_index."""
+    _chk(idx, "idx", torch.int32)
+    B = idx.shape[0]
+    E = idx[0].numel()
+    off = torch.empty((B, num_source + 1), dtype=torch.int32, device=idx.device)
+    rows = torch.empty((B, E), dtype=torch.int32, device=idx.device)
+    _ffi.call("demf_invert_index", B, num_source, E, _p(idx), _p(off), _p(rows), _stream())
+    return off, rows
 
 
 def group_concat_cl(xyz, center, feat, idx, radius, normalize_xyz, ldo=None, xyz_col=None,
-                    feat_col=0):
+                    feat_col=0, inverse=None):
     """Fused QueryAndGroup on point-major features.
     xyz (B,N,3), center (B,M,3), feat (B,N,C)|None, idx (B,M,ns) -> (B,M,ns,ldo) rows
-    ``[feat | (xyz_j - center)/radius | 0-pad]`` (column order chosen by the caller)."""
+    ``[feat | (xyz_j - center)/radius | 0-pad]`` (column order chosen by the caller).
+    ``inverse`` = invert_index(idx, N): the feature gradient is then gathered instead of
+    scattered with atomics."""
     C = 0 if feat is None else feat.shape[2]
     if xyz_col is None:
         xyz_col = feat_col + C
     if ldo is None:
         ldo = max(xyz_col + 3, feat_col + C)
+    inv_off, inv_rows = inverse if inverse is not None else (None, None)
     return _GroupConcatCL.apply(xyz, center, feat, idx, radius, normalize_xyz, ldo, xyz_col,
-                                feat_col)
+                                feat_col, inv_off, inv_rows)
 
 
 class _GatherRowsCL(Function):

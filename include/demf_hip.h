@@ -149,6 +149,19 @@ int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out, const int* 
                         float* grad_x /* (R,ns,C), fully written */,
                         demf_stream_t stream);
 
+/* Inverse neighbour lists of a ball-query result: idx (B,E) int32 with values in [0,N), E = M*ns
+ * -> CSR by source point: off (B,N+1), rows (B,E) = entry positions e = m*ns+s, ascending within a
+ * list.  N <= 16384.  Coordinate-only (QueryAndGroup's idx, class_agnostic_vote_head.py:383). */
+int demf_invert_index(int B, int N, int E, const int* idx, int* off, int* rows, demf_stream_t stream);
+
+/* grad_feat (B,N,C) of demf_group_concat_cl_fwd through the inverse lists: every source point sums
+ * the grad_out rows (B,E,ldo)[.., feat_col:feat_col+C] that gathered it.  No atomics; grad_feat is
+ * fully written (need not arrive zeroed).  C % 4 == 0.  Same result as demf_group_concat_cl_bwd's
+ * grad_feat up to summation order. */
+int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int feat_col,
+                                    const float* grad_out, const int* off, const int* rows,
+                                    float* grad_feat, demf_stream_t stream);
+
 /* out (N) += column sums of x (R,N; row stride ld).  out arrives zeroed.  The bias gradient of the
  * path's linear layers (mmcv FFN / MultiheadAttention / MultiScaleDeformableAttention projections,
  * transformer.py:73; conv_cls / conv_reg, class_agnostic_vote_head.py:398) - replaces

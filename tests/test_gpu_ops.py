@@ -124,8 +124,10 @@ def test_three_interpolate(ops):
 # ---- point-major fused variants vs the channel-major oracle -----------------
 @pytest.mark.parametrize("C,ldo,feat_col,xyz_col", [(128, 132, 0, 128), (1, 4, 3, 0),
                                                      (0, 4, 0, 0), (5, 11, 4, 0),
-                                                     (1, 4, 0, 1), (2, 8, 0, 2), (3, 7, 0, 3)])
-def test_group_concat_cl(ops, C, ldo, feat_col, xyz_col):
+                                                     (1, 4, 0, 1), (2, 8, 0, 2), (3, 7, 0, 3),
+                                                     (256, 260, 0, 256), (64, 72, 4, 0)])
+@pytest.mark.parametrize("use_inverse", [False, True])
+def test_group_concat_cl(ops, C, ldo, feat_col, xyz_col, use_inverse):
     rng = np.random.default_rng(3)
     B, N, M, ns, r = 2, 900, 70, 16, 0.4
     xyz = scene_points(B, N, seed=1)
@@ -133,8 +135,9 @@ def test_group_concat_cl(ops, C, ldo, feat_col, xyz_col):
     idx = ok.ball_query(0.0, r, ns, xyz, center)
     feat = rng.standard_normal((B, N, C)).astype(np.float32) if C else None
     f = dev(feat).requires_grad_() if C else None
+    inverse = ops.invert_index(dev(idx), N) if use_inverse else None
     out = ops.group_concat_cl(dev(xyz), dev(center), f, dev(idx), r, True, ldo=ldo,
-                              xyz_col=xyz_col, feat_col=feat_col)
+                              xyz_col=xyz_col, feat_col=feat_col, inverse=inverse)
     o = out.detach().cpu().numpy()
     gx = ok.group_points_fwd(xyz.transpose(0, 2, 1), idx)  # (B,3,M,ns)
     rel = ((gx - center.transpose(0, 2, 1)[..., None]) / np.float32(r))
@@ -238,3 +241,20 @@ def test_colsum_matches_fp64_sum(R, N):
     _ffi.call("demf_colsum_f32", R, N, N, x.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     ref = x.double().sum(0)
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * (R ** 0.5))
+
+
+@pytest.mark.parametrize("B,N,M,ns", [(2, 900, 70, 16), (3, 2048, 1024, 32), (1, 7, 3, 4), (2, 16384, 64, 8)])
+def test_invert_index(ops, B, N, M, ns):
+    """demf_invert_index: CSR inverse of a ball-query result - every list holds exactly the
+    entry positions that reference the point, ascending (bit-exact against numpy)."""
+    rng = np.random.default_rng(B * N + M)
+    idx = rng.integers(0, N, size=(B, M, ns)).astype(np.int32)
+    idx[:, 0, :] = idx[:, 0, :1]                      # a centre with one neighbour repeated ns times
+    off, rows = ops.invert_index(dev(idx), N)
+    off, rows = off.cpu().numpy(), rows.cpu().numpy()
+    for b in range(B):
+        flat = idx[b].reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        counts = np.bincount(flat, minlength=N)
+        np.testing.assert_array_equal(off[b], np.concatenate([[0], np.cumsum(counts)]))
+        np.testing.assert_array_equal(rows[b], order)
