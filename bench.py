@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--stream-priority", action="store_true",
+                    help="run the step graph on a high-priority HIP stream (experiment)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="compute the FPS/ball-query pre-pass inside the step instead of pipelining it")
     ap.add_argument("--cu-mask", action="store_true",
@@ -141,6 +143,12 @@ def main():
     if not args.no_graph and args.cu_mask:
         # FPS pre-pass of the next batch on B dedicated CUs, the step on the other 256-B
         main_s, trainer.side_stream = engine.cu_masked_streams(list(range(args.batch)))
+        torch.cuda.set_stream(main_s)
+    if not args.no_graph and args.stream_priority:
+        # experiment: step graph on a high-priority stream, pre-pass on a normal one
+        main_s = torch.cuda.Stream(priority=-1)
+        trainer.side_stream = torch.cuda.Stream(priority=0)
+        main_s.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_s)
     step = (lambda: trainer.step(batch)) if args.no_graph else \
         trainer.capture(batch, prefetch_geometry=not args.no_prefetch)

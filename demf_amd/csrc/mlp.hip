@@ -285,15 +285,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
 }
 
 // ---- BN statistics -> per-channel scale/shift (+ running stats, saved mean/invstd) -----------
-__global__ void bn_finalize_kernel(int N, double count, const double* __restrict__ stats,
+__global__ void bn_finalize_kernel(int N, double count, double* __restrict__ stats,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ ss,
-                                   float* __restrict__ mi) {
+                                   float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches_tracked,
+                                   float* __restrict__ ss, float* __restrict__ mi) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (c >= N) return;
   const double mean = stats[c] / count;
   double var = stats[N + c] / count - mean * mean;  // biased, as BN normalises with
+  stats[c] = 0.0;                                   // consumed: the accumulator is left zeroed
+  stats[N + c] = 0.0;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * invstd);
@@ -457,13 +461,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
 }
 
 // g1,g2 -> the 5 backward vectors + dgamma, dbeta
-__global__ void bn_bwd_vectors_k(int N, double count, const double* __restrict__ g12,
+__global__ void bn_bwd_vectors_k(int N, double count, double* __restrict__ g12,
                                  const float* __restrict__ gamma, const float* __restrict__ ss,
                                  const float* __restrict__ mi, float* __restrict__ vec,
                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N) return;
   const double g1 = g12[c], g2 = g12[N + c];
+  g12[c] = 0.0;                                     // consumed: left zeroed for the next user
+  g12[N + c] = 0.0;
   const double mean = mi[c], is = mi[N + c];
   const double gi = (double)gamma[c] * is;
   const double a = -gi * is * (g2 / count);
@@ -695,15 +701,16 @@ extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
   return stats ? launch_gemm<PRO_NONE, true>(a, s) : launch_gemm<PRO_NONE, false>(a, s);
 }
 
-extern "C" int demf_bn_finalize(int N, long long count, const double* stats, const float* gamma,
+extern "C" int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,
                                 const float* beta, float eps, float momentum,
-                                float* running_mean, float* running_var, float* scale_shift,
+                                float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float* scale_shift,
                                 float* mean_invstd, demf_stream_t stream) {
   DEMF_REQUIRE(N >= 1 && count >= 1 && stats && gamma && beta && scale_shift && mean_invstd,
                "bn_finalize: bad arguments");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
                      (double)count, stats, gamma, beta, eps, momentum, running_mean, running_var,
-                     scale_shift, mean_invstd);
+                     num_batches_tracked, scale_shift, mean_invstd);
   return check_launch("bn_finalize");
 }
 
@@ -753,7 +760,7 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
   return check_launch("bn_bwd_reduce");
 }
 
-extern "C" int demf_bn_bwd_vectors(int N, long long count, const double* g12, const float* gamma,
+extern "C" int demf_bn_bwd_vectors(int N, long long count, double* g12, const float* gamma,
                                    const float* scale_shift, const float* mean_invstd, float* vec6,
                                    float* dgamma, float* dbeta, demf_stream_t stream) {
   DEMF_REQUIRE(N >= 1 && count >= 1 && g12 && gamma && scale_shift && mean_invstd && vec6 &&

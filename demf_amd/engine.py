@@ -203,14 +203,12 @@ class Trainer:
             loss = self._fwd_bwd(batch, static_geo)
 
         def flat_tensors(g):
-            out = []
-            for lvl in g["sa"]:
-                out += list(lvl)
-            for lvl in g["fp"]:
-                out += list(lvl)
-            if "sample_indices" in g:
-                out.append(g["sample_indices"])
-            return out
+            """Every tensor of the (nested) geometry structure, in a deterministic order."""
+            if torch.is_tensor(g):
+                return [g]
+            if isinstance(g, dict):
+                return [t for k in sorted(g) for t in flat_tensors(g[k])]
+            return [t for v in g for t in flat_tensors(v)]
 
         geo_graph, fresh, static_pts = None, None, None
         if can_prefetch:

@@ -42,9 +42,7 @@ def fused_rows(blocks, x, ns=1, first_weight=None):
         bn = blk.bn
         w = first_weight if (i == 0 and first_weight is not None) else blk.weight2d()
         layers.append((w.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                       blk.conv.bias))
-        if training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+                       blk.conv.bias, bn.num_batches_tracked))
     bn0 = blocks[0].bn
     return ops.shared_mlp_pool(x, ns, layers, training=training, eps=bn0.eps, momentum=bn0.momentum)
 

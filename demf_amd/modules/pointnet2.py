@@ -75,11 +75,12 @@ class PointSAModule(nn.Module):
         return indices, new_xyz, group_idx
 
     def forward(self, points_xyz, features=None, indices=None, target_xyz=None, group_idx=None,
-                group_inv=None):
+                group_inv=None, new_xyz=None):
         B, N, _ = points_xyz.shape
         if indices is not None:
             assert indices.shape[1] == self.num_point
-            new_xyz = ops.gather_rows_cl(points_xyz, indices)
+            if new_xyz is None:
+                new_xyz = ops.gather_rows_cl(points_xyz, indices)
         elif target_xyz is not None:
             new_xyz = target_xyz.contiguous()
         else:
@@ -183,33 +184,45 @@ class PointNet2SASSG(nn.Module):
         trains (demf_amd/engine.py) - FPS is a latency-bound chain that occupies only B of the
         256 CUs."""
         xyz = points[..., 0:3].contiguous()
+        B, N = xyz.shape[:2]
         sa, cur = [], xyz
+        chain = [torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()]
         for i, m in enumerate(self.SA_modules):
             lvl = m.index_geometry(cur, with_inverse=i > 0)   # level 0 gathers the raw input
             sa.append(lvl)
             cur = lvl[1]
+            chain.append(torch.gather(chain[-1], 1, lvl[0].long()))   # indices into the input cloud
         sa_xyz = [xyz] + [t[1] for t in sa]
         fp = [PointFPModule.index_geometry(sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i])
               for i in range(self.num_fp)]
-        return dict(sa=sa, fp=fp)
+        geo = dict(sa=sa, fp=fp, xyz=xyz, sa_indices=chain)
+        if points.shape[-1] > 3:
+            geo["feat_rows"] = points[..., 3:].contiguous()        # (B,N,C0) point-major input features
+        return geo
 
     def forward(self, points, geometry=None):
-        xyz = points[..., 0:3].contiguous()
-        features = points[..., 3:].transpose(1, 2) if points.shape[-1] > 3 else None
-        B, N = xyz.shape[:2]
-        indices = torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()
+        if geometry is not None:
+            xyz = geometry["xyz"]
+            features = geometry["feat_rows"].transpose(1, 2) if "feat_rows" in geometry else None
+            indices = geometry["sa_indices"][0]
+        else:
+            xyz = points[..., 0:3].contiguous()
+            features = points[..., 3:].transpose(1, 2) if points.shape[-1] > 3 else None
+            B, N = xyz.shape[:2]
+            indices = torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()
         sa_xyz, sa_features, sa_indices = [xyz], [features], [indices]
         for i in range(self.num_sa):
             if geometry is not None:
                 lvl = geometry["sa"][i]
                 cur_xyz, cur_feat, cur_idx = self.SA_modules[i](
                     sa_xyz[i], sa_features[i], indices=lvl[0], target_xyz=None, group_idx=lvl[2],
-                    group_inv=tuple(lvl[3:5]) if len(lvl) >= 5 else None)
+                    group_inv=tuple(lvl[3:5]) if len(lvl) >= 5 else None, new_xyz=lvl[1])
+                sa_indices.append(geometry["sa_indices"][i + 1])
             else:
                 cur_xyz, cur_feat, cur_idx = self.SA_modules[i](sa_xyz[i], sa_features[i])
+                sa_indices.append(torch.gather(sa_indices[-1], 1, cur_idx.long()))
             sa_xyz.append(cur_xyz)
             sa_features.append(cur_feat)
-            sa_indices.append(torch.gather(sa_indices[-1], 1, cur_idx.long()))
         fp_xyz, fp_features, fp_indices = [sa_xyz[-1]], [sa_features[-1]], [sa_indices[-1]]
         for i in range(self.num_fp):
             fp_features.append(self.FP_modules[i](sa_xyz[self.num_sa - i - 1],

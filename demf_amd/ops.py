@@ -528,6 +528,23 @@ def linear(x, weight, bias=None):
 # --------------------------------------------------------------------------
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------
+_ACCUM64 = {}
+
+
+def _accum64(n, device):
+    """A persistent, zero-initialised fp64 accumulator of >= n elements per device.  The kernels
+    that consume it (demf_bn_finalize, demf_bn_bwd_vectors) leave it zeroed again, so the step
+    issues no fill for it.  Never (re)allocated inside a graph capture."""
+    key = str(device)
+    buf = _ACCUM64.get(key)
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(n, dtype=torch.float64, device=device)
+        buf = torch.zeros(max(n, 4096), dtype=torch.float64, device=device)
+        _ACCUM64[key] = buf
+    return buf
+
+
 class _SharedMLPPool(Function):
     """x (R, ld) rows -> pooled (R/ns, C_L).  Per layer l the tensors are
     (W_l (N_l, K_l), gamma_l, beta_l, running_mean_l, running_var_l, conv_bias_l|None);
@@ -541,18 +558,18 @@ class _SharedMLPPool(Function):
     def forward(ctx, x, ns, training, eps, momentum, *tensors):
         _chk(x, "x")
         R, ld = x.shape
-        L = len(tensors) // 6
-        assert len(tensors) == 6 * L and R % ns == 0
+        L = len(tensors) // 7
+        assert len(tensors) == 7 * L and R % ns == 0
         dev = x.device
         st = _stream()
         Ys, sss, mis = [], [], []
         cur, cur_ld, pro = x, ld, None
-        # one zero-filled fp64 workspace for every layer's statistics (one fill, not L)
-        ws = torch.zeros(2 * sum(tensors[6 * l].shape[0] for l in range(L)), dtype=torch.float64,
-                         device=dev) if training else None
+        # the self-cleaning fp64 accumulator holds every layer's statistics (no fill launches)
+        ws = _accum64(2 * sum(tensors[7 * l].shape[0] for l in range(L)), dev) if training else None
         woff = 0
         for l in range(L):
-            W, gamma, beta, rmean, rvar = tensors[6 * l:6 * l + 5]
+            W, gamma, beta, rmean, rvar = tensors[7 * l:7 * l + 5]
+            nbt = tensors[7 * l + 6]
             _chk(W, "weight")
             N, K = W.shape
             assert K == cur_ld, f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
@@ -565,7 +582,7 @@ class _SharedMLPPool(Function):
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           _p(stats), st)
                 _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                          float(momentum), _p(rmean), _p(rvar), _p(ss), _p(mi), st)
+                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
             else:
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           None, st)
@@ -583,9 +600,9 @@ class _SharedMLPPool(Function):
         arg = torch.empty((R // ns, C), dtype=torch.int32, device=dev)
         _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
                   _p(arg), st)
-        ctx.save_for_backward(x, arg, *Ys, *sss, *mis, *[tensors[6 * l] for l in range(L)],
-                              *[tensors[6 * l + 1] for l in range(L)])
-        ctx.bias_shapes = [None if tensors[6 * l + 5] is None else tensors[6 * l + 5].shape
+        ctx.save_for_backward(x, arg, *Ys, *sss, *mis, *[tensors[7 * l] for l in range(L)],
+                              *[tensors[7 * l + 1] for l in range(L)])
+        ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
         ctx.mark_non_differentiable(arg)
@@ -604,10 +621,11 @@ class _SharedMLPPool(Function):
         dev, st = x.device, _stream()
         dP = grad_out.contiguous()
         G = None
-        grads = [None] * (6 * L)
+        grads = [None] * (7 * L)
         dx = None
-        # zero-filled workspaces for all layers at once: BN reductions (fp64), weight grads (fp32)
-        ws64 = torch.zeros(2 * sum(W.shape[0] for W in Ws), dtype=torch.float64, device=dev)
+        # BN reductions go through the self-cleaning fp64 accumulator; the weight gradients of all
+        # layers share one zero-filled fp32 workspace
+        ws64 = _accum64(2 * sum(W.shape[0] for W in Ws), dev)
         ws32 = torch.zeros(sum(W.numel() for W in Ws), dtype=torch.float32, device=dev)
         o64 = o32 = 0
         for l in range(L - 1, -1, -1):
@@ -630,9 +648,9 @@ class _SharedMLPPool(Function):
             _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
                       _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(xprev),
                       _p(sss[l - 1] if l > 0 else None), _p(dW), st)
-            grads[6 * l], grads[6 * l + 1], grads[6 * l + 2] = dW, dgamma, dbeta
+            grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
             if ctx.bias_shapes[l] is not None:
-                grads[6 * l + 5] = torch.zeros(ctx.bias_shapes[l], dtype=torch.float32, device=dev)
+                grads[7 * l + 5] = torch.zeros(ctx.bias_shapes[l], dtype=torch.float32, device=dev)
             if l > 0 or ctx.needs_input_grad[0]:
                 Wtt = W.t().contiguous()
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
@@ -647,16 +665,19 @@ class _SharedMLPPool(Function):
 
 def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1):
     """Fused (conv1x1 -> BN -> ReLU) x L -> max over ``ns`` consecutive rows (ns=1: none).
-    ``layers`` = [(weight (N,K), gamma, beta, running_mean, running_var[, conv_bias]), ...].
+    ``layers`` = [(weight (N,K), gamma, beta, running_mean, running_var[, conv_bias
+    [, num_batches_tracked]]), ...].
     A conv bias in front of a train-mode BN cancels in the normalised output (and its gradient
-    is identically zero); it only shifts the running mean, which is applied here."""
+    is identically zero); it only shifts the running mean, which is applied here.
+    ``num_batches_tracked`` (int64 scalar tensor) is incremented by the statistics kernel."""
     flat = []
     for layer in layers:
         W, gamma, beta, rmean, rvar = layer[:5]
         bias = layer[5] if len(layer) > 5 else None
+        nbt = layer[6] if len(layer) > 6 and training else None
         if not training and bias is not None:
             rmean = rmean - bias.detach()      # eval: BN sees y + bias
-        flat += [W, gamma, beta, rmean, rvar, bias]
+        flat += [W, gamma, beta, rmean, rvar, bias, nbt]
     out = _SharedMLPPool.apply(x, ns, training, eps, momentum, *flat)
     if training:
         with torch.no_grad():

@@ -35,7 +35,7 @@ typedef void* demf_stream_t;
 #define DEMF_ELAUNCH (-2)  /* hipGetLastError() reported a launch failure   */
 #define DEMF_EUNSUPPORTED (-3)
 
-#define DEMF_ABI_VERSION 1
+#define DEMF_ABI_VERSION 2
 
 int demf_version(void);
 const char* demf_last_error(void);
@@ -184,11 +184,13 @@ int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
                       double* stats, demf_stream_t stream);
 
 /* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
- * running statistics (momentum, unbiased variance) when they are non-NULL.      */
-int demf_bn_finalize(int N, long long count, const double* stats, const float* gamma,
+ * running statistics (momentum, unbiased variance) and increments *num_batches_tracked when
+ * they are non-NULL (BatchNorm's train-mode bookkeeping).  The consumed accumulator is left
+ * ZEROED, so a persistent stats buffer needs no per-step clearing.                */
+int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean,
-                     float* running_var, float* scale_shift, float* mean_invstd,
-                     demf_stream_t stream);
+                     float* running_var, long long* num_batches_tracked, float* scale_shift,
+                     float* mean_invstd, demf_stream_t stream);
 
 /* out (R,C) = max over s of act(Y (R,ns,C)); arg = first maximising s.           */
 int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y, const float* scale_shift,
@@ -202,8 +204,9 @@ int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP, co
                        double* g12, demf_stream_t stream);
 
 /* g12 -> the five per-channel vectors the backward GEMM prologues consume (vec6: 5N floats:
- * scale, shift, gi = gamma*invstd, a, b with dY = gi*dZ + a*y + b) + dgamma, dbeta.     */
-int demf_bn_bwd_vectors(int N, long long count, const double* g12, const float* gamma,
+ * scale, shift, gi = gamma*invstd, a, b with dY = gi*dZ + a*y + b) + dgamma, dbeta.  The
+ * consumed g12 is left ZEROED.                                                            */
+int demf_bn_bwd_vectors(int N, long long count, double* g12, const float* gamma,
                         const float* scale_shift, const float* mean_invstd, float* vec6,
                         float* dgamma, float* dbeta, demf_stream_t stream);
 

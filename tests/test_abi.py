@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_ffi_table_matches_header():
     decls = _header_decls()
     lib = _ffi.load()
-    assert lib.demf_version() == 1
+    assert lib.demf_version() == 2
     assert lib.demf_last_error() is not None
     for name, argtypes in _ffi.SIGNATURES.items():
         assert name in decls, f"{name} bound in _ffi.py but not declared in the header"
