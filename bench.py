@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU (BASELINE configs[2])")
+    ap.add_argument("--msda-points", type=int, default=2,
+                    help="sampling points per level of the fusion attention: 2 = reference config "
+                         "(demf_votenet.py:83), 4 = BASELINE.json's wording; secondary figure only")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -129,7 +132,11 @@ def main():
     from demf_amd import ops
     from demf_amd.modules import DeMFHotPath
     torch.manual_seed(0)
-    model = DeMFHotPath(DeMFCfg()).to(device).train()
+    cfg = DeMFCfg()
+    if args.msda_points != cfg.head.num_points:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, head=dataclasses.replace(cfg.head, num_points=args.msda_points))
+    model = DeMFHotPath(cfg).to(device).train()
     trainer = engine.Trainer(model)
     batch, _ = make_batch(args.batch, seed=1000 + rank, device=device)   # weak scaling: B per GPU
 
@@ -191,7 +198,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: full DeMF fusion hot path fwd+loss+bwd+"
                                    "allreduce+AdamW, 8 scenes/GPU x (20000 pts, 800x1120 -> "
-                                   "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=2, fp32",
+                                   f"4-level 256-ch pyramid), 256 queries, H=8 L=4 P={args.msda_points}, fp32",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else "hipGraph(fwd+loss+bwd) + eager allreduce/AdamW; "
                                  "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
