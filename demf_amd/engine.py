@@ -154,7 +154,8 @@ class Trainer:
         losses = self.model.forward_train(batch["points"], batch["img_features"],
                                           batch["img_metas"], batch["gt_bboxes_3d"],
                                           batch["gt_labels_3d"], **kw)
-        total = torch.stack(list(losses.values())).sum()
+        # the head hands out the sum of its losses directly (one node instead of 8 selects)
+        total = losses["_total"] if "_total" in losses else torch.stack(list(losses.values())).sum()
         self.flat.backward_into(total)
         return total.detach()
 

@@ -265,20 +265,45 @@ class DeMFVoteHead(nn.Module):
         bbox_preds = dict(bbox_preds)
         decode_res_all = bbox_preds.pop("decode_res_all")
         targets = self.get_targets(points, gt_bboxes_3d, gt_labels_3d, bbox_preds, vote_pack)
+        assert self.num_fusion_layers + 1 == len(decode_res_all)
+        if all(self._fusable(d) for d in decode_res_all):
+            # device path: one 7-vector per decode layer, averaged as a vector; the vote loss does
+            # not depend on the decode layer, so it is evaluated once ((v+v)/2 == v exactly).
+            # "_total" (sum of all eight) is what a training loop should differentiate: it avoids
+            # the per-entry select/stack nodes of the dict.
+            vecs, vote = zip(*[self._loss_fused({**bbox_preds, **d}, targets, d["_rows"],
+                                                 with_vote=(i == 0))
+                               for i, d in enumerate(decode_res_all)])
+            mean7 = vecs[0]
+            for v in vecs[1:]:
+                mean7 = mean7 + v
+            mean7 = mean7 / len(vecs)
+            losses = dict(vote_loss=vote[0])
+            for i, name in enumerate(ops.HEAD_LOSS_NAMES):
+                losses[name] = mean7[i]
+            losses["_total"] = mean7.sum() + vote[0]
+            return losses
         losses_all = [self._loss({**bbox_preds, **d}, targets) for d in decode_res_all]
-        assert self.num_fusion_layers + 1 == len(losses_all)
         return {k: sum(l[k] for l in losses_all) / (self.num_fusion_layers + 1)
                 for k in losses_all[0]}
+
+    def _fusable(self, decode_res):
+        rows = decode_res.get("_rows")
+        c = self.loss_cfg
+        return rows is not None and rows[0].is_cuda and rows[0].shape[-1] == 12 and \
+            rows[1].shape[-1] == 30 and c["semantic"] is not None and bool(c["iou"])
 
     def _loss(self, bbox_preds, targets):
         (vote_targets, vote_target_masks, dir_class_targets, dir_res_targets, mask_targets,
          objectness_targets, objectness_weights, box_loss_weights, distance_targets,
          dir_targets, size_targets, center_targets) = targets
         c = self.loss_cfg
-        rows = bbox_preds.get("_rows")
-        if rows is not None and rows[0].is_cuda and rows[0].shape[-1] == 12 and \
-                rows[1].shape[-1] == 30 and c["semantic"] is not None and c["iou"]:
-            return self._loss_fused(bbox_preds, targets, rows)
+        if self._fusable(bbox_preds):
+            seven, vote = self._loss_fused(bbox_preds, targets, bbox_preds["_rows"])
+            losses = dict(vote_loss=vote)
+            for i, name in enumerate(ops.HEAD_LOSS_NAMES):
+                losses[name] = seven[i]
+            return losses
         vote_loss = self.vote_module.get_loss(bbox_preds["seed_points"], bbox_preds["vote_points"],
                                               bbox_preds["seed_indices"], vote_target_masks,
                                               vote_targets)
@@ -322,9 +347,10 @@ class DeMFVoteHead(nn.Module):
                                                              c["iou"].get("loss_weight", 1.0))
         return losses
 
-    def _loss_fused(self, bbox_preds, targets, rows):
+    def _loss_fused(self, bbox_preds, targets, rows, with_vote=True):
         """The same eight losses through csrc/loss.hip: one kernel for the seven per-proposal
-        reductions and one for the vote loss (instead of ~100 small kernels each way)."""
+        reductions and one for the vote loss (instead of ~100 small kernels each way).
+        -> (seven (7,) in ops.HEAD_LOSS_NAMES order, vote loss | None)"""
         (vote_targets, vote_target_masks, dir_class_targets, dir_res_targets, mask_targets,
          objectness_targets, objectness_weights, box_loss_weights, distance_targets,
          dir_targets, size_targets, center_targets) = targets
@@ -344,13 +370,11 @@ class DeMFVoteHead(nn.Module):
             dir_class_targets.reshape(R), dir_res_targets.reshape(R).contiguous(),
             mask_targets.reshape(R), objectness_targets.reshape(R),
             objectness_weights.reshape(R).contiguous(), box_loss_weights.reshape(R).contiguous())
-        losses = dict(vote_loss=ops.vote_loss(bbox_preds["vote_points"], bbox_preds["seed_points"],
-                                              bbox_preds["seed_indices"], vote_target_masks,
-                                              vote_targets, self.gt_per_seed,
-                                              self.vote_module.vote_loss_dst_weight))
-        for i, name in enumerate(ops.HEAD_LOSS_NAMES):
-            losses[name] = seven[i]
-        return losses
+        vote = ops.vote_loss(bbox_preds["vote_points"], bbox_preds["seed_points"],
+                             bbox_preds["seed_indices"], vote_target_masks, vote_targets,
+                             self.gt_per_seed, self.vote_module.vote_loss_dst_weight) \
+            if with_vote else None
+        return seven, vote
 
     # ---- targets: :756-941, batched ----------------------------------------------
     @staticmethod

@@ -149,9 +149,8 @@ class MultiScaleDeformableAttention(nn.Module):
         if not self.batch_first:
             value = value.permute(1, 0, 2)
         bs, num_value, _ = value.shape
-        value = ops.linear(value, self.value_proj.weight, self.value_proj.bias)
-        if key_padding_mask is not None:
-            value = ops.mask_rows(value, key_padding_mask)
+        value = ops.linear(value, self.value_proj.weight, self.value_proj.bias,
+                           row_mask=key_padding_mask)
         return value.view(bs, num_value, self.num_heads, -1)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,

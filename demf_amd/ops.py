@@ -460,20 +460,31 @@ def _identity_dy_vectors(n, device):
 
 
 class _LinearRows(Function):
-    """y = x W^T + b on rows.  GEMMs through hipBLASLt; the bias gradient through
-    demf_colsum_f32 instead of at::sum (see include/demf_hip.h)."""
+    """y = x W^T + b on rows [, rows selected by ``row_mask`` zeroed].  GEMMs through hipBLASLt
+    (the slab-split dW kernel for long reductions); the bias gradient through demf_colsum_f32
+    instead of at::sum (see include/demf_hip.h).  The row mask is applied in place on the fresh
+    output / on the incoming gradient: one pass each, no autograd view+in-place machinery."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, row_mask):
         ctx.has_bias = bias is not None
-        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+        y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+        if row_mask is not None:
+            y.masked_fill_(row_mask.unsqueeze(-1), 0.0)
+            ctx.save_for_backward(x, weight, row_mask)
+        else:
+            ctx.save_for_backward(x, weight)
+        return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight = ctx.saved_tensors[:2]
         g = g.contiguous()
+        if len(ctx.saved_tensors) == 3:
+            # the incoming gradient is a temporary of the producer (the MSDA backward's
+            # grad_value); it is masked in place rather than cloned (152 MB at the bench size)
+            g.masked_fill_(ctx.saved_tensors[2].unsqueeze(-1), 0.0)
         gx = g @ weight if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:
@@ -490,38 +501,17 @@ class _LinearRows(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device)
             _ffi.call("demf_colsum_f32", g.shape[0], g.shape[1], g.shape[1], _p(g), _p(gb), _stream())
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-class _MaskRows(Function):
-    """x.masked_fill(mask[..., None], 0) for a freshly produced x: in place, forward and backward
-    (one pass each instead of torch's clone + fill; x is 152 MB at the bench size)."""
-
-    @staticmethod
-    def forward(ctx, x, mask):
-        ctx.save_for_backward(mask)
-        ctx.mark_dirty(x)
-        return x.masked_fill_(mask.unsqueeze(-1), 0.0)
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
-        (mask,) = ctx.saved_tensors
-        # g is the value gradient produced by the MSDA backward for this use only
-        return g.masked_fill_(mask.unsqueeze(-1), 0.0), None
-
-
-def mask_rows(x, mask):
-    """Zero the rows of x (..., C) selected by the boolean mask (...) - in place."""
-    return _MaskRows.apply(x, mask)
-
-
-def linear(x, weight, bias=None):
-    """F.linear(x (..., K), weight (N, K), bias (N)) for device tensors of the hot path."""
+def linear(x, weight, bias=None, row_mask=None):
+    """F.linear(x (..., K), weight (N, K), bias (N)) for device tensors of the hot path;
+    ``row_mask`` (...) bool: output rows to zero (the padding mask of the value projection)."""
     if not x.is_cuda:
         raise RuntimeError("x must be a GPU (HIP) tensor: demf_amd operators have no CPU path")
     lead = x.shape[:-1]
-    y = _LinearRows.apply(x.reshape(-1, x.shape[-1]), weight, bias)
+    y = _LinearRows.apply(x.reshape(-1, x.shape[-1]), weight, bias,
+                          None if row_mask is None else row_mask.reshape(-1))
     return y.view(*lead, weight.shape[0])
 
 

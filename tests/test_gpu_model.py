@@ -58,9 +58,11 @@ def test_hot_path_vs_real_reference_goldens(name, seed, B, n_gt, golden_dir):
                 continue
             _close_to_gold(v.detach().cpu().numpy(), gold[f"decode{i}.{k}"], f"decode{i}.{k}")
     losses = model.pts_bbox_head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
+    total = losses.pop("_total")            # what a training loop differentiates
     for k, v in losses.items():
         np.testing.assert_allclose(v.item(), gold["loss." + k], rtol=5e-4, err_msg=k)
-    sum(losses.values()).backward()
+    np.testing.assert_allclose(total.item(), sum(v.item() for v in losses.values()), rtol=1e-5)
+    total.backward()
     gn = _grad_norms(model)
     assert sorted(gn) == list(gold["grad_names"])
     np.testing.assert_allclose([gn[n] for n in sorted(gn)], gold["grad_norms"], rtol=5e-3, atol=1e-4)  # BN-shadowed biases: exact 0 + noise
@@ -124,7 +126,7 @@ def _run_triple(cfg, B, N, pyramid, in_shape, img_shape, seed):
     points, f_d, gb, gl = _to_dev(batch, gtb, gtl)
     preds = model.forward_head(points, f_d, batch["img_metas"])
     losses = model.pts_bbox_head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
-    sum(losses.values()).backward()
+    losses.pop("_total").backward()
     return dict(truth=truth, cpu32=cpu32, gpu=dict(model=model, preds=preds, losses=losses))
 
 

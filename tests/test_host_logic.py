@@ -20,7 +20,10 @@ def _torch_linear_on_cpu(monkeypatch):
     one value projection, which this CPU test runs through torch's own linear instead."""
     import torch.nn.functional as F
     from demf_amd import ops
-    monkeypatch.setattr(ops, "linear", F.linear)
+    def linear(x, w, b=None, row_mask=None):
+        y = F.linear(x, w, b)
+        return y if row_mask is None else y.masked_fill(row_mask.unsqueeze(-1), 0.0)
+    monkeypatch.setattr(ops, "linear", linear)
 
 
 NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
