@@ -239,6 +239,62 @@ __global__ __launch_bounds__(256) void vote_loss_k(
   }
 }
 
+
+// ---- vote targets (get_targets_single :828-858, batched) ---------------------------------------
+// One thread per point: membership in the (<= 64) ground-truth boxes of its scene, votes towards the
+// gravity centres of the first / second / last containing box.  Arithmetic follows the torch
+// restatement operation by operation (mul and add kept separate: the library is built with
+// -ffp-contract=off), so the result is bit-identical to it; cos/sin of -yaw are passed in.
+__global__ __launch_bounds__(256) void vote_targets_k(int N, int pstride, int G,
+                                                      const float* __restrict__ points,
+                                                      const float* __restrict__ gt,
+                                                      const float* __restrict__ cs,
+                                                      const float* __restrict__ sn,
+                                                      const unsigned char* __restrict__ valid,
+                                                      float* __restrict__ vt,
+                                                      long long* __restrict__ mask) {
+  __shared__ float s_box[64 * 8];   // cx, cy, cz(gravity), hx, hy, hz, cos, sin
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < G; i += blockDim.x) {
+    const float* g = gt + ((size_t)b * G + i) * 7;
+    float* o = s_box + i * 8;
+    o[0] = g[0]; o[1] = g[1];
+    o[2] = g[2] + g[5] * 0.5f;
+    o[3] = g[3] * 0.5f; o[4] = g[4] * 0.5f; o[5] = g[5] * 0.5f;
+    o[6] = cs[(size_t)b * G + i];
+    o[7] = valid[(size_t)b * G + i] ? sn[(size_t)b * G + i] : __builtin_nanf("");  // NaN = invalid
+  }
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* p = points + ((size_t)b * N + n) * pstride;
+  const float px = p[0], py = p[1], pz = p[2];
+  int total = 0;
+  float v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f}, vl[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < G; ++i) {
+    const float* o = s_box + i * 8;
+    if (o[7] != o[7]) continue;                       // padded slot
+    const float r0 = px - o[0], r1 = py - o[1], r2 = pz - o[2];
+    const float lx = r0 * o[6] + r1 * o[7];
+    const float ly = (-r0) * o[7] + r1 * o[6];
+    const bool in = (fabsf(r2) <= o[5]) && (fabsf(lx) < o[3]) && (fabsf(ly) < o[4]);
+    if (in) {
+      ++total;
+      if (total == 1) { v1[0] = -r0; v1[1] = -r1; v1[2] = -r2; }
+      if (total == 2) { v2[0] = -r0; v2[1] = -r1; v2[2] = -r2; }
+      vl[0] = -r0; vl[1] = -r1; vl[2] = -r2;
+    }
+  }
+  float* o = vt + ((size_t)b * N + n) * 9;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[c] = total > 0 ? v1[c] : 0.f;
+    o[3 + c] = total > 0 ? (total >= 2 ? v2[c] : v1[c]) : 0.f;
+    o[6 + c] = total > 0 ? (total >= 3 ? vl[c] : v1[c]) : 0.f;
+  }
+  mask[(size_t)b * N + n] = total > 0 ? 1 : 0;
+}
+
 }  // namespace demf
 
 using namespace demf;
@@ -307,4 +363,20 @@ extern "C" int demf_vote_loss(int B, int S, int N, int gt_per_seed, float dst_we
                      (const long long*)seed_indices, (const long long*)vote_target_masks,
                      vote_targets, mask_sum, grad_out, out, grad_vote);
   return check_launch("vote_loss");
+}
+
+extern "C" int demf_vote_targets(int B, int N, int point_stride, int G, const float* points,
+                                 const float* gt_boxes, const float* cos_neg_yaw,
+                                 const float* sin_neg_yaw, const unsigned char* valid,
+                                 float* vote_targets, int64_t* vote_target_masks,
+                                 demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 0 && point_stride >= 3 && G >= 1 && G <= 64,
+               "vote_targets: bad sizes B=%d N=%d stride=%d G=%d (G <= 64)", B, N, point_stride, G);
+  if (B * N == 0) return DEMF_OK;
+  DEMF_REQUIRE(points && gt_boxes && cos_neg_yaw && sin_neg_yaw && valid && vote_targets &&
+                   vote_target_masks, "vote_targets: null pointer");
+  hipLaunchKernelGGL(vote_targets_k, dim3(cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, N,
+                     point_stride, G, points, gt_boxes, cos_neg_yaw, sin_neg_yaw, valid,
+                     vote_targets, (long long*)vote_target_masks);
+  return check_launch("vote_targets");
 }

@@ -377,25 +377,36 @@ class DeMFVoteHead(nn.Module):
         return seven, vote
 
     # ---- targets: :756-941, batched ----------------------------------------------
+    _PAD_CACHE = {}
+
     @staticmethod
     def pad_gt(gt_bboxes_3d, gt_labels_3d, device):
         """list[DepthBoxes|(n,7) tensor], list[(n,) long] -> padded (B,G,7), (B,G), valid (B,G).
-        An empty scene gets the reference's single all-zero fake box (:766-773)."""
+        An empty scene gets the reference's single all-zero fake box (:766-773).
+        One concatenation + one indexed write per tensor; the slot indices and the valid mask
+        depend only on the per-scene counts and are cached per count signature."""
         boxes = [b.tensor if isinstance(b, DepthBoxes) else b for b in gt_bboxes_3d]
-        G = max(1, max(int(b.shape[0]) for b in boxes))
+        counts = tuple(int(b.shape[0]) for b in boxes)
+        G = max(1, max(counts))
         B = len(boxes)
-        gt = torch.zeros((B, G, 7), dtype=torch.float32, device=device)
-        lab = torch.zeros((B, G), dtype=torch.long, device=device)
-        valid = torch.zeros((B, G), dtype=torch.bool, device=device)
-        for i, (b, l) in enumerate(zip(boxes, gt_labels_3d)):
-            n = int(b.shape[0])
-            if n:
-                gt[i, :n] = b.to(device)
-                lab[i, :n] = l.to(device)
-                valid[i, :n] = True
-            else:
-                valid[i, 0] = True
-        return gt, lab, valid
+        key = (counts, str(device))
+        cache = DeMFVoteHead._PAD_CACHE
+        if key not in cache:
+            if len(cache) > 64:
+                cache.clear()
+            pos = [i * G + j for i, n in enumerate(counts) for j in range(n)]
+            valid = np.zeros((B, G), dtype=bool)
+            for i, n in enumerate(counts):
+                valid[i, :max(n, 1)] = True
+            cache[key] = (torch.as_tensor(pos, dtype=torch.long, device=device),
+                          torch.as_tensor(valid, device=device))
+        pos, valid = cache[key]
+        gt = torch.zeros((B * G, 7), dtype=torch.float32, device=device)
+        lab = torch.zeros((B * G,), dtype=torch.long, device=device)
+        if pos.numel():
+            gt.index_copy_(0, pos, torch.cat([b.to(device) for b in boxes if b.shape[0]]).float())
+            lab.index_copy_(0, pos, torch.cat([l.to(device) for l, n in zip(gt_labels_3d, counts) if n]))
+        return gt.view(B, G, 7), lab.view(B, G), valid
 
     @torch.no_grad()
     def vote_targets(self, points, gt_bboxes_3d, gt_labels_3d):
@@ -413,6 +424,12 @@ class DeMFVoteHead(nn.Module):
         p = points[..., :3]
         center = torch.cat([gt[..., :2], gt[..., 2:3] + gt[..., 5:6] * 0.5], dim=-1)  # gravity
         dims, yaw = gt[..., 3:6], gt[..., 6]
+        if points.is_cuda and G <= 64 and points.is_contiguous() and gt.is_contiguous():
+            # one kernel (csrc/loss.hip: vote_targets_k) instead of ~45 broadcast kernels; the torch
+            # code below is its specification (and what the CPU golden tests run)
+            vote_targets, masks = ops.vote_targets(points, gt, valid)
+            return dict(gt=gt, lab=lab, valid=valid, center=center, dims=dims, yaw=yaw,
+                        vote_targets=vote_targets, vote_target_masks=masks)
         rel = p[:, :, None, :] - center[:, None, :, :]                        # (B,N,G,3)
         cs, sn = torch.cos(-yaw)[:, None], torch.sin(-yaw)[:, None]
         lx = rel[..., 0] * cs + rel[..., 1] * sn

@@ -767,3 +767,20 @@ def vote_loss(vote_points, seed_points, seed_indices, vote_target_masks, vote_ta
     return _VoteLoss.apply(vote_points.contiguous(), seed_points.contiguous(), seed_indices.contiguous(),
                            vote_target_masks.contiguous(), vote_targets.contiguous(), gt_per_seed,
                            dst_weight)
+
+
+def vote_targets(points, gt, valid):
+    """points (B,N,>=3), gt (B,G,7), valid (B,G) bool -> (vote_targets (B,N,9), masks (B,N) int64):
+    the per-point half of DeMFVoteHead.get_targets (class_agnostic_vote_head.py:828-858)."""
+    _chk(points, "points")
+    _chk(gt, "gt")
+    B, N, stride = points.shape
+    G = gt.shape[1]
+    yaw = gt[..., 6]
+    cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
+    v = valid.to(torch.uint8).contiguous()
+    vt = torch.empty((B, N, 9), dtype=torch.float32, device=points.device)
+    mask = torch.empty((B, N), dtype=torch.int64, device=points.device)
+    _ffi.call("demf_vote_targets", B, N, stride, G, _p(points), _p(gt), _p(cs), _p(sn), _p(v),
+              _p(vt), _p(mask), _stream())
+    return vt, mask

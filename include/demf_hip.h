@@ -283,6 +283,16 @@ int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
                       float* grad_value, float* grad_sampling_loc,
                       float* grad_attn_weight, demf_stream_t stream);
 
+/* Per-point vote targets of DeMFVoteHead.get_targets_single (class_agnostic_vote_head.py:828-858),
+ * batched: points (B,N,point_stride>=3), gt_boxes (B,G,7) = (x,y,z_bottom,dx,dy,dz,yaw) padded to
+ * G <= 64 with valid (B,G) bytes, cos/sin of -yaw (B,G) -> vote_targets (B,N,9) = votes to the
+ * gravity centres of the first | second-or-first | last-or-first containing box, zeros outside
+ * every box; vote_target_masks (B,N) int64 = inside any box.                                  */
+int demf_vote_targets(int B, int N, int point_stride, int G, const float* points,
+                      const float* gt_boxes, const float* cos_neg_yaw, const float* sin_neg_yaw,
+                      const unsigned char* valid, float* vote_targets, int64_t* vote_target_masks,
+                      demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Optimizer step on flat buffers: torch.optim.AdamW + clip_grad_norm_ as the reference's
  * runner applies them (configs/_base_/schedules/schedule_3x.py:6-7: AdamW lr 0.008, wd 0.01,

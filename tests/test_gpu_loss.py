@@ -57,3 +57,41 @@ def test_fused_losses_match_torch_composition(seed):
     gf = torch.autograd.grad(total_f, [cls, reg, base, vote_points])
     for a, b, n in zip(gf, gr, ("cls", "reg", "base", "vote_points")):
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-5 * max(1.0, b.abs().max().item()), msg=n)
+
+
+@pytest.mark.parametrize("B,N,G,seed", [(2, 5000, 6, 0), (3, 20000, 17, 1), (1, 257, 1, 2), (2, 1000, 64, 3)])
+def test_vote_targets_kernel_bit_exact(B, N, G, seed):
+    """demf_vote_targets against its torch specification (the batched restatement of
+    class_agnostic_vote_head.py:828-858 in DeMFVoteHead.vote_targets, run on the CPU): bit-exact,
+    including points inside 0, 1, 2 and >= 3 boxes, padded (invalid) GT slots and an empty scene."""
+    from demf_amd import ops
+    from demf_amd.modules.head import DeMFVoteHead
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-3, -3, 0, 0], [3, 3, 3, 3], size=(B, N, 4)).astype(np.float32)
+    gt = np.zeros((B, G, 7), np.float32)
+    gt[..., :3] = rng.uniform([-2.5, -2.5, 0], [2.5, 2.5, 1.5], size=(B, G, 3))
+    gt[..., 3:6] = rng.uniform(0.5, 3.0, size=(B, G, 3))         # big boxes: plenty of overlaps
+    gt[..., 6] = rng.uniform(-np.pi, np.pi, size=(B, G))
+    valid = np.ones((B, G), bool)
+    if G > 2:
+        valid[0, G // 2:] = False
+        gt[0, G // 2:] = 0.0
+    if B > 1:                                                        # the reference's fake box
+        valid[1] = False
+        valid[1, 0] = True
+        gt[1] = 0.0
+    head = DeMFVoteHead.__new__(DeMFVoteHead)                        # vote_targets uses no state
+    spec = DeMFVoteHead.vote_targets(head, torch.from_numpy(pts), torch.from_numpy(gt),
+                                     torch.from_numpy(valid.astype(np.int64)))
+    # padded-tensor call path: (gt, labels) tensors -> valid == all ones; emulate masks via the
+    # list path instead when slots are invalid
+    boxes = [torch.from_numpy(gt[b][valid[b]]) if not (B > 1 and b == 1) else torch.zeros((0, 7))
+             for b in range(B)]
+    labels = [torch.zeros(len(bx), dtype=torch.long) for bx in boxes]
+    spec = DeMFVoteHead.vote_targets(head, torch.from_numpy(pts), boxes, labels)
+    g_pad, _, v_pad = DeMFVoteHead.pad_gt(boxes, labels, torch.device("cpu"))
+    vt, mask = ops.vote_targets(torch.from_numpy(pts).cuda(), g_pad.cuda(), v_pad.cuda())
+    np.testing.assert_array_equal(mask.cpu().numpy(), spec["vote_target_masks"].numpy())
+    np.testing.assert_array_equal(vt.cpu().numpy(), spec["vote_targets"].numpy())
+    inside = spec["vote_target_masks"].numpy()
+    assert 0 < inside.sum() < inside.size
