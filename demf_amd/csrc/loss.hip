@@ -295,6 +295,66 @@ __global__ __launch_bounds__(256) void vote_targets_k(int N, int pstride, int G,
   mask[(size_t)b * N + n] = total > 0 ? 1 : 0;
 }
 
+
+// ---- proposal targets (get_targets_single :877-934, batched) -----------------------------------
+// One thread per proposal: nearest valid ground-truth centre (first minimum), the gathered box
+// targets, the canonical-frame distance targets and the objectness label / mask.  Per-box
+// quantities that involve transcendental functions (direction class / residual, cos / sin of -yaw)
+// are computed by the caller; the arithmetic here mirrors the torch restatement term by term.
+struct PropTargetArgs {
+  int Q, G, with_rot;
+  float pos_thr, neg_thr, res_scale;   // res_scale = pi / num_dir_bins
+  const float *agg, *gt, *cs, *sn, *dir_res;
+  const long long *dir_cls, *lab;
+  const unsigned char* valid;
+  float *center_t, *size_t_, *dir_res_t, *dir_t, *dist_t, *obj_mask;
+  long long *dir_cls_t, *mask_t, *obj_t;
+};
+
+__global__ __launch_bounds__(256) void proposal_targets_k(PropTargetArgs a) {
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.Q) return;
+  const size_t r = (size_t)b * a.Q + q;
+  const float px = a.agg[r * 3], py = a.agg[r * 3 + 1], pz = a.agg[r * 3 + 2];
+  float best = __builtin_inff();
+  int bi = 0;
+  for (int g = 0; g < a.G; ++g) {
+    const size_t o = (size_t)b * a.G + g;
+    if (!a.valid[o]) continue;
+    const float* t = a.gt + o * 7;
+    const float dx = px - t[0], dy = py - t[1], dz = pz - (t[2] + t[5] * 0.5f);
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d < best) { best = d; bi = g; }
+  }
+  const size_t o = (size_t)b * a.G + bi;
+  const float* t = a.gt + o * 7;
+  const float cx = t[0], cy = t[1], cz = t[2] + t[5] * 0.5f;
+  const float euc = sqrtf(best + 1e-6f);
+  a.center_t[r * 3] = cx; a.center_t[r * 3 + 1] = cy; a.center_t[r * 3 + 2] = cz;
+  a.size_t_[r * 3] = t[3]; a.size_t_[r * 3 + 1] = t[4]; a.size_t_[r * 3 + 2] = t[5];
+  a.dir_cls_t[r] = a.dir_cls[o];
+  a.dir_res_t[r] = a.dir_res[o] / a.res_scale;
+  a.dir_t[r] = t[6];
+  a.mask_t[r] = a.lab[o];
+  float x = px - cx, y = py - cy;
+  const float z = pz - cz;
+  if (a.with_rot) {
+    const float c = a.cs[o], s = a.sn[o];
+    const float xr = x * c + y * s;
+    const float yr = (-x) * s + y * c;
+    x = xr; y = yr;
+  }
+  const float hx = t[3] / 2.0f, hy = t[4] / 2.0f, hz = t[5] / 2.0f;
+  float* dt = a.dist_t + r * 6;
+  dt[0] = hx - x; dt[1] = hy - y; dt[2] = hz - z;
+  dt[3] = hx + x; dt[4] = hy + y; dt[5] = hz + z;
+  const bool inside = dt[0] >= 0.f && dt[1] >= 0.f && dt[2] >= 0.f && dt[3] >= 0.f &&
+                      dt[4] >= 0.f && dt[5] >= 0.f;
+  a.obj_t[r] = (euc < a.pos_thr && inside) ? 1 : 0;
+  a.obj_mask[r] = (euc < a.pos_thr || euc > a.neg_thr) ? 1.f : 0.f;
+}
+
 }  // namespace demf
 
 using namespace demf;
@@ -379,4 +439,35 @@ extern "C" int demf_vote_targets(int B, int N, int point_stride, int G, const fl
                      point_stride, G, points, gt_boxes, cos_neg_yaw, sin_neg_yaw, valid,
                      vote_targets, (long long*)vote_target_masks);
   return check_launch("vote_targets");
+}
+
+extern "C" int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, float neg_thr,
+                                     float res_scale, const float* aggregated_points,
+                                     const float* gt_boxes, const float* cos_neg_yaw,
+                                     const float* sin_neg_yaw, const int64_t* gt_dir_class,
+                                     const float* gt_dir_res, const int64_t* gt_labels,
+                                     const unsigned char* valid, float* center_targets,
+                                     float* size_targets, int64_t* dir_class_targets,
+                                     float* dir_res_targets, float* dir_targets,
+                                     int64_t* mask_targets, float* distance_targets,
+                                     int64_t* objectness_targets, float* objectness_masks,
+                                     demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && Q >= 0 && G >= 1 && res_scale > 0.f, "proposal_targets: bad sizes");
+  if (B * Q == 0) return DEMF_OK;
+  DEMF_REQUIRE(aggregated_points && gt_boxes && cos_neg_yaw && sin_neg_yaw && gt_dir_class &&
+                   gt_dir_res && gt_labels && valid && center_targets && size_targets &&
+                   dir_class_targets && dir_res_targets && dir_targets && mask_targets &&
+                   distance_targets && objectness_targets && objectness_masks,
+               "proposal_targets: null pointer");
+  PropTargetArgs a;
+  a.Q = Q; a.G = G; a.with_rot = with_rot; a.pos_thr = pos_thr; a.neg_thr = neg_thr;
+  a.res_scale = res_scale; a.agg = aggregated_points; a.gt = gt_boxes; a.cs = cos_neg_yaw;
+  a.sn = sin_neg_yaw; a.dir_res = gt_dir_res; a.dir_cls = (const long long*)gt_dir_class;
+  a.lab = (const long long*)gt_labels; a.valid = valid; a.center_t = center_targets;
+  a.size_t_ = size_targets; a.dir_res_t = dir_res_targets; a.dir_t = dir_targets;
+  a.dist_t = distance_targets; a.obj_mask = objectness_masks;
+  a.dir_cls_t = (long long*)dir_class_targets; a.mask_t = (long long*)mask_targets;
+  a.obj_t = (long long*)objectness_targets;
+  hipLaunchKernelGGL(proposal_targets_k, dim3(cdiv(Q, 256), B), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("proposal_targets");
 }

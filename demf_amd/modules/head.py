@@ -463,12 +463,23 @@ class DeMFVoteHead(nn.Module):
 
         # -- proposal targets (:877-934)
         dir_class_t, dir_res_t = self.bbox_coder.angle2class(yaw)
+        pos_thr = self.train_cfg["pos_distance_thr"]
+        neg_thr = self.train_cfg["neg_distance_thr"]
+        if agg.is_cuda and "gt" in vp and vp["gt"].is_contiguous():
+            # one kernel (csrc/loss.hip: proposal_targets_k); the torch code below is its spec
+            t = ops.proposal_targets(agg.contiguous(), vp["gt"], lab, valid, dir_class_t, dir_res_t,
+                                     self.bbox_coder.with_rot, pos_thr, neg_thr,
+                                     np.pi / self.num_dir_bins)
+            objectness_masks, objectness_targets = t["objectness_masks"], t["objectness"]
+            objectness_weights = objectness_masks / (objectness_masks.sum() + 1e-6)
+            box_loss_weights = objectness_targets.float() / (objectness_targets.sum().float() + 1e-6)
+            return (vote_targets, vote_target_masks, t["dir_class"], t["dir_res"], t["mask"],
+                    objectness_targets, objectness_weights, box_loss_weights, t["distance"],
+                    t["dir"], t["size"], t["center"])
         d = ((agg[:, :, None, :] - center[:, None, :, :]) ** 2).sum(-1)       # (B,Q,G) mse-sum
         d = d.masked_fill(~valid[:, None, :], float("inf"))
         distance1, assignment = d.min(-1)
         euc = torch.sqrt(distance1 + 1e-6)
-        pos_thr = self.train_cfg["pos_distance_thr"]
-        neg_thr = self.train_cfg["neg_distance_thr"]
         objectness_masks = ((euc < pos_thr) | (euc > neg_thr)).to(agg.dtype)
         g3 = assignment.unsqueeze(-1).expand(-1, -1, 3)
         center_targets = torch.gather(center, 1, g3)

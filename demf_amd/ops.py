@@ -784,3 +784,27 @@ def vote_targets(points, gt, valid):
     _ffi.call("demf_vote_targets", B, N, stride, G, _p(points), _p(gt), _p(cs), _p(sn), _p(v),
               _p(vt), _p(mask), _stream())
     return vt, mask
+
+
+def proposal_targets(agg, gt, lab, valid, dir_class, dir_res, with_rot, pos_thr, neg_thr, res_scale):
+    """The per-proposal half of DeMFVoteHead.get_targets (class_agnostic_vote_head.py:877-934) in
+    one kernel.  agg (B,Q,3), gt (B,G,7), lab / valid (B,G), dir_class / dir_res = angle2class(yaw).
+    -> dict(center, size, dir_class, dir_res, dir, mask, distance, objectness, objectness_masks)"""
+    _chk(agg, "agg")
+    _chk(gt, "gt")
+    B, Q, _ = agg.shape
+    G = gt.shape[1]
+    dev = agg.device
+    yaw = gt[..., 6]
+    cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    l = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)
+    out = dict(center=f(B, Q, 3), size=f(B, Q, 3), dir_class=l(B, Q), dir_res=f(B, Q), dir=f(B, Q),
+               mask=l(B, Q), distance=f(B, Q, 6), objectness=l(B, Q), objectness_masks=f(B, Q))
+    _ffi.call("demf_proposal_targets", B, Q, G, int(bool(with_rot)), float(pos_thr), float(neg_thr),
+              float(res_scale), _p(agg), _p(gt), _p(cs), _p(sn), _p(dir_class.contiguous()),
+              _p(dir_res.contiguous()), _p(lab.contiguous()), _p(valid.to(torch.uint8).contiguous()),
+              _p(out["center"]), _p(out["size"]), _p(out["dir_class"]), _p(out["dir_res"]),
+              _p(out["dir"]), _p(out["mask"]), _p(out["distance"]), _p(out["objectness"]),
+              _p(out["objectness_masks"]), _stream())
+    return out

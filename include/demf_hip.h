@@ -293,6 +293,21 @@ int demf_vote_targets(int B, int N, int point_stride, int G, const float* points
                       const unsigned char* valid, float* vote_targets, int64_t* vote_target_masks,
                       demf_stream_t stream);
 
+/* Per-proposal targets of DeMFVoteHead.get_targets_single (class_agnostic_vote_head.py:877-934),
+ * batched over scenes: nearest valid ground-truth centre (first minimum of the squared distance),
+ * the gathered centre / size / direction / class targets, the distance targets in the box frame
+ * (rotation by -yaw when with_rot) and objectness label + mask (pos/neg distance thresholds).
+ * gt_dir_class / gt_dir_res = bbox_coder.angle2class(yaw) per box; res_scale = pi/num_dir_bins.  */
+int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, float neg_thr,
+                          float res_scale, const float* aggregated_points, const float* gt_boxes,
+                          const float* cos_neg_yaw, const float* sin_neg_yaw,
+                          const int64_t* gt_dir_class, const float* gt_dir_res,
+                          const int64_t* gt_labels, const unsigned char* valid,
+                          float* center_targets, float* size_targets, int64_t* dir_class_targets,
+                          float* dir_res_targets, float* dir_targets, int64_t* mask_targets,
+                          float* distance_targets, int64_t* objectness_targets,
+                          float* objectness_masks, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Optimizer step on flat buffers: torch.optim.AdamW + clip_grad_norm_ as the reference's
  * runner applies them (configs/_base_/schedules/schedule_3x.py:6-7: AdamW lr 0.008, wd 0.01,

@@ -81,10 +81,7 @@ def test_vote_targets_kernel_bit_exact(B, N, G, seed):
         valid[1, 0] = True
         gt[1] = 0.0
     head = DeMFVoteHead.__new__(DeMFVoteHead)                        # vote_targets uses no state
-    spec = DeMFVoteHead.vote_targets(head, torch.from_numpy(pts), torch.from_numpy(gt),
-                                     torch.from_numpy(valid.astype(np.int64)))
-    # padded-tensor call path: (gt, labels) tensors -> valid == all ones; emulate masks via the
-    # list path instead when slots are invalid
+    # list-of-boxes call path, so that padded (invalid) slots exist
     boxes = [torch.from_numpy(gt[b][valid[b]]) if not (B > 1 and b == 1) else torch.zeros((0, 7))
              for b in range(B)]
     labels = [torch.zeros(len(bx), dtype=torch.long) for bx in boxes]
@@ -95,3 +92,49 @@ def test_vote_targets_kernel_bit_exact(B, N, G, seed):
     np.testing.assert_array_equal(vt.cpu().numpy(), spec["vote_targets"].numpy())
     inside = spec["vote_target_masks"].numpy()
     assert 0 < inside.sum() < inside.size
+
+
+@pytest.mark.parametrize("B,Q,G,seed", [(2, 256, 5, 0), (8, 256, 12, 1), (3, 33, 1, 2)])
+def test_proposal_targets_kernel_matches_spec(B, Q, G, seed):
+    """demf_proposal_targets against the torch specification in DeMFVoteHead.get_targets (the
+    batched restatement of class_agnostic_vote_head.py:877-934) evaluated on the CPU: integer
+    targets and the assignment exact, gathered float targets bit-exact, rotated ones to 1e-6."""
+    from oracle import fixtures
+    from demf_amd.modules import DeMFHotPath
+    rng = np.random.default_rng(seed)
+    head = DeMFHotPath(fixtures.tiny_cfg()).pts_bbox_head
+    N = 512
+    pts = rng.uniform([-3, -3, 0, 0], [3, 3, 3, 3], size=(B, N, 4)).astype(np.float32)
+    boxes, labels = [], []
+    for b in range(B):
+        n = G if b != 1 else max(G - 2, 0)                  # one scene with fewer (or zero) boxes
+        g = np.zeros((n, 7), np.float32)
+        g[:, :3] = rng.uniform([-2.5, -2.5, 0], [2.5, 2.5, 1.5], size=(n, 3))
+        g[:, 3:6] = rng.uniform(0.4, 2.0, size=(n, 3))
+        g[:, 6] = rng.uniform(-np.pi, np.pi, size=n)
+        boxes.append(torch.from_numpy(g))
+        labels.append(torch.from_numpy(rng.integers(0, 10, size=n)))
+    agg = rng.uniform([-3, -3, 0], [3, 3, 3], size=(B, Q, 3)).astype(np.float32)
+    for b in range(B):                                        # some proposals right at box centres
+        if len(boxes[b]):
+            c = boxes[b][0].numpy()
+            agg[b, :8] = [c[0], c[1], c[2] + 0.5 * c[5]] + rng.normal(0, 0.05, size=(8, 3))
+    names = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
+             "mask_targets", "objectness_targets", "objectness_weights", "box_loss_weights",
+             "distance_targets", "dir_targets", "size_targets", "center_targets")
+    spec = head.get_targets(torch.from_numpy(pts), boxes, labels,
+                            dict(aggregated_points=torch.from_numpy(agg)))
+    got = head.get_targets(torch.from_numpy(pts).cuda(), [b.cuda() for b in boxes],
+                           [l.cuda() for l in labels], dict(aggregated_points=torch.from_numpy(agg).cuda()))
+    assert int(spec[5].sum()) > 0                             # positives exist
+    for n, a, b in zip(names, spec, got):
+        a, b = a.numpy(), b.cpu().numpy()
+        if a.dtype.kind in "iu":
+            np.testing.assert_array_equal(a, b, err_msg=n)
+        elif n in ("objectness_weights", "box_loss_weights"):
+            np.testing.assert_allclose(a, b, rtol=1e-6, err_msg=n)    # normalised by a float sum
+        elif n == "distance_targets":
+            # rotated by cos/sin(-yaw): device and host libm differ in the last ulp
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, err_msg=n)
+        else:
+            np.testing.assert_array_equal(a, b, err_msg=n)
