@@ -38,6 +38,8 @@ SIGNATURES = {
     "demf_maxpool_ns_bwd": [_c_int] * 3 + [_ptr] * 4,
     "demf_colsum_f32": [_c_int] * 3 + [_ptr] * 3,
     "demf_vote_targets": [_c_int] * 4 + [_ptr] * 8,
+    "demf_box_extent_count": [_c_int] * 4 + [_ptr] * 8,
+    "demf_aligned_nms": [_c_int, _c_int, _c_float] + [_ptr] * 6,
     "demf_proposal_targets": [_c_int] * 4 + [_c_float] * 3 + [_ptr] * 18,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,

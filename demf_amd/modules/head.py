@@ -376,6 +376,47 @@ class DeMFVoteHead(nn.Module):
             if with_vote else None
         return seven, vote
 
+    # ---- test-time decode + NMS: :714-754 --------------------------------------------
+    @torch.no_grad()
+    def get_bboxes(self, points, bbox_preds, input_metas, rescale=False, use_nms=True):
+        """Same contract as the reference: the decode results of ``test_cfg.ensemble_layers`` are
+        concatenated, boxes holding <= 5 points are dropped, class-aware aligned NMS
+        (csrc/postprocess.hip) and the score threshold select the survivors, and every survivor is
+        reported once per class (``per_class_proposal``).  -> list of (boxes, scores, labels) per
+        scene, or the raw (B,K,7) boxes when ``use_nms`` is False."""
+        decode_res_all = bbox_preds["decode_res_all"]
+        tc = self.test_cfg
+        obj, sem, box = [], [], []
+        for i in tc["ensemble_layers"]:
+            d = decode_res_all[i]
+            obj.append(F.softmax(d["obj_scores"], dim=-1)[..., -1])
+            sem.append(F.softmax(d["sem_scores"], dim=-1))
+            box.append(self.bbox_coder.decode(d))
+        obj, sem = torch.cat(obj, 1).contiguous(), torch.cat(sem, 1)
+        box = torch.cat(box, 1).contiguous()
+        if not use_nms:
+            return box
+        if isinstance(points, (list, tuple)):
+            points = torch.stack(points)
+        bottom, extent, count = ops.box_extent_count(points.contiguous(), box)
+        classes = torch.argmax(sem, -1)
+        keep = ops.aligned_nms(extent, obj, classes, count > 5, tc["nms_thr"])
+        selected = keep & (obj > tc["score_thr"])
+        results = []
+        for b in range(box.shape[0]):
+            sel = selected[b]
+            bx, sc, cl = bottom[b][sel], obj[b][sel], classes[b][sel]
+            if tc["per_class_proposal"]:
+                C = sem.shape[-1]
+                ss = sem[b][sel]                                           # (n, C)
+                bx = bx.repeat(C, 1)
+                sc = (sc[None, :] * ss.t()).reshape(-1)
+                cl = torch.arange(C, device=cl.device, dtype=cl.dtype).repeat_interleave(int(sel.sum()))
+            wrap = input_metas[b].get("box_type_3d") if input_metas is not None else None
+            results.append((wrap(bx, box_dim=bx.shape[-1], with_yaw=self.bbox_coder.with_rot)
+                            if wrap is not None else DepthBoxes(bx), sc, cl))
+        return results
+
     # ---- targets: :756-941, batched ----------------------------------------------
     _PAD_CACHE = {}
 

@@ -808,3 +808,32 @@ def proposal_targets(agg, gt, lab, valid, dir_class, dir_res, with_rot, pos_thr,
               _p(out["dir"]), _p(out["mask"]), _p(out["distance"]), _p(out["objectness"]),
               _p(out["objectness_masks"]), _stream())
     return out
+
+
+def box_extent_count(points, boxes7):
+    """points (B,N,>=3), boxes7 (B,K,7) gravity-centre boxes -> (boxes_bottom (B,K,7),
+    extent (B,K,6), count (B,K) int32): see demf_box_extent_count."""
+    _chk(points, "points")
+    _chk(boxes7, "boxes7")
+    B, N, stride = points.shape
+    K = boxes7.shape[1]
+    yaw = boxes7[..., 6]
+    c, s = torch.cos(yaw).contiguous(), torch.sin(yaw).contiguous()
+    out = torch.empty_like(boxes7)
+    ext = torch.empty((B, K, 6), dtype=torch.float32, device=points.device)
+    cnt = torch.empty((B, K), dtype=torch.int32, device=points.device)
+    _ffi.call("demf_box_extent_count", B, N, stride, K, _p(points), _p(boxes7), _p(c), _p(s),
+              _p(out), _p(ext), _p(cnt), _stream())
+    return out, ext, cnt
+
+
+def aligned_nms(extent, scores, classes, valid, iou_thr):
+    """Class-aware greedy NMS on axis-aligned extents (B,K,6) per scene -> keep (B,K) bool."""
+    _chk(extent, "extent")
+    _chk(scores, "scores")
+    _chk(classes, "classes", torch.int64)
+    B, K = scores.shape
+    keep = torch.empty((B, K), dtype=torch.uint8, device=scores.device)
+    _ffi.call("demf_aligned_nms", B, K, float(iou_thr), _p(extent), _p(scores), _p(classes),
+              _p(valid.to(torch.uint8).contiguous()), _p(keep), _stream())
+    return keep.bool()

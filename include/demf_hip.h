@@ -309,6 +309,24 @@ int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, floa
                           float* objectness_masks, demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
+ * Test-time post-processing: DeMFVoteHead.get_bboxes (class_agnostic_vote_head.py:714-754) +
+ * the inherited mmdet3d VoteHead.multiclass_nms_single / aligned_3d_nms.
+ * ------------------------------------------------------------------ */
+
+/* boxes7 (B,K,7) = decode() output (gravity centre, size, yaw) with cos/sin(yaw) (B,K) ->
+ * boxes_bottom (B,K,7) upstream's bottom-centre form, extent6 (B,K,6) = min|max over the 8 rotated
+ * corners, count (B,K) = scene points inside the box (points (B,N,point_stride>=3)).           */
+int demf_box_extent_count(int B, int N, int point_stride, int K, const float* points,
+                          const float* boxes7, const float* cos_yaw, const float* sin_yaw,
+                          float* boxes_bottom, float* extent6, int* count, demf_stream_t stream);
+
+/* aligned_3d_nms per scene over the boxes with valid != 0 (K <= 1024): descending score order, a
+ * kept box removes same-class boxes with IoU > iou_thr.  keep (B,K) bytes.                     */
+int demf_aligned_nms(int B, int K, float iou_thr, const float* extent6, const float* scores,
+                     const int64_t* classes, const unsigned char* valid, unsigned char* keep,
+                     demf_stream_t stream);
+
+/* ------------------------------------------------------------------ *
  * Optimizer step on flat buffers: torch.optim.AdamW + clip_grad_norm_ as the reference's
  * runner applies them (configs/_base_/schedules/schedule_3x.py:6-7: AdamW lr 0.008, wd 0.01,
  * grad_clip max_norm 10; configs/demf/demf_votenet.py:16-24: 'decoder' lr_mult 0.05).  One call

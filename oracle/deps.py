@@ -457,18 +457,43 @@ def rotation_3d_in_axis(points, angles, axis=0):
 
 
 class DepthInstance3DBoxes:
-    """The slice of mmdet3d DepthInstance3DBoxes that class_agnostic_vote_head.py:825-911
-    and coder.py:142-166 touch.  tensor (n,7) = x, y, z_bottom, dx, dy, dz, yaw."""
+    """The slice of mmdet3d DepthInstance3DBoxes that class_agnostic_vote_head.py:714-754,
+    :825-911 and coder.py:142-166 touch.  tensor (n,7) = x, y, z_bottom, dx, dy, dz, yaw.
+    ``origin`` as upstream: the relative position of (x,y,z) inside the box the caller's tensor
+    uses; it is converted to the bottom centre (0.5, 0.5, 0)."""
 
-    def __init__(self, tensor, box_dim=7, with_yaw=True):
+    def __init__(self, tensor, box_dim=7, with_yaw=True, origin=(0.5, 0.5, 0)):
         t = torch.as_tensor(tensor)
-        self.tensor = (t if t.is_floating_point() else t.float()).reshape(-1, 7)
+        t = (t if t.is_floating_point() else t.float()).reshape(-1, 7)
+        if tuple(origin) != (0.5, 0.5, 0):
+            t = t.clone()
+            dst = t.new_tensor((0.5, 0.5, 0))
+            src = t.new_tensor(origin)
+            t[:, :3] += t[:, 3:6] * (dst - src)
+        self.tensor = t
 
     def to(self, device):
         return DepthInstance3DBoxes(self.tensor.to(device))
 
     def new_box(self, data):
         return DepthInstance3DBoxes(data)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        return DepthInstance3DBoxes(self.tensor[item].reshape(-1, 7))
+
+    @property
+    def corners(self):
+        """(n,8,3): dims * {0,1}^3 corners relative to the bottom centre, rotated about z by yaw."""
+        dims = self.dims
+        import numpy as _np
+        cn = torch.from_numpy(_np.stack(_np.unravel_index(_np.arange(8), [2] * 3), axis=1)).to(dims)
+        cn = cn[[0, 1, 3, 2, 4, 5, 7, 6]] - dims.new_tensor([0.5, 0.5, 0])
+        corners = dims.view(-1, 1, 3) * cn.reshape(1, 8, 3)
+        corners = rotation_3d_in_axis(corners, self.tensor[:, 6], axis=2)
+        return corners + self.tensor[:, :3].view(-1, 1, 3)
 
     @property
     def gravity_center(self):
@@ -584,3 +609,57 @@ def multi_apply(func, *args, **kwargs):
     """mmdet.core.multi_apply."""
     pfunc = partial(func, **kwargs) if kwargs else func
     return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def aligned_3d_nms(boxes, scores, classes, thresh):
+    """mmdet3d.core.post_processing.aligned_3d_nms: greedy NMS on axis-aligned (x1,y1,z1,x2,y2,z2)
+    boxes; a box suppresses lower-scored boxes of the SAME class whose IoU exceeds ``thresh``."""
+    x1, y1, z1, x2, y2, z2 = (boxes[:, i] for i in range(6))
+    area = (x2 - x1) * (y2 - y1) * (z2 - z1)
+    zero = boxes.new_zeros(1)
+    order = torch.argsort(scores)
+    pick = []
+    while order.shape[0] != 0:
+        last = order.shape[0]
+        i = order[-1]
+        pick.append(int(i))
+        rest = order[:last - 1]
+        xx1, yy1, zz1 = torch.max(x1[i], x1[rest]), torch.max(y1[i], y1[rest]), torch.max(z1[i], z1[rest])
+        xx2, yy2, zz2 = torch.min(x2[i], x2[rest]), torch.min(y2[i], y2[rest]), torch.min(z2[i], z2[rest])
+        l, w, h = torch.max(zero, xx2 - xx1), torch.max(zero, yy2 - yy1), torch.max(zero, zz2 - zz1)
+        inter = l * w * h
+        iou = inter / (area[i] + area[rest] - inter)
+        iou = iou * (classes[i] == classes[rest]).float()
+        order = rest[torch.nonzero(iou <= thresh, as_tuple=False).flatten()]
+    return torch.as_tensor(pick, dtype=torch.long)
+
+
+def multiclass_nms_single(head, obj_scores, sem_scores, bbox, points, input_meta):
+    """mmdet3d VoteHead.multiclass_nms_single (0.18.1), which DeMFVoteHead inherits and calls at
+    class_agnostic_vote_head.py:741-744: boxes with more than 5 points inside -> aligned 3-D NMS
+    on their corner extents -> score threshold -> (per-class) outputs."""
+    tc = head.test_cfg
+    get = (lambda k: tc[k]) if isinstance(tc, dict) else (lambda k: getattr(tc, k))
+    bbox = input_meta["box_type_3d"](bbox, box_dim=bbox.shape[-1], with_yaw=head.bbox_coder.with_rot,
+                                     origin=(0.5, 0.5, 0.5))
+    box_indices = bbox.points_in_boxes(points)
+    corner3d = bbox.corners
+    minmax = corner3d.new_zeros((corner3d.shape[0], 6))
+    minmax[:, :3] = torch.min(corner3d, dim=1)[0]
+    minmax[:, 3:] = torch.max(corner3d, dim=1)[0]
+    nonempty = box_indices.T.sum(1) > 5
+    bbox_classes = torch.argmax(sem_scores, -1)
+    nms_selected = aligned_3d_nms(minmax[nonempty], obj_scores[nonempty], bbox_classes[nonempty],
+                                  get("nms_thr"))
+    scores_mask = obj_scores > get("score_thr")
+    nonempty_inds = torch.nonzero(nonempty, as_tuple=False).flatten()
+    nonempty_mask = torch.zeros_like(bbox_classes).scatter(0, nonempty_inds[nms_selected], 1)
+    selected = nonempty_mask.bool() & scores_mask.bool()
+    if get("per_class_proposal"):
+        bs, ss, ls = [], [], []
+        for k in range(sem_scores.shape[-1]):
+            bs.append(bbox[selected].tensor)
+            ss.append(obj_scores[selected] * sem_scores[selected][:, k])
+            ls.append(torch.zeros_like(bbox_classes[selected]).fill_(k))
+        return torch.cat(bs, 0), torch.cat(ss, 0), torch.cat(ls, 0)
+    return bbox[selected].tensor, obj_scores[selected], bbox_classes[selected]

@@ -68,3 +68,37 @@ def seed_weights(module, seed=0):
 
 
 from demf_amd.synthetic import depth2img, make_scene_batch  # noqa: E402,F401  (seeded scenes)
+
+
+def make_decode_results(seed, B=2, K=48, N=4096, layers=2, num_classes=10, num_dir_bins=12):
+    """Synthetic inputs of DeMFVoteHead.get_bboxes (class_agnostic_vote_head.py:714-754): a point
+    cloud made of clusters, and per decode layer K proposals whose boxes sit on the clusters
+    (overlapping duplicates of equal and different classes, empty boxes, low scores) so that
+    every branch of the decode -> points-in-box filter -> aligned NMS -> threshold chain fires.
+    -> (points (B,N,4) float32, [dict(obj_scores, sem_scores, center, size, dir_class, dir_res)])"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_cl = 12
+    ctr = rng.uniform([-2.5, -2.5, 0.3], [2.5, 2.5, 1.5], size=(B, n_cl, 3))
+    pts = (ctr[:, :, None, :] + rng.normal(0, 0.12, size=(B, n_cl, N // n_cl, 3))).reshape(B, -1, 3)
+    pad = N - pts.shape[1]
+    pts = np.concatenate([pts, rng.uniform(-3, 3, size=(B, pad, 3))], 1)
+    points = np.concatenate([pts, pts[..., 2:3]], -1).astype(np.float32)
+    out = []
+    for _ in range(layers):
+        which = rng.integers(0, n_cl + 3, size=(B, K))                 # >= n_cl: box on empty space
+        c = np.where((which < n_cl)[..., None], np.take_along_axis(
+            ctr, np.minimum(which, n_cl - 1)[..., None].repeat(3, -1), 1),
+            rng.uniform([-3, -3, 2.5], [3, 3, 3.0], size=(B, K, 3)))
+        center = c + rng.normal(0, 0.05, size=(B, K, 3))
+        size = rng.uniform(0.3, 0.9, size=(B, K, 3))
+        size[:, ::7] *= -1.0                                            # raw regression can be negative
+        obj = rng.normal(0, 2.0, size=(B, K, 2))
+        sem = rng.normal(0, 1.0, size=(B, K, num_classes))
+        sem[np.arange(B)[:, None], np.arange(K)[None], which % 3] += 4.0   # few distinct classes
+        dcl = rng.normal(0, 1.0, size=(B, K, num_dir_bins))
+        dres = rng.normal(0, 0.1, size=(B, K, num_dir_bins))
+        out.append({k: v.astype(np.float32) for k, v in dict(
+            obj_scores=obj, sem_scores=sem, center=center, size=size, dir_class=dcl,
+            dir_res=dres).items()})
+    return points, out

@@ -116,6 +116,24 @@ class OracleHead(nn.Module):
     def conv_pred(self, i):
         return getattr(self, f"conv_pred{i}")
 
+    # :714-754 (+ the inherited VoteHead.multiclass_nms_single, oracle/deps.py)
+    def get_bboxes(self, points, decode_res_all, use_nms=True):
+        """-> per scene (boxes (n,7) bottom-centre form, scores (n,), labels (n,))."""
+        tc = self.kw["test_cfg"]
+        obj, sem, box = [], [], []
+        for i in tc["ensemble_layers"]:                                        # :724-731
+            d = decode_res_all[i]
+            obj.append(F.softmax(d["obj_scores"], dim=-1)[..., -1])
+            sem.append(F.softmax(d["sem_scores"], dim=-1))
+            box.append(self.coder.decode(d))
+        obj, sem, box = torch.cat(obj, 1), torch.cat(sem, 1), torch.cat(box, 1)  # :733-735
+        if not use_nms:
+            return box
+        shell = type("H", (), dict(test_cfg=tc, bbox_coder=type("C", (), dict(with_rot=True))()))()
+        meta = dict(box_type_3d=deps.DepthInstance3DBoxes)
+        return [deps.multiclass_nms_single(shell, obj[b], sem[b], box[b], points[b, ..., :3], meta)
+                for b in range(box.shape[0])]                                  # :737-751
+
     # :405-466 (sample_mod == 'seed', the mode configs/demf/demf_votenet.py:171 selects)
     def forward(self, seed_points, seed_features, seed_indices, img_features, img_metas):
         vote_points, vote_features, vote_offset = self.vote_module(seed_points, seed_features)

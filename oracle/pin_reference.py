@@ -143,6 +143,31 @@ def glue_goldens():
     return out
 
 
+def bbox_goldens(seeds=(0, 1)):
+    """REAL reference DeMFVoteHead.get_bboxes (class_agnostic_vote_head.py:714-754, with the
+    inherited VoteHead.multiclass_nms_single restated in oracle/deps.py) on the synthetic decode
+    results of fixtures.make_decode_results(seed): per scene the selected boxes / scores / labels."""
+    from demf_amd.config import head_kwargs
+    ref = shim.reference()
+    kw = fixtures.to_attr(head_kwargs(fixtures.tiny_cfg()))
+    kw["bbox_coder"].update(num_sizes=10, mean_sizes=[[1.0, 1.0, 1.0]] * 10)
+    head = ref.head.DeMFVoteHead(**kw)
+    out = {}
+    for seed in seeds:
+        pts, dec = fixtures.make_decode_results(seed)
+        preds = dict(decode_res_all=[{k: torch.from_numpy(v) for k, v in d.items()} for d in dec])
+        metas = [dict(box_type_3d=deps.DepthInstance3DBoxes) for _ in range(pts.shape[0])]
+        res = head.get_bboxes(torch.from_numpy(pts), preds, metas)
+        for b, (bx, sc, lb) in enumerate(res):
+            out[f"s{seed}.b{b}.boxes"] = bx.tensor.numpy()
+            out[f"s{seed}.b{b}.scores"] = sc.numpy()
+            out[f"s{seed}.b{b}.labels"] = lb.numpy()
+        raw = head.get_bboxes(torch.from_numpy(pts), dict(decode_res_all=[
+            {k: torch.from_numpy(v) for k, v in d.items()} for d in dec]), metas, use_nms=False)
+        out[f"s{seed}.bbox3d"] = raw.numpy()
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     cfg = fixtures.tiny_cfg()
@@ -153,6 +178,7 @@ def main():
         np.savez_compressed(os.path.join(GOLD, f"ref_head_{name}.npz"), **out)
         print(name, {k: float(v) for k, v in out.items() if k.startswith("loss.")})
     np.savez_compressed(os.path.join(GOLD, "ref_glue.npz"), **glue_goldens())
+    np.savez_compressed(os.path.join(GOLD, "ref_bboxes.npz"), **bbox_goldens())
     print("golden vectors written to", GOLD)
 
 

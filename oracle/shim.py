@@ -91,6 +91,10 @@ class _BaseModule(nn.Module):
         """mmdet3d VoteHead._extract_input (used at class_agnostic_vote_head.py:408-409)."""
         return feat_dict["seed_points"], feat_dict["seed_features"], feat_dict["seed_indices"]
 
+    def multiclass_nms_single(self, obj_scores, sem_scores, bbox, points, input_meta):
+        """mmdet3d VoteHead.multiclass_nms_single (called at class_agnostic_vote_head.py:741)."""
+        return deps.multiclass_nms_single(self, obj_scores, sem_scores, bbox, points, input_meta)
+
 
 def load(relpath, name):
     spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))

@@ -96,3 +96,24 @@ def test_coder_and_posembed_match_real_reference(golden_dir):
     pe.train()
     np.testing.assert_allclose(pe(torch.from_numpy(g["posembed.in"])).detach().numpy(),
                                g["posembed.out"], rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_get_bboxes_vs_real_reference(golden_dir):
+    """oracle/model.py's restatement of DeMFVoteHead.get_bboxes (class_agnostic_vote_head.py:714-754)
+    reproduces the real reference's survivors, scores and labels bit for bit."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import fixtures
+    from oracle.model import OracleDeMF
+    gold = np.load(os.path.join(golden_dir, "ref_bboxes.npz"))
+    head = OracleDeMF(fixtures.tiny_cfg()).pts_bbox_head
+    for seed in (0, 1):
+        pts, dec = fixtures.make_decode_results(seed)
+        dd = [{k: torch.from_numpy(v) for k, v in d.items()} for d in dec]
+        np.testing.assert_array_equal(head.get_bboxes(torch.from_numpy(pts), dd, use_nms=False).numpy(),
+                                      gold[f"s{seed}.bbox3d"])
+        for b, (bx, sc, lb) in enumerate(head.get_bboxes(torch.from_numpy(pts), dd)):
+            np.testing.assert_array_equal(bx.numpy(), gold[f"s{seed}.b{b}.boxes"])
+            np.testing.assert_array_equal(sc.numpy(), gold[f"s{seed}.b{b}.scores"])
+            np.testing.assert_array_equal(lb.numpy(), gold[f"s{seed}.b{b}.labels"])
