@@ -52,3 +52,19 @@ class DepthBoxes:
         inside = (rel[..., 2].abs() <= half[..., 2]) & (lx.abs() < half[..., 0]) & \
                  (ly.abs() < half[..., 1])
         return inside
+
+
+def level_masks(img_metas, spatial_shapes):
+    """Padding masks of the image pyramid (class_agnostic_vote_head.py:559-568 and
+    deform_detr_encoder.py:70-82): the (B,Hpad,Wpad) mask that is 0 on ``img_shape`` resized to
+    every level with nearest-neighbour ``F.interpolate`` - an index lookup, evaluated on the host.
+    -> list of numpy bool (B,h,w), True = padding."""
+    import numpy as np
+    hw = np.asarray([m["img_shape"][:2] for m in img_metas], dtype=np.int64)
+    in_h, in_w = img_metas[0]["batch_input_shape"]
+    masks = []
+    for h, w in spatial_shapes:
+        ys = np.floor(np.arange(h, dtype=np.float32) * np.float32(in_h / h)).astype(np.int64)
+        xs = np.floor(np.arange(w, dtype=np.float32) * np.float32(in_w / w)).astype(np.int64)
+        masks.append((ys[None, :, None] >= hw[:, 0, None, None]) | (xs[None, None, :] >= hw[:, 1, None, None]))
+    return masks

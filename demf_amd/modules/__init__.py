@@ -1,6 +1,7 @@
 from .coder import DeMFClassAgnosticBBoxCoder
 from .detector import DeMFHotPath, head_kwargs
 from .head import DeMFVoteHead
+from .image_stream import ChannelMapper, DeformableDetrEncoder, ImageStream, ResNet50
 from .pointnet2 import PointFPModule, PointNet2SASSG, PointSAModule, build_sa_module
 from .transformer import (DeMFTransformerDecoderLayer, MultiScaleDeformableAttention,
                           PositionEmbeddingLearned)
@@ -9,4 +10,5 @@ from .vote import BaseConvBboxHead, VoteModule
 __all__ = ["DeMFClassAgnosticBBoxCoder", "DeMFHotPath", "head_kwargs", "DeMFVoteHead",
            "PointFPModule", "PointNet2SASSG", "PointSAModule", "build_sa_module",
            "DeMFTransformerDecoderLayer", "MultiScaleDeformableAttention",
-           "PositionEmbeddingLearned", "BaseConvBboxHead", "VoteModule"]
+           "PositionEmbeddingLearned", "BaseConvBboxHead", "VoteModule", "ImageStream",
+           "ResNet50", "ChannelMapper", "DeformableDetrEncoder"]

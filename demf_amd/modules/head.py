@@ -17,7 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from ..geometry import DepthBoxes, rotation_3d_in_axis_z
+from ..geometry import DepthBoxes, level_masks, rotation_3d_in_axis_z
 from . import losses as L
 from .coder import DeMFClassAgnosticBBoxCoder
 from .pointnet2 import build_sa_module
@@ -201,12 +201,8 @@ class DeMFVoteHead(nn.Module):
             # index lookup, and the valid ratios (:514-522) count its first column / row - both
             # functions of the metas alone, so they are built here once per metas object
             hw = np.asarray([m["img_shape"][:2] for m in img_metas], dtype=np.int64)
-            in_h, in_w = img_metas[0]["batch_input_shape"]
             masks, ratios = [], []
-            for h, w in mlvl_shapes:
-                ys = np.floor(np.arange(h, dtype=np.float32) * np.float32(in_h / h)).astype(np.int64)
-                xs = np.floor(np.arange(w, dtype=np.float32) * np.float32(in_w / w)).astype(np.int64)
-                m = (ys[None, :, None] >= hw[:, 0, None, None]) | (xs[None, None, :] >= hw[:, 1, None, None])
+            for (h, w), m in zip(mlvl_shapes, level_masks(img_metas, mlvl_shapes)):
                 masks.append(m.reshape(len(img_metas), h * w))
                 valid_h = (~m[:, :, 0]).sum(1).astype(np.float32)
                 valid_w = (~m[:, 0, :]).sum(1).astype(np.float32)
@@ -241,11 +237,16 @@ class DeMFVoteHead(nn.Module):
         padding masks, flattened tokens, valid ratios - plus the per-layer value projection of
         the fusion attention.  Independent of the point stream, so the detector runs it on a
         side stream while furthest-point sampling occupies 8 of the 256 CUs."""
-        spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-        dev = mlvl_feats[0].device
-        mt = self._meta_tensors(img_metas, spatial, dev, mlvl_feats[0].dtype)
+        if isinstance(mlvl_feats, dict):
+            # channels-last tokens (B,S,C) straight from demf_amd.modules.ImageStream.tokens():
+            # no flatten + concat copy of the pyramid (:570-591)
+            spatial, feat_flatten = list(mlvl_feats["spatial"]), mlvl_feats["tokens"]
+        else:
+            spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
+            feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
+        dev = feat_flatten.device
+        mt = self._meta_tensors(img_metas, spatial, dev, feat_flatten.dtype)
         mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
-        feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         feat_flatten = feat_flatten.permute(1, 0, 2)
         value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)
                            for layer in self.decoder]

@@ -663,3 +663,168 @@ def multiclass_nms_single(head, obj_scores, sem_scores, bbox, points, input_meta
             ls.append(torch.zeros_like(bbox_classes[selected]).fill_(k))
         return torch.cat(bs, 0), torch.cat(ss, 0), torch.cat(ls, 0)
     return bbox[selected].tensor, obj_scores[selected], bbox_classes[selected]
+
+
+# ---------------------------------------------------------------------------------------------
+# Frozen image stream dependencies: mmdet 2.14 ResNet (pytorch style),
+# ChannelMapper, SinePositionalEncoding and mmcv's BaseTransformerLayer / DetrTransformerEncoder
+# for operation_order ('self_attn','norm','ffn','norm') - configs/deformdetr/imvotenet_image.py:3-20,
+# configs/demf/demf_votenet.py:28-47.  dep-recall, parity with upstream binaries unpinned.
+# ---------------------------------------------------------------------------------------------
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)  # style='pytorch'
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                        nn.BatchNorm2d(planes * 4)) if downsample else None
+
+    def forward(self, x):
+        out = F.relu(self.bn1(self.conv1(x)))
+        out = F.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return F.relu(out + (x if self.downsample is None else self.downsample(x)))
+
+
+class ResNet50(nn.Module):
+    """mmdet ResNet(depth=50, num_stages=4, out_indices=(1,2,3), style='pytorch', norm_eval)."""
+
+    def __init__(self, out_indices=(1, 2, 3), base=64, blocks=(3, 4, 6, 3)):
+        super().__init__()
+        self.out_indices = out_indices
+        self.conv1 = nn.Conv2d(3, base, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(base)
+        inplanes = base
+        for i, n in enumerate(blocks):
+            planes, stride = base * 2 ** i, 1 if i == 0 else 2
+            layers = [Bottleneck(inplanes, planes, stride, downsample=True)]
+            inplanes = planes * 4
+            layers += [Bottleneck(inplanes, planes) for _ in range(n - 1)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*layers))
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        outs = []
+        for i in range(4):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+class _ConvGN(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, padding=0, groups=32):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False)
+        self.gn = nn.GroupNorm(groups, cout)
+
+    def forward(self, x):
+        return self.gn(self.conv(x))
+
+
+class ChannelMapper(nn.Module):
+    """mmdet ChannelMapper(kernel_size=1, norm GN32, act None, num_outs > len(in): extra 3x3 s2)."""
+
+    def __init__(self, in_channels, out_channels=256, num_outs=4, groups=32):
+        super().__init__()
+        self.convs = nn.ModuleList([_ConvGN(c, out_channels, 1, groups=groups) for c in in_channels])
+        self.extra_convs = nn.ModuleList()
+        for i in range(len(in_channels), num_outs):
+            cin = in_channels[-1] if i == len(in_channels) else out_channels
+            self.extra_convs.append(_ConvGN(cin, out_channels, 3, stride=2, padding=1, groups=groups))
+
+    def forward(self, inputs):
+        outs = [c(x) for c, x in zip(self.convs, inputs)]
+        for i, c in enumerate(self.extra_convs):
+            outs.append(c(inputs[-1] if i == 0 else outs[-1]))
+        return tuple(outs)
+
+
+class SinePositionalEncoding(nn.Module):
+    """mmdet SinePositionalEncoding(num_feats, temperature=10000, normalize, scale=2pi, eps, offset)."""
+
+    def __init__(self, num_feats, temperature=10000, normalize=False, scale=2 * math.pi, eps=1e-6,
+                 offset=0.0, **kw):
+        super().__init__()
+        self.num_feats, self.temperature, self.normalize = num_feats, temperature, normalize
+        self.scale, self.eps, self.offset = scale, eps, offset
+
+    def forward(self, mask):
+        mask = mask.to(torch.int)
+        not_mask = 1 - mask
+        y_embed = not_mask.cumsum(1, dtype=torch.float32)
+        x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            y_embed = (y_embed + self.offset) / (y_embed[:, -1:, :] + self.eps) * self.scale
+            x_embed = (x_embed + self.offset) / (x_embed[:, :, -1:] + self.eps) * self.scale
+        dim_t = torch.arange(self.num_feats, dtype=torch.float32, device=mask.device)
+        dim_t = self.temperature ** (2 * (dim_t // 2) / self.num_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        B, H, W = mask.size()
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).view(B, H, W, -1)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class EncoderLayer(nn.Module):
+    """mmcv BaseTransformerLayer, operation_order ('self_attn','norm','ffn','norm')."""
+
+    def __init__(self, attn_cfgs=None, feedforward_channels=1024, ffn_dropout=0.0,
+                 operation_order=("self_attn", "norm", "ffn", "norm"), **kw):
+        super().__init__()
+        assert tuple(operation_order) == ("self_attn", "norm", "ffn", "norm")
+        a = dict(attn_cfgs)
+        a.pop("type", None)
+        self.attentions = nn.ModuleList([MultiScaleDeformableAttention(**a)])
+        e = self.attentions[0].embed_dims
+        self.ffns = nn.ModuleList([FFN(e, feedforward_channels, ffn_dropout)])
+        self.norms = nn.ModuleList([nn.LayerNorm(e), nn.LayerNorm(e)])
+
+    def forward(self, query, key=None, value=None, query_pos=None, key_pos=None,
+                query_key_padding_mask=None, key_padding_mask=None, **kw):
+        query = self.attentions[0](query, query, query, None, query_pos=query_pos, key_pos=query_pos,
+                                   key_padding_mask=query_key_padding_mask, **kw)
+        query = self.norms[0](query)
+        query = self.ffns[0](query, None)
+        return self.norms[1](query)
+
+
+class DetrTransformerEncoder(nn.Module):
+    """mmdet DetrTransformerEncoder(num_layers, transformerlayers): post_norm only when pre-norm."""
+
+    def __init__(self, num_layers, transformerlayers, **kw):
+        super().__init__()
+        t = dict(transformerlayers)
+        t.pop("type", None)
+        self.layers = nn.ModuleList([EncoderLayer(**t) for _ in range(num_layers)])
+
+    def forward(self, query, *args, **kw):
+        for layer in self.layers:
+            query = layer(query, *args, **kw)
+        return query
+
+
+def build_transformer_layer_sequence(cfg):
+    cfg = dict(cfg)
+    assert cfg.pop("type") == "DetrTransformerEncoder"
+    return DetrTransformerEncoder(**cfg)
+
+
+def build_positional_encoding(cfg):
+    cfg = dict(cfg)
+    assert cfg.pop("type") == "SinePositionalEncoding"
+    return SinePositionalEncoding(**cfg)
+
+
+def xavier_init(module, gain=1, bias=0, distribution="normal"):
+    if hasattr(module, "weight") and module.weight is not None:
+        (nn.init.xavier_uniform_ if distribution == "uniform" else nn.init.xavier_normal_)(module.weight, gain=gain)
+    if hasattr(module, "bias") and module.bias is not None:
+        nn.init.constant_(module.bias, bias)

@@ -102,3 +102,23 @@ def make_decode_results(seed, B=2, K=48, N=4096, layers=2, num_classes=10, num_d
             obj_scores=obj, sem_scores=sem, center=center, size=size, dir_class=dcl,
             dir_res=dres).items()})
     return points, out
+
+
+TINY_IMAGE_STREAM = dict(base=8, blocks=(1, 1, 1, 1), embed_dims=32, num_layers=2, num_heads=4,
+                         feedforward_channels=64, gn_groups=8, num_feats=16)
+
+
+def make_images(seed, B=2, H=64, W=96):
+    """Synthetic padded image batch + metas for the image stream: (B,3,H,W) float32, every image
+    valid on its own (img_h, img_w) <= (H, W)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    img = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    metas = []
+    for b in range(B):
+        h = int(rng.integers(H * 3 // 4, H + 1)) if b else H
+        w = int(rng.integers(W * 3 // 4, W + 1)) if b != 1 else W
+        img[b, :, h:, :] = 0
+        img[b, :, :, w:] = 0
+        metas.append(dict(batch_input_shape=(H, W), img_shape=(h, w, 3)))
+    return img, metas

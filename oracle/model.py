@@ -314,3 +314,88 @@ class OracleDeMF(nn.Module):
         boxes = [deps.DepthInstance3DBoxes(b) for b in gt_boxes]
         losses, targets = self.pts_bbox_head.loss(preds, points, boxes, gt_labels)  # demfnet.py:167
         return losses, preds, targets
+
+
+# ---------------------------------------------------------------- frozen image stream (a15 / 8f-1)
+class OracleEncoder(nn.Module):
+    """DeformableDetrEncoder - demf/modeling/layers/deform_detr_encoder.py:12-154."""
+
+    def __init__(self, encoder, positional_encoding, num_feature_levels=4, embed_dims=256):
+        super().__init__()
+        self.encoder = deps.build_transformer_layer_sequence(encoder)           # :24
+        self.positional_encoding = deps.build_positional_encoding(positional_encoding)  # :25-26
+        self.level_embeds = nn.Parameter(torch.zeros(num_feature_levels, embed_dims))  # :28-29
+
+    @staticmethod
+    def valid_ratio(mask):                                                       # :38-46
+        _, H, W = mask.shape
+        vh = torch.sum(~mask[:, :, 0], 1).float() / H
+        vw = torch.sum(~mask[:, 0, :], 1).float() / W
+        return torch.stack([vw, vh], -1)
+
+    @staticmethod
+    def reference_points(spatial_shapes, valid_ratios):                          # :48-66
+        refs = []
+        for lvl, (H, W) in enumerate(spatial_shapes):
+            ry, rx = torch.meshgrid(torch.linspace(0.5, H - 0.5, H), torch.linspace(0.5, W - 0.5, W),
+                                    indexing="ij")
+            ry = ry.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+            rx = rx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+            refs.append(torch.stack((rx, ry), -1))
+        return torch.cat(refs, 1)[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, mlvl_feats, img_metas):                                    # :68-154
+        B = mlvl_feats[0].size(0)
+        ih, iw = img_metas[0]["batch_input_shape"]
+        img_masks = mlvl_feats[0].new_ones((B, ih, iw))
+        for i in range(B):
+            h, w, _ = img_metas[i]["img_shape"]
+            img_masks[i, :h, :w] = 0
+        masks = [F.interpolate(img_masks[None], size=f.shape[-2:]).to(torch.bool).squeeze(0)
+                 for f in mlvl_feats]
+        pos = [self.positional_encoding(m) for m in masks]
+        feat_f, mask_f, pos_f, shapes = [], [], [], []
+        for lvl, (f, m, p) in enumerate(zip(mlvl_feats, masks, pos)):
+            shapes.append(tuple(f.shape[-2:]))
+            feat_f.append(f.flatten(2).transpose(1, 2))
+            mask_f.append(m.flatten(1))
+            pos_f.append(p.flatten(2).transpose(1, 2) + self.level_embeds[lvl].view(1, 1, -1))
+        feat_f, mask_f, pos_f = torch.cat(feat_f, 1), torch.cat(mask_f, 1), torch.cat(pos_f, 1)
+        ss = torch.as_tensor(shapes, dtype=torch.long)
+        lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+        vr = torch.stack([self.valid_ratio(m) for m in masks], 1)
+        memory = self.encoder(query=feat_f.permute(1, 0, 2), key=None, value=None,
+                              query_pos=pos_f.permute(1, 0, 2), query_key_padding_mask=mask_f,
+                              spatial_shapes=ss, reference_points=self.reference_points(shapes, vr),
+                              level_start_index=lsi, valid_ratios=vr)
+        memory = memory.permute(1, 2, 0)
+        outs, start = [], 0
+        C = memory.shape[1]
+        for h, w in shapes:
+            outs.append(memory[:, :, start:start + h * w].reshape(B, C, h, w))
+            start += h * w
+        return outs
+
+
+class OracleImageStream(nn.Module):
+    """DeMFVoteNet.extract_img_feat (demfnet.py:124-132): backbone -> neck -> encoder, eval."""
+
+    def __init__(self, base=64, blocks=(3, 4, 6, 3), embed_dims=256, num_layers=6, num_heads=8,
+                 feedforward_channels=1024, gn_groups=32, num_feats=None):
+        super().__init__()
+        self.img_backbone = deps.ResNet50((1, 2, 3), base, blocks)
+        self.img_neck = deps.ChannelMapper([base * 4 * 2 ** i for i in (1, 2, 3)], embed_dims, 4, gn_groups)
+        self.img_encoder = OracleEncoder(
+            dict(type="DetrTransformerEncoder", num_layers=num_layers, transformerlayers=dict(
+                type="BaseTransformerLayer", attn_cfgs=dict(
+                    type="MultiScaleDeformableAttention", embed_dims=embed_dims, num_heads=num_heads),
+                feedforward_channels=feedforward_channels, ffn_dropout=0.1,
+                operation_order=("self_attn", "norm", "ffn", "norm"))),
+            dict(type="SinePositionalEncoding",
+                 num_feats=num_feats if num_feats is not None else embed_dims // 2,
+                 normalize=True, offset=-0.5), 4, embed_dims)
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, img, img_metas):
+        return self.img_encoder(self.img_neck(self.img_backbone(img)), img_metas)

@@ -168,6 +168,36 @@ def bbox_goldens(seeds=(0, 1)):
     return out
 
 
+def encoder_goldens(seed=4):
+    """REAL reference DeformableDetrEncoder (demf/modeling/layers/deform_detr_encoder.py) under the
+    shim, fed by the restated ResNet/ChannelMapper on fixtures.make_images(seed): the four encoder
+    output maps.  Weights: fixtures.seed_weights on identical state-dict keys."""
+    from oracle.model import OracleImageStream
+    ref = shim.reference()
+    t = fixtures.TINY_IMAGE_STREAM
+    stream = OracleImageStream(**t)
+    real = ref.encoder.DeformableDetrEncoder(
+        encoder=dict(type="DetrTransformerEncoder", num_layers=t["num_layers"], transformerlayers=dict(
+            type="BaseTransformerLayer", attn_cfgs=dict(type="MultiScaleDeformableAttention",
+                                                        embed_dims=t["embed_dims"], num_heads=t["num_heads"]),
+            feedforward_channels=t["feedforward_channels"], ffn_dropout=0.1,
+            operation_order=("self_attn", "norm", "ffn", "norm"))),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=t["num_feats"],
+                                 normalize=True, offset=-0.5),
+        num_feature_levels=4, embed_dims=t["embed_dims"])
+    assert sorted(real.state_dict()) == sorted(stream.img_encoder.state_dict())
+    stream.img_encoder = real
+    fixtures.seed_weights(stream, seed)
+    stream.eval()
+    img, metas = fixtures.make_images(seed)
+    with torch.no_grad():
+        pyramid = stream.img_neck(stream.img_backbone(torch.from_numpy(img)))
+        outs = real(pyramid, metas)
+    out = {f"neck{i}": p.numpy() for i, p in enumerate(pyramid)}
+    out.update({f"enc{i}": o.numpy() for i, o in enumerate(outs)})
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     cfg = fixtures.tiny_cfg()
@@ -179,6 +209,7 @@ def main():
         print(name, {k: float(v) for k, v in out.items() if k.startswith("loss.")})
     np.savez_compressed(os.path.join(GOLD, "ref_glue.npz"), **glue_goldens())
     np.savez_compressed(os.path.join(GOLD, "ref_bboxes.npz"), **bbox_goldens())
+    np.savez_compressed(os.path.join(GOLD, "ref_encoder.npz"), **encoder_goldens())
     print("golden vectors written to", GOLD)
 
 

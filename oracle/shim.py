@@ -53,11 +53,14 @@ def install():
     passthrough = lambda *a, **k: (lambda f: f)
     _mod("mmcv")
     _mod("mmcv.runner", BaseModule=_BaseModule, force_fp32=passthrough)
-    _mod("mmcv.cnn")
+    _mod("mmcv.runner.base_module", BaseModule=_BaseModule)
+    _mod("mmcv.cnn", xavier_init=deps.xavier_init)
     _mod("mmcv.cnn.bricks")
     _mod("mmcv.cnn.bricks.registry", TRANSFORMER_LAYER=TRANSFORMER_LAYER)
     _mod("mmcv.cnn.bricks.transformer", build_transformer_layer=TRANSFORMER_LAYER.build,
-         MultiScaleDeformableAttention=deps.MultiScaleDeformableAttention)
+         MultiScaleDeformableAttention=deps.MultiScaleDeformableAttention,
+         build_positional_encoding=deps.build_positional_encoding,
+         build_transformer_layer_sequence=deps.build_transformer_layer_sequence)
     _mod("mmcv.ops")
     _mod("mmcv.ops.multi_scale_deform_attn",
          MultiScaleDeformableAttention=deps.MultiScaleDeformableAttention)
@@ -66,6 +69,7 @@ def install():
     _mod("mmdet.core.bbox")
     _mod("mmdet.core.bbox.builder", BBOX_CODERS=BBOX_CODERS)
     _mod("mmdet.models", HEADS=HEADS)
+    _mod("mmdet.models.builder", HEADS=HEADS)
     _mod("mmdet3d")
     _mod("mmdet3d.core")
     _mod("mmdet3d.core.bbox", points_cam2img=deps.points_cam2img)
@@ -114,5 +118,6 @@ def reference():
         coder = load("demf/core/bbox/coders/class_agnostic_bbox_coder.py", "_ref_coder")
         trans = load("demf/modeling/layers/transformer.py", "_ref_transformer")
         head = load("demf/modeling/heads/class_agnostic_vote_head.py", "_ref_head")
-        _cache.update(coder=coder, transformer=trans, head=head)
+        enc = load("demf/modeling/layers/deform_detr_encoder.py", "_ref_encoder")
+        _cache.update(coder=coder, transformer=trans, head=head, encoder=enc)
     return types.SimpleNamespace(**_cache)

@@ -1,0 +1,97 @@
+"""The frozen image stream on the GPU: against golden vectors of the REAL
+reference DeformableDetrEncoder, against the CPU oracle at a larger size, and the channels-last
+token hand-over to the head."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures
+from oracle.model import OracleImageStream
+
+pytestmark = pytest.mark.gpu
+
+
+def _valid(metas, shape):
+    """(B,1,h,w) bool: positions of a level that lie on the image, not on its padding.  On padded
+    positions the reference's positional encoding evaluates sin/cos of arguments ~1e6
+    ((0 - 0.5) / (0 + 1e-6) * 2pi): the last bit of the argument decides the value, so those
+    outputs are not comparable between any two libm's - and nothing consumes them (every consumer
+    masks the padding)."""
+    from demf_amd.geometry import level_masks
+    return torch.from_numpy(~level_masks(metas, [shape])[0])[:, None]
+
+
+def _assert_close_on_image(got, want, metas, tol):
+    v = _valid(metas, tuple(want.shape[-2:])).expand_as(want)
+    err = ((got - want).abs() * v).max().item()
+    assert err <= tol * max(1.0, (want.abs() * v).max().item()), err
+
+
+def _product(cfg, seed):
+    from demf_amd.modules import ImageStream
+    m = ImageStream(**cfg)
+    fixtures.seed_weights(m, seed)
+    return m.cuda()
+
+
+def test_image_stream_vs_real_reference_encoder(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "ref_encoder.npz"))
+    m = _product(fixtures.TINY_IMAGE_STREAM, 4)
+    img, metas = fixtures.make_images(4)
+    x = torch.from_numpy(img).cuda()
+    pyramid = m.img_neck(m.img_backbone(x))
+    # the convolutional part is library code (MIOpen picks Winograd / implicit-GEMM kernels whose
+    # fp32 round-off is ~1e-4 relative per layer): checked loosely ...
+    for i, p in enumerate(pyramid):
+        np.testing.assert_allclose(p.cpu().numpy(), gold[f"neck{i}"], rtol=2e-3, atol=2e-3)
+    # ... and the encoder - this package's MSDA kernel + linears - on the reference's own inputs
+    neck = [torch.from_numpy(gold[f"neck{i}"]).cuda() for i in range(4)]
+    for i, o in enumerate(m.img_encoder(neck, metas)):
+        _assert_close_on_image(o.cpu(), torch.from_numpy(gold[f"enc{i}"]), metas, 1e-4)
+
+
+def test_image_stream_vs_oracle_mid_size():
+    """128x192 images, 3 scenes, wider network: the encoder within 1e-4 (relative to the output
+    scale) of the CPU oracle on identical inputs, the whole stream within the library-convolution
+    tolerance; tokens() equals forward() re-laid out."""
+    cfg = dict(base=16, blocks=(2, 2, 2, 2), embed_dims=64, num_layers=3, num_heads=8,
+               feedforward_channels=128, gn_groups=16, num_feats=32)
+    img, metas = fixtures.make_images(9, B=3, H=128, W=192)
+    ref = OracleImageStream(**cfg)
+    fixtures.seed_weights(ref, 9)
+    want = ref(torch.from_numpy(img), metas)
+    m = _product(cfg, 9)
+    x = torch.from_numpy(img).cuda()
+    got = m(x, metas)
+    for w, g in zip(want, got):                    # end to end: library-convolution tolerance
+        assert tuple(w.shape) == tuple(g.shape)
+        _assert_close_on_image(g.cpu(), w, metas, 5e-3)
+    with torch.no_grad():                          # encoder alone, on the oracle's pyramid: 1e-4
+        pyr = ref.img_neck(ref.img_backbone(torch.from_numpy(img)))
+        want_enc = ref.img_encoder(pyr, metas)
+    for w, g in zip(want_enc, m.img_encoder([p.cuda() for p in pyr], metas)):
+        _assert_close_on_image(g.cpu(), w, metas, 1e-4)
+    tok = m.tokens(x, metas)
+    flat = torch.cat([g.flatten(2).transpose(1, 2) for g in got], 1)
+    assert torch.allclose(tok["tokens"], flat, rtol=1e-4, atol=1e-4)   # two runs of library convs
+    assert tok["spatial"] == [tuple(g.shape[-2:]) for g in got]
+
+
+def test_head_accepts_tokens():
+    """prepare_image_inputs on the channels-last tokens == on the NCHW pyramid."""
+    from demf_amd.modules import DeMFHotPath
+    cfg = fixtures.tiny_cfg()
+    head = DeMFHotPath(cfg).pts_bbox_head.cuda()
+    raw = fixtures.make_scene_batch(2, 256, fixtures.TINY_PYRAMID, fixtures.TINY_INPUT,
+                                    cfg.head.embed_dims, seed=3, n_gt=2)
+    feats = [torch.from_numpy(f).cuda() for f in raw["img_features"]]
+    a = head.prepare_image_inputs(feats, raw["img_metas"])
+    tokens = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1).contiguous()
+    b = head.prepare_image_inputs(dict(tokens=tokens, spatial=[tuple(f.shape[-2:]) for f in feats]),
+                                  raw["img_metas"])
+    assert torch.equal(a["feat_flatten"], b["feat_flatten"])
+    assert torch.equal(a["mask_flatten"], b["mask_flatten"])
+    for x, y in zip(a["value_projected"], b["value_projected"]):
+        assert torch.allclose(x, y, rtol=0, atol=1e-6)     # GEMM on differently strided inputs

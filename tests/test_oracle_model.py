@@ -117,3 +117,23 @@ def test_oracle_get_bboxes_vs_real_reference(golden_dir):
             np.testing.assert_array_equal(bx.numpy(), gold[f"s{seed}.b{b}.boxes"])
             np.testing.assert_array_equal(sc.numpy(), gold[f"s{seed}.b{b}.scores"])
             np.testing.assert_array_equal(lb.numpy(), gold[f"s{seed}.b{b}.labels"])
+
+
+def test_oracle_image_stream_vs_real_encoder(golden_dir):
+    """oracle/model.py's OracleImageStream (restated ResNet-50 / ChannelMapper + the restatement of
+    deform_detr_encoder.py) against the REAL reference DeformableDetrEncoder's output maps
+    (tests/golden/ref_encoder.npz, generated by oracle/pin_reference.py): bit-exact."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import fixtures
+    from oracle.model import OracleImageStream
+    gold = np.load(os.path.join(golden_dir, "ref_encoder.npz"))
+    m = OracleImageStream(**fixtures.TINY_IMAGE_STREAM)
+    fixtures.seed_weights(m, 4)
+    img, metas = fixtures.make_images(4)
+    pyramid = m.img_neck(m.img_backbone(torch.from_numpy(img)))
+    for i, p in enumerate(pyramid):
+        np.testing.assert_array_equal(p.detach().numpy(), gold[f"neck{i}"])
+    for i, o in enumerate(m(torch.from_numpy(img), metas)):
+        np.testing.assert_array_equal(o.numpy(), gold[f"enc{i}"])
