@@ -187,6 +187,19 @@ class DeMFVoteHead(nn.Module):
         valid_W = torch.sum(~mask[:, 0, :], 1)
         return torch.stack([valid_W.float() / W, valid_H.float() / H], -1)
 
+    def refresh_metas(self, static_metas, new_metas):
+        """A hipGraph-replayed step reads the device constants cached for the ``static_metas``
+        object; this overwrites them IN PLACE with the constants of ``new_metas`` (same batch size
+        and padded image size), so the next replay sees the new batch's calibration / masks."""
+        cache = self.__dict__.get("_meta_cache", {})
+        for (mid, shapes, dev), entry in list(cache.items()):
+            if mid != id(static_metas):
+                continue
+            fresh = self._build_meta_tensors(new_metas, shapes, torch.device(dev), entry["M"].dtype)
+            for k, v in fresh.items():
+                if torch.is_tensor(v) and torch.is_tensor(entry.get(k)):
+                    entry[k].copy_(v)
+
     def _meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
         """Device-side constants derived from the (host) img_metas, cached per metas object:
         the step then issues no host->device copy and can be captured in a hipGraph."""
@@ -195,30 +208,33 @@ class DeMFVoteHead(nn.Module):
         if key not in cache:
             if len(cache) > 8:
                 cache.clear()
-            comp = [compose_projection(m) for m in img_metas]
-            sizes = [h * w for h, w in mlvl_shapes]
-            # padding masks (:559-568): nearest-neighbour resize of the (B,Hpad,Wpad) mask is an
-            # index lookup, and the valid ratios (:514-522) count its first column / row - both
-            # functions of the metas alone, so they are built here once per metas object
-            hw = np.asarray([m["img_shape"][:2] for m in img_metas], dtype=np.int64)
-            masks, ratios = [], []
-            for (h, w), m in zip(mlvl_shapes, level_masks(img_metas, mlvl_shapes)):
-                masks.append(m.reshape(len(img_metas), h * w))
-                valid_h = (~m[:, :, 0]).sum(1).astype(np.float32)
-                valid_w = (~m[:, 0, :]).sum(1).astype(np.float32)
-                ratios.append(np.stack([valid_w / np.float32(w), valid_h / np.float32(h)], -1))
-            empty = len(mlvl_shapes) == 0
-            cache[key] = dict(
-                M=torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev),
-                ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
-                hw=torch.as_tensor(hw, device=dev),
-                mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
-                valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
-                spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
-                level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
-                                                  dtype=torch.long, device=dev),
-                keep=img_metas)   # keep the keyed object alive so its id stays unique
+            cache[key] = self._build_meta_tensors(img_metas, mlvl_shapes, dev, dt)
+            cache[key]["keep"] = img_metas   # keep the keyed object alive so its id stays unique
         return cache[key]
+
+    def _build_meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
+        comp = [compose_projection(m) for m in img_metas]
+        sizes = [h * w for h, w in mlvl_shapes]
+        # padding masks (:559-568): nearest-neighbour resize of the (B,Hpad,Wpad) mask is an
+        # index lookup, and the valid ratios (:514-522) count its first column / row - both
+        # functions of the metas alone, so they are built here once per metas object
+        hw = np.asarray([m["img_shape"][:2] for m in img_metas], dtype=np.int64)
+        masks, ratios = [], []
+        for (h, w), m in zip(mlvl_shapes, level_masks(img_metas, mlvl_shapes)):
+            masks.append(m.reshape(len(img_metas), h * w))
+            valid_h = (~m[:, :, 0]).sum(1).astype(np.float32)
+            valid_w = (~m[:, 0, :]).sum(1).astype(np.float32)
+            ratios.append(np.stack([valid_w / np.float32(w), valid_h / np.float32(h)], -1))
+        empty = len(mlvl_shapes) == 0
+        return dict(
+            M=torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev),
+            ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
+            hw=torch.as_tensor(hw, device=dev),
+            mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
+            valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
+            spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
+            level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
+                                              dtype=torch.long, device=dev))
 
     # ---- :524-547 ------------------------------------------------------------
     def get_reference_points(self, seeds_3d_batch, img_metas, mlvl_shapes=()):
@@ -460,8 +476,10 @@ class DeMFVoteHead(nn.Module):
         if isinstance(gt_bboxes_3d, (list, tuple)):
             gt, lab, valid = self.pad_gt(gt_bboxes_3d, gt_labels_3d, points.device)
         else:
-            gt, lab = gt_bboxes_3d, gt_labels_3d
-            valid = torch.ones(gt.shape[:2], dtype=torch.bool, device=gt.device)
+            # already padded (B,G,7) / (B,G): label -1 marks a padding slot (static-shape loops)
+            gt = gt_bboxes_3d
+            valid = gt_labels_3d >= 0
+            lab = gt_labels_3d.clamp(min=0)
         B, G = gt.shape[:2]
         p = points[..., :3]
         center = torch.cat([gt[..., :2], gt[..., 2:3] + gt[..., 5:6] * 0.5], dim=-1)  # gravity

@@ -7,7 +7,7 @@ from oracle import fixtures
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=3):
+def _setup(seed=3, lr=1e-3):
     from demf_amd import engine, synthetic
     from demf_amd.modules import DeMFHotPath
     cfg = fixtures.tiny_cfg()
@@ -21,7 +21,7 @@ def _setup(seed=3):
                  img_metas=raw["img_metas"],
                  gt_bboxes_3d=[torch.from_numpy(b).cuda() for b in raw["gt_boxes"]],
                  gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]])
-    return engine.Trainer(model, lr=1e-3), model, batch
+    return engine.Trainer(model, lr=lr), model, batch
 
 
 def test_graph_replay_matches_eager():
@@ -120,3 +120,42 @@ def test_flat_adamw_matches_torch_adamw():
         tr._update()
     for (n, p), q in zip(ref.named_parameters(), dev.parameters()):
         assert torch.allclose(p, q.cpu(), atol=2e-6, rtol=0), n
+
+
+def _tiny_batch(seed, n_gt):
+    from demf_amd import synthetic
+    cfg = fixtures.tiny_cfg()
+    raw = synthetic.make_scene_batch(3, 1024, fixtures.TINY_PYRAMID, fixtures.TINY_INPUT,
+                                     cfg.head.embed_dims, seed=seed, n_gt=n_gt)
+    return dict(points=torch.from_numpy(raw["points"]).cuda(),
+                img_features=[torch.from_numpy(f).cuda() for f in raw["img_features"]],
+                img_metas=raw["img_metas"],
+                gt_bboxes_3d=[torch.from_numpy(b).cuda() for b in raw["gt_boxes"]],
+                gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]])
+
+
+def test_replay_with_changing_batches_matches_eager():
+    """The captured step fed through its static input buffers (load()) with the pipelined
+    pre-pass of the NEXT batch: three different batches (points, image features, metas, GT counts)
+    cycled through the graph give the same losses and parameters as eager steps on them."""
+    batches = [_tiny_batch(11, 4), _tiny_batch(12, 2), _tiny_batch(13, 5)]
+    # a small learning rate keeps the two runs from drifting apart through the (legitimately
+    # nondeterministic) fp32 atomics: the losses then mainly reflect WHICH batch was consumed
+    te, me, _ = _setup(lr=2e-5)
+    tg, mg, _ = _setup(lr=2e-5)
+    order = [0, 1, 2, 0, 2, 1]
+    for _ in range(2):                       # capture() warms up with real steps on its batch
+        te.step(batches[order[0]])
+    eager = [float(te.step(batches[i])) for i in order]
+    replay = tg.capture(batches[order[0]], warmup=2, max_gt=8)
+    got = []
+    for k, i in enumerate(order):
+        if k:
+            replay.load(batches[i])
+        nxt = batches[order[k + 1]]["points"] if k + 1 < len(order) else None
+        got.append(float(replay(next_points=nxt)))
+    torch.cuda.synchronize()
+    assert eager == pytest.approx(got, rel=2e-3), (eager, got)
+    assert max(eager) - min(eager) > 0.05 * max(eager)        # the batches really differ
+    for (n, p), q in zip(me.named_parameters(), mg.parameters()):
+        assert torch.allclose(p, q, rtol=1e-2, atol=2e-4), n
