@@ -259,7 +259,11 @@ class DeMFVoteHead(nn.Module):
             spatial, feat_flatten = list(mlvl_feats["spatial"]), mlvl_feats["tokens"]
         else:
             spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-            feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
+            if mlvl_feats[0].is_cuda and not any(f.requires_grad for f in mlvl_feats) and \
+                    all(f.is_contiguous() for f in mlvl_feats):
+                feat_flatten = ops.pyramid_to_tokens(mlvl_feats)     # tiled transposes, no autograd
+            else:
+                feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         dev = feat_flatten.device
         mt = self._meta_tensors(img_metas, spatial, dev, feat_flatten.dtype)
         mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]

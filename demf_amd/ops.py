@@ -837,3 +837,18 @@ def aligned_nms(extent, scores, classes, valid, iou_thr):
     _ffi.call("demf_aligned_nms", B, K, float(iou_thr), _p(extent), _p(scores), _p(classes),
               _p(valid.to(torch.uint8).contiguous()), _p(keep), _stream())
     return keep.bool()
+
+
+def pyramid_to_tokens(mlvl_feats):
+    """list of (B,C,H_l,W_l) -> (B, sum H_l W_l, C) channels-last tokens (no gradient: the image
+    pyramid is an input of the hot path)."""
+    B, C = mlvl_feats[0].shape[:2]
+    sizes = [f.shape[2] * f.shape[3] for f in mlvl_feats]
+    S = sum(sizes)
+    out = torch.empty((B, S, C), dtype=torch.float32, device=mlvl_feats[0].device)
+    row0 = 0
+    for f, hw in zip(mlvl_feats, sizes):
+        _chk(f, "feature map")
+        _ffi.call("demf_nchw_to_tokens", B, C, hw, S, row0, _p(f), _p(out), _stream())
+        row0 += hw
+    return out

@@ -258,3 +258,14 @@ def test_invert_index(ops, B, N, M, ns):
         counts = np.bincount(flat, minlength=N)
         np.testing.assert_array_equal(off[b], np.concatenate([[0], np.cumsum(counts)]))
         np.testing.assert_array_equal(rows[b], order)
+
+
+@pytest.mark.parametrize("B,C,shapes", [(2, 256, [(100, 140), (50, 70), (25, 35), (13, 18)]),
+                                        (3, 37, [(5, 7), (1, 1), (33, 2)])])
+def test_pyramid_to_tokens(B, C, shapes):
+    """demf_nchw_to_tokens == flatten(2).transpose(1,2) + cat (bit-exact: a pure re-layout)."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(C)
+    feats = [torch.randn(B, C, h, w, generator=g).cuda() for h, w in shapes]
+    want = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1)
+    assert torch.equal(ops.pyramid_to_tokens(feats), want)
