@@ -49,6 +49,12 @@ struct MlpArgs {
   const float* Bt;             // (N x K) row-major
   float* Y;                    // (R x N) output
   double* stats;               // optional (2N): column sum, column sum of squares
+  // optional fused pooling epilogue (forward, last layer): per group of ns consecutive rows and
+  // column, the max / min of the raw output and the row offset where each is attained
+  float* pmax;                 // (R/ns x N) or null
+  float* pmin;
+  int* amax;
+  int* amin;
 };
 
 // Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
@@ -146,7 +152,44 @@ __device__ __forceinline__ float4 mlp_load_a(const MlpArgs& p, const float* __re
 // RT = 32-row tiles per wave (2 when the accumulators fit: twice the MFMA work per Bt fragment
 // and per barrier).  The prologue's per-channel vectors are copied to LDS once per block.
 constexpr int MLP_MAXK = 512;
-template <int NT, int RT, int PRO, bool STATS>
+// Fused max-pool epilogue.  max_s relu(sc*y_s + sh) = relu(sc*y* + sh) with y* = max_s y_s when
+// sc >= 0 and min_s y_s otherwise (sc*y + sh is monotone in y and so is its rounding), so the GEMM can
+// reduce the RAW output over each group of NS rows before the batch statistics exist; the
+// consumer picks max or min once the scale is known (pool_select_k).  C/D layout: a lane owns one
+// column and the rows (r&3) + 8*(r>>2) + 4*(lane>>5) of each 32-row tile; the partner lane^32 owns
+// the other 16 rows.  Ties resolve to the smallest row offset (first maximum, as max_pool2d).
+template <int RT, int NT, int NS>
+__device__ __forceinline__ void pool_epilogue(const MlpArgs& p, const f32x16 (&acc)[RT][NT], int nt,
+                                              int row0, int col, int lh) {
+  constexpr int GROUPS = (32 * RT) / NS;           // groups inside this wave's rows
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    float mx = -__builtin_inff(), mn = __builtin_inff();
+    int ax = 0, an = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho_w = rt * 32 + (r & 3) + 8 * (r >> 2);      // + 4*lh, added below
+        if (rho_w / NS != g) continue;                            // compile-time after unrolling
+        const int rho = rho_w % NS + 4 * lh;
+        const float v = acc[rt][nt][r];
+        if (v > mx || (v == mx && rho < ax)) { mx = v; ax = rho; }
+        if (v < mn || (v == mn && rho < an)) { mn = v; an = rho; }
+      }
+    const float omx = __shfl_xor(mx, 32), omn = __shfl_xor(mn, 32);
+    const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
+    if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+    if (omn < mn || (omn == mn && oan < an)) { mn = omn; an = oan; }
+    const int row = row0 + g * NS;
+    if (lh == 0 && row < p.R && col < p.N) {
+      const size_t o = (size_t)(row / NS) * p.N + col;
+      p.pmax[o] = mx; p.pmin[o] = mn; p.amax[o] = ax; p.amin[o] = an;
+    }
+  }
+}
+
+template <int NT, int RT, int PRO, bool STATS, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   constexpr int WROWS = 32 * RT;          // rows per wave
   constexpr int BROWS = 4 * WROWS;        // rows per block tile
@@ -221,7 +264,10 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     for (int i = 0; i < NT; ++i)
       *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
     __syncthreads();
-    if (step + 1 < nsteps) prefetch(step + 1);
+    // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
+    // operands are fetched after it instead of being held in flight across it
+    const bool defer_prefetch = POOL && ks == ksteps - 1;
+    if (step + 1 < nsteps && !defer_prefetch) prefetch(step + 1);
     const int kchunks = min(MLP_BK / 8, (p.K - k0 + 7) / 8);
     for (int c8 = 0; c8 < kchunks; ++c8) {
       float4 a4[RT];
@@ -260,6 +306,17 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           }
         cs1[nt] += s1;
         cs2[nt] += s2;
+        if constexpr (POOL) {
+          {
+            const int col = cofs + nt * 32 + lr;
+            if (p.ns == 16) pool_epilogue<RT, NT, 16>(p, acc, nt, row0, col, lh);
+            else if (p.ns == 32) pool_epilogue<RT, NT, 32>(p, acc, nt, row0, col, lh);
+            else if constexpr (RT == 2) pool_epilogue<RT, NT, 64>(p, acc, nt, row0, col, lh);
+          }
+        }
+      }
+      if constexpr (POOL) {
+        if (step + 1 < nsteps) prefetch(step + 1);
       }
     }
   }
@@ -336,6 +393,27 @@ __global__ __launch_bounds__(256) void bnrelu_maxpool_fwd_k(long long RC, int ns
     }
     out[t] = best;
     arg[t] = bi;
+  }
+}
+
+// ---- tail for the fused pooling epilogue: pick max or min by the sign of the BN scale -----------
+__global__ __launch_bounds__(256) void pool_select_k(long long RC, int C,
+                                                     const float* __restrict__ pmax,
+                                                     const float* __restrict__ pmin,
+                                                     const int* __restrict__ amax,
+                                                     const int* __restrict__ amin,
+                                                     const float* __restrict__ ss,
+                                                     float* __restrict__ out,
+                                                     int* __restrict__ arg) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; t < RC; t += stride) {
+    const int c = (int)(t % C);
+    const float sc = ss[c], sh = ss[C + c];
+    const bool up = sc > 0.f;
+    const float y = up ? pmax[t] : pmin[t];
+    out[t] = fmaxf(0.f, __builtin_fmaf(y, sc, sh));
+    arg[t] = sc == 0.f ? 0 : (up ? amax[t] : amin[t]);      // constant activation: first slot wins
   }
 }
 
@@ -626,7 +704,7 @@ static int mlp_grid(int R, int brows) {
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
-template <int PRO, bool STATS>
+template <int PRO, bool STATS, bool POOL = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
@@ -642,6 +720,22 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
               NT_MAX * 32);
     return DEMF_EUNSUPPORTED;
   }
+  if constexpr (POOL) {
+    // pooled epilogue: 64-row wave tiles for ns = 64 (a group must live in one wave), 32-row ones
+    // otherwise; at most 2 (resp. 4) column tiles per block so that the accumulators, the
+    // prefetch and the epilogue's temporaries fit in 256 VGPRs - wider outputs go to blockIdx.y
+    const bool rt2 = a.ns == 64;
+    const int ntl = rt2 ? (nt < 2 ? nt : 2) : (nt < 4 ? nt : 4);
+    const dim3 grid(mlp_grid(a.R, rt2 ? 256 : 128), (nt + ntl - 1) / ntl);
+#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true>), grid, block, 0, s, a)
+    if (rt2) { if (ntl == 1) PGO(1, 2); else PGO(2, 2); }
+    else if (ntl == 1) PGO(1, 1);
+    else if (ntl == 2) PGO(2, 1);
+    else if (ntl == 3) PGO(3, 1);
+    else PGO(4, 1);
+#undef PGO
+    return check_launch("mlp_gemm_pool");
+  } else {
   const int tiles1 = (a.R + 127) / 128;
   if (tiles1 < 192 && nt > 1) {
     int ysplit = (256 + tiles1 - 1) / tiles1;
@@ -650,7 +744,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     const dim3 grid(tiles1, (nt + ntl - 1) / ntl);
     switch (ntl) {
 #define SPLIT(NTv)                                                                              \
-      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS>), grid, block, 0, s, a); break;
+      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS, POOL>), grid, block, 0, s, a); break;
       SPLIT(1) SPLIT(2) SPLIT(3) SPLIT(4)
 #undef SPLIT
       default: break;
@@ -658,7 +752,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     if (ntl <= 4) return check_launch("mlp_gemm");
   }
 #define GO(NTv, RTv)                                                                            \
-  hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS>), dim3(mlp_grid(a.R, 128 * RTv)),   \
+  hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL>), dim3(mlp_grid(a.R, 128 * RTv)), \
                      block, 0, s, a)
 #define CASE(NTv)                                                                               \
   case NTv:                                                                                     \
@@ -672,6 +766,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
 #undef CASE
 #undef GO
   return check_launch("mlp_gemm");
+  }
 }
 
 static int mlp_check(int R, int K, int N, int ldx) {
@@ -699,6 +794,43 @@ extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
   if (pro_scale_shift)
     return stats ? launch_gemm<PRO_BNRELU, true>(a, s) : launch_gemm<PRO_BNRELU, false>(a, s);
   return stats ? launch_gemm<PRO_NONE, true>(a, s) : launch_gemm<PRO_NONE, false>(a, s);
+}
+
+// Same GEMM with the fused max-pool epilogue (last layer of a PointSAModule stack): besides Y
+// and the statistics it emits, per group of ns rows and column, max / min of the raw output and
+// their row offsets.  Supported: ns 16 / 32 / 64; anything else returns DEMF_EUNSUPPORTED (callers
+// then run demf_bnrelu_maxpool_fwd on Y).
+extern "C" int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float* X,
+                                      const float* pro_scale_shift, const float* Wt, float* Y,
+                                      double* stats, int ns, float* pmax, float* pmin, int* amax,
+                                      int* amin, demf_stream_t stream) {
+  if (int e = mlp_check(R, K, N, ldx)) return e;
+  const bool ok = (ns == 16 || ns == 32 || ns == 64) && R % ns == 0;
+  if (!ok) {
+    set_error("mlp_gemm_fwd_pool: ns=%d with R=%d N=%d is not fused", ns, R, N);
+    return DEMF_EUNSUPPORTED;
+  }
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(X && Wt && Y && pro_scale_shift && stats && pmax && pmin && amax && amin,
+               "mlp_gemm_fwd_pool: null pointer");
+  MlpArgs a{};
+  a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
+  a.Y = Y; a.stats = stats; a.ns = ns; a.pmax = pmax; a.pmin = pmin; a.amax = amax; a.amin = amin;
+  return launch_gemm<PRO_BNRELU, true, true>(a, (hipStream_t)stream);
+}
+
+extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,
+                                const int* amax, const int* amin, const float* scale_shift,
+                                float* out, int* arg, demf_stream_t stream) {
+  DEMF_REQUIRE(Rp >= 0 && C >= 1, "pool_select: bad sizes");
+  if (Rp == 0) return DEMF_OK;
+  DEMF_REQUIRE(pmax && pmin && amax && amin && scale_shift && out && arg, "pool_select: null pointer");
+  const long long RC = (long long)Rp * C;
+  long long g = (RC + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(pool_select_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, RC, C, pmax,
+                     pmin, amax, amin, scale_shift, out, arg);
+  return check_launch("pool_select");
 }
 
 extern "C" int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,

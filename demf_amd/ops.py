@@ -519,6 +519,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
+_NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
 
 def _accum64(n, device):
@@ -554,6 +555,7 @@ class _SharedMLPPool(Function):
         st = _stream()
         Ys, sss, mis = [], [], []
         cur, cur_ld, pro = x, ld, None
+        fuse_pool = False
         # the self-cleaning fp64 accumulator holds every layer's statistics (no fill launches)
         ws = _accum64(2 * sum(tensors[7 * l].shape[0] for l in range(L)), dev) if training else None
         woff = 0
@@ -566,7 +568,19 @@ class _SharedMLPPool(Function):
             Y = torch.empty((R, N), dtype=torch.float32, device=dev)
             ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
             mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
-            if training:
+            fuse_pool = training and l == L - 1 and l > 0 and not _NO_FUSED_POOL and \
+                ns in (16, 32, 64)
+            if fuse_pool:
+                # last layer: the max over the ns neighbours rides in the GEMM epilogue
+                stats = ws[woff:woff + 2 * N]
+                woff += 2 * N
+                pm = torch.empty((2, R // ns, N), dtype=torch.float32, device=dev)
+                am = torch.empty((2, R // ns, N), dtype=torch.int32, device=dev)
+                _ffi.call("demf_mlp_gemm_fwd_pool", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                          _p(stats), ns, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]), st)
+                _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
+                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
+            elif training:
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
@@ -588,8 +602,12 @@ class _SharedMLPPool(Function):
         C = Ys[-1].shape[1]
         out = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
         arg = torch.empty((R // ns, C), dtype=torch.int32, device=dev)
-        _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
-                  _p(arg), st)
+        if fuse_pool:
+            _ffi.call("demf_pool_select", R // ns, C, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]),
+                      _p(sss[-1]), _p(out), _p(arg), st)
+        else:
+            _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
+                      _p(arg), st)
         ctx.save_for_backward(x, arg, *Ys, *sss, *mis, *[tensors[7 * l] for l in range(L)],
                               *[tensors[7 * l + 1] for l in range(L)])
         ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape

@@ -189,6 +189,21 @@ int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
                       const float* pro_scale_shift, const float* Wt, float* Y,
                       double* stats, demf_stream_t stream);
 
+/* demf_mlp_gemm_fwd with the max-pool of the PointSAModule fused into the epilogue: per group of
+ * ns consecutive rows and column, pmax/pmin (R/ns,N) = max/min of the raw output and amax/amin
+ * their row offsets (first on ties).  max_s relu(sc*y_s+sh) = relu(sc*(sc>0 ? pmax : pmin)+sh), so
+ * the pooled activation follows from these once the batch statistics are known
+ * (demf_pool_select) without re-reading Y.  ns 16, 32 or 64; DEMF_EUNSUPPORTED otherwise.                                                                   */
+int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float* X,
+                           const float* pro_scale_shift, const float* Wt, float* Y, double* stats,
+                           int ns, float* pmax, float* pmin, int* amax, int* amin,
+                           demf_stream_t stream);
+
+/* out (Rp,C) = relu(scale*y*+shift), arg = row offset of y* (see demf_mlp_gemm_fwd_pool). */
+int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin, const int* amax,
+                     const int* amin, const float* scale_shift, float* out, int* arg,
+                     demf_stream_t stream);
+
 /* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
  * running statistics (momentum, unbiased variance) and increments *num_batches_tracked when
  * they are non-NULL (BatchNorm's train-mode bookkeeping).  The consumed accumulator is left
