@@ -58,7 +58,7 @@ __device__ __forceinline__ float wave_allmax(float v) {
       float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-// sum over aligned groups of G lanes (G in {1,2,4,8,16}); every lane of the
+// sum over aligned groups of G lanes (G in {1,2,4,8,16,32,64}); every lane of the
 // group receives the total.
 template <int G>
 __device__ __forceinline__ float group_allsum(float v) {
@@ -66,6 +66,8 @@ __device__ __forceinline__ float group_allsum(float v) {
   if constexpr (G >= 4) v += dpp_f32<0x4E>(v, v);
   if constexpr (G >= 8) v += dpp_f32<0x141>(v, v);
   if constexpr (G >= 16) v += dpp_f32<0x140>(v, v);
+  if constexpr (G >= 32) v += __shfl_xor(v, 16);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32);
   return v;
 }
 

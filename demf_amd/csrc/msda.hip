@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (c.ok[k] != 0.f) {
+        if (gvalue != nullptr && c.ok[k] != 0.f) {
           const float s = c.cw[k] * aw;
           float* g = gvb + c.off[k];
           atomicAdd(g + 0, s * top.x);
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
       g_x += top * gw;
       g_y += top * gh;
       for (int k = 0; k < 4; ++k)
-        if (c.ok[k] != 0.f) atomicAdd(gvalue + boff + c.off[k] + ch, c.cw[k] * aw * top);
+        if (gvalue != nullptr && c.ok[k] != 0.f)
+          atomicAdd(gvalue + boff + c.off[k] + ch, c.cw[k] * aw * top);
     }
     gattw[item * nlp + i] = g_w;
     gloc[(item * nlp + i) * 2 + 0] = g_x * aw * (float)Wl;
@@ -305,7 +306,8 @@ extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   hipStream_t s = (hipStream_t)stream;
   const long long items = (long long)B * Q * H;
   const int G = Dh / 4;
-  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) &&
+  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 ||
+                                      G == 64) &&
                     (((uintptr_t)value | (uintptr_t)out) % 16 == 0);
   if (!fast) {
     hipLaunchKernelGGL(msda_fwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
@@ -322,7 +324,9 @@ extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
     case 2: GO(2); break;
     case 4: GO(4); break;
     case 8: GO(8); break;
-    default: GO(16); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
   }
 #undef GO
   return check_launch("msda_fwd");
@@ -337,12 +341,13 @@ extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
   if (B == 0 || Q == 0) return DEMF_OK;
   DEMF_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight &&
-                   grad_out && grad_value && grad_sampling_loc && grad_attn_weight,
-               "msda_bwd: null pointer");
+                   grad_out && grad_sampling_loc && grad_attn_weight,
+               "msda_bwd: null pointer");   // grad_value may be NULL: no gradient wrt value wanted
   hipStream_t s = (hipStream_t)stream;
   const long long items = (long long)B * Q * H;
   const int G = Dh / 4;
-  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16) &&
+  const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 ||
+                                      G == 64) &&
                     (((uintptr_t)value | (uintptr_t)grad_out) % 16 == 0);
   if (!fast) {
     hipLaunchKernelGGL(msda_bwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
@@ -361,7 +366,9 @@ extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
     case 2: GO(2); break;
     case 4: GO(4); break;
     case 8: GO(8); break;
-    default: GO(16); break;
+    case 16: GO(16); break;
+    case 32: GO(32); break;
+    default: GO(64); break;
   }
 #undef GO
   return check_launch("msda_bwd");

@@ -91,7 +91,8 @@ class DeMFHotPath(nn.Module):
         seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points)
         main.wait_stream(s_img)
         for t in [image_inputs["feat_flatten"], image_inputs["mask_flatten"],
-                  image_inputs["valid_ratios"], *image_inputs["value_projected"]]:
+                  image_inputs["valid_ratios"], *(image_inputs["value_projected"] or []),
+                  *(image_inputs["value_tokens"] or [])]:
             t.record_stream(main)
         feat_dict = dict(seed_points=seeds_3d, seed_features=seed_3d_features,
                          seed_indices=seed_indices)

@@ -167,7 +167,9 @@ class DeMFVoteHead(nn.Module):
                                     spatial_shapes=spatial_shapes,
                                     level_start_index=level_start_index,
                                     valid_ratios=valid_ratios,
-                                    value_projected=image_inputs["value_projected"][i])
+                                    value_projected=(image_inputs["value_projected"][i]
+                                                     if image_inputs["value_projected"] is not None else None),
+                                    value_tokens=image_inputs.get("value_tokens"))
             cls_p, reg_p = self.conv_preds[i + 1](query.permute(1, 2, 0))
             decode_res = self._split(cls_p, reg_p, aggregated_points)
             decode_res_all.append(decode_res)
@@ -231,6 +233,9 @@ class DeMFVoteHead(nn.Module):
             ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
             hw=torch.as_tensor(hw, device=dev),
             mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
+            keep4=None if empty else torch.as_tensor(np.stack(
+                [~np.concatenate(masks, 1)] + [np.zeros_like(np.concatenate(masks, 1))] * 3, -1),
+                dtype=dt, device=dev),
             valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
             spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
             level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
@@ -253,6 +258,7 @@ class DeMFVoteHead(nn.Module):
         padding masks, flattened tokens, valid ratios - plus the per-layer value projection of
         the fusion attention.  Independent of the point stream, so the detector runs it on a
         side stream while furthest-point sampling occupies 8 of the 256 CUs."""
+        own_tokens = not isinstance(mlvl_feats, dict)     # a buffer made here may be edited in place
         if isinstance(mlvl_feats, dict):
             # channels-last tokens (B,S,C) straight from demf_amd.modules.ImageStream.tokens():
             # no flatten + concat copy of the pyramid (:570-591)
@@ -267,12 +273,27 @@ class DeMFVoteHead(nn.Module):
         dev = feat_flatten.device
         mt = self._meta_tensors(img_metas, spatial, dev, feat_flatten.dtype)
         mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
+        B, S, C = feat_flatten.shape
+        att = self.decoder[0].layer.attentions[1]
+        samples = self.num_proposal * att.num_levels * att.num_points * 4
+        value_tokens, value_projected = None, None
+        if feat_flatten.is_cuda and not feat_flatten.requires_grad and samples < S and C % 4 == 0 \
+                and C <= 256:
+            # the decoder samples far fewer corners than there are tokens: keep the tokens
+            # unprojected (padding rows zeroed) and project after sampling
+            # (ops.msda_sample_then_project); no (B,S,C) value tensor per decoder layer
+            masked = feat_flatten.masked_fill_(mask_flatten.unsqueeze(-1), 0.0) if own_tokens \
+                else feat_flatten.masked_fill(mask_flatten.unsqueeze(-1), 0.0)
+            value_tokens = (masked, mt["keep4"])
+            feat_flatten = masked
         feat_flatten = feat_flatten.permute(1, 0, 2)
-        value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)
-                           for layer in self.decoder]
+        if value_tokens is None:
+            value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)
+                               for layer in self.decoder]
         return dict(feat_flatten=feat_flatten, mask_flatten=mask_flatten, spatial=spatial,
                     spatial_shapes=mt["spatial_shapes"], level_start_index=mt["level_start_index"],
-                    valid_ratios=valid_ratios, value_projected=value_projected)
+                    valid_ratios=valid_ratios, value_projected=value_projected,
+                    value_tokens=value_tokens)
 
     def prepare_decoder_inputs(self, seeds_3d, mlvl_feats, img_metas):
         ii = self.prepare_image_inputs(mlvl_feats, img_metas)

@@ -155,7 +155,7 @@ class MultiScaleDeformableAttention(nn.Module):
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None,
                 key_padding_mask=None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, value_projected=None, **kwargs):
+                level_start_index=None, value_projected=None, value_tokens=None, **kwargs):
         if value is None:
             value = query
         if identity is None:
@@ -165,8 +165,9 @@ class MultiScaleDeformableAttention(nn.Module):
         if not self.batch_first:
             query = query.permute(1, 0, 2)
         bs, num_query, _ = query.shape
-        value = value_projected if value_projected is not None else \
-            self.project_value(value, key_padding_mask)
+        if value_tokens is None:
+            value = value_projected if value_projected is not None else \
+                self.project_value(value, key_padding_mask)
         offsets = ops.linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(bs, num_query, self.num_heads, self.num_levels,
                                                     self.num_points, 2)
         weights = ops.linear(query, self.attention_weights.weight, self.attention_weights.bias).view(bs, num_query, self.num_heads,
@@ -177,9 +178,17 @@ class MultiScaleDeformableAttention(nn.Module):
         normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
         locations = reference_points[:, :, None, :, None, :] + \
             offsets / normalizer[None, None, None, :, None, :]
-        output = MultiScaleDeformableAttnFunction.apply(
-            value.contiguous(), spatial_shapes, level_start_index, locations.contiguous(),
-            weights.contiguous(), self.im2col_step)
+        if value_tokens is not None:
+            # few queries against many tokens: sample the (masked) tokens first, project the
+            # sampled rows afterwards (ops.msda_sample_then_project) - same result, no (B,S,C) GEMM
+            tokens, keep4 = value_tokens
+            output = ops.msda_sample_then_project(
+                tokens, keep4, spatial_shapes, level_start_index, locations.contiguous(),
+                weights.contiguous(), self.value_proj.weight, self.value_proj.bias)
+        else:
+            output = MultiScaleDeformableAttnFunction.apply(
+                value.contiguous(), spatial_shapes, level_start_index, locations.contiguous(),
+                weights.contiguous(), self.im2col_step)
         output = ops.linear(output, self.output_proj.weight, self.output_proj.bias)
         if not self.batch_first:
             output = output.permute(1, 0, 2)

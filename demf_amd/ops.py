@@ -250,7 +250,8 @@ class MultiScaleDeformableAttnFunction(Function):
         grad_output = grad_output.contiguous()
         B, S, H, Dh = value.shape
         _, Q, _, L, P, _ = loc.shape
-        grad_value = torch.zeros_like(value)
+        # no gradient wrt value wanted (e.g. frozen image tokens): the scatter is skipped
+        grad_value = torch.zeros_like(value) if ctx.needs_input_grad[0] else None
         grad_loc = torch.empty_like(loc)
         grad_attw = torch.empty_like(attw)
         _ffi.call("demf_msda_bwd_f32", B, S, H, Dh, L, Q, P, _p(value), _p(shapes), _p(lsi),
@@ -870,3 +871,32 @@ def pyramid_to_tokens(mlvl_feats):
         _ffi.call("demf_nchw_to_tokens", B, C, hw, S, row0, _p(f), _p(out), _stream())
         row0 += hw
     return out
+
+
+def msda_sample_then_project(tokens, keep4, spatial_shapes, level_start_index, sampling_locations,
+                             attention_weights, weight, bias):
+    """Multi-scale deformable attention with the value projection applied AFTER sampling:
+
+        sum_s w_s * bilinear(keep * (W x + b))[s]  ==  W_h (sum_s w_s * bilinear(keep * x)[s])
+                                                       + b_h  sum_s w_s * bilinear(keep)[s]
+
+    (everything is linear in x).  ``tokens`` (B,S,C) = keep * x, ``keep4`` (B,S,4) = [keep,0,0,0],
+    locations (B,Q,H,L,P,2), weights (B,Q,H,L,P), ``weight`` (H*Dh, C) / ``bias`` (H*Dh) = the
+    module's value_proj.  With Q*L*P*4 sampled corners << S tokens this replaces a (B*S, C) x (C, C)
+    GEMM, its masking passes, the (B,S,C) value / grad-value buffers and the fp32 atomics of the
+    backward by two gathers on the same kernels (H=1, Dh=C) plus H small batched GEMMs.
+    No gradient flows to the tokens (they are the frozen image stream's output).  -> (B,Q,H*Dh)"""
+    B, S, C = tokens.shape
+    _, Q, H, L, P, _ = sampling_locations.shape
+    Dh = weight.shape[0] // H
+    loc = sampling_locations.reshape(B, Q * H, 1, L, P, 2)
+    aw = attention_weights.reshape(B, Q * H, 1, L, P)
+    z = MultiScaleDeformableAttnFunction.apply(tokens.view(B, S, 1, C), spatial_shapes,
+                                               level_start_index, loc, aw)          # (B,Q*H,C)
+    ksum = MultiScaleDeformableAttnFunction.apply(keep4.view(B, S, 1, 4), spatial_shapes,
+                                                  level_start_index, loc, aw)[..., 0]  # (B,Q*H)
+    zh = z.view(B * Q, H, C).transpose(0, 1)                                  # (H, B*Q, C)
+    out = torch.baddbmm(                                                      # (H, B*Q, Dh)
+        (ksum.view(B * Q, H).t().unsqueeze(-1) * bias.view(H, 1, Dh)),
+        zh, weight.view(H, Dh, C).transpose(1, 2))
+    return out.transpose(0, 1).reshape(B, Q, H * Dh)

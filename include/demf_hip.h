@@ -295,8 +295,8 @@ int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
                       const int64_t* level_start_index, const float* sampling_loc,
                       const float* attn_weight, float* out, demf_stream_t stream);
 
-/* backward: grad_out (B,Q,H*Dh) -> grad_value (B,S,H,Dh) accumulated,
- * grad_sampling_loc (B,Q,H,L,P,2) and grad_attn_weight (B,Q,H,L,P) written.   */
+/* backward: grad_out (B,Q,H*Dh) -> grad_value (B,S,H,Dh) accumulated (NULL: not wanted, the
+ * scatter is skipped), grad_sampling_loc (B,Q,H,L,P,2) and grad_attn_weight (B,Q,H,L,P) written. */
 int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
                       const float* value, const int64_t* spatial_shapes,
                       const int64_t* level_start_index, const float* sampling_loc,

@@ -269,3 +269,41 @@ def test_pyramid_to_tokens(B, C, shapes):
     feats = [torch.randn(B, C, h, w, generator=g).cuda() for h, w in shapes]
     want = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1)
     assert torch.equal(ops.pyramid_to_tokens(feats), want)
+
+
+@pytest.mark.parametrize("B,Q,P,with_mask", [(2, 64, 2, True), (3, 256, 4, True), (1, 17, 2, False)])
+def test_msda_sample_then_project_matches_project_then_sample(B, Q, P, with_mask):
+    """The fusion attention's two evaluation orders: value_proj on all tokens then MSDA
+    (the reference's order, mmcv MultiScaleDeformableAttention.forward) vs MSDA on the masked
+    tokens then the per-head projection (ops.msda_sample_then_project).  Output and every gradient
+    (sampling locations, attention weights, value_proj weight and bias) agree to 2e-5 relative."""
+    from demf_amd import ops
+    torch.manual_seed(Q + P)
+    H, Dh, C = 8, 32, 256
+    shapes = [(25, 35), (13, 18), (7, 9), (4, 5)]
+    S = sum(h * w for h, w in shapes)
+    ss = torch.tensor(shapes, dtype=torch.long, device="cuda")
+    lsi = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+    x = torch.randn(B, S, C, device="cuda")
+    mask = (torch.rand(B, S, device="cuda") < 0.2) if with_mask else torch.zeros(B, S, dtype=torch.bool, device="cuda")
+    W = (torch.randn(H * Dh, C, device="cuda") / 16).requires_grad_()
+    bias = (0.3 * torch.randn(H * Dh, device="cuda")).requires_grad_()
+    loc = (torch.rand(B, Q, H, 4, P, 2, device="cuda") * 1.2 - 0.1).requires_grad_()   # some outside
+    aw = torch.softmax(torch.randn(B, Q, H, 4 * P, device="cuda"), -1).view(B, Q, H, 4, P).requires_grad_()
+    go = torch.randn(B, Q, H * Dh, device="cuda")
+
+    value = ops.linear(x, W, bias, row_mask=mask).view(B, S, H, Dh)
+    ref = ops.MultiScaleDeformableAttnFunction.apply(value, ss, lsi, loc, aw)
+    g_ref = torch.autograd.grad(ref, [loc, aw, W, bias], go)
+
+    keep = (~mask).float()
+    keep4 = torch.stack([keep, torch.zeros_like(keep), torch.zeros_like(keep), torch.zeros_like(keep)], -1)
+    out = ops.msda_sample_then_project(x * keep[..., None], keep4, ss, lsi, loc, aw, W, bias)
+    g_out = torch.autograd.grad(out, [loc, aw, W, bias], go)
+
+    def close(a, b, name):
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()), f"{name}: {err:.3e}"
+    close(out, ref, "out")
+    for n, a, b in zip(("grad_loc", "grad_attw", "grad_W", "grad_bias"), g_out, g_ref):
+        close(a, b, n)
