@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void colsum_k(int R, int N, int ld, int rows_p
 // 570-591) as a tiled transpose through LDS (both sides coalesced).
 __global__ __launch_bounds__(256) void nchw_to_tokens_k(int C, int HW, int S, int row0,
                                                         const float* __restrict__ src,
+                                                        const unsigned char* __restrict__ mask,
                                                         float* __restrict__ dst) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
@@ -415,6 +416,7 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_k(int C, int HW, int S, in
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
   src += (size_t)b * C * HW;
   dst += ((size_t)b * S + row0) * C;
+  if (mask != nullptr) mask += (size_t)b * S + row0;
   for (int j = ty; j < 32; j += 8) {
     const int c = c0 + j, p = p0 + tx;
     tile[j][tx] = (c < C && p < HW) ? src[(size_t)c * HW + p] : 0.f;
@@ -422,7 +424,8 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_k(int C, int HW, int S, in
   __syncthreads();
   for (int j = ty; j < 32; j += 8) {
     const int p = p0 + j, c = c0 + tx;
-    if (p < HW && c < C) dst[(size_t)p * C + c] = tile[tx][j];
+    if (p < HW && c < C)
+      dst[(size_t)p * C + c] = (mask != nullptr && mask[p]) ? 0.f : tile[tx][j];   // padding token
   }
 }
 
@@ -637,12 +640,12 @@ extern "C" int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int l
 }
 
 extern "C" int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const float* src,
-                                   float* dst, demf_stream_t stream) {
+                                   const unsigned char* mask, float* dst, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && C >= 1 && HW >= 1 && row0 >= 0 && row0 + HW <= S,
                "nchw_to_tokens: bad sizes C=%d HW=%d S=%d row0=%d", C, HW, S, row0);
   if (B == 0) return DEMF_OK;
   DEMF_REQUIRE(src && dst, "nchw_to_tokens: null pointer");
   hipLaunchKernelGGL(nchw_to_tokens_k, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
-                     (hipStream_t)stream, C, HW, S, row0, src, dst);
+                     (hipStream_t)stream, C, HW, S, row0, src, mask, dst);
   return check_launch("nchw_to_tokens");
 }

@@ -258,34 +258,37 @@ class DeMFVoteHead(nn.Module):
         padding masks, flattened tokens, valid ratios - plus the per-layer value projection of
         the fusion attention.  Independent of the point stream, so the detector runs it on a
         side stream while furthest-point sampling occupies 8 of the 256 CUs."""
-        own_tokens = not isinstance(mlvl_feats, dict)     # a buffer made here may be edited in place
+        att = self.decoder[0].layer.attentions[1]
+        samples = self.num_proposal * att.num_levels * att.num_points * 4
         if isinstance(mlvl_feats, dict):
             # channels-last tokens (B,S,C) straight from demf_amd.modules.ImageStream.tokens():
             # no flatten + concat copy of the pyramid (:570-591)
             spatial, feat_flatten = list(mlvl_feats["spatial"]), mlvl_feats["tokens"]
+            on_gpu, C0 = feat_flatten.is_cuda and not feat_flatten.requires_grad, feat_flatten.shape[2]
         else:
             spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-            if mlvl_feats[0].is_cuda and not any(f.requires_grad for f in mlvl_feats) and \
-                    all(f.is_contiguous() for f in mlvl_feats):
-                feat_flatten = ops.pyramid_to_tokens(mlvl_feats)     # tiled transposes, no autograd
+            feat_flatten = None
+            on_gpu = mlvl_feats[0].is_cuda and not any(f.requires_grad for f in mlvl_feats) and \
+                all(f.is_contiguous() for f in mlvl_feats)
+            C0 = mlvl_feats[0].shape[1]
+        dev = mlvl_feats["tokens"].device if isinstance(mlvl_feats, dict) else mlvl_feats[0].device
+        dt = mlvl_feats["tokens"].dtype if isinstance(mlvl_feats, dict) else mlvl_feats[0].dtype
+        mt = self._meta_tensors(img_metas, spatial, dev, dt)
+        mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
+        S = mask_flatten.shape[1]
+        # the decoder samples far fewer corners than there are tokens: keep the tokens unprojected
+        # (padding rows zeroed) and project after sampling (ops.msda_sample_then_project); no
+        # (B,S,C) value tensor per decoder layer
+        sample_first = on_gpu and samples < S and C0 % 4 == 0 and C0 <= 256
+        if feat_flatten is None:
+            if on_gpu:           # tiled transposes; the padding mask rides along when wanted
+                feat_flatten = ops.pyramid_to_tokens(mlvl_feats, mask_flatten if sample_first else None)
             else:
                 feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
-        dev = feat_flatten.device
-        mt = self._meta_tensors(img_metas, spatial, dev, feat_flatten.dtype)
-        mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
-        B, S, C = feat_flatten.shape
-        att = self.decoder[0].layer.attentions[1]
-        samples = self.num_proposal * att.num_levels * att.num_points * 4
-        value_tokens, value_projected = None, None
-        if feat_flatten.is_cuda and not feat_flatten.requires_grad and samples < S and C % 4 == 0 \
-                and C <= 256:
-            # the decoder samples far fewer corners than there are tokens: keep the tokens
-            # unprojected (padding rows zeroed) and project after sampling
-            # (ops.msda_sample_then_project); no (B,S,C) value tensor per decoder layer
-            masked = feat_flatten.masked_fill_(mask_flatten.unsqueeze(-1), 0.0) if own_tokens \
-                else feat_flatten.masked_fill(mask_flatten.unsqueeze(-1), 0.0)
-            value_tokens = (masked, mt["keep4"])
-            feat_flatten = masked
+        elif sample_first:
+            feat_flatten = feat_flatten.masked_fill(mask_flatten.unsqueeze(-1), 0.0)
+        value_tokens = (feat_flatten, mt["keep4"]) if sample_first else None
+        value_projected = None
         feat_flatten = feat_flatten.permute(1, 0, 2)
         if value_tokens is None:
             value_projected = [layer.layer.attentions[1].project_value(feat_flatten, mask_flatten)

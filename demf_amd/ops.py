@@ -858,17 +858,19 @@ def aligned_nms(extent, scores, classes, valid, iou_thr):
     return keep.bool()
 
 
-def pyramid_to_tokens(mlvl_feats):
+def pyramid_to_tokens(mlvl_feats, zero_mask=None):
     """list of (B,C,H_l,W_l) -> (B, sum H_l W_l, C) channels-last tokens (no gradient: the image
-    pyramid is an input of the hot path)."""
+    pyramid is an input of the hot path).  ``zero_mask`` (B,S) bool: tokens to write as zeros
+    (image padding), fused into the transposes."""
     B, C = mlvl_feats[0].shape[:2]
     sizes = [f.shape[2] * f.shape[3] for f in mlvl_feats]
     S = sum(sizes)
     out = torch.empty((B, S, C), dtype=torch.float32, device=mlvl_feats[0].device)
+    m = None if zero_mask is None else zero_mask.to(torch.uint8).contiguous()
     row0 = 0
     for f, hw in zip(mlvl_feats, sizes):
         _chk(f, "feature map")
-        _ffi.call("demf_nchw_to_tokens", B, C, hw, S, row0, _p(f), _p(out), _stream())
+        _ffi.call("demf_nchw_to_tokens", B, C, hw, S, row0, _p(f), _p(m), _p(out), _stream())
         row0 += hw
     return out
 

@@ -164,9 +164,10 @@ int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int fea
 
 /* One pyramid level (B,C,HW) channel-major -> rows [row0,row0+HW) of the channels-last token buffer
  * (B,S,C): the flatten + transpose + concat of prepare_decoder_inputs
- * (class_agnostic_vote_head.py:570-591) as a tiled transpose.                                   */
-int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const float* src, float* dst,
-                        demf_stream_t stream);
+ * (class_agnostic_vote_head.py:570-591) as a tiled transpose.  mask (B,S) bytes or NULL: tokens
+ * with a non-zero mask byte (image padding) are written as zeros.                               */
+int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const float* src,
+                        const unsigned char* mask, float* dst, demf_stream_t stream);
 
 /* out (N) += column sums of x (R,N; row stride ld).  out arrives zeroed.  The bias gradient of the
  * path's linear layers (mmcv FFN / MultiheadAttention / MultiScaleDeformableAttention projections,

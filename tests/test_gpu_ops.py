@@ -269,6 +269,8 @@ def test_pyramid_to_tokens(B, C, shapes):
     feats = [torch.randn(B, C, h, w, generator=g).cuda() for h, w in shapes]
     want = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1)
     assert torch.equal(ops.pyramid_to_tokens(feats), want)
+    mask = torch.rand(want.shape[:2], generator=g).cuda() < 0.3
+    assert torch.equal(ops.pyramid_to_tokens(feats, mask), want.masked_fill(mask[..., None], 0.0))
 
 
 @pytest.mark.parametrize("B,Q,P,with_mask", [(2, 64, 2, True), (3, 256, 4, True), (1, 17, 2, False)])
