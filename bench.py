@@ -237,10 +237,10 @@ def main():
             "roofline": {"kernel": "fps_reg_kernel<1024,20> (20000->2048)", "bound": "hbm",
                          "achieved": algo_bytes / (fps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / (fps_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         # profiles/r01_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, B=8:
-                         # FETCH_SIZE 986.2 KiB x2 (gfx950 half-count correction, calibrated on the
+                         # profiles/r01_i_pmc_{FETCH,WRITE}_SIZE.csv, separate --pmc passes, B=8:
+                         # FETCH_SIZE 984.9 KiB x2 (gfx950 half-count correction, calibrated on the
                          # SA1 dx GEMM) + WRITE_SIZE 64.0 KiB per launch
-                         "traffic": (2 * 986.2 + 64.0) * 1024 if args.batch == 8 else None,
+                         "traffic": (2 * 984.9 + 64.0) * 1024 if args.batch == 8 else None,
                          "avg_launch_ms": fps_ms,
                          "note": "latency-bound chain of 2047 dependent rounds; see DESIGN.md"},
         }
@@ -252,9 +252,12 @@ def main():
             "kernel": "mlp_gemm_kernel<2,2,BNRELU,STATS,POOL> (SA1 layer 3: 64->128, R=%d)" % sa1_rows,
             "bound": "hbm", "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": None, "avg_launch_ms": mlp_ms,
+            # same PMC passes: FETCH_SIZE 262978.0 KiB x2 + WRITE_SIZE 558080.1 KiB per launch
+            "traffic": (2 * 262978.0 + 558080.1) * 1024 if args.batch == 8 else None,
+            "avg_launch_ms": mlp_ms,
             "note": "8.6 GFLOP fp32 MFMA per launch as well; the input rows are read twice "
-                    "(two 64-column halves) so that the pooling epilogue fits in registers"}
+                    "(two 64-column halves) so that the pooling epilogue fits in registers - hence "
+                    "traffic = 1.32 x the algorithmic bytes"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
