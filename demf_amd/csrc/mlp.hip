@@ -55,6 +55,7 @@ struct MlpArgs {
   float* pmin;
   int* amax;
   int* amin;
+  int halves;                  // pooled launches: 2 = two column halves interleaved in a 1-D grid
 };
 
 // Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
@@ -208,10 +209,21 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
   float* sa = s_a[wave];
   // few-row launches split the output columns over blockIdx.y so the chip is still filled
-  const int cofs = blockIdx.y * NT * 32;
+  // Pooled launches with two column halves use a 1-D grid in which blocks b and b+8 - the same
+  // XCD under round-robin dispatch - take the two halves of the same row tiles at the same time,
+  // so the second read of the A rows is an L2 hit instead of a second trip to HBM.
+  int bx = blockIdx.x, gx = gridDim.x, by = blockIdx.y;
+  if constexpr (POOL) {
+    if (p.halves == 2) {
+      by = (bx >> 3) & 1;
+      bx = (bx & 7) | ((bx >> 4) << 3);
+      gx >>= 1;
+    }
+  }
+  const int cofs = by * NT * 32;
   const int ntiles = (p.R + BROWS - 1) / BROWS;
   const int ksteps = (p.K + MLP_BK - 1) / MLP_BK;
-  const int my_tiles = ntiles > (int)blockIdx.x ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int my_tiles = ntiles > bx ? (ntiles - 1 - bx) / gx + 1 : 0;
   const int nsteps = my_tiles * ksteps;
   float cs1[NT], cs2[NT];
 #pragma unroll
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   bool pok[4 * RT];
   float4 preb[NT];
   auto prefetch = [&](int step) {
-    const int tile = blockIdx.x + (step / ksteps) * gridDim.x;
+    const int tile = bx + (step / ksteps) * gx;
     const int k0 = (step % ksteps) * MLP_BK;
     const int row0 = tile * BROWS + wave * WROWS;
 #pragma unroll
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   for (int step = 0; step < nsteps; ++step) {
     const int ks = step % ksteps;
     const int k0 = ks * MLP_BK;
-    const int row0 = (blockIdx.x + (step / ksteps) * gridDim.x) * BROWS + wave * WROWS;
+    const int row0 = (bx + (step / ksteps) * gx) * BROWS + wave * WROWS;
     float* sb = s_b;
     if (ks == 0) {
 #pragma unroll
@@ -726,8 +738,16 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     // prefetch and the epilogue's temporaries fit in 256 VGPRs - wider outputs go to blockIdx.y
     const bool rt2 = a.ns == 64;
     const int ntl = rt2 ? (nt < 2 ? nt : 2) : (nt < 4 ? nt : 4);
-    const dim3 grid(mlp_grid(a.R, rt2 ? 256 : 128), (nt + ntl - 1) / ntl);
-#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true>), grid, block, 0, s, a)
+    const int ys = (nt + ntl - 1) / ntl;
+    int gx = mlp_grid(a.R, rt2 ? 256 : 128);
+    MlpArgs a2 = a;
+    dim3 grid(gx, ys);
+    if (ys == 2) {                       // interleaved halves: multiple of 16 blocks
+      gx = ((gx + 7) / 8) * 8;
+      a2.halves = 2;
+      grid = dim3(2 * gx, 1);
+    }
+#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true>), grid, block, 0, s, a2)
     if (rt2) { if (ntl == 1) PGO(1, 2); else PGO(2, 2); }
     else if (ntl == 1) PGO(1, 1);
     else if (ntl == 2) PGO(2, 1);
