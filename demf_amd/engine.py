@@ -23,10 +23,15 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DEMF_SHARE_DEVICE"):
+        # test hook: several ranks on ONE GPU (with DEMF_DIST_BACKEND=gloo), to exercise the
+        # multi-rank code path of bench.py on a single-GPU box
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("DEMF_DIST_BACKEND") or \
+            ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
