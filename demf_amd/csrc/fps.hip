@@ -96,10 +96,105 @@ __device__ long long g_fps_prof[8];
 #define FPS_ACC(i, a, b)
 #endif
 
+constexpr int FPS_PREFIX_MAX = 1024;   // largest M for the ordered-input check (12 KB of LDS)
+
+// ---- already-ordered input?  The points of SA level l+1 are the FPS order of level l, and the
+// first M points of an FPS order are the FPS order of that cloud again - UNLESS a tie is broken
+// differently in the subset.  That can be verified without the M-round dependency chain: with
+// E[k] = min_{i<k} d(q_i, q_k), the sequential algorithm picks k at step k iff E[k] is strictly
+// greater than min_{i<k} d(q_i, q_j) for every j > k - N*M/1024 independent distance evaluations
+// per thread, no barrier inside.  A first pass over the first 16 steps rejects unordered clouds
+// in a microsecond.  On success idx = 0..M-1 is written and flag[b] = 1 makes the FPS kernel
+// return at once; any tie or violation leaves flag[b] = 0 and the real loop runs, so the result is
+// always the reference's.
+__global__ __launch_bounds__(1024) void fps_ordered_check_k(int N, int M,
+                                                            const float* __restrict__ xyz,
+                                                            int* __restrict__ idx,
+                                                            int* __restrict__ flag) {
+  constexpr int BS = 1024;
+  asm volatile("" ::: "v127");                 // whole register file of the CU, as fps_reg_kernel
+  __shared__ float4 s_q[FPS_PREFIX_MAX];       // {x, y, z, E[k]}: one broadcast 16-byte read per k
+  __shared__ int s_bad;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  xyz += (size_t)b * N * 3;
+  idx += (size_t)b * M;
+  for (int t = tid; t < M; t += BS) s_q[t] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], 0.f);
+  if (tid == 0) { s_bad = 0; flag[b] = 0; }
+  __syncthreads();
+  auto e_of = [&](int k) {
+    const float4 q = s_q[k];
+    float e = 1e10f;
+    int i = 0;
+    for (; i + 8 <= k; i += 8) {
+      float d[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float4 o = s_q[i + v];
+        d[v] = dist2(o.x - q.x, o.y - q.y, o.z - q.z);
+      }
+      e = fminf(e, fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
+                         fminf(fminf(d[4], d[5]), fminf(d[6], d[7]))));
+    }
+    for (; i < k; ++i) {
+      const float4 o = s_q[i];
+      e = fminf(e, dist2(o.x - q.x, o.y - q.y, o.z - q.z));
+    }
+    return e;
+  };
+  // every j against the steps [k0, k1) given the running minimum over the steps before k0
+  auto test = [&](int k0, int k1) {
+    bool bad = false;
+    for (int j = tid; j < N && !bad; j += BS) {
+      const float qx = xyz[3 * j], qy = xyz[3 * j + 1], qz = xyz[3 * j + 2];
+      float r = 1e10f;
+      const int kmax = j < k1 ? j : k1;
+      int k = 0;
+      for (; k + 8 <= kmax && !bad; k += 8) {
+        float d[8], e[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const float4 o = s_q[k + v];
+          d[v] = dist2(o.x - qx, o.y - qy, o.z - qz);
+          e[v] = o.w;
+        }
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          bad |= (k + v >= k0 && k + v >= 1) && !(e[v] > r);
+          r = fminf(r, d[v]);
+        }
+      }
+      for (; k < kmax; ++k) {
+        const float4 o = s_q[k];
+        bad |= (k >= k0 && k >= 1) && !(o.w > r);
+        r = fminf(r, dist2(o.x - qx, o.y - qy, o.z - qz));
+      }
+    }
+    return bad;
+  };
+  const int quick = M < 16 ? M : 16;
+  if (tid < quick) s_q[tid].w = e_of(tid);
+  __syncthreads();
+  if (test(0, quick)) s_bad = 1;
+  __syncthreads();
+  if (s_bad != 0) return;                       // the usual case for an arbitrary cloud
+  float ek = 0.f;
+  if (tid >= quick && tid < M) ek = e_of(tid);
+  __syncthreads();
+  if (tid >= quick && tid < M) s_q[tid].w = ek;
+  __syncthreads();
+  if (test(quick, M)) s_bad = 1;
+  __syncthreads();
+  if (s_bad == 0) {
+    for (int t = tid; t < M; t += BS) idx[t] = t;
+    if (tid == 0) flag[b] = 1;
+  }
+}
+
 template <int BS, int PPT>
 __global__ __launch_bounds__(BS) void fps_reg_kernel(int N, int M,
                                                      const float* __restrict__ xyz,
-                                                     int* __restrict__ idx) {
+                                                     int* __restrict__ idx,
+                                                     const int* __restrict__ skip) {
   constexpr int NW = BS / 64;
   // Claim the CU's whole vector register file (BS/256 waves per SIMD x the per-wave budget):
   // this latency-bound chain runs for milliseconds on one CU per scene, and any other kernel's
@@ -115,6 +210,9 @@ __global__ __launch_bounds__(BS) void fps_reg_kernel(int N, int M,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // already-ordered input, verified by fps_ordered_check_k: nothing to do for this scene
+  if (skip != nullptr && skip[b] != 0) return;
 
   // two points per 64-bit register pair: the distance math runs on the packed-fp32 pipe
   // (v_pk_add/mul/fma_f32, bit-identical to the scalar ops)
@@ -293,8 +391,9 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int N, int M, int BSR
 }
 
 template <int BS, int PPT>
-static void launch_reg(int B, int N, int M, const float* xyz, int* idx, hipStream_t s) {
-  hipLaunchKernelGGL((fps_reg_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, M, xyz, idx);
+static void launch_reg(int B, int N, int M, const float* xyz, int* idx, const int* skip,
+                       hipStream_t s) {
+  hipLaunchKernelGGL((fps_reg_kernel<BS, PPT>), dim3(B), dim3(BS), 0, s, N, M, xyz, idx, skip);
 }
 
 }  // namespace demf
@@ -310,25 +409,32 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
   int bs = 1;
   while (bs * 2 <= N && bs < 1024) bs *= 2;  // upstream opt_n_threads()
   const int ppt = cdiv(N, bs);
+  // level l+1 of the backbone is handed the FPS order of level l: try the dependency-free check
+  // first (needs B ints of scratch in `temp`); scenes it verifies are skipped by the main kernel
+  const int* skip = nullptr;
+  if (temp != nullptr && M >= 2 && M <= FPS_PREFIX_MAX && N <= 4 * M && bs >= 64 && ppt <= 24) {
+    hipLaunchKernelGGL(fps_ordered_check_k, dim3(B), dim3(1024), 0, s, N, M, xyz, idx, (int*)temp);
+    skip = (const int*)temp;
+  }
   bool done = true;
   if (bs == 1024) {
-    if (ppt <= 2) launch_reg<1024, 2>(B, N, M, xyz, idx, s);
-    else if (ppt <= 4) launch_reg<1024, 4>(B, N, M, xyz, idx, s);
-    else if (ppt <= 6) launch_reg<1024, 6>(B, N, M, xyz, idx, s);
-    else if (ppt <= 8) launch_reg<1024, 8>(B, N, M, xyz, idx, s);
-    else if (ppt <= 12) launch_reg<1024, 12>(B, N, M, xyz, idx, s);
-    else if (ppt <= 16) launch_reg<1024, 16>(B, N, M, xyz, idx, s);
-    else if (ppt <= 20) launch_reg<1024, 20>(B, N, M, xyz, idx, s);
-    else if (ppt <= 24) launch_reg<1024, 24>(B, N, M, xyz, idx, s);
+    if (ppt <= 2) launch_reg<1024, 2>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 4) launch_reg<1024, 4>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 6) launch_reg<1024, 6>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 8) launch_reg<1024, 8>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 12) launch_reg<1024, 12>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 16) launch_reg<1024, 16>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 20) launch_reg<1024, 20>(B, N, M, xyz, idx, skip, s);
+    else if (ppt <= 24) launch_reg<1024, 24>(B, N, M, xyz, idx, skip, s);
     else done = false;
   } else if (bs == 512) {
-    launch_reg<512, 2>(B, N, M, xyz, idx, s);
+    launch_reg<512, 2>(B, N, M, xyz, idx, skip, s);
   } else if (bs == 256) {
-    launch_reg<256, 2>(B, N, M, xyz, idx, s);
+    launch_reg<256, 2>(B, N, M, xyz, idx, skip, s);
   } else if (bs == 128) {
-    launch_reg<128, 2>(B, N, M, xyz, idx, s);
+    launch_reg<128, 2>(B, N, M, xyz, idx, skip, s);
   } else if (bs == 64) {
-    launch_reg<64, 2>(B, N, M, xyz, idx, s);
+    launch_reg<64, 2>(B, N, M, xyz, idx, skip, s);
   } else {
     done = false;
   }

@@ -174,6 +174,7 @@ constexpr int INV_MAX_N = 16384;
 __global__ __launch_bounds__(1024) void invert_index_k(int N, int E, const int* __restrict__ idx,
                                                        int* __restrict__ off,
                                                        int* __restrict__ rows) {
+  asm volatile("" ::: "v127");            // one WG per scene for ~100s of us: keep the CU to itself
   extern __shared__ int s_inv[];          // cnt[N] | start[N+1]
   int* cnt = s_inv;
   int* start = s_inv + N;

@@ -276,6 +276,10 @@ class Trainer:
             main = torch.cuda.current_stream()
             if can_prefetch and next_points is not None:
                 static_pts.copy_(next_points)
+            if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
+                graph.replay()
+                self._update()
+                return loss
             if can_prefetch:
                 # the pre-pass goes first: enqueueing the ~900-node step graph takes the host
                 # about a millisecond, which would otherwise delay the start of the FPS chain

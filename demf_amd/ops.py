@@ -55,6 +55,10 @@ class _FurthestPointSampling(Function):
         temp = None
         if N < 64 or N > 24 * 1024:
             temp = torch.empty((B, N), dtype=torch.float32, device=points_xyz.device)
+        elif 2 <= num_points <= 1024 and N <= 4 * num_points and not _NO_FPS_CHECK:
+            # B flags for the ordered-input check (every SA level after the first samples a cloud
+            # that already is in FPS order)
+            temp = torch.empty((B,), dtype=torch.float32, device=points_xyz.device)
         _ffi.call("demf_fps_f32", B, N, num_points, _p(points_xyz), _p(temp), _p(idx),
                   _stream())
         ctx.mark_non_differentiable(idx)
@@ -520,6 +524,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
+_NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
 

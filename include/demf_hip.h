@@ -55,7 +55,10 @@ int demf_stream_create_cu_masked(const int* cus, int n, int invert, void** out);
  * (configs/demf/demf_votenet.py:48-62,155-162).  Stands in for mmdet3d.ops
  * furthest_point_sample.  idx[b,0] = 0; ties resolve exactly as the upstream
  * block reduction does (see DESIGN.md "canonical arithmetic").
- * `temp` is the (B,N) scratch the upstream ABI carries; it may be NULL here.  */
+ * `temp` is the (B,N) scratch the upstream ABI carries; it may be NULL for 64 <= N <= 24576.
+ * When it is given (>= B ints) and N <= 4M <= 4096, a dependency-free check first tests whether
+ * the cloud already is in FPS order (as every SA level after the first is) and, if so, answers
+ * 0..M-1 without running the M-round chain; ties fall back to the chain, results are identical. */
 int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, int* idx,
                  demf_stream_t stream);
 

@@ -309,3 +309,20 @@ def test_msda_sample_then_project_matches_project_then_sample(B, Q, P, with_mask
     close(out, ref, "out")
     for n, a, b in zip(("grad_loc", "grad_attw", "grad_W", "grad_bias"), g_out, g_ref):
         close(a, b, n)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "grid"])
+@pytest.mark.parametrize("n,m,m2", [(2048, 1024, 512), (1024, 512, 256), (1000, 250, 250), (700, 300, 64)])
+def test_fps_of_fps_ordered_cloud(ops, kind, n, m, m2):
+    """FPS on a cloud that already is in FPS order (what every set-abstraction level after the
+    first sees): the kernel's ordered-input check may answer without running the chain, and must
+    still reproduce the oracle bit for bit - including grid-snapped clouds, where ties make the
+    shortcut invalid and the kernel has to fall back."""
+    pts = scene_points(2, n, seed=n + m, grid=8 if kind == "grid" else None)
+    first = ok.fps(pts, m)
+    ordered = np.stack([pts[b][first[b]] for b in range(2)])
+    want = ok.fps(ordered, m2)
+    got = ops.furthest_point_sample(dev(ordered), m2).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    if kind == "uniform":
+        np.testing.assert_array_equal(want, np.tile(np.arange(m2, dtype=want.dtype), (2, 1)))
