@@ -640,7 +640,9 @@ class _SharedMLPPool(Function):
         # BN reductions go through the self-cleaning fp64 accumulator; the weight gradients of all
         # layers share one zero-filled fp32 workspace
         ws64 = _accum64(2 * sum(W.shape[0] for W in Ws), dev)
-        ws32 = torch.zeros(sum(W.numel() for W in Ws), dtype=torch.float32, device=dev)
+        # (+ room for the exact-zero gradients of conv biases shadowed by BatchNorm)
+        nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
+        ws32 = torch.zeros(sum(W.numel() for W in Ws) + nbias, dtype=torch.float32, device=dev)
         o64 = o32 = 0
         for l in range(L - 1, -1, -1):
             W = Ws[l]
@@ -664,7 +666,8 @@ class _SharedMLPPool(Function):
                       _p(sss[l - 1] if l > 0 else None), _p(dW), st)
             grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
             if ctx.bias_shapes[l] is not None:
-                grads[7 * l + 5] = torch.zeros(ctx.bias_shapes[l], dtype=torch.float32, device=dev)
+                grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
+                o32 += N
             if l > 0 or ctx.needs_input_grad[0]:
                 Wtt = W.t().contiguous()
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
