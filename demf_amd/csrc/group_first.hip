@@ -1,0 +1,227 @@
+// First shared-MLP layer of a set-abstraction level WITHOUT the grouped tensor.
+//
+// Upstream (PointSAModule via build_sa_module, class_agnostic_vote_head.py:383,455 and the
+// backbone) gathers ns neighbours per centre into rows [(xyz_j - centre)/radius (3) | feat_j (C)]
+// and feeds them to a 1x1 convolution W (C1, 3+C).  The convolution is linear, so
+//
+//     y[m,s,:] = feat[idx[m,s]] . Wf^T + rel(m,s) . Wx^T = U[idx[m,s], :] + rel(m,s) . Wx^T
+//
+// with U = feat . Wf^T computed ONCE per source point (N rows) instead of once per neighbour
+// (M*ns rows, 16 x more at SA2).  The forward kernel is then a row gather of U plus three fmas
+// per element and the BN statistics of y; the backward kernel sums the (BN-backward transformed)
+// gradient rows of every source point through the inverse neighbour lists (demf_invert_index) ->
+// dU, from which the weight / feature gradients are two N-row GEMMs, and reduces the 3 x C1 xyz
+// weight gradient on the way.  Both are HBM/L2 byte movers: y written once (fwd), dZ and y read
+// once (bwd); the (M*ns, 3+C) grouped rows and their gradient never exist.
+#include "common.h"
+
+namespace demf {
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int LPR>  // lanes per row = C1 / 4
+__global__ __launch_bounds__(512) void group_first_fwd_k(
+    int N, int M, int ns, float div, const float* __restrict__ xyz,
+    const float* __restrict__ center, const int* __restrict__ idx, const float* __restrict__ U,
+    const float* __restrict__ Wx, float* __restrict__ Y, double* __restrict__ stats,
+    long long rows) {
+  constexpr int C1 = LPR * 4;
+  constexpr int GPB = 512 / LPR;  // rows in flight per block and unroll step
+  constexpr int UNR = 4;
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int c = sub * 4;
+  const float4 w0 = *reinterpret_cast<const float4*>(Wx + c);
+  const float4 w1 = *reinterpret_cast<const float4*>(Wx + C1 + c);
+  const float4 w2 = *reinterpret_cast<const float4*>(Wx + 2 * C1 + c);
+  float4 s = f4_zero(), q = f4_zero();
+  const long long stride = (long long)gridDim.x * GPB;
+  for (long long row0 = (long long)blockIdx.x * GPB + grp; row0 < rows; row0 += stride * UNR) {
+    float4 u[UNR];
+    float rx[UNR], ry[UNR], rz[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const long long row = row0 + k * stride;
+      u[k] = f4_zero();
+      rx[k] = ry[k] = rz[k] = 0.f;
+      if (row < rows) {
+        const long long bm = row / ns;
+        const int b = (int)(bm / M);
+        const int i = idx[row];
+        const size_t src = (size_t)b * N + i;
+        const float* p = xyz + src * 3;
+        const float* o = center + bm * 3;
+        rx[k] = (p[0] - o[0]) / div;  // upstream: grouped_xyz /= max_radius
+        ry[k] = (p[1] - o[1]) / div;
+        rz[k] = (p[2] - o[2]) / div;
+        u[k] = *reinterpret_cast<const float4*>(U + src * C1 + c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UNR; ++k) {
+      const long long row = row0 + k * stride;
+      if (row < rows) {
+        float4 y;
+#define GF_Y(m) y.m = __builtin_fmaf(rz[k], w2.m, __builtin_fmaf(ry[k], w1.m, __builtin_fmaf(rx[k], w0.m, u[k].m)));
+        GF_Y(x) GF_Y(y) GF_Y(z) GF_Y(w)
+#undef GF_Y
+        *reinterpret_cast<float4*>(Y + row * C1 + c) = y;
+        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+        q.x = __builtin_fmaf(y.x, y.x, q.x); q.y = __builtin_fmaf(y.y, y.y, q.y);
+        q.z = __builtin_fmaf(y.z, y.z, q.z); q.w = __builtin_fmaf(y.w, y.w, q.w);
+      }
+    }
+  }
+  if (stats == nullptr) return;
+  __shared__ float4 red[2][GPB][LPR];
+  red[0][grp][sub] = s;
+  red[1][grp][sub] = q;
+  __syncthreads();
+  // 2*C1 column totals, one thread each (fp64 from here on)
+  for (int t = threadIdx.x; t < 2 * C1; t += 512) {
+    const int which = t / C1, col = t - which * C1;
+    const float* base = reinterpret_cast<const float*>(&red[which][0][0]) + col;
+    double tot = 0.0;
+#pragma unroll 4
+    for (int g = 0; g < GPB; ++g) tot += (double)base[g * C1];
+    atomicAdd(stats + which * C1 + col, tot);
+  }
+}
+
+// One group of LPR lanes per source point: sums dY over the rows that gathered the point.
+template <int LPR>
+__global__ __launch_bounds__(256) void group_first_bwd_k(
+    int N, int M, int ns, float div, const float* __restrict__ xyz,
+    const float* __restrict__ center, const float* __restrict__ G, const float* __restrict__ Yl,
+    const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
+    float* __restrict__ dU, float* __restrict__ dWx, long long points) {
+  constexpr int C1 = LPR * 4;
+  constexpr int GPB = 256 / LPR;
+  constexpr int UNR = 4;
+  const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+  const int c = sub * 4;
+  const int E = M * ns;
+  // dY = gi*dZ + (a*y + b), dZ = G where y*scale+shift > 0   (vec = demf_bn_bwd_vectors)
+  const float4 sc = *reinterpret_cast<const float4*>(vec + c);
+  const float4 sh = *reinterpret_cast<const float4*>(vec + C1 + c);
+  const float4 gi = *reinterpret_cast<const float4*>(vec + 2 * C1 + c);
+  const float4 va = *reinterpret_cast<const float4*>(vec + 3 * C1 + c);
+  const float4 vb = *reinterpret_cast<const float4*>(vec + 4 * C1 + c);
+  float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();
+  for (long long pt = (long long)blockIdx.x * GPB + grp; pt < points;
+       pt += (long long)gridDim.x * GPB) {
+    const int b = (int)(pt / N), j = (int)(pt - (long long)b * N);
+    const int* o = off + (size_t)b * (N + 1) + j;
+    const int e0 = o[0], e1 = o[1];
+    const int* r = rows_ + (size_t)b * E;
+    const size_t rbase = (size_t)b * E;
+    const float* cb = center + (size_t)b * M * 3;
+    const float px = xyz[pt * 3], py = xyz[pt * 3 + 1], pz = xyz[pt * 3 + 2];
+    float4 acc = f4_zero();
+    for (int e = e0; e < e1; e += UNR) {
+      float4 g[UNR], y[UNR];
+      float rx[UNR], ry[UNR], rz[UNR];
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        g[k] = f4_zero();
+        y[k] = f4_zero();
+        rx[k] = ry[k] = rz[k] = 0.f;
+        if (e + k < e1) {
+          const int row = r[e + k];
+          const float* q = cb + (size_t)(row / ns) * 3;
+          rx[k] = (px - q[0]) / div;
+          ry[k] = (py - q[1]) / div;
+          rz[k] = (pz - q[2]) / div;
+          g[k] = *reinterpret_cast<const float4*>(G + (rbase + row) * C1 + c);
+          y[k] = *reinterpret_cast<const float4*>(Yl + (rbase + row) * C1 + c);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        if (e + k < e1) {
+          float4 d;
+#define GF_DY(m)                                                                   \
+          {                                                                        \
+            const float dz = __builtin_fmaf(y[k].m, sc.m, sh.m) > 0.f ? g[k].m : 0.f; \
+            d.m = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, y[k].m, vb.m));    \
+            acc.m += d.m;                                                          \
+            wa0.m = __builtin_fmaf(rx[k], d.m, wa0.m);                             \
+            wa1.m = __builtin_fmaf(ry[k], d.m, wa1.m);                             \
+            wa2.m = __builtin_fmaf(rz[k], d.m, wa2.m);                             \
+          }
+          GF_DY(x) GF_DY(y) GF_DY(z) GF_DY(w)
+#undef GF_DY
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dU + pt * C1 + c) = acc;
+  }
+  __shared__ float4 red[3][GPB][LPR];
+  red[0][grp][sub] = wa0;
+  red[1][grp][sub] = wa1;
+  red[2][grp][sub] = wa2;
+  __syncthreads();
+  for (int t = threadIdx.x; t < 3 * C1; t += 256) {
+    const int which = t / C1, col = t - which * C1;
+    const float* base = reinterpret_cast<const float*>(&red[which][0][0]) + col;
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < GPB; ++g) tot += base[g * C1];
+    atomicAdd(dWx + which * C1 + col, tot);
+  }
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius,
+                                    int normalize_xyz, const float* xyz, const float* center,
+                                    const int* idx, const float* U, const float* Wx, float* Y,
+                                    double* stats, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
+               "group_first_fwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
+  if (B == 0 || M == 0) return DEMF_OK;
+  DEMF_REQUIRE(xyz && center && idx && U && Wx && Y, "group_first_fwd: null pointer");
+  const long long rows = (long long)B * M * ns;
+  const float div = normalize_xyz ? radius : 1.0f;
+  hipStream_t s = (hipStream_t)stream;
+  const int lpr = C1 / 4, gpb = 512 / lpr;
+  long long blocks = (rows + (long long)gpb * 4 - 1) / ((long long)gpb * 4);
+  if (blocks > 256) blocks = 256;  // one fp64 atomic per column per block: keep the tail short
+  const dim3 grid((unsigned)blocks);
+#define GF_FWD(L)                                                                          \
+  hipLaunchKernelGGL(group_first_fwd_k<L>, grid, dim3(512), 0, s, N, M, ns, div, xyz, center, \
+                     idx, U, Wx, Y, stats, rows)
+  if (lpr == 64) GF_FWD(64);
+  else if (lpr == 32) GF_FWD(32);
+  else GF_FWD(16);
+#undef GF_FWD
+  return check_launch("group_first_fwd");
+}
+
+extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius,
+                                    int normalize_xyz, const float* xyz, const float* center,
+                                    const float* G, const float* Y, const float* vec6,
+                                    const int* inv_off, const int* inv_rows, float* dU,
+                                    float* dWx, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
+               "group_first_bwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(xyz && center && G && Y && vec6 && inv_off && inv_rows && dU && dWx,
+               "group_first_bwd: null pointer");
+  const long long points = (long long)B * N;
+  const float div = normalize_xyz ? radius : 1.0f;
+  hipStream_t s = (hipStream_t)stream;
+  const int lpr = C1 / 4, gpb = 256 / lpr;
+  long long blocks = (points + gpb - 1) / gpb;
+  if (blocks > 512) blocks = 512;  // 3*C1 fp32 atomics per block
+  const dim3 grid((unsigned)blocks);
+#define GF_BWD(L)                                                                          \
+  hipLaunchKernelGGL(group_first_bwd_k<L>, grid, dim3(256), 0, s, N, M, ns, div, xyz, center, \
+                     G, Y, vec6, inv_off, inv_rows, dU, dWx, points)
+  if (lpr == 64) GF_BWD(64);
+  else if (lpr == 32) GF_BWD(32);
+  else GF_BWD(16);
+#undef GF_BWD
+  return check_launch("group_first_bwd");
+}

@@ -32,7 +32,7 @@ class ConvBNReLU(nn.Module):
         return self.conv.weight.view(self.cout, self.cin)
 
 
-def fused_rows(blocks, x, ns=1, first_weight=None):
+def fused_rows(blocks, x, ns=1, first_weight=None, geo=None):
     """Run a stack of ConvBNReLU blocks on rows x (R, K) through the fused gfx950 kernels
     (ops.shared_mlp_pool): GEMM + BN statistics + BN/ReLU, optionally max over ``ns`` rows."""
     from .. import ops
@@ -44,7 +44,8 @@ def fused_rows(blocks, x, ns=1, first_weight=None):
         layers.append((w.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                        blk.conv.bias, bn.num_batches_tracked))
     bn0 = blocks[0].bn
-    return ops.shared_mlp_pool(x, ns, layers, training=training, eps=bn0.eps, momentum=bn0.momentum)
+    return ops.shared_mlp_pool(x, ns, layers, training=training, eps=bn0.eps, momentum=bn0.momentum,
+                               geo=geo)
 
 
 class RowsMLP(nn.Sequential):
@@ -55,6 +56,7 @@ class RowsMLP(nn.Sequential):
         for i in range(len(channels) - 1):
             self.add_module(f"layer{i}", ConvBNReLU(channels[i], channels[i + 1], dim, bias))
 
-    def forward_rows(self, x, first_weight=None, ns=1):
-        """x (R, K) -> (R/ns, C_out): the whole stack (+ max over ns neighbours) fused."""
-        return fused_rows(list(self), x.contiguous(), ns, first_weight)
+    def forward_rows(self, x, first_weight=None, ns=1, geo=None):
+        """x (R, K) -> (R/ns, C_out): the whole stack (+ max over ns neighbours) fused.
+        ``geo``: see ops.shared_mlp_pool (first layer applied per source point)."""
+        return fused_rows(list(self), x.contiguous(), ns, first_weight, geo)

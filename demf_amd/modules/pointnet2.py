@@ -96,15 +96,28 @@ class PointSAModule(nn.Module):
         if group_inv is None and feat is not None and feat.requires_grad and C % 4 == 0 \
                 and N <= 16384:
             group_inv = ops.invert_index(idx, N)
-        grouped = ops.group_concat_cl(points_xyz, new_xyz, feat, idx, self.radius,
-                                      self.normalize_xyz, ldo=ld,
-                                      xyz_col=C if self.use_xyz else 0, feat_col=0,
-                                      inverse=group_inv) \
-            if self.use_xyz else ops.gather_rows_cl(
-                feat, idx.view(B, M * self.num_sample)).view(B, M, self.num_sample, C)
-        x = grouped.view(B * M * self.num_sample, ld)
-        # shared MLP + BN + ReLU + max over the ns neighbours: one fused chain (csrc/mlp.hip)
-        x = self.mlps[0].forward_rows(x, self._first_weight(ld), ns=self.num_sample)
+        mlp = self.mlps[0]
+        needs_grad = feat is not None and feat.requires_grad and torch.is_grad_enabled()
+        xyz_grad = torch.is_grad_enabled() and (points_xyz.requires_grad or new_xyz.requires_grad)
+        if self.use_xyz and feat is not None and len(mlp) >= 2 and C % 4 == 0 \
+                and mlp[0].cout in (64, 128, 256) and not ops._NO_GROUP_FIRST \
+                and (group_inv is not None or not needs_grad) and not xyz_grad:
+            # first layer per SOURCE point: y = (feat . Wf^T)[idx] + rel_xyz . Wx^T, the grouped
+            # rows (B*M*ns, 3+C) are never built (csrc/group_first.hip)
+            inv_off, inv_rows = group_inv if group_inv is not None else (None, None)
+            x = mlp.forward_rows(feat.view(B * N, C), ns=self.num_sample,
+                                 geo=(points_xyz, new_xyz, idx, inv_off, inv_rows, self.radius,
+                                      self.normalize_xyz))
+        else:
+            grouped = ops.group_concat_cl(points_xyz, new_xyz, feat, idx, self.radius,
+                                          self.normalize_xyz, ldo=ld,
+                                          xyz_col=C if self.use_xyz else 0, feat_col=0,
+                                          inverse=group_inv) \
+                if self.use_xyz else ops.gather_rows_cl(
+                    feat, idx.view(B, M * self.num_sample)).view(B, M, self.num_sample, C)
+            x = grouped.view(B * M * self.num_sample, ld)
+            # shared MLP + BN + ReLU + max over the ns neighbours: one fused chain (csrc/mlp.hip)
+            x = mlp.forward_rows(x, self._first_weight(ld), ns=self.num_sample)
         new_features = x.view(B, M, -1).transpose(1, 2)  # (B,C',M) view of point-major
         return new_xyz, new_features, indices
 

@@ -525,6 +525,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
 _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
+_NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
 
@@ -552,10 +553,20 @@ class _SharedMLPPool(Function):
     BN+ReLU is fused with the max over the ``ns`` neighbours (ns == 1: plain activation)."""
 
     @staticmethod
-    def forward(ctx, x, ns, training, eps, momentum, *tensors):
+    def forward(ctx, x, ns, training, eps, momentum, geo, *tensors):
         _chk(x, "x")
         R, ld = x.shape
         L = len(tensors) // 7
+        if geo is not None:
+            # x = per-point feature rows (B*N, C); the grouped rows never exist (csrc/group_first.hip)
+            g_xyz, g_center, g_idx, g_off, g_rows, g_radius, g_norm = geo
+            _chk(g_xyz, "xyz")
+            _chk(g_center, "center")
+            _chk(g_idx, "idx", torch.int32)
+            gB, gN, _ = g_xyz.shape
+            _, gM, gns = g_idx.shape
+            assert gns == ns and R == gB * gN and L >= 2 and tensors[0].shape[1] == ld + 3
+            R = gB * gM * ns
         assert len(tensors) == 7 * L and R % ns == 0
         dev = x.device
         st = _stream()
@@ -570,13 +581,35 @@ class _SharedMLPPool(Function):
             nbt = tensors[7 * l + 6]
             _chk(W, "weight")
             N, K = W.shape
-            assert K == cur_ld, f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
+            first_geo = geo is not None and l == 0
+            assert first_geo or K == cur_ld, \
+                f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
             Y = torch.empty((R, N), dtype=torch.float32, device=dev)
             ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
             mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
             fuse_pool = training and l == L - 1 and l > 0 and not _NO_FUSED_POOL and \
                 ns in (16, 32, 64)
-            if fuse_pool:
+            if first_geo:
+                # reference column order [xyz(3) | feat(C)]: U = feat . Wf^T once per source point
+                U = torch.mm(x, W[:, 3:].t())
+                Wx = W[:, :3].t().contiguous()
+                stats = None
+                if training:
+                    stats = ws[woff:woff + 2 * N]
+                    woff += 2 * N
+                _ffi.call("demf_group_first_fwd", gB, gN, gM, ns, N, float(g_radius),
+                          int(bool(g_norm)), _p(g_xyz), _p(g_center), _p(g_idx), _p(U), _p(Wx),
+                          _p(Y), _p(stats), st)
+                if training:
+                    _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
+                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
+                else:
+                    invstd = torch.rsqrt(rvar + eps)
+                    ss[:N] = gamma * invstd
+                    ss[N:] = beta - rmean * gamma * invstd
+                    mi[:N] = rmean
+                    mi[N:] = invstd
+            elif fuse_pool:
                 # last layer: the max over the ns neighbours rides in the GEMM epilogue
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
@@ -619,6 +652,9 @@ class _SharedMLPPool(Function):
         ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
+        ctx.geo = None
+        if geo is not None:
+            ctx.geo = (g_xyz, g_center, g_off, g_rows, float(g_radius), int(bool(g_norm)))
         ctx.mark_non_differentiable(arg)
         return out
 
@@ -656,6 +692,29 @@ class _SharedMLPPool(Function):
             dbeta = torch.empty(N, dtype=torch.float32, device=dev)
             _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12), _p(gammas[l]), _p(sss[l]), _p(mis[l]),
                       _p(vec6), _p(dgamma), _p(dbeta), st)
+            if l == 0 and ctx.geo is not None:
+                # factored first layer: dU per source point through the inverse lists, then the
+                # feature half of dW and the input gradient are GEMMs over the source points
+                g_xyz, g_center, g_off, g_rows, g_radius, g_norm = ctx.geo
+                if g_off is None:
+                    raise RuntimeError("shared_mlp_pool: backward of the factored first layer "
+                                       "needs the inverse neighbour lists")
+                gB, gN, _ = g_xyz.shape
+                gM = g_center.shape[1]
+                dU = torch.empty((gB * gN, N), dtype=torch.float32, device=dev)
+                dWx = ws32[o32:o32 + 3 * N]
+                o32 += N * K
+                _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
+                          _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
+                          _p(dWx), st)
+                grads[0] = torch.cat([dWx.view(3, N).t(), torch.mm(dU.t(), x)], dim=1)
+                grads[1], grads[2] = dgamma, dbeta
+                if ctx.bias_shapes[0] is not None:
+                    grads[5] = ws32[o32:o32 + N].view(ctx.bias_shapes[0])
+                    o32 += N
+                if ctx.needs_input_grad[0]:
+                    dx = torch.mm(dU, W[:, 3:])
+                break
             xprev = Ys[l - 1] if l > 0 else x
             ldx = xprev.shape[1]
             dW = ws32[o32:o32 + N * K].view(N, K)
@@ -677,16 +736,20 @@ class _SharedMLPPool(Function):
                     G = dX
                 else:
                     dx = dX
-        return (dx, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, *grads)
 
 
-def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1):
+def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1, geo=None):
     """Fused (conv1x1 -> BN -> ReLU) x L -> max over ``ns`` consecutive rows (ns=1: none).
     ``layers`` = [(weight (N,K), gamma, beta, running_mean, running_var[, conv_bias
     [, num_batches_tracked]]), ...].
     A conv bias in front of a train-mode BN cancels in the normalised output (and its gradient
     is identically zero); it only shifts the running mean, which is applied here.
-    ``num_batches_tracked`` (int64 scalar tensor) is incremented by the statistics kernel."""
+    ``num_batches_tracked`` (int64 scalar tensor) is incremented by the statistics kernel.
+    ``geo`` = (xyz (B,N,3), centres (B,M,3), idx (B,M,ns), inv_off|None, inv_rows|None, radius,
+    normalize_xyz): x is then the per-point feature rows (B*N, C) and layer 0 (weight (C1, 3+C) in
+    the reference column order [xyz | feat]) is applied WITHOUT building the grouped rows:
+    y = (feat . Wf^T)[idx] + rel_xyz . Wx^T  (linearity of the convolution; csrc/group_first.hip)."""
     flat = []
     for layer in layers:
         W, gamma, beta, rmean, rvar = layer[:5]
@@ -695,7 +758,7 @@ def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1):
         if not training and bias is not None:
             rmean = rmean - bias.detach()      # eval: BN sees y + bias
         flat += [W, gamma, beta, rmean, rvar, bias, nbt]
-    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, *flat)
+    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, geo, *flat)
     if training:
         with torch.no_grad():
             for layer in layers:

@@ -165,6 +165,25 @@ int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int fea
                                     const float* grad_out, const int* off, const int* rows,
                                     float* grad_feat, demf_stream_t stream);
 
+/* First 1x1 convolution of a set-abstraction level without the grouped tensor (PointSAModule built by
+ * build_sa_module, class_agnostic_vote_head.py:383,455; QueryAndGroup with use_xyz / normalize_xyz).
+ * The grouped row is [(xyz_j - centre)/radius | feat_j]; with U (B*N, C1) = feat . Wf^T computed per
+ * SOURCE point and Wx (3, C1) the xyz columns of the weight (k-major),
+ *   Y[b,m,s,:] = U[b, idx[b,m,s], :] + rel(b,m,s) . Wx          (rows (B*M*ns, C1), fully written)
+ * stats (2*C1 fp64: column sum | sum of squares, accumulated, as demf_mlp_gemm_fwd) or NULL.
+ * C1 in {64,128,256}. */
+int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
+                         const float* xyz, const float* center, const int* idx, const float* U,
+                         const float* Wx, float* Y, double* stats, demf_stream_t stream);
+/* Backward of the above through the inverse lists of demf_invert_index: with dY the BN-backward
+ * transform of (G, Y) by vec6 (demf_bn_bwd_vectors; same formula as demf_mlp_gemm_bwd_dx),
+ *   dU[b,j,:]  = sum of dY over the rows that gathered point j        (fully written, no atomics)
+ *   dWx[k,:]  += sum over all rows of rel_k . dY                      (3*C1 fp32, arrives zeroed) */
+int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
+                         const float* xyz, const float* center, const float* G, const float* Y,
+                         const float* vec6, const int* inv_off, const int* inv_rows, float* dU,
+                         float* dWx, demf_stream_t stream);
+
 /* One pyramid level (B,C,HW) channel-major -> rows [row0,row0+HW) of the channels-last token buffer
  * (B,S,C): the flatten + transpose + concat of prepare_decoder_inputs
  * (class_agnostic_vote_head.py:570-591) as a tiled transpose.  mask (B,S) bytes or NULL: tokens

@@ -99,3 +99,100 @@ def test_shared_mlp_pool_eval_mode():
     out = ops.shared_mlp_pool(x, 16, [(W, g, b, rm.clone(), rv.clone())], training=False)
     ref = F.relu(F.batch_norm(F.linear(x, W), rm, rv, g, b, False, 0.1, 1e-5)).view(40, 16, 128).max(1)[0]
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,M,ns,C,chans,radius,norm", [
+    (2, 600, 150, 16, 128, (128, 128, 256), 0.8, True),     # SA3/SA4-like
+    (3, 1100, 300, 32, 128, (128, 128, 256), 0.4, True),    # SA2-like
+    (1, 257, 33, 16, 64, (64, 128), 1.2, False),            # 2 layers, no xyz normalisation
+    (2, 300, 64, 64, 8, (256, 64, 64), 0.9, True),          # C1 = 256, ns = 64
+])
+def test_factored_first_layer_matches_grouped_reference(B, N, M, ns, C, chans, radius, norm):
+    """ops.shared_mlp_pool(geo=...) - first layer applied per source point, grouped rows never
+    built (csrc/group_first.hip) - against the plain fp64 chain on the explicitly grouped rows
+    [(xyz_j - centre)/radius | feat_j] (QueryAndGroup + the SA MLP upstream)."""
+    from demf_amd import ops
+    torch.manual_seed(N + ns)
+    xyz = torch.rand(B, N, 3, dtype=torch.float64) * 2.0
+    feat = torch.randn(B, N, C, dtype=torch.float64) * 0.6
+    xyz_g = xyz.float().cuda()
+    fidx = ops.furthest_point_sample(xyz_g, M)
+    centre_g = ops.gather_rows_cl(xyz_g, fidx)
+    idx = ops.ball_query(0.0, radius, ns, xyz_g, centre_g)
+    inv = ops.invert_index(idx, N)
+    layers64, k = [], C + 3
+    for n in chans:
+        layers64.append((torch.randn(n, k, dtype=torch.float64) / np.sqrt(k),
+                         1.0 + 0.2 * torch.randn(n, dtype=torch.float64),
+                         0.1 * torch.randn(n, dtype=torch.float64)))
+        k = n
+    layers64[0][1][0] = -0.7
+    go = torch.randn(B * M, chans[-1], dtype=torch.float64)
+
+    # reference on explicit grouped rows (fp64, coordinates as the fp32 values the kernels see)
+    fr = feat.clone().requires_grad_()
+    lr = [tuple(t.clone().requires_grad_() for t in l) for l in layers64]
+    li = idx.long().cpu()
+    bi = torch.arange(B).view(B, 1, 1).expand(B, M, ns)
+    centre64 = centre_g.double().cpu()
+    rel = xyz_g.double().cpu()[bi, li] - centre64[:, :, None, :]
+    if norm:
+        rel = rel / radius
+    rows = torch.cat([rel, fr[bi, li]], dim=-1).view(B * M * ns, C + 3)
+    out_r = _ref(rows, ns, lr)
+    out_r.backward(go)
+
+    fg = feat.float().cuda().view(B * N, C).requires_grad_()
+    lg = []
+    for W, g, b in layers64:
+        n = W.shape[0]
+        lg.append((W.float().cuda().requires_grad_(), g.float().cuda().requires_grad_(),
+                   b.float().cuda().requires_grad_(), torch.zeros(n, device="cuda"),
+                   torch.ones(n, device="cuda")))
+    out = ops.shared_mlp_pool(fg, ns, lg, training=True,
+                              geo=(xyz_g, centre_g, idx, inv[0], inv[1], radius, norm))
+    out.backward(go.float().cuda())
+
+    def close(a, b, tol, name):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), f"{name}: err {err:.3e}"
+
+    # second reference: the same chain in plain fp32 torch on the GPU.  One arg-max / ReLU decision
+    # that differs between fp32 and fp64 (a near-tie) moves a whole gradient row, which shows up in
+    # every layer-0 gradient; such a case must then agree with the fp32 chain instead.
+    f32 = feat.float().cuda().requires_grad_()
+    l32 = [tuple(t.float().cuda().requires_grad_() for t in l) for l in layers64]
+    rows32 = torch.cat([rel.float().cuda(), f32[bi.cuda(), li.cuda()]], dim=-1)
+    _ref(rows32.view(B * M * ns, C + 3), ns, l32).backward(go.float().cuda())
+
+    def close2(a, r64, r32, tol, name):
+        a, r64, r32 = a.detach().double().cpu(), r64.detach().double(), r32.detach().double().cpu()
+        scale = max(1.0, r64.abs().max().item())
+        e64, e32 = (a - r64).abs().max().item(), (a - r32).abs().max().item()
+        assert e64 <= tol * scale or e32 <= 0.1 * tol * scale, \
+            f"{name}: err {e64:.3e} vs fp64, {e32:.3e} vs fp32 chain (scale {scale:.3e})"
+
+    close(out, out_r, 1e-4, "out")
+    for i, (gl, rl, l3) in enumerate(zip(lg, lr, l32)):
+        close2(gl[0].grad, rl[0].grad, l3[0].grad, 1e-3, f"dW{i}")
+        close2(gl[1].grad, rl[1].grad, l3[1].grad, 1e-3, f"dgamma{i}")
+        close2(gl[2].grad, rl[2].grad, l3[2].grad, 1e-3, f"dbeta{i}")
+    a, b = fg.grad.detach().double().cpu(), fr.grad.detach().view(B * N, C)
+    row_err = (a - b).abs().max(1).values
+    bad = torch.nonzero(row_err > 1e-3 * max(1.0, b.abs().max().item())).flatten()
+    assert len(bad) <= 4, f"dfeat: {len(bad)} rows off, e.g. {bad[:6].tolist()}"
+    y0 = F.linear(rows.detach(), layers64[0][0])
+    close(lg[0][3], 0.1 * y0.mean(0), 1e-4, "running_mean0")
+    close(lg[0][4], 0.9 + 0.1 * y0.var(0, unbiased=True), 1e-4, "running_var0")
+
+    # eval mode (running statistics), forward only, no inverse lists needed
+    with torch.no_grad():
+        ev = [(l[0], l[1], l[2], l[3].clone(), l[4].clone()) for l in lg]
+        out_e = ops.shared_mlp_pool(fg.detach(), ns, ev, training=False,
+                                    geo=(xyz_g, centre_g, idx, None, None, radius, norm))
+        h = rows.detach()
+        for (W, g, b), l in zip(layers64, ev):
+            h = F.relu(F.batch_norm(F.linear(h, W), l[3].double().cpu(), l[4].double().cpu(),
+                                    g, b, False, 0.1, 1e-5))
+        close(out_e, h.view(B * M, ns, -1).max(1)[0], 1e-4, "eval out")
