@@ -19,55 +19,72 @@ namespace demf {
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int LPR>  // lanes per row = C1 / 4
+// A group of LPR = C1/4 lanes owns one output row at a time (4 columns per lane).  Indices and
+// relative coordinates are fetched for LPR consecutive rows at once - lane t of the group owns
+// row t of the chunk - and handed round with ds_bpermute, so the row loop has no dependent index
+// load, one division per row instead of one per lane, and its U-row gathers are all in flight
+// together.
+template <int LPR>
+__device__ __forceinline__ float grp_bcast(float v, int src) { return __shfl(v, src, LPR); }
+template <int LPR>
+__device__ __forceinline__ int grp_bcast(int v, int src) { return __shfl(v, src, LPR); }
+
+template <int LPR>
 __global__ __launch_bounds__(512) void group_first_fwd_k(
     int N, int M, int ns, float div, const float* __restrict__ xyz,
     const float* __restrict__ center, const int* __restrict__ idx, const float* __restrict__ U,
     const float* __restrict__ Wx, float* __restrict__ Y, double* __restrict__ stats,
     long long rows) {
   constexpr int C1 = LPR * 4;
-  constexpr int GPB = 512 / LPR;  // rows in flight per block and unroll step
-  constexpr int UNR = 4;
+  constexpr int GPB = 512 / LPR;
+  constexpr int UNR = 8;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int c = sub * 4;
   const float4 w0 = *reinterpret_cast<const float4*>(Wx + c);
   const float4 w1 = *reinterpret_cast<const float4*>(Wx + C1 + c);
   const float4 w2 = *reinterpret_cast<const float4*>(Wx + 2 * C1 + c);
   float4 s = f4_zero(), q = f4_zero();
-  const long long stride = (long long)gridDim.x * GPB;
-  for (long long row0 = (long long)blockIdx.x * GPB + grp; row0 < rows; row0 += stride * UNR) {
-    float4 u[UNR];
-    float rx[UNR], ry[UNR], rz[UNR];
-#pragma unroll
-    for (int k = 0; k < UNR; ++k) {
-      const long long row = row0 + k * stride;
-      u[k] = f4_zero();
-      rx[k] = ry[k] = rz[k] = 0.f;
-      if (row < rows) {
-        const long long bm = row / ns;
-        const int b = (int)(bm / M);
-        const int i = idx[row];
-        const size_t src = (size_t)b * N + i;
-        const float* p = xyz + src * 3;
-        const float* o = center + bm * 3;
-        rx[k] = (p[0] - o[0]) / div;  // upstream: grouped_xyz /= max_radius
-        ry[k] = (p[1] - o[1]) / div;
-        rz[k] = (p[2] - o[2]) / div;
-        u[k] = *reinterpret_cast<const float4*>(U + src * C1 + c);
-      }
+  const long long chunks = (rows + LPR - 1) / LPR;
+  for (long long ch = (long long)blockIdx.x * GPB + grp; ch < chunks;
+       ch += (long long)gridDim.x * GPB) {
+    const long long row0 = ch * LPR;
+    const int n = rows - row0 < LPR ? (int)(rows - row0) : LPR;
+    // this lane's row of the chunk: source row in U and relative coordinates
+    int my_src = 0;
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    if (sub < n) {
+      const long long row = row0 + sub;
+      const long long bm = row / ns;
+      const int b = (int)(bm / M);
+      my_src = b * N + idx[row];
+      const float* p = xyz + (size_t)my_src * 3;
+      const float* o = center + bm * 3;
+      mx = (p[0] - o[0]) / div;  // upstream: grouped_xyz /= max_radius
+      my = (p[1] - o[1]) / div;
+      mz = (p[2] - o[2]) / div;
     }
+    for (int k0 = 0; k0 < n; k0 += UNR) {
+      float4 u[UNR];
 #pragma unroll
-    for (int k = 0; k < UNR; ++k) {
-      const long long row = row0 + k * stride;
-      if (row < rows) {
-        float4 y;
-#define GF_Y(m) y.m = __builtin_fmaf(rz[k], w2.m, __builtin_fmaf(ry[k], w1.m, __builtin_fmaf(rx[k], w0.m, u[k].m)));
-        GF_Y(x) GF_Y(y) GF_Y(z) GF_Y(w)
+      for (int k = 0; k < UNR; ++k) {
+        const int src = grp_bcast<LPR>(my_src, k0 + k);
+        u[k] = f4_zero();
+        if (k0 + k < n) u[k] = *reinterpret_cast<const float4*>(U + (size_t)src * C1 + c);
+      }
+#pragma unroll
+      for (int k = 0; k < UNR; ++k) {
+        const float rx = grp_bcast<LPR>(mx, k0 + k), ry = grp_bcast<LPR>(my, k0 + k),
+                    rz = grp_bcast<LPR>(mz, k0 + k);
+        if (k0 + k < n) {
+          float4 y;
+#define GF_Y(m) y.m = __builtin_fmaf(rz, w2.m, __builtin_fmaf(ry, w1.m, __builtin_fmaf(rx, w0.m, u[k].m)));
+          GF_Y(x) GF_Y(y) GF_Y(z) GF_Y(w)
 #undef GF_Y
-        *reinterpret_cast<float4*>(Y + row * C1 + c) = y;
-        s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
-        q.x = __builtin_fmaf(y.x, y.x, q.x); q.y = __builtin_fmaf(y.y, y.y, q.y);
-        q.z = __builtin_fmaf(y.z, y.z, q.z); q.w = __builtin_fmaf(y.w, y.w, q.w);
+          *reinterpret_cast<float4*>(Y + (row0 + k0 + k) * C1 + c) = y;
+          s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w;
+          q.x = __builtin_fmaf(y.x, y.x, q.x); q.y = __builtin_fmaf(y.y, y.y, q.y);
+          q.z = __builtin_fmaf(y.z, y.z, q.z); q.w = __builtin_fmaf(y.w, y.w, q.w);
+        }
       }
     }
   }
@@ -87,10 +104,12 @@ __global__ __launch_bounds__(512) void group_first_fwd_k(
   }
 }
 
-// One group of LPR lanes per source point: sums dY over the rows that gathered the point.
+// One group of LPR lanes per source point: sums dY over the rows that gathered the point.  The
+// list entries (and the centre of each entry's row) are fetched LPR at a time, one per lane, and
+// broadcast inside the group.
 template <int LPR>
 __global__ __launch_bounds__(256) void group_first_bwd_k(
-    int N, int M, int ns, float div, const float* __restrict__ xyz,
+    int N, int M, int ns, int ns_shift, float inv_div, const float* __restrict__ xyz,
     const float* __restrict__ center, const float* __restrict__ G, const float* __restrict__ Yl,
     const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
     float* __restrict__ dU, float* __restrict__ dWx, long long points) {
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
   const float4 gi = *reinterpret_cast<const float4*>(vec + 2 * C1 + c);
   const float4 va = *reinterpret_cast<const float4*>(vec + 3 * C1 + c);
   const float4 vb = *reinterpret_cast<const float4*>(vec + 4 * C1 + c);
-  float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();
+  float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();  // sum (p - q)_k * dY, scaled at the end
   for (long long pt = (long long)blockIdx.x * GPB + grp; pt < points;
        pt += (long long)gridDim.x * GPB) {
     const int b = (int)(pt / N), j = (int)(pt - (long long)b * N);
@@ -117,39 +136,47 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     const float* cb = center + (size_t)b * M * 3;
     const float px = xyz[pt * 3], py = xyz[pt * 3 + 1], pz = xyz[pt * 3 + 2];
     float4 acc = f4_zero();
-    for (int e = e0; e < e1; e += UNR) {
-      float4 g[UNR], y[UNR];
-      float rx[UNR], ry[UNR], rz[UNR];
-#pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        g[k] = f4_zero();
-        y[k] = f4_zero();
-        rx[k] = ry[k] = rz[k] = 0.f;
-        if (e + k < e1) {
-          const int row = r[e + k];
-          const float* q = cb + (size_t)(row / ns) * 3;
-          rx[k] = (px - q[0]) / div;
-          ry[k] = (py - q[1]) / div;
-          rz[k] = (pz - q[2]) / div;
-          g[k] = *reinterpret_cast<const float4*>(G + (rbase + row) * C1 + c);
-          y[k] = *reinterpret_cast<const float4*>(Yl + (rbase + row) * C1 + c);
-        }
+    for (int eb = e0; eb < e1; eb += LPR) {
+      const int n = e1 - eb < LPR ? e1 - eb : LPR;
+      int my_row = 0;
+      float mx = 0.f, my = 0.f, mz = 0.f;
+      if (sub < n) {
+        my_row = r[eb + sub];
+        const int m = ns_shift >= 0 ? my_row >> ns_shift : my_row / ns;
+        const float* q = cb + (size_t)m * 3;
+        mx = px - q[0];
+        my = py - q[1];
+        mz = pz - q[2];
       }
+      for (int k0 = 0; k0 < n; k0 += UNR) {
+        float4 g[UNR], y[UNR];
 #pragma unroll
-      for (int k = 0; k < UNR; ++k) {
-        if (e + k < e1) {
-          float4 d;
-#define GF_DY(m)                                                                   \
-          {                                                                        \
-            const float dz = __builtin_fmaf(y[k].m, sc.m, sh.m) > 0.f ? g[k].m : 0.f; \
-            d.m = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, y[k].m, vb.m));    \
-            acc.m += d.m;                                                          \
-            wa0.m = __builtin_fmaf(rx[k], d.m, wa0.m);                             \
-            wa1.m = __builtin_fmaf(ry[k], d.m, wa1.m);                             \
-            wa2.m = __builtin_fmaf(rz[k], d.m, wa2.m);                             \
+        for (int k = 0; k < UNR; ++k) {
+          const int row = grp_bcast<LPR>(my_row, k0 + k);
+          g[k] = f4_zero();
+          y[k] = f4_zero();
+          if (k0 + k < n) {
+            g[k] = *reinterpret_cast<const float4*>(G + (rbase + row) * C1 + c);
+            y[k] = *reinterpret_cast<const float4*>(Yl + (rbase + row) * C1 + c);
           }
-          GF_DY(x) GF_DY(y) GF_DY(z) GF_DY(w)
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+          const float rx = grp_bcast<LPR>(mx, k0 + k), ry = grp_bcast<LPR>(my, k0 + k),
+                      rz = grp_bcast<LPR>(mz, k0 + k);
+          if (k0 + k < n) {
+#define GF_DY(m)                                                                       \
+            {                                                                          \
+              const float dz = __builtin_fmaf(y[k].m, sc.m, sh.m) > 0.f ? g[k].m : 0.f; \
+              const float d = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, y[k].m, vb.m)); \
+              acc.m += d;                                                              \
+              wa0.m = __builtin_fmaf(rx, d, wa0.m);                                    \
+              wa1.m = __builtin_fmaf(ry, d, wa1.m);                                    \
+              wa2.m = __builtin_fmaf(rz, d, wa2.m);                                    \
+            }
+            GF_DY(x) GF_DY(y) GF_DY(z) GF_DY(w)
 #undef GF_DY
+          }
         }
       }
     }
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     float tot = 0.f;
 #pragma unroll
     for (int g = 0; g < GPB; ++g) tot += base[g * C1];
-    atomicAdd(dWx + which * C1 + col, tot);
+    atomicAdd(dWx + which * C1 + col, tot * inv_div);
   }
 }
 
@@ -186,8 +213,9 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
   const float div = normalize_xyz ? radius : 1.0f;
   hipStream_t s = (hipStream_t)stream;
   const int lpr = C1 / 4, gpb = 512 / lpr;
-  long long blocks = (rows + (long long)gpb * 4 - 1) / ((long long)gpb * 4);
-  if (blocks > 256) blocks = 256;  // one fp64 atomic per column per block: keep the tail short
+  const long long chunks = (rows + lpr - 1) / lpr;
+  long long blocks = (chunks + gpb - 1) / gpb;
+  if (blocks > 512) blocks = 512;  // one fp64 atomic per column per block: keep the tail short
   const dim3 grid((unsigned)blocks);
 #define GF_FWD(L)                                                                          \
   hipLaunchKernelGGL(group_first_fwd_k<L>, grid, dim3(512), 0, s, N, M, ns, div, xyz, center, \
@@ -210,14 +238,16 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   DEMF_REQUIRE(xyz && center && G && Y && vec6 && inv_off && inv_rows && dU && dWx,
                "group_first_bwd: null pointer");
   const long long points = (long long)B * N;
-  const float div = normalize_xyz ? radius : 1.0f;
+  const float inv_div = normalize_xyz ? 1.0f / radius : 1.0f;
+  int ns_shift = -1;
+  if ((ns & (ns - 1)) == 0) { ns_shift = 0; while ((1 << ns_shift) < ns) ++ns_shift; }
   hipStream_t s = (hipStream_t)stream;
   const int lpr = C1 / 4, gpb = 256 / lpr;
   long long blocks = (points + gpb - 1) / gpb;
-  if (blocks > 512) blocks = 512;  // 3*C1 fp32 atomics per block
+  if (blocks > 1024) blocks = 1024;  // 3*C1 fp32 atomics per block
   const dim3 grid((unsigned)blocks);
 #define GF_BWD(L)                                                                          \
-  hipLaunchKernelGGL(group_first_bwd_k<L>, grid, dim3(256), 0, s, N, M, ns, div, xyz, center, \
+  hipLaunchKernelGGL(group_first_bwd_k<L>, grid, dim3(256), 0, s, N, M, ns, ns_shift, inv_div, xyz, center, \
                      G, Y, vec6, inv_off, inv_rows, dU, dWx, points)
   if (lpr == 64) GF_BWD(64);
   else if (lpr == 32) GF_BWD(32);
