@@ -707,7 +707,12 @@ class _SharedMLPPool(Function):
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
                           _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
                           _p(dWx), st)
-                grads[0] = torch.cat([dWx.view(3, N).t(), torch.mm(dU.t(), x)], dim=1)
+                # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
+                C0 = K - 3
+                dWf = ws32[o32 - N * K + 3 * N:o32].view(N, C0)
+                _ffi.call("demf_mlp_gemm_bwd_dw", gB * gN, N, C0, C0, _p(dU), None, None, 1, _p(dU),
+                          _p(_identity_dy_vectors(N, dev)), _p(x), None, _p(dWf), st)
+                grads[0] = torch.cat([dWx.view(3, N).t(), dWf], dim=1)
                 grads[1], grads[2] = dgamma, dbeta
                 if ctx.bias_shapes[0] is not None:
                     grads[5] = ws32[o32:o32 + N].view(ctx.bias_shapes[0])
