@@ -232,7 +232,7 @@ def main():
                                    "allreduce+AdamW, 8 scenes/GPU x (20000 pts, 800x1120 -> "
                                    f"4-level 256-ch pyramid), 256 queries, H=8 L=4 P={args.msda_points}, fp32",
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraph(fwd+loss+bwd) + eager allreduce/AdamW; "
+                       "launch": "eager" if args.no_graph else "hipGraphs(fwd+loss | bwd) + eager allreduce/AdamW; "
                                  "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
             "roofline": {"kernel": "fps_reg_kernel<1024,20> (20000->2048)", "bound": "hbm",
                          "achieved": algo_bytes / (fps_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -23,12 +23,17 @@
 // k = k0 + 4*(lane>>5) .. +3, and feeds component m to MFMA m: MFMA m then contracts over
 // k in {k0+m, k0+4+m} on both operands consistently - four MFMAs consume the two float4.
 #include "common.h"
+#include <atomic>
 
 namespace demf {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
 constexpr int MLP_BK = 32;        // K step staged per iteration
+constexpr int SCHED_GROUPS = 16;  // counters per dynamically scheduled persistent launch
+constexpr int DW_CHUNK = 16;      // 32-row slabs per claim of the weight-gradient kernel
+constexpr int DW_MAX_SUB = 32;    // blockIdx.y columns with their own counter
+constexpr int SCHED_INTS = 2 * DW_MAX_SUB;   // ints per counter set (>= 2*SCHED_GROUPS + 1)
 constexpr int MLP_LD = MLP_BK + 4;  // LDS row stride (floats), +16 B pad
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
@@ -56,6 +61,8 @@ struct MlpArgs {
   int* amax;
   int* amin;
   int halves;                  // pooled launches: 2 = two column halves interleaved in a 1-D grid
+  int sched_dbg;
+  int* sched;                  // persistent launches: SCHED_GROUPS tile counters, 1 + SCHED_GROUPS exit counters, or null
 };
 
 // Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
@@ -223,8 +230,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   const int cofs = by * NT * 32;
   const int ntiles = (p.R + BROWS - 1) / BROWS;
   const int ksteps = (p.K + MLP_BK - 1) / MLP_BK;
-  const int my_tiles = ntiles > bx ? (ntiles - 1 - bx) / gx + 1 : 0;
-  const int nsteps = my_tiles * ksteps;
+  // Persistent launches take their first tile by block index and every further one from a device
+  // counter, claimed one tile ahead (the atomic's latency hides behind a whole tile): blocks that
+  // run slower - e.g. while the furthest-point chain of the next batch is resident on the chip -
+  // simply take fewer tiles instead of holding the launch back.  sched == null: static striding.
+  // Same-address atomics serialise (~60 ns each), so the blocks are split into SCHED_GROUPS
+  // groups that interleave over the XCDs and over the tile range in runs of 8; a group owns every
+  // SCHED_GROUPS-th run of 8 tiles and has its own counter (32 claimants instead of 512).
+  __shared__ int s_next;
+  const bool dyn = p.sched != nullptr;
+  const int grp = (bx >> 3) & (SCHED_GROUPS - 1);
+  const int grp_first = gx / SCHED_GROUPS;          // tiles per group taken by block index
+  auto group_tile = [&](int j) { return (((j >> 3) * SCHED_GROUPS + grp) << 3) + (j & 7); };
+  int claimed = 0;
   float cs1[NT], cs2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
@@ -235,9 +253,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   MlpRaw<PRO> pre[4 * RT];
   bool pok[4 * RT];
   float4 preb[NT];
-  auto prefetch = [&](int step) {
-    const int tile = bx + (step / ksteps) * gx;
-    const int k0 = (step % ksteps) * MLP_BK;
+  auto prefetch = [&](int tile, int ks) {
+    const int k0 = ks * MLP_BK;
     const int row0 = tile * BROWS + wave * WROWS;
 #pragma unroll
     for (int it = 0; it < 4 * RT; ++it) {
@@ -252,12 +269,22 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       if (n < p.N && col < p.K) preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * p.K + col);
     }
   };
-  if (nsteps > 0) prefetch(0);
+  int tile = bx;
+  if (tile < ntiles) prefetch(tile, 0);
 
-  for (int step = 0; step < nsteps; ++step) {
-    const int ks = step % ksteps;
+  int ks = 0;
+  while (tile < ntiles) {
     const int k0 = ks * MLP_BK;
-    const int row0 = (bx + (step / ksteps) * gx) * BROWS + wave * WROWS;
+    const int row0 = tile * BROWS + wave * WROWS;
+    const bool last_ks = ks == ksteps - 1;
+    if (dyn && threadIdx.x == 0) {
+      if (p.sched_dbg == 1) { if (last_ks) s_next = tile + gx; }
+      else if (p.sched_dbg == 2) { if (ks == 0) claimed = atomicAdd(p.sched + grp, 1); if (last_ks) s_next = claimed < 0 ? 0 : tile + gx; }
+      else {
+      if (ks == 0) claimed = group_tile(grp_first + atomicAdd(p.sched + grp, 1));
+      if (last_ks) s_next = claimed;
+      }
+    }
     float* sb = s_b;
     if (ks == 0) {
 #pragma unroll
@@ -278,8 +305,10 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     __syncthreads();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
-    const bool defer_prefetch = POOL && ks == ksteps - 1;
-    if (step + 1 < nsteps && !defer_prefetch) prefetch(step + 1);
+    const bool defer_prefetch = POOL && last_ks;
+    const int next_tile = last_ks ? (dyn ? s_next : tile + gx) : tile;
+    const int next_ks = last_ks ? 0 : ks + 1;
+    if (next_tile < ntiles && !defer_prefetch) prefetch(next_tile, next_ks);
     const int kchunks = min(MLP_BK / 8, (p.K - k0 + 7) / 8);
     for (int c8 = 0; c8 < kchunks; ++c8) {
       float4 a4[RT];
@@ -298,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         }
       }
     }
-    if (ks == ksteps - 1) {
+    if (last_ks) {
       // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -328,7 +357,25 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         }
       }
       if constexpr (POOL) {
-        if (step + 1 < nsteps) prefetch(step + 1);
+        if (next_tile < ntiles) prefetch(next_tile, next_ks);
+      }
+    }
+    tile = next_tile;
+    ks = next_ks;
+  }
+  if (dyn) {
+    // the last block out re-arms the counter pair for the next launch that uses this slot
+    if (threadIdx.x == 0) {
+      // (no fence: only atomics touch the counters, and an agent-scope release here would write the
+      // XCD's whole L2 back once per block)
+      // two-level count (512 same-address atomics with a return value would hold the last block
+      // back by ~30 us): group members first, then the 16 group-lasts
+      int* gdone = p.sched + SCHED_GROUPS;
+      const int members = (int)(gridDim.x * gridDim.y) / SCHED_GROUPS;
+      if (atomicAdd(gdone + 1 + grp, 1) == members - 1) {
+        atomicExch(gdone + 1 + grp, 0);
+        atomicExch(p.sched + grp, 0);
+        if (atomicAdd(gdone, 1) == SCHED_GROUPS - 1) atomicExch(gdone, 0);
       }
     }
   }
@@ -589,6 +636,8 @@ struct DwArgs {
   float* dW;           // (N x K), accumulated
   int n0, k0, NTn, NTk;  // output sub-block of a block (derived from blockIdx.y inside the kernel)
   int nsub_k;            // sub-blocks along K
+  int chunk;             // 32-row slabs per claim
+  int* sched;            // dynamic slab chunks: per-blockIdx.y {next chunk}, {finished}, + total; or null
 };
 
 // Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
@@ -648,10 +697,22 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
       mlp_fetch<PRO_NONE>(ax, row0 + r2, p.k0 * 32 + c2, oka[jj], ra[jj]);
     }
   };
+  // Rows are handed out in chunks of p.chunk 32-row slabs: the first chunk by block index, every
+  // further one from a device counter per sub-block column (blockIdx.y), claimed a chunk ahead.
   const int nslab = (p.R + 31) / 32;
-  int slab = blockIdx.x;
-  if (slab < nslab) prefetch(slab);
-  for (; slab < nslab; slab += gridDim.x) {
+  const int nchunk = (nslab + p.chunk - 1) / p.chunk;
+  __shared__ int s_next;
+  const bool dyn = p.sched != nullptr;
+  int claimed = 0;
+  int chunk = blockIdx.x, si = 0;
+  if (chunk < nchunk) prefetch(chunk * p.chunk);
+  while (chunk < nchunk) {
+    const int slab = chunk * p.chunk + si;
+    const bool last = si == p.chunk - 1 || slab + 1 >= nslab;
+    if (dyn && threadIdx.x == 0) {
+      if (si == 0) claimed = (int)gridDim.x + atomicAdd(p.sched + blockIdx.y, 1);
+      if (last) s_next = claimed;
+    }
     __syncthreads();                                 // previous slab fully consumed (and s_v* ready)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -673,7 +734,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
       }
     }
     __syncthreads();
-    if (slab + (int)gridDim.x < nslab) prefetch(slab + gridDim.x);
+    const int next_chunk = last ? (dyn ? s_next : chunk + (int)gridDim.x) : chunk;
+    const int next_si = last ? 0 : si + 1;
+    if (next_chunk < nchunk) prefetch(next_chunk * p.chunk + next_si);
     // A-op: dY^T -> lane supplies dY[r = 2m + lh][n = tn*32 + lr]; B-op: A[r][k = tk*32 + lr]
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) {
@@ -687,6 +750,16 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
 #pragma unroll
         for (int j = 0; j < TK; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    chunk = next_chunk;
+    si = next_si;
+  }
+  if (dyn && threadIdx.x == 0) {
+    // re-arm the counters for the next launch that is handed this set: column-lasts, then the last
+    int* done = p.sched + DW_MAX_SUB;
+    if (atomicAdd(done + blockIdx.y, 1) == (int)gridDim.x - 1) {
+      atomicExch(done + blockIdx.y, 0);
+      atomicExch(p.sched + blockIdx.y, 0);
     }
   }
 #pragma unroll
@@ -708,6 +781,24 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
+}
+
+// Counter sets {next tile per group, finished blocks} of the dynamically scheduled persistent
+// launches.  A launch takes the next set of a ring; the last block of the launch leaves it zeroed, so
+// a captured launch can be replayed with the set it was given.  Launches that share a set are
+// 1024 launches apart on the calling thread's stream order (the MLP path is single-stream).
+constexpr int SCHED_SLOTS = 1024;
+__device__ int g_tile_sched[SCHED_INTS * SCHED_SLOTS];
+static int* sched_slot() {
+  static int* base = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (base == nullptr) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_tile_sched)) != hipSuccess) return nullptr;
+    base = (int*)ptr;
+  }
+  if (env_int("DEMF_STATIC_TILES", 0)) return nullptr;     // A/B switch
+  return base + SCHED_INTS * (next.fetch_add(1) % SCHED_SLOTS);
 }
 
 static int mlp_grid(int R, int brows) {
@@ -772,8 +863,14 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     if (ntl <= 4) return check_launch("mlp_gemm");
   }
 #define GO(NTv, RTv)                                                                            \
-  hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL>), dim3(mlp_grid(a.R, 128 * RTv)), \
-                     block, 0, s, a)
+  do {                                                                                          \
+    MlpArgs a3 = a;                                                                             \
+    const int gxv = mlp_grid(a.R, 128 * RTv);                                                   \
+    const int tilesv = (a.R + 128 * RTv - 1) / (128 * RTv);                                     \
+    if (tilesv > gxv && a.K > MLP_BK && gxv % (8 * SCHED_GROUPS) == 0) a3.sched = sched_slot();           \
+    a3.sched_dbg = env_int("DEMF_SCHED_DBG", 0);                                \
+    hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL>), dim3(gxv), block, 0, s, a3); \
+  } while (0)
 #define CASE(NTv)                                                                               \
   case NTv:                                                                                     \
     if constexpr (NTv <= NT_MAX) {                                                              \
@@ -970,6 +1067,17 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
   const int cap = tot / nsub > 16 ? tot / nsub : 16;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
+  // dynamic chunk claims (DEMF_DW_DYN=1): measured neutral on the training step, so the default
+  // stays the static slab striding (chunk = 1)
+  a.chunk = 1;
+  if (env_int("DEMF_DW_DYN", 0)) {
+    const int nslab = cdiv(R, 32);
+    a.chunk = nslab / (gx * 4);                  // >= 4 claims per block, at most DW_CHUNK slabs each
+    a.chunk = a.chunk < 1 ? 1 : (a.chunk > DW_CHUNK ? DW_CHUNK : a.chunk);
+    const int nchunk = cdiv(nslab, a.chunk);
+    if (gx > nchunk) gx = nchunk;
+    if (nchunk > 2 * gx && nsub <= DW_MAX_SUB) a.sched = sched_slot();
+  }
   const dim3 grid(gx, nsub);
 #define DW(TNv, TKv)                                                                             \
   if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), grid, dim3(256), lds, s, a);       \
