@@ -1,4 +1,8 @@
 export PYTHONPATH=.
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py 2>&1 | tail -1 > gpurun_out/bench_l.json; cut -c1-240 gpurun_out/bench_l.json
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+ms() { python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+for i in 1 2; do
+echo "default      $(python bench.py --steps 60 2>&1 | tail -1 | ms)"
+echo "GEO_AT_FWD   $(DEMF_GEO_AT_FWD=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
+echo "DW_DYN       $(DEMF_DW_DYN=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
+echo "STATIC_TILES $(DEMF_STATIC_TILES=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
+done
