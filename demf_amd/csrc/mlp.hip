@@ -51,7 +51,8 @@ struct MlpArgs {
   const int* arg;              //                and arg-max slot (R/ns x K)
   int ns;
   const float* vec;            // BNRELU: [scale|shift] (2K);  DY: 5 vectors of length K
-  const float* Bt;             // (N x K) row-major
+  const float* Bt;             // (N x K) row-major; or, with ldb > 0, the (K x >=N) matrix whose
+  int ldb;                     // TRANSPOSE is the B operand (row stride ldb): W itself for dX = dY.W
   float* Y;                    // (R x N) output
   double* stats;               // optional (2N): column sum, column sum of squares
   // optional fused pooling epilogue (forward, last layer): per group of ns consecutive rows and
@@ -266,7 +267,13 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     for (int i = 0; i < NT; ++i) {
       const int n = cofs + br + 32 * i, col = k0 + pc;
       preb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.N && col < p.K) preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * p.K + col);
+      if (p.ldb > 0) {
+        // transposed source: this thread's float4 runs along the OUTPUT columns of reduction row br
+        const int kk = k0 + br, nn = cofs + 32 * i + pc;
+        if (kk < p.K && nn < p.N) preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)kk * p.ldb + nn);
+      } else if (n < p.N && col < p.K) {
+        preb[i] = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * p.K + col);
+      }
     }
   };
   int tile = bx;
@@ -301,7 +308,12 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           mlp_xform<PRO>(p, s_vec, k0 + pc, pok[it], pre[it]);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
-      *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
+      if (p.ldb > 0) {
+        float* d = sb + (32 * i + pc) * MLP_LD + br;
+        d[0] = preb[i].x; d[MLP_LD] = preb[i].y; d[2 * MLP_LD] = preb[i].z; d[3 * MLP_LD] = preb[i].w;
+      } else {
+        *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
+      }
     __syncthreads();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
@@ -1022,7 +1034,7 @@ extern "C" int demf_bn_bwd_vectors(int N, long long count, double* g12, const fl
 
 // dX(R x K) = dY(R x N) @ W(N x K), dY formed on the fly.  Wtt = W^T as (K x N) row-major.
 // dX has row stride ldo >= K; K may be any multiple of 4 (handled in chunks of <= 128 columns).
-extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
+static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const float* G, const float* dP,
                                     const int* arg, int ns, const float* Y, const float* vec6,
                                     const float* Wtt, float* dX, demf_stream_t stream) {
   DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 1 && ldo >= K,
@@ -1034,12 +1046,27 @@ extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G
     // here the reduction runs over this layer's N channels and the output has K columns
     MlpArgs a{};
     a.R = R; a.K = N; a.N = (K - c0) < 128 ? (K - c0) : 128; a.ldx = N; a.ldy = ldo; a.X = Y;
-    a.G = G; a.dP = dP; a.arg = arg; a.ns = ns; a.vec = vec6; a.Bt = Wtt + (size_t)c0 * N;
+    a.G = G; a.dP = dP; a.arg = arg; a.ns = ns; a.vec = vec6;
+    if (w_direct) { a.Bt = Wtt + c0; a.ldb = K; }      // Wtt is W (N x K) itself: columns c0.. of it
+    else a.Bt = Wtt + (size_t)c0 * N;
     a.Y = dX + c0; a.stats = nullptr;
     const int e = G ? launch_gemm<PRO_DY_DENSE, false>(a, s) : launch_gemm<PRO_DY_SPARSE, false>(a, s);
     if (e) return e;
   }
   return DEMF_OK;
+}
+
+extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
+                                    const int* arg, int ns, const float* Y, const float* vec6,
+                                    const float* Wtt, float* dX, demf_stream_t stream) {
+  return mlp_bwd_dx_impl(false, R, N, K, ldo, G, dP, arg, ns, Y, vec6, Wtt, dX, stream);
+}
+
+// Same, reading the layer's weight W (N x K row-major) directly: no transposed copy per step.
+extern "C" int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float* G, const float* dP,
+                                      const int* arg, int ns, const float* Y, const float* vec6,
+                                      const float* W, float* dX, demf_stream_t stream) {
+  return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, stream);
 }
 
 extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,

@@ -733,10 +733,16 @@ class _SharedMLPPool(Function):
                 grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
                 o32 += N
             if l > 0 or ctx.needs_input_grad[0]:
-                Wtt = W.t().contiguous()
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
-                _ffi.call("demf_mlp_gemm_bwd_dx", R, N, K, K, _p(G), _p(dP if sparse else None),
-                          _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(Wtt), _p(dX), st)
+                if K % 4 == 0:
+                    # W read as it is: the kernel transposes the slab on its way into LDS
+                    _ffi.call("demf_mlp_gemm_bwd_dx_w", R, N, K, K, _p(G), _p(dP if sparse else None),
+                              _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX), st)
+                else:
+                    Wtt = W.t().contiguous()
+                    _ffi.call("demf_mlp_gemm_bwd_dx", R, N, K, K, _p(G), _p(dP if sparse else None),
+                              _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(Wtt), _p(dX),
+                              st)
                 if l > 0:
                     G = dX
                 else:

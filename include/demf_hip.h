@@ -259,6 +259,11 @@ int demf_bn_bwd_vectors(int N, long long count, double* g12, const float* gamma,
 int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
                          const int* arg, int ns, const float* Y, const float* vec6,
                          const float* Wtt, float* dX, demf_stream_t stream);
+/* Same, reading the layer's weight W (N x K row-major, K % 4 == 0) itself instead of a transposed
+ * copy made per step (the B slab is transposed on its way into LDS). */
+int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float* G, const float* dP,
+                         const int* arg, int ns, const float* Y, const float* vec6,
+                         const float* W, float* dX, demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */

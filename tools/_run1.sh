@@ -1,8 +1,3 @@
 export PYTHONPATH=.
-ms() { python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
-for i in 1 2; do
-echo "default      $(python bench.py --steps 60 2>&1 | tail -1 | ms)"
-echo "GEO_AT_FWD   $(DEMF_GEO_AT_FWD=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
-echo "DW_DYN       $(DEMF_DW_DYN=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
-echo "STATIC_TILES $(DEMF_STATIC_TILES=1 python bench.py --steps 60 2>&1 | tail -1 | ms)"
-done
+python -m pytest tests/test_gpu_mlp.py tests/test_gpu_model.py tests/test_abi.py -x -q 2>&1 | tail -3
+for i in 1 2; do python bench.py --steps 40 2>&1 | tail -1 | cut -c1-240; done
