@@ -62,7 +62,14 @@ struct MlpArgs {
   int* amax;
   int* amin;
   int halves;                  // pooled launches: 2 = two column halves interleaved in a 1-D grid
-  int sched_dbg;
+  // FIRST epilogue (backward of a stack whose first layer has a 4-float input and no input
+  // gradient): the output tile IS the gradient of layer 0's activation; instead of storing it, the
+  // raw sums of layer 0's whole backward are taken from it (see mlp_first_finish_k)
+  const float* fX;             // (R x 4) input rows of layer 0
+  const float* fY;             // (R x N) pre-BN output of layer 0
+  const float* fss;            // layer 0 [scale|shift] (2N)
+  const float* fmi;            // layer 0 [mean|invstd] (2N)
+  double* fsum;                // g1(N) | g2(N) | P(N x 4) | Q(N x 4) | cx(4), accumulated
   int* sched;                  // persistent launches: SCHED_GROUPS tile counters, 1 + SCHED_GROUPS exit counters, or null
 };
 
@@ -198,7 +205,7 @@ __device__ __forceinline__ void pool_epilogue(const MlpArgs& p, const f32x16 (&a
   }
 }
 
-template <int NT, int RT, int PRO, bool STATS, bool POOL = false>
+template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   constexpr int WROWS = 32 * RT;          // rows per wave
   constexpr int BROWS = 4 * WROWS;        // rows per block tile
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   __shared__ __attribute__((aligned(16))) float s_a[4][WROWS * MLP_LD];
   __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * MLP_LD];
   __shared__ __attribute__((aligned(16))) float s_vec[NVEC ? NVEC * MLP_MAXK : 4];
-  __shared__ float s_red[STATS ? 4 * NT * 32 * 2 : 1];
+  __shared__ float s_red[STATS ? 4 * NT * 32 * 2 : (FIRST ? 4 * NT * 32 * 10 + 16 : 1)];
   if constexpr (NVEC > 0) {
     // compact copy: vector v of length K lives at s_vec + v*K (same addressing as global)
     for (int i = threadIdx.x; i < NVEC * p.K; i += 256) s_vec[i] = p.vec[i];
@@ -247,6 +254,14 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   float cs1[NT], cs2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
+  float fs[FIRST ? NT : 1][10];
+  float4 fcx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 10; ++q) fs[nt][q] = 0.f;
+  }
   f32x16 acc[RT][NT];
 
   const int pr = lane >> 3, pc = (lane & 7) * 4;   // this lane's slot in a 32 x BK slab
@@ -285,12 +300,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     const int row0 = tile * BROWS + wave * WROWS;
     const bool last_ks = ks == ksteps - 1;
     if (dyn && threadIdx.x == 0) {
-      if (p.sched_dbg == 1) { if (last_ks) s_next = tile + gx; }
-      else if (p.sched_dbg == 2) { if (ks == 0) claimed = atomicAdd(p.sched + grp, 1); if (last_ks) s_next = claimed < 0 ? 0 : tile + gx; }
-      else {
       if (ks == 0) claimed = group_tile(grp_first + atomicAdd(p.sched + grp, 1));
       if (last_ks) s_next = claimed;
-      }
     }
     float* sb = s_b;
     if (ks == 0) {
@@ -317,10 +328,38 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     __syncthreads();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
-    const bool defer_prefetch = POOL && last_ks;
+    const bool defer_prefetch = (POOL || FIRST) && last_ks;
     const int next_tile = last_ks ? (dyn ? s_next : tile + gx) : tile;
     const int next_ks = last_ks ? 0 : ks + 1;
     if (next_tile < ntiles && !defer_prefetch) prefetch(next_tile, next_ks);
+    // FIRST: the wave's 64 x 32 half tile of layer 0's output (coalesced float4 rows) and its input
+    // rows are fetched before the MFMAs of the last k-step and staged through the wave's A slab
+    float4 yq[FIRST ? 2 * RT * 2 : 1];
+    float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto first_load = [&](int half) {
+#pragma unroll
+      for (int j = 0; j < 2 * RT * 2; ++j) {
+        const int id = lane + 64 * j;
+        const int row = row0 + (id >> 3);
+        yq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < p.R && cofs + 32 * half + 4 * (id & 7) < p.N)
+          yq[j] = *reinterpret_cast<const float4*>(p.fY + (size_t)row * p.N + cofs + 32 * half + 4 * (id & 7));
+      }
+    };
+    auto first_store = [&]() {
+#pragma unroll
+      for (int j = 0; j < 2 * RT * 2; ++j) {
+        const int id = lane + 64 * j;
+        *reinterpret_cast<float4*>(sa + (id >> 3) * MLP_LD + 4 * (id & 7)) = yq[j];
+      }
+    };
+    if constexpr (FIRST) {
+      if (last_ks) {
+        first_load(0);
+        if (lane < WROWS && row0 + lane < p.R)
+          xq = *reinterpret_cast<const float4*>(p.fX + (size_t)(row0 + lane) * 4);
+      }
+    }
     const int kchunks = min(MLP_BK / 8, (p.K - k0 + 7) / 8);
     for (int c8 = 0; c8 < kchunks; ++c8) {
       float4 a4[RT];
@@ -344,6 +383,39 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float s1 = 0.f, s2 = 0.f;
+        if constexpr (FIRST) {
+          const int col = cofs + nt * 32 + lr;
+          const bool cok = col < p.N;
+          const float sc0 = cok ? p.fss[col] : 0.f, sh0 = cok ? p.fss[p.N + col] : 0.f;
+          const float mu0 = cok ? p.fmi[col] : 0.f, is0 = cok ? p.fmi[p.N + col] : 0.f;
+          // stage this half of Y0 (and, once, the input rows in the 4 pad columns) in the A slab
+          first_store();
+          if (nt == 0 && lane < WROWS) *reinterpret_cast<float4*>(sa + lane * MLP_LD + MLP_BK) = xq;
+          if (nt + 1 < NT) first_load(nt + 1);       // next half in flight during this one's sums
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int rl = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads from piling up
+              if (row0 + rl < p.R && cok) {
+                const float y = sa[rl * MLP_LD + lr];
+                const float4 x = *reinterpret_cast<const float4*>(sa + rl * MLP_LD + MLP_BK);
+                const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? acc[rt][nt][r] : 0.f;
+                fs[nt][0] += dz;
+                fs[nt][1] = __builtin_fmaf(dz, (y - mu0) * is0, fs[nt][1]);
+                fs[nt][2] = __builtin_fmaf(dz, x.x, fs[nt][2]);
+                fs[nt][3] = __builtin_fmaf(dz, x.y, fs[nt][3]);
+                fs[nt][4] = __builtin_fmaf(dz, x.z, fs[nt][4]);
+                fs[nt][5] = __builtin_fmaf(dz, x.w, fs[nt][5]);
+                fs[nt][6] = __builtin_fmaf(y, x.x, fs[nt][6]);
+                fs[nt][7] = __builtin_fmaf(y, x.y, fs[nt][7]);
+                fs[nt][8] = __builtin_fmaf(y, x.z, fs[nt][8]);
+                fs[nt][9] = __builtin_fmaf(y, x.w, fs[nt][9]);
+                if (nt == 0 && lr == 0 && by == 0) { fcx.x += x.x; fcx.y += x.y; fcx.z += x.z; fcx.w += x.w; }
+              }
+            }
+        } else {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -357,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
               s2 = __builtin_fmaf(v, v, s2);
             }
           }
+        }
         cs1[nt] += s1;
         cs2[nt] += s2;
         if constexpr (POOL) {
@@ -368,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           }
         }
       }
-      if constexpr (POOL) {
+      if constexpr (POOL || FIRST) {
         if (next_tile < ntiles) prefetch(next_tile, next_ks);
       }
     }
@@ -389,6 +462,39 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         atomicExch(p.sched + grp, 0);
         if (atomicAdd(gdone, 1) == SCHED_GROUPS - 1) atomicExch(gdone, 0);
       }
+    }
+  }
+  if constexpr (FIRST) {
+    // lanes l and l+32 hold the same column: fold, then the 4 waves through LDS, then fp64 atomics
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        const float v = fs[nt][q] + __shfl_xor(fs[nt][q], 32);
+        if (lh == 0) s_red[((wave * NT + nt) * 10 + q) * 32 + lr] = v;
+      }
+    fcx.x += __shfl_xor(fcx.x, 32); fcx.y += __shfl_xor(fcx.y, 32);
+    fcx.z += __shfl_xor(fcx.z, 32); fcx.w += __shfl_xor(fcx.w, 32);
+    if (lane == 0) {
+      float* c = s_red + 4 * NT * 32 * 10 + wave * 4;
+      c[0] = fcx.x; c[1] = fcx.y; c[2] = fcx.z; c[3] = fcx.w;
+    }
+    __syncthreads();
+    constexpr int PER = NT * 10 * 32;
+    for (int i = threadIdx.x; i < PER; i += 256) {
+      const float v = s_red[i] + s_red[PER + i] + s_red[2 * PER + i] + s_red[3 * PER + i];
+      const int nt = i / 320, q = (i / 32) % 10, c = i & 31;
+      const int col = cofs + nt * 32 + c;
+      if (col < p.N) {
+        // layout: g1 | g2 | P (N x 4) | Q (N x 4) | cx(4)
+        const int dst = q < 2 ? q * p.N + col : (q < 6 ? 2 * p.N + col * 4 + (q - 2) : 6 * p.N + col * 4 + (q - 6));
+        atomicAdd(p.fsum + dst, (double)v);
+      }
+    }
+    if (threadIdx.x < 4 && by == 0) {
+      const float* c = s_red + 4 * NT * 32 * 10;
+      atomicAdd(p.fsum + 10 * p.N + threadIdx.x,
+                (double)(c[threadIdx.x] + c[4 + threadIdx.x] + c[8 + threadIdx.x] + c[12 + threadIdx.x]));
     }
   }
   if constexpr (STATS) {
@@ -882,8 +988,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     MlpArgs a3 = a;                                                                             \
     const int gxv = mlp_grid(a.R, 128 * RTv);                                                   \
     const int tilesv = (a.R + 128 * RTv - 1) / (128 * RTv);                                     \
-    if (tilesv > gxv && a.K > MLP_BK && gxv % (8 * SCHED_GROUPS) == 0) a3.sched = sched_slot();           \
-    a3.sched_dbg = env_int("DEMF_SCHED_DBG", 0);                                \
+    if (tilesv > gxv && a.K > MLP_BK && gxv % (8 * SCHED_GROUPS) == 0) a3.sched = sched_slot();                                \
     hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL>), dim3(gxv), block, 0, s, a3); \
   } while (0)
 #define CASE(NTv)                                                                               \
@@ -1070,6 +1175,75 @@ extern "C" int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float*
                                       const int* arg, int ns, const float* Y, const float* vec6,
                                       const float* W, float* dX, demf_stream_t stream) {
   return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, stream);
+}
+
+// ---- first layer of a stack with a 4-float input and no input gradient (SA1) --------------------
+// dY0 = gi*dZ0 + a*y0 + b is linear in (dZ0, y0, 1), so layer 0's whole backward follows from raw
+// sums that do not depend on the BN-backward scalars: g1 = sum dZ0, g2 = sum dZ0*xhat,
+// P = dZ0^T X, Q = y0^T X, cx = colsum(X).  The dx GEMM of layer 1 takes them from its output tile
+// (FIRST epilogue) instead of storing the (R x N0) gradient, which is then never written nor read:
+//   dW0 = gi*P + a*Q + b*cx^T,  dgamma0 = g2,  dbeta0 = g1.
+__global__ void mlp_first_finish_k(int N, double count, double* __restrict__ sums,
+                                   const float* __restrict__ gamma, const float* __restrict__ mi,
+                                   float* __restrict__ dW, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta) {
+  __shared__ double s_cx[4];
+  if (threadIdx.x < 4) s_cx[threadIdx.x] = sums[10 * N + threadIdx.x];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < N) {
+    const double g1 = sums[c], g2 = sums[N + c];
+    const double mean = mi[c], is = mi[N + c];
+    const double gi = (double)gamma[c] * is;
+    const double a = -gi * is * (g2 / count);
+    const double b = -gi * (g1 / count) - a * mean;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      dW[c * 4 + k] = (float)(gi * sums[2 * N + c * 4 + k] + a * sums[6 * N + c * 4 + k] + b * s_cx[k]);
+      sums[2 * N + c * 4 + k] = 0.0;               // consumed: the accumulator is left zeroed
+      sums[6 * N + c * 4 + k] = 0.0;
+    }
+    sums[c] = 0.0;
+    sums[N + c] = 0.0;
+    dgamma[c] = (float)g2;
+    dbeta[c] = (float)g1;
+  }
+  if (threadIdx.x < 4) sums[10 * N + threadIdx.x] = 0.0;
+}
+
+extern "C" int demf_mlp_gemm_bwd_dx_first(int R, int N, int K0, const float* G, const float* Y1,
+                                          const float* vec6, const float* W1, const float* X0,
+                                          const float* Y0, const float* ss0, const float* mi0,
+                                          double* sums, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 1 && N >= 4 && N % 4 == 0 && N <= MLP_MAXK && K0 >= 4 && K0 % 4 == 0 && K0 <= 64,
+               "mlp_gemm_bwd_dx_first: bad sizes R=%d N=%d K0=%d (K0 <= 64)", R, N, K0);
+  DEMF_REQUIRE(G && Y1 && vec6 && W1 && X0 && Y0 && ss0 && mi0 && sums,
+               "mlp_gemm_bwd_dx_first: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  MlpArgs a{};
+  a.R = R; a.K = N; a.N = K0; a.ldx = N; a.ldy = K0; a.X = Y1; a.G = G; a.vec = vec6;
+  a.Bt = W1; a.ldb = K0; a.Y = nullptr; a.stats = nullptr;
+  a.fX = X0; a.fY = Y0; a.fss = ss0; a.fmi = mi0; a.fsum = sums;
+  // 32-row wave tiles: with 64-row ones the staged half tile + the 24 running sums do not fit next
+  // to the accumulators in 256 VGPRs
+  const int gx = mlp_grid(R, 128);
+  const int tiles = (R + 127) / 128;
+  if (tiles > gx && a.K > MLP_BK && gx % (8 * SCHED_GROUPS) == 0) a.sched = sched_slot();
+  if (K0 <= 32)
+    hipLaunchKernelGGL((mlp_gemm_kernel<1, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((mlp_gemm_kernel<2, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
+  return check_launch("mlp_gemm_bwd_dx_first");
+}
+
+extern "C" int demf_mlp_first_finish(int N0, long long count, double* sums, const float* gamma0,
+                                     const float* mean_invstd0, float* dW0, float* dgamma0,
+                                     float* dbeta0, demf_stream_t stream) {
+  DEMF_REQUIRE(N0 >= 1 && N0 <= 64 && count >= 1 && sums && gamma0 && mean_invstd0 && dW0 && dgamma0 &&
+                   dbeta0, "mlp_first_finish: bad arguments");
+  hipLaunchKernelGGL(mlp_first_finish_k, dim3(1), dim3(64), 0, (hipStream_t)stream, N0, (double)count,
+                     sums, gamma0, mean_invstd0, dW0, dgamma0, dbeta0);
+  return check_launch("mlp_first_finish");
 }
 
 extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,

@@ -525,6 +525,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
 _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
+_NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
@@ -675,7 +676,12 @@ class _SharedMLPPool(Function):
         dx = None
         # BN reductions go through the self-cleaning fp64 accumulator; the weight gradients of all
         # layers share one zero-filled fp32 workspace
-        ws64 = _accum64(2 * sum(W.shape[0] for W in Ws), dev)
+        # SA1-like stacks (4-float input rows, no input gradient, >= 3 layers): layer 0's backward is
+        # taken from the output tile of layer 1's dx GEMM, whose (R x N0) result is never stored
+        fuse_first = (ctx.geo is None and L >= 3 and not ctx.needs_input_grad[0] and ld == 4
+                      and Ws[0].shape[0] <= 64 and Ws[0].shape[0] % 4 == 0 and not _NO_FIRST_FUSE)
+        n64 = 2 * sum(W.shape[0] for W in Ws) + (10 * Ws[0].shape[0] + 4 if fuse_first else 0)
+        ws64 = _accum64(n64, dev)
         # (+ room for the exact-zero gradients of conv biases shadowed by BatchNorm)
         nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
         ws32 = torch.zeros(sum(W.numel() for W in Ws) + nbias, dtype=torch.float32, device=dev)
@@ -732,6 +738,23 @@ class _SharedMLPPool(Function):
             if ctx.bias_shapes[l] is not None:
                 grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
                 o32 += N
+            if l == 1 and fuse_first:
+                N0 = K
+                sums = ws64[o64:o64 + 10 * N0 + 4]
+                o64 += 10 * N0 + 4
+                _ffi.call("demf_mlp_gemm_bwd_dx_first", R, N, N0, _p(G), _p(Ys[1]), _p(vec6), _p(W),
+                          _p(x), _p(Ys[0]), _p(sss[0]), _p(mis[0]), _p(sums), st)
+                dW0 = ws32[o32:o32 + N0 * 4].view(N0, 4)
+                o32 += N0 * 4
+                dgamma0 = torch.empty(N0, dtype=torch.float32, device=dev)
+                dbeta0 = torch.empty(N0, dtype=torch.float32, device=dev)
+                _ffi.call("demf_mlp_first_finish", N0, R, _p(sums), _p(gammas[0]), _p(mis[0]),
+                          _p(dW0), _p(dgamma0), _p(dbeta0), st)
+                grads[0], grads[1], grads[2] = dW0, dgamma0, dbeta0
+                if ctx.bias_shapes[0] is not None:
+                    grads[5] = ws32[o32:o32 + N0].view(ctx.bias_shapes[0])
+                    o32 += N0
+                break
             if l > 0 or ctx.needs_input_grad[0]:
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
                 if K % 4 == 0:

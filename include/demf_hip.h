@@ -265,6 +265,21 @@ int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float* G, const f
                          const int* arg, int ns, const float* Y, const float* vec6,
                          const float* W, float* dX, demf_stream_t stream);
 
+/* Backward of a shared-MLP stack whose FIRST layer has a 4-float input row and needs no input
+ * gradient (SA1: [height | rel_xyz]).  The dx GEMM of layer 1 (dY1 from (G, Y1, vec6); W1 (N x K0))
+ * does not store its (R x K0) output - the gradient of layer 0's activation - but takes the raw
+ * sums of layer 0's whole backward from it: sums (10*K0 + 4 fp64, accumulated, arrives zeroed) =
+ * g1 | g2 | P = dZ0^T X0 (K0 x 4) | Q = Y0^T X0 (K0 x 4) | colsum(X0).  K0 <= 64, K0 % 4 == 0.
+ * demf_mlp_first_finish then forms dW0 (K0 x 4) = gi*P + a*Q + b*cx^T, dgamma0 = g2, dbeta0 = g1
+ * (the BN-backward identities of demf_bn_bwd_vectors) and leaves the sums zeroed. */
+int demf_mlp_gemm_bwd_dx_first(int R, int N, int K0, const float* G, const float* Y1,
+                               const float* vec6, const float* W1, const float* X0,
+                               const float* Y0, const float* scale_shift0,
+                               const float* mean_invstd0, double* sums, demf_stream_t stream);
+int demf_mlp_first_finish(int N0, long long count, double* sums, const float* gamma0,
+                          const float* mean_invstd0, float* dW0, float* dgamma0, float* dbeta0,
+                          demf_stream_t stream);
+
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */
 int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,

@@ -1,6 +1,3 @@
 export PYTHONPATH=.
-ms() { python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
-for i in 1 2; do
-echo "fwd order $(DEMF_SKIP_GEO=1 python bench.py --steps 40 2>&1 | tail -1 | ms)"
-echo "reversed  $(DEMF_SKIP_GEO=1 DEMF_BNRED_REV=1 python bench.py --steps 40 2>&1 | tail -1 | ms)"
-done
+python -m pytest tests/test_gpu_mlp.py tests/test_gpu_model.py -x -q 2>&1 | tail -3
+for i in 1 2; do python bench.py --steps 40 2>&1 | tail -1 | cut -c100-240; DEMF_NO_FIRST_FUSE=1 python bench.py --steps 40 2>&1 | tail -1 | cut -c100-240; done
