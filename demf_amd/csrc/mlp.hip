@@ -70,6 +70,10 @@ struct MlpArgs {
   const float* fss;            // layer 0 [scale|shift] (2N)
   const float* fmi;            // layer 0 [mean|invstd] (2N)
   double* fsum;                // g1(N) | g2(N) | P(N x 4) | Q(N x 4) | cx(4), accumulated
+  // RED epilogue (dx GEMM of layer l): besides storing dX = the gradient of layer l-1's activation,
+  // layer l-1's BN-backward sums (sum dZ, sum dZ*xhat) are taken from the tile -> stats; the layer
+  // l-1 operands are addressed with row stride / vector length fld and column offset fc0
+  int fld, fc0;
   int* sched;                  // persistent launches: SCHED_GROUPS tile counters, 1 + SCHED_GROUPS exit counters, or null
 };
 
@@ -205,15 +209,16 @@ __device__ __forceinline__ void pool_epilogue(const MlpArgs& p, const f32x16 (&a
   }
 }
 
-template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false>
+template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
+  static_assert(!(STATS && RED) && !(FIRST && RED), "one column-sum epilogue at a time");
   constexpr int WROWS = 32 * RT;          // rows per wave
   constexpr int BROWS = 4 * WROWS;        // rows per block tile
   constexpr int NVEC = PRO == PRO_NONE ? 0 : (PRO == PRO_BNRELU ? 2 : 5);
   __shared__ __attribute__((aligned(16))) float s_a[4][WROWS * MLP_LD];
   __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * MLP_LD];
   __shared__ __attribute__((aligned(16))) float s_vec[NVEC ? NVEC * MLP_MAXK : 4];
-  __shared__ float s_red[STATS ? 4 * NT * 32 * 2 : (FIRST ? 4 * NT * 32 * 10 + 16 : 1)];
+  __shared__ float s_red[(STATS || RED) ? 4 * NT * 32 * 2 : (FIRST ? 4 * NT * 32 * 10 + 16 : 1)];
   if constexpr (NVEC > 0) {
     // compact copy: vector v of length K lives at s_vec + v*K (same addressing as global)
     for (int i = threadIdx.x; i < NVEC * p.K; i += 256) s_vec[i] = p.vec[i];
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     if (next_tile < ntiles && !defer_prefetch) prefetch(next_tile, next_ks);
     // FIRST: the wave's 64 x 32 half tile of layer 0's output (coalesced float4 rows) and its input
     // rows are fetched before the MFMAs of the last k-step and staged through the wave's A slab
-    float4 yq[FIRST ? 2 * RT * 2 : 1];
+    float4 yq[(FIRST || RED) ? 2 * RT * 2 : 1];
     float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
     auto first_load = [&](int half) {
 #pragma unroll
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         const int row = row0 + (id >> 3);
         yq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < p.R && cofs + 32 * half + 4 * (id & 7) < p.N)
-          yq[j] = *reinterpret_cast<const float4*>(p.fY + (size_t)row * p.N + cofs + 32 * half + 4 * (id & 7));
+          yq[j] = *reinterpret_cast<const float4*>(p.fY + (size_t)row * p.fld + p.fc0 + cofs + 32 * half + 4 * (id & 7));
       }
     };
     auto first_store = [&]() {
@@ -353,6 +358,9 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         *reinterpret_cast<float4*>(sa + (id >> 3) * MLP_LD + 4 * (id & 7)) = yq[j];
       }
     };
+    if constexpr (RED) {
+      if (last_ks) first_load(0);
+    }
     if constexpr (FIRST) {
       if (last_ks) {
         first_load(0);
@@ -386,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         if constexpr (FIRST) {
           const int col = cofs + nt * 32 + lr;
           const bool cok = col < p.N;
-          const float sc0 = cok ? p.fss[col] : 0.f, sh0 = cok ? p.fss[p.N + col] : 0.f;
-          const float mu0 = cok ? p.fmi[col] : 0.f, is0 = cok ? p.fmi[p.N + col] : 0.f;
+          const float sc0 = cok ? p.fss[p.fc0 + col] : 0.f, sh0 = cok ? p.fss[p.fld + p.fc0 + col] : 0.f;
+          const float mu0 = cok ? p.fmi[p.fc0 + col] : 0.f, is0 = cok ? p.fmi[p.fld + p.fc0 + col] : 0.f;
           // stage this half of Y0 (and, once, the input rows in the 4 pad columns) in the A slab
           first_store();
           if (nt == 0 && lane < WROWS) *reinterpret_cast<float4*>(sa + lane * MLP_LD + MLP_BK) = xq;
@@ -416,6 +424,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
               }
             }
         } else {
+        float sc0 = 0.f, sh0 = 0.f, mu0 = 0.f, is0 = 0.f;
+        if constexpr (RED) {
+          const int col = cofs + nt * 32 + lr;
+          if (col < p.N) {
+            sc0 = p.fss[p.fc0 + col]; sh0 = p.fss[p.fld + p.fc0 + col];
+            mu0 = p.fmi[p.fc0 + col]; is0 = p.fmi[p.fld + p.fc0 + col];
+          }
+          first_store();                             // this half of Y_{l-1} through the wave's A slab
+          if (nt + 1 < NT) first_load(nt + 1);
+        }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -424,6 +442,15 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
             const float v = acc[rt][nt][r];
             if (row < p.R && cofs + nt * 32 + lr < p.N)
               p.Y[(size_t)row * p.ldy + cofs + nt * 32 + lr] = v;
+            if constexpr (RED) {
+              if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+              if (row < p.R && cofs + nt * 32 + lr < p.N) {
+                const float y = sa[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MLP_LD + lr];
+                const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? v : 0.f;
+                s1 += dz;
+                s2 = __builtin_fmaf(dz, (y - mu0) * is0, s2);
+              }
+            }
             if constexpr (STATS) {
               s1 += v;                     // rows >= R are exact zeros (their A rows are zero)
               s2 = __builtin_fmaf(v, v, s2);
@@ -497,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
                 (double)(c[threadIdx.x] + c[4 + threadIdx.x] + c[8 + threadIdx.x] + c[12 + threadIdx.x]));
     }
   }
-  if constexpr (STATS) {
+  if constexpr (STATS || RED) {
     // lanes l and l+32 hold the same column: fold, then the 4 waves, then one fp64 atomic
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       const float v = s_red[i] + s_red[NT * 64 + i] + s_red[2 * NT * 64 + i] + s_red[3 * NT * 64 + i];
       const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
       if (cofs + nt * 32 + c < p.N)
-        atomicAdd(p.stats + which * p.N + cofs + nt * 32 + c, (double)v);
+        atomicAdd(p.stats + which * (RED ? p.fld : p.N) + (RED ? p.fc0 : 0) + cofs + nt * 32 + c, (double)v);
     }
   }
 }
@@ -928,7 +955,7 @@ static int mlp_grid(int R, int brows) {
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
-template <int PRO, bool STATS, bool POOL = false>
+template <int PRO, bool STATS, bool POOL = false, bool RED = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
@@ -976,7 +1003,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     const dim3 grid(tiles1, (nt + ntl - 1) / ntl);
     switch (ntl) {
 #define SPLIT(NTv)                                                                              \
-      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS, POOL>), grid, block, 0, s, a); break;
+      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS, POOL, false, RED>), grid, block, 0, s, a); break;
       SPLIT(1) SPLIT(2) SPLIT(3) SPLIT(4)
 #undef SPLIT
       default: break;
@@ -989,12 +1016,12 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     const int gxv = mlp_grid(a.R, 128 * RTv);                                                   \
     const int tilesv = (a.R + 128 * RTv - 1) / (128 * RTv);                                     \
     if (tilesv > gxv && a.K > MLP_BK && gxv % (8 * SCHED_GROUPS) == 0) a3.sched = sched_slot();                                \
-    hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL>), dim3(gxv), block, 0, s, a3); \
+    hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL, false, RED>), dim3(gxv), block, 0, s, a3); \
   } while (0)
 #define CASE(NTv)                                                                               \
   case NTv:                                                                                     \
     if constexpr (NTv <= NT_MAX) {                                                              \
-      if constexpr (NTv <= RT2_MAX) GO(NTv, 2); else GO(NTv, 1);                                \
+      if constexpr (NTv <= RT2_MAX && !RED) GO(NTv, 2); else GO(NTv, 1);                        \
     }                                                                                           \
     break;
   switch (nt) {
@@ -1142,9 +1169,16 @@ extern "C" int demf_bn_bwd_vectors(int N, long long count, double* g12, const fl
 
 // dX(R x K) = dY(R x N) @ W(N x K), dY formed on the fly.  Wtt = W^T as (K x N) row-major.
 // dX has row stride ldo >= K; K may be any multiple of 4 (handled in chunks of <= 128 columns).
+struct DxReduce {            // optional: layer l-1 operands for the RED epilogue
+  const float* Yprev;        // (R x K) pre-BN output of layer l-1
+  const float* ss;           // [scale|shift] (2K)
+  const float* mi;           // [mean|invstd] (2K)
+  double* g12;               // (2K) accumulated
+};
+
 static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const float* G, const float* dP,
-                                    const int* arg, int ns, const float* Y, const float* vec6,
-                                    const float* Wtt, float* dX, demf_stream_t stream) {
+                           const int* arg, int ns, const float* Y, const float* vec6,
+                           const float* Wtt, float* dX, const DxReduce* red, demf_stream_t stream) {
   DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 1 && ldo >= K,
                "mlp_gemm_bwd_dx: bad sizes R=%d N=%d K=%d ldo=%d", R, N, K, ldo);
   if (R == 0) return DEMF_OK;
@@ -1158,7 +1192,14 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
     if (w_direct) { a.Bt = Wtt + c0; a.ldb = K; }      // Wtt is W (N x K) itself: columns c0.. of it
     else a.Bt = Wtt + (size_t)c0 * N;
     a.Y = dX + c0; a.stats = nullptr;
-    const int e = G ? launch_gemm<PRO_DY_DENSE, false>(a, s) : launch_gemm<PRO_DY_SPARSE, false>(a, s);
+    int e;
+    if (red) {
+      a.fY = red->Yprev; a.fss = red->ss; a.fmi = red->mi; a.stats = red->g12; a.fld = K; a.fc0 = c0;
+      e = G ? launch_gemm<PRO_DY_DENSE, false, false, true>(a, s)
+            : launch_gemm<PRO_DY_SPARSE, false, false, true>(a, s);
+    } else {
+      e = G ? launch_gemm<PRO_DY_DENSE, false>(a, s) : launch_gemm<PRO_DY_SPARSE, false>(a, s);
+    }
     if (e) return e;
   }
   return DEMF_OK;
@@ -1167,14 +1208,27 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
 extern "C" int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const float* dP,
                                     const int* arg, int ns, const float* Y, const float* vec6,
                                     const float* Wtt, float* dX, demf_stream_t stream) {
-  return mlp_bwd_dx_impl(false, R, N, K, ldo, G, dP, arg, ns, Y, vec6, Wtt, dX, stream);
+  return mlp_bwd_dx_impl(false, R, N, K, ldo, G, dP, arg, ns, Y, vec6, Wtt, dX, nullptr, stream);
 }
 
 // Same, reading the layer's weight W (N x K row-major) directly: no transposed copy per step.
 extern "C" int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float* G, const float* dP,
                                       const int* arg, int ns, const float* Y, const float* vec6,
                                       const float* W, float* dX, demf_stream_t stream) {
-  return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, stream);
+  return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, nullptr, stream);
+}
+
+// Same + the BN-backward sums of layer l-1 (what demf_bn_bwd_reduce(R, K, G = dX, Yprev, ...) would
+// add to g12_prev) taken from the output tiles on the way out: that pass over dX and Yprev is gone.
+extern "C" int demf_mlp_gemm_bwd_dx_red(int R, int N, int K, int ldo, const float* G, const float* dP,
+                                        const int* arg, int ns, const float* Y, const float* vec6,
+                                        const float* W, float* dX, const float* Yprev,
+                                        const float* scale_shift_prev, const float* mean_invstd_prev,
+                                        double* g12_prev, demf_stream_t stream) {
+  DEMF_REQUIRE(K % 4 == 0 && Yprev && scale_shift_prev && mean_invstd_prev && g12_prev,
+               "mlp_gemm_bwd_dx_red: bad arguments (K %% 4 == 0)");
+  const DxReduce red{Yprev, scale_shift_prev, mean_invstd_prev, g12_prev};
+  return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, &red, stream);
 }
 
 // ---- first layer of a stack with a 4-float input and no input gradient (SA1) --------------------
@@ -1223,7 +1277,7 @@ extern "C" int demf_mlp_gemm_bwd_dx_first(int R, int N, int K0, const float* G, 
   MlpArgs a{};
   a.R = R; a.K = N; a.N = K0; a.ldx = N; a.ldy = K0; a.X = Y1; a.G = G; a.vec = vec6;
   a.Bt = W1; a.ldb = K0; a.Y = nullptr; a.stats = nullptr;
-  a.fX = X0; a.fY = Y0; a.fss = ss0; a.fmi = mi0; a.fsum = sums;
+  a.fX = X0; a.fY = Y0; a.fss = ss0; a.fmi = mi0; a.fsum = sums; a.fld = K0; a.fc0 = 0;
   // 32-row wave tiles: with 64-row ones the staged half tile + the 24 running sums do not fit next
   // to the accumulators in 256 VGPRs
   const int gx = mlp_grid(R, 128);

@@ -525,6 +525,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
 _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
+_NO_RED_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_RED_FUSE', '0')))        # A/B switch
 _NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
@@ -686,13 +687,18 @@ class _SharedMLPPool(Function):
         nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
         ws32 = torch.zeros(sum(W.numel() for W in Ws) + nbias, dtype=torch.float32, device=dev)
         o64 = o32 = 0
+        g12_ready = None      # layer l's sums already taken by the dx GEMM of layer l+1 (RED epilogue)
         for l in range(L - 1, -1, -1):
             W = Ws[l]
             N, K = W.shape
-            g12 = ws64[o64:o64 + 2 * N]
-            o64 += 2 * N
-            _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
-                      _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12), st)
+            if g12_ready is not None:
+                g12, g12_ready = g12_ready, None
+            else:
+                g12 = ws64[o64:o64 + 2 * N]
+                o64 += 2 * N
+                _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
+                          _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12),
+                          st)
             vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
             dgamma = torch.empty(N, dtype=torch.float32, device=dev)
             dbeta = torch.empty(N, dtype=torch.float32, device=dev)
@@ -757,7 +763,14 @@ class _SharedMLPPool(Function):
                 break
             if l > 0 or ctx.needs_input_grad[0]:
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
-                if K % 4 == 0:
+                if K % 4 == 0 and l > 0 and not _NO_RED_FUSE:
+                    # + layer l-1's BN-backward sums from the output tiles (no separate reduce pass)
+                    g12_ready = ws64[o64:o64 + 2 * K]
+                    o64 += 2 * K
+                    _ffi.call("demf_mlp_gemm_bwd_dx_red", R, N, K, K, _p(G), _p(dP if sparse else None),
+                              _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX),
+                              _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(g12_ready), st)
+                elif K % 4 == 0:
                     # W read as it is: the kernel transposes the slab on its way into LDS
                     _ffi.call("demf_mlp_gemm_bwd_dx_w", R, N, K, K, _p(G), _p(dP if sparse else None),
                               _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX), st)

@@ -264,6 +264,14 @@ int demf_mlp_gemm_bwd_dx(int R, int N, int K, int ldo, const float* G, const flo
 int demf_mlp_gemm_bwd_dx_w(int R, int N, int K, int ldo, const float* G, const float* dP,
                          const int* arg, int ns, const float* Y, const float* vec6,
                          const float* W, float* dX, demf_stream_t stream);
+/* demf_mlp_gemm_bwd_dx_w that also adds layer l-1's BN-backward sums - exactly what
+ * demf_bn_bwd_reduce(R, K, G = dX, Yprev, ...) would add to g12_prev (2K fp64) - taken from the
+ * output tiles on their way out, so that pass over dX and Yprev disappears.  K % 4 == 0. */
+int demf_mlp_gemm_bwd_dx_red(int R, int N, int K, int ldo, const float* G, const float* dP,
+                             const int* arg, int ns, const float* Y, const float* vec6,
+                             const float* W, float* dX, const float* Yprev,
+                             const float* scale_shift_prev, const float* mean_invstd_prev,
+                             double* g12_prev, demf_stream_t stream);
 
 /* Backward of a shared-MLP stack whose FIRST layer has a 4-float input row and needs no input
  * gradient (SA1: [height | rel_xyz]).  The dx GEMM of layer 1 (dY1 from (G, Y1, vec6); W1 (N x K0))
