@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void group_concat_cl_bwd_k(
 constexpr int INV_MAX_N = 16384;
 __global__ __launch_bounds__(1024) void invert_index_k(int N, int E, const int* __restrict__ idx,
                                                        int* __restrict__ off,
-                                                       int* __restrict__ rows) {
+                                                       int* __restrict__ rows, int lds_rows) {
   asm volatile("" ::: "v127");            // one WG per scene for ~100s of us: keep the CU to itself
   extern __shared__ int s_inv[];          // cnt[N] | start[N+1]
   int* cnt = s_inv;
@@ -210,6 +210,24 @@ __global__ __launch_bounds__(1024) void invert_index_k(int N, int E, const int* 
   __syncthreads();
   for (int j = tid; j < N; j += 1024) cnt[j] = 0;      // reuse as fill cursors
   __syncthreads();
+  if (lds_rows) {
+    // the unsorted lists stay in LDS; every entry then counts the smaller entries of its own list
+    // (its rank) and is written straight to its final place: no dependent chain, no global sort
+    int* s_rows = s_inv + 2 * N + 1;
+    for (int e = tid; e < E; e += 1024) {
+      const int j = idx[e];
+      s_rows[start[j] + atomicAdd(&cnt[j], 1)] = e;
+    }
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) {
+      const int j = idx[e];
+      const int s = start[j], n = cnt[j];
+      int rank = 0;
+      for (int i = 0; i < n; ++i) rank += s_rows[s + i] < e ? 1 : 0;
+      rows[s + rank] = e;
+    }
+    return;
+  }
   for (int e = tid; e < E; e += 1024) {
     const int j = idx[e];
     rows[start[j] + atomicAdd(&cnt[j], 1)] = e;
@@ -605,8 +623,26 @@ extern "C" int demf_invert_index(int B, int N, int E, const int* idx, int* off, 
   }
   if (B == 0) return DEMF_OK;
   DEMF_REQUIRE(idx && off && rows, "invert_index: null pointer");
-  hipLaunchKernelGGL(invert_index_k, dim3(B), dim3(1024), sizeof(int) * (2 * N + 1),
-                     (hipStream_t)stream, N, E, idx, off, rows);
+  // E more ints of LDS hold the unsorted lists when they fit next to the histogram (<= 150 KB)
+  size_t lds = sizeof(int) * (2 * (size_t)N + 1);
+  int lds_rows = 0;
+  if (lds + sizeof(int) * (size_t)E <= 150 * 1024) {
+    lds += sizeof(int) * (size_t)E;
+    lds_rows = 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)invert_index_k, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              150 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        lds -= sizeof(int) * (size_t)E;
+        lds_rows = 0;
+      } else {
+        attr_set = true;
+      }
+    }
+  }
+  hipLaunchKernelGGL(invert_index_k, dim3(B), dim3(1024), lds, (hipStream_t)stream, N, E, idx, off,
+                     rows, lds_rows);
   return check_launch("invert_index");
 }
 
