@@ -45,7 +45,7 @@ SIGNATURES = {
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
     "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 8,
-    "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 10,
+    "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 13,
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,

@@ -108,11 +108,22 @@ __global__ __launch_bounds__(512) void group_first_fwd_k(
 // list entries (and the centre of each entry's row) are fetched LPR at a time, one per lane, and
 // broadcast inside the group.
 template <int LPR>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o, LPR);
+  return v;
+}
+
+// XG: the coordinates carry a gradient too (the vote aggregation: vote points are predicted):
+// d rel = dY . Wx^T per row -> + to the source point (summed here, written once), - to the centre
+// (3 atomics per row).
+template <int LPR, bool XG>
 __global__ __launch_bounds__(256) void group_first_bwd_k(
     int N, int M, int ns, int ns_shift, float inv_div, const float* __restrict__ xyz,
     const float* __restrict__ center, const float* __restrict__ G, const float* __restrict__ Yl,
     const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
-    float* __restrict__ dU, float* __restrict__ dWx, long long points) {
+    float* __restrict__ dU, float* __restrict__ dWx, long long points,
+    const float* __restrict__ Wx, float* __restrict__ dxyz, float* __restrict__ dcenter) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 256 / LPR;
   constexpr int UNR = 4;
@@ -126,6 +137,12 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
   const float4 va = *reinterpret_cast<const float4*>(vec + 3 * C1 + c);
   const float4 vb = *reinterpret_cast<const float4*>(vec + 4 * C1 + c);
   float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();  // sum (p - q)_k * dY, scaled at the end
+  float4 wx0 = f4_zero(), wx1 = f4_zero(), wx2 = f4_zero();
+  if constexpr (XG) {
+    wx0 = *reinterpret_cast<const float4*>(Wx + c);
+    wx1 = *reinterpret_cast<const float4*>(Wx + C1 + c);
+    wx2 = *reinterpret_cast<const float4*>(Wx + 2 * C1 + c);
+  }
   for (long long pt = (long long)blockIdx.x * GPB + grp; pt < points;
        pt += (long long)gridDim.x * GPB) {
     const int b = (int)(pt / N), j = (int)(pt - (long long)b * N);
@@ -136,13 +153,15 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     const float* cb = center + (size_t)b * M * 3;
     const float px = xyz[pt * 3], py = xyz[pt * 3 + 1], pz = xyz[pt * 3 + 2];
     float4 acc = f4_zero();
+    float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int eb = e0; eb < e1; eb += LPR) {
       const int n = e1 - eb < LPR ? e1 - eb : LPR;
-      int my_row = 0;
+      int my_row = 0, my_m = 0;
       float mx = 0.f, my = 0.f, mz = 0.f;
       if (sub < n) {
         my_row = r[eb + sub];
         const int m = ns_shift >= 0 ? my_row >> ns_shift : my_row / ns;
+        my_m = m;
         const float* q = cb + (size_t)m * 3;
         mx = px - q[0];
         my = py - q[1];
@@ -164,20 +183,41 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
         for (int k = 0; k < UNR; ++k) {
           const float rx = grp_bcast<LPR>(mx, k0 + k), ry = grp_bcast<LPR>(my, k0 + k),
                       rz = grp_bcast<LPR>(mz, k0 + k);
+          const int mrow = XG ? grp_bcast<LPR>(my_m, k0 + k) : 0;
           if (k0 + k < n) {
+            float4 d;
 #define GF_DY(m)                                                                       \
             {                                                                          \
               const float dz = __builtin_fmaf(y[k].m, sc.m, sh.m) > 0.f ? g[k].m : 0.f; \
-              const float d = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, y[k].m, vb.m)); \
-              acc.m += d;                                                              \
-              wa0.m = __builtin_fmaf(rx, d, wa0.m);                                    \
-              wa1.m = __builtin_fmaf(ry, d, wa1.m);                                    \
-              wa2.m = __builtin_fmaf(rz, d, wa2.m);                                    \
+              d.m = __builtin_fmaf(gi.m, dz, __builtin_fmaf(va.m, y[k].m, vb.m));      \
+              acc.m += d.m;                                                            \
+              wa0.m = __builtin_fmaf(rx, d.m, wa0.m);                                  \
+              wa1.m = __builtin_fmaf(ry, d.m, wa1.m);                                  \
+              wa2.m = __builtin_fmaf(rz, d.m, wa2.m);                                  \
             }
             GF_DY(x) GF_DY(y) GF_DY(z) GF_DY(w)
 #undef GF_DY
+            if constexpr (XG) {
+              const float t0 = grp_sum<LPR>(d.x * wx0.x + d.y * wx0.y + d.z * wx0.z + d.w * wx0.w);
+              const float t1 = grp_sum<LPR>(d.x * wx1.x + d.y * wx1.y + d.z * wx1.z + d.w * wx1.w);
+              const float t2 = grp_sum<LPR>(d.x * wx2.x + d.y * wx2.y + d.z * wx2.z + d.w * wx2.w);
+              gx += t0; gy += t1; gz += t2;
+              if (sub == 0) {
+                float* dc = dcenter + ((size_t)b * M + mrow) * 3;
+                atomicAdd(dc, -t0 * inv_div);
+                atomicAdd(dc + 1, -t1 * inv_div);
+                atomicAdd(dc + 2, -t2 * inv_div);
+              }
+            }
           }
         }
+      }
+    }
+    if constexpr (XG) {
+      if (sub == 0) {
+        dxyz[pt * 3] = gx * inv_div;
+        dxyz[pt * 3 + 1] = gy * inv_div;
+        dxyz[pt * 3 + 2] = gz * inv_div;
       }
     }
     *reinterpret_cast<float4*>(dU + pt * C1 + c) = acc;
@@ -231,7 +271,8 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
                                     int normalize_xyz, const float* xyz, const float* center,
                                     const float* G, const float* Y, const float* vec6,
                                     const int* inv_off, const int* inv_rows, float* dU,
-                                    float* dWx, demf_stream_t stream) {
+                                    float* dWx, const float* Wx, float* dxyz, float* dcenter,
+                                    demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_bwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0) return DEMF_OK;
@@ -246,9 +287,19 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   long long blocks = (points + gpb - 1) / gpb;
   if (blocks > 1024) blocks = 1024;  // 3*C1 fp32 atomics per block
   const dim3 grid((unsigned)blocks);
+  DEMF_REQUIRE((dxyz == nullptr) == (dcenter == nullptr) && (dxyz == nullptr || Wx != nullptr),
+               "group_first_bwd: dxyz, dcenter (and Wx) must be given together");
 #define GF_BWD(L)                                                                          \
-  hipLaunchKernelGGL(group_first_bwd_k<L>, grid, dim3(256), 0, s, N, M, ns, ns_shift, inv_div, xyz, center, \
-                     G, Y, vec6, inv_off, inv_rows, dU, dWx, points)
+  do {                                                                                     \
+  if (dxyz)                                                                                \
+    hipLaunchKernelGGL((group_first_bwd_k<L, true>), grid, dim3(256), 0, s, N, M, ns, ns_shift,    \
+                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, points, Wx, \
+                       dxyz, dcenter);                                                     \
+  else                                                                                     \
+    hipLaunchKernelGGL((group_first_bwd_k<L, false>), grid, dim3(256), 0, s, N, M, ns, ns_shift,   \
+                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, points, Wx, \
+                       dxyz, dcenter);                                                     \
+  } while (0)
   if (lpr == 64) GF_BWD(64);
   else if (lpr == 32) GF_BWD(32);
   else GF_BWD(16);

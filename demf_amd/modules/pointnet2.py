@@ -93,15 +93,14 @@ class PointSAModule(nn.Module):
             ops.ball_query(0.0, self.radius, self.num_sample, points_xyz, new_xyz)
         assert self.use_xyz or feat is not None
         ld = _pad4(C + 3) if self.use_xyz else C
-        if group_inv is None and feat is not None and feat.requires_grad and C % 4 == 0 \
-                and N <= 16384:
+        needs_grad = feat is not None and torch.is_grad_enabled() and \
+            (feat.requires_grad or points_xyz.requires_grad or new_xyz.requires_grad)
+        if group_inv is None and needs_grad and C % 4 == 0 and N <= 16384:
             group_inv = ops.invert_index(idx, N)
         mlp = self.mlps[0]
-        needs_grad = feat is not None and feat.requires_grad and torch.is_grad_enabled()
-        xyz_grad = torch.is_grad_enabled() and (points_xyz.requires_grad or new_xyz.requires_grad)
         if self.use_xyz and feat is not None and len(mlp) >= 2 and C % 4 == 0 \
                 and mlp[0].cout in (64, 128, 256) and not ops._NO_GROUP_FIRST \
-                and (group_inv is not None or not needs_grad) and not xyz_grad:
+                and (group_inv is not None or not needs_grad):
             # first layer per SOURCE point: y = (feat . Wf^T)[idx] + rel_xyz . Wx^T, the grouped
             # rows (B*M*ns, 3+C) are never built (csrc/group_first.hip)
             inv_off, inv_rows = group_inv if group_inv is not None else (None, None)

@@ -555,7 +555,7 @@ class _SharedMLPPool(Function):
     BN+ReLU is fused with the max over the ``ns`` neighbours (ns == 1: plain activation)."""
 
     @staticmethod
-    def forward(ctx, x, ns, training, eps, momentum, geo, *tensors):
+    def forward(ctx, x, ns, training, eps, momentum, geo, geo_xyz, geo_center, *tensors):
         _chk(x, "x")
         R, ld = x.shape
         L = len(tensors) // 7
@@ -674,7 +674,7 @@ class _SharedMLPPool(Function):
         dP = grad_out.contiguous()
         G = None
         grads = [None] * (7 * L)
-        dx = None
+        dx = dxyz = dcenter = None
         # BN reductions go through the self-cleaning fp64 accumulator; the weight gradients of all
         # layers share one zero-filled fp32 workspace
         # SA1-like stacks (4-float input rows, no input gradient, >= 3 layers): layer 0's backward is
@@ -716,9 +716,15 @@ class _SharedMLPPool(Function):
                 dU = torch.empty((gB * gN, N), dtype=torch.float32, device=dev)
                 dWx = ws32[o32:o32 + 3 * N]
                 o32 += N * K
+                dxyz = dcenter = Wx = None
+                if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+                    # the coordinates carry a gradient too (vote aggregation)
+                    Wx = W[:, :3].t().contiguous()
+                    dxyz = torch.empty((gB, gN, 3), dtype=torch.float32, device=dev)
+                    dcenter = torch.zeros((gB, gM, 3), dtype=torch.float32, device=dev)
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
                           _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
-                          _p(dWx), st)
+                          _p(dWx), _p(Wx), _p(dxyz), _p(dcenter), st)
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3
                 dWf = ws32[o32 - N * K + 3 * N:o32].view(N, C0)
@@ -783,7 +789,9 @@ class _SharedMLPPool(Function):
                     G = dX
                 else:
                     dx = dX
-        return (dx, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None,
+                dxyz if ctx.needs_input_grad[6] else None,
+                dcenter if ctx.needs_input_grad[7] else None, *grads)
 
 
 def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1, geo=None):
@@ -805,7 +813,11 @@ def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1, geo=No
         if not training and bias is not None:
             rmean = rmean - bias.detach()      # eval: BN sees y + bias
         flat += [W, gamma, beta, rmean, rvar, bias, nbt]
-    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, geo, *flat)
+    gx = gc = None
+    if geo is not None and torch.is_grad_enabled():
+        gx = geo[0] if geo[0].requires_grad else None
+        gc = geo[1] if geo[1].requires_grad else None
+    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, geo, gx, gc, *flat)
     if training:
         with torch.no_grad():
             for layer in layers:

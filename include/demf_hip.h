@@ -178,11 +178,16 @@ int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius, int 
 /* Backward of the above through the inverse lists of demf_invert_index: with dY the BN-backward
  * transform of (G, Y) by vec6 (demf_bn_bwd_vectors; same formula as demf_mlp_gemm_bwd_dx),
  *   dU[b,j,:]  = sum of dY over the rows that gathered point j        (fully written, no atomics)
- *   dWx[k,:]  += sum over all rows of rel_k . dY                      (3*C1 fp32, arrives zeroed) */
+ *   dWx[k,:]  += sum over all rows of rel_k . dY                      (3*C1 fp32, arrives zeroed)
+ * and, when the coordinates carry a gradient (the vote aggregation), d rel = dY . Wx^T per row:
+ *   dxyz[b,j,:] = + sum over the rows of point j / radius,  dcenter[b,m,:] -= sum over s / radius */
 int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
                          const float* xyz, const float* center, const float* G, const float* Y,
                          const float* vec6, const int* inv_off, const int* inv_rows, float* dU,
-                         float* dWx, demf_stream_t stream);
+                         float* dWx, const float* Wx /* needed with dxyz */,
+                         float* dxyz /* (B,N,3) fully written, or NULL */,
+                         float* dcenter /* (B,M,3) accumulated: arrives zeroed, or NULL */,
+                         demf_stream_t stream);
 
 /* One pyramid level (B,C,HW) channel-major -> rows [row0,row0+HW) of the channels-last token buffer
  * (B,S,C): the flatten + transpose + concat of prepare_decoder_inputs

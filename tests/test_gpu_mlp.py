@@ -196,3 +196,52 @@ def test_factored_first_layer_matches_grouped_reference(B, N, M, ns, C, chans, r
             h = F.relu(F.batch_norm(F.linear(h, W), l[3].double().cpu(), l[4].double().cpu(),
                                     g, b, False, 0.1, 1e-5))
         close(out_e, h.view(B * M, ns, -1).max(1)[0], 1e-4, "eval out")
+
+
+def test_factored_first_layer_coordinate_gradients():
+    """The vote aggregation groups PREDICTED points: the factored first layer must also return the
+    gradient of the coordinates (source points and centres, which are a gather of the same cloud)."""
+    from demf_amd import ops
+    torch.manual_seed(5)
+    B, N, M, ns, C, chans, radius = 2, 400, 64, 16, 256, (128, 128, 128), 0.45
+    xyz = torch.rand(B, N, 3, dtype=torch.float64) * 1.5
+    feat = torch.randn(B, N, C, dtype=torch.float64) * 0.5
+    xyz_g = xyz.float().cuda().requires_grad_()
+    fidx = ops.furthest_point_sample(xyz_g.detach(), M)
+    centre_g = ops.gather_rows_cl(xyz_g, fidx)              # differentiable gather
+    idx = ops.ball_query(0.0, radius, ns, xyz_g.detach(), centre_g.detach())
+    inv = ops.invert_index(idx, N)
+    layers64, k = [], C + 3
+    for n in chans:
+        layers64.append((torch.randn(n, k, dtype=torch.float64) / np.sqrt(k),
+                         1.0 + 0.2 * torch.randn(n, dtype=torch.float64),
+                         0.1 * torch.randn(n, dtype=torch.float64)))
+        k = n
+    go = torch.randn(B * M, chans[-1], dtype=torch.float64)
+
+    xr = xyz_g.detach().double().cpu().requires_grad_()
+    fr = feat.clone().requires_grad_()
+    lr = [tuple(t.clone().requires_grad_() for t in l) for l in layers64]
+    li, fi = idx.long().cpu(), fidx.long().cpu()
+    bi = torch.arange(B).view(B, 1, 1).expand(B, M, ns)
+    centre_r = xr[torch.arange(B).view(B, 1), fi]
+    rel = (xr[bi, li] - centre_r[:, :, None, :]) / radius
+    rows = torch.cat([rel, fr[bi, li]], dim=-1).view(B * M * ns, C + 3)
+    _ref(rows, ns, lr).backward(go)
+
+    fg = feat.float().cuda().view(B * N, C).requires_grad_()
+    lg = [(W.float().cuda().requires_grad_(), g.float().cuda().requires_grad_(),
+           b.float().cuda().requires_grad_(), torch.zeros(W.shape[0], device="cuda"),
+           torch.ones(W.shape[0], device="cuda")) for W, g, b in layers64]
+    out = ops.shared_mlp_pool(fg, ns, lg, training=True,
+                              geo=(xyz_g, centre_g, idx, inv[0], inv[1], radius, True))
+    out.backward(go.float().cuda())
+
+    def close(a, b, tol, name):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), f"{name}: err {err:.3e} (scale {b.abs().max().item():.3e})"
+
+    close(xyz_g.grad, xr.grad, 1e-3, "dxyz")
+    close(lg[0][0].grad, lr[0][0].grad, 1e-3, "dW0")
+    close(fg.grad, fr.grad.view(B * N, C), 1e-3, "dfeat")
