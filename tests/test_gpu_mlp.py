@@ -26,6 +26,9 @@ CASES = [  # (rows/ns, ns, ld, channels, x_grad)
     (4096, 64, 4, (64, 64, 128), False),      # SA1 rows > 24576: 64-row wave tiles, fused pool
     (1500, 32, 132, (128, 128, 256), True),   # persistent path (>= 192 row tiles) with ns = 32
     (50, 8, 36, (32, 32, 64), True),          # ns = 8: unfused pooling kernel
+    (900, 64, 4, (32, 96, 64), False),        # fused first-layer backward with N0 = 32, 96-wide dx (3 column tiles)
+    (77, 16, 20, (48, 80, 112), True),        # widths that are not multiples of 32; ragged row tiles
+    (3000, 32, 4, (64, 64, 128), False),      # fused first-layer backward on the persistent (dynamic-tile) path
 ]
 
 
