@@ -604,8 +604,10 @@ extern "C" int demf_colsum_f32(int R, int N, int ld, const float* x, float* out,
   DEMF_REQUIRE(x && out, "colsum: null pointer");
   DEMF_REQUIRE(ld >= N, "colsum: ld=%d < N=%d", ld, N);
   // at most ~256 blocks: each ends in N same-address atomics, which serialise in L2
+  // and at least DEMF_COLSUM_ROWS rows per block (2 k-row layers: 32 blocks, atomic depth 32)
   int rpb = (R + 255) / 256;
-  rpb = rpb < 16 ? 16 : rpb;
+  static const int min_rows = [] { const char* v = getenv("DEMF_COLSUM_ROWS"); return v ? atoi(v) : 64; }();
+  rpb = rpb < min_rows ? min_rows : rpb;
   const dim3 grid((R + rpb - 1) / rpb);
   if (N % 4 == 0 && ld % 4 == 0 && ((size_t)x & 15) == 0)
     hipLaunchKernelGGL(colsum_k<4>, grid, dim3(256), 0, (hipStream_t)stream, R, N, ld, rpb, x, out);
