@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     const float* __restrict__ Wx, float* __restrict__ dxyz, float* __restrict__ dcenter) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 256 / LPR;
-  constexpr int UNR = 4;
+  constexpr int UNR = 8;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int c = sub * 4;
   const int E = M * ns;
