@@ -249,17 +249,16 @@ def main():
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 4 * (sa1_rows // 64) * 128 * 4
         out["roofline_critical_path"] = {
-            "kernel": "mlp_gemm_kernel<2,2,BNRELU,STATS,POOL> (SA1 layer 3: 64->128, R=%d)" % sa1_rows,
+            "kernel": "mlp_gemm_kernel<4,1,BNRELU,STATS,POOL> (SA1 layer 3: 64->128, R=%d)" % sa1_rows,
             "bound": "hbm", "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # PMC passes (profiles/r01_m_pmc_*.csv): FETCH_SIZE 132978.7 KiB x2 (gfx950 reports half)
             # + WRITE_SIZE 558080.0 KiB per launch
             "traffic": (2 * 132978.7 + 558080.0) * 1024 if args.batch == 8 else None,
             "avg_launch_ms": mlp_ms,
-            "note": "17 GFLOP fp32 MFMA per launch as well; the input rows are needed twice (two "
-                    "64-column halves, so that the pooling epilogue fits in registers) but the "
-                    "halves are co-scheduled on one XCD: the second read is an L2 hit and the HBM "
-                    "traffic equals the algorithmic bytes"}
+            "note": "17 GFLOP fp32 MFMA per launch as well; 128-row block tiles x all 128 columns, "
+                    "the 64-neighbour max/min merged across a wave pair through LDS: the input rows "
+                    "are read once and the HBM traffic equals the algorithmic bytes"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))

@@ -194,8 +194,11 @@ __device__ __forceinline__ void pool_epilogue(const MlpArgs& p, const f32x16 (&a
         if (rho_w / NS != g) continue;                            // compile-time after unrolling
         const int rho = rho_w % NS + 4 * lh;
         const float v = acc[rt][nt][r];
-        if (v > mx || (v == mx && rho < ax)) { mx = v; ax = rho; }
-        if (v < mn || (v == mn && rho < an)) { mn = v; an = rho; }
+        // a lane visits its rows in ascending order, so "first extremum wins" is the strict compare
+        // (branch-free: one v_cmp + two v_cndmask each)
+        const bool up = v > mx, dn = v < mn;
+        mx = up ? v : mx; ax = up ? rho : ax;
+        mn = dn ? v : mn; an = dn ? rho : an;
       }
     const float omx = __shfl_xor(mx, 32), omn = __shfl_xor(mn, 32);
     const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
@@ -209,6 +212,32 @@ __device__ __forceinline__ void pool_epilogue(const MlpArgs& p, const f32x16 (&a
   }
 }
 
+// NS = 64 with 32-row wave tiles: a group spans the row tiles of two neighbouring waves (2w, 2w+1).
+// Each wave reduces its 32 rows, both publish through LDS, the even wave merges (its offsets are the
+// smaller ones, so it wins ties) and writes.  s_pool: [wave][nt][lane&31] x {max, min, amax, amin}.
+template <int NT>
+__device__ __forceinline__ void pool_half_reduce(const f32x16 (&acc)[1][NT], int nt, int wave, int lr,
+                                                 int lh, float4* __restrict__ s_pool) {
+  float mx = -__builtin_inff(), mn = __builtin_inff();
+  int ax = 0, an = 0;
+  const int base = (wave & 1) * 32 + 4 * lh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rho = base + (r & 3) + 8 * (r >> 2);
+    const float v = acc[0][nt][r];
+    const bool up = v > mx, dn = v < mn;          // rows ascend: the strict compare keeps the first
+    mx = up ? v : mx; ax = up ? rho : ax;
+    mn = dn ? v : mn; an = dn ? rho : an;
+  }
+  const float omx = __shfl_xor(mx, 32), omn = __shfl_xor(mn, 32);
+  const int oax = __shfl_xor(ax, 32), oan = __shfl_xor(an, 32);
+  if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+  if (omn < mn || (omn == mn && oan < an)) { mn = omn; an = oan; }
+  if (lh == 0)
+    s_pool[(wave * NT + nt) * 32 + lr] =
+        make_float4(mx, mn, __builtin_bit_cast(float, ax), __builtin_bit_cast(float, an));
+}
+
 template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   static_assert(!(STATS && RED) && !(FIRST && RED), "one column-sum epilogue at a time");
@@ -219,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * MLP_LD];
   __shared__ __attribute__((aligned(16))) float s_vec[NVEC ? NVEC * MLP_MAXK : 4];
   __shared__ float s_red[(STATS || RED) ? 4 * NT * 32 * 2 : (FIRST ? 4 * NT * 32 * 10 + 16 : 1)];
+  __shared__ float4 s_pool[(POOL && RT == 1) ? 4 * NT * 32 : 1];
   if constexpr (NVEC > 0) {
     // compact copy: vector v of length K lives at s_vec + v*K (same addressing as global)
     for (int i = threadIdx.x; i < NVEC * p.K; i += 256) s_vec[i] = p.vec[i];
@@ -333,7 +363,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     __syncthreads();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
-    const bool defer_prefetch = (POOL || FIRST) && last_ks;
+    constexpr bool DEFER = (POOL && RT == 2) || FIRST;   // epilogues that need the prefetch registers
+    const bool defer_prefetch = DEFER && last_ks;
     const int next_tile = last_ks ? (dyn ? s_next : tile + gx) : tile;
     const int next_ks = last_ks ? 0 : ks + 1;
     if (next_tile < ntiles && !defer_prefetch) prefetch(next_tile, next_ks);
@@ -465,10 +496,33 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
             if (p.ns == 16) pool_epilogue<RT, NT, 16>(p, acc, nt, row0, col, lh);
             else if (p.ns == 32) pool_epilogue<RT, NT, 32>(p, acc, nt, row0, col, lh);
             else if constexpr (RT == 2) pool_epilogue<RT, NT, 64>(p, acc, nt, row0, col, lh);
+            else pool_half_reduce<NT>(acc, nt, wave, lr, lh, s_pool);
           }
         }
       }
-      if constexpr (POOL || FIRST) {
+      if constexpr (POOL && RT == 1) {
+        if (p.ns == 64) {                       // merge the two half groups of each wave pair
+          __syncthreads();
+          if ((wave & 1) == 0 && lh == 0) {
+            const int grow = row0;              // first row of this wave pair's group
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int col = cofs + nt * 32 + lr;
+              const float4 a = s_pool[(wave * NT + nt) * 32 + lr];
+              const float4 b = s_pool[((wave + 1) * NT + nt) * 32 + lr];
+              float mx = a.x, mn = a.y;
+              int ax = __builtin_bit_cast(int, a.z), an = __builtin_bit_cast(int, a.w);
+              if (b.x > mx) { mx = b.x; ax = __builtin_bit_cast(int, b.z); }
+              if (b.y < mn) { mn = b.y; an = __builtin_bit_cast(int, b.w); }
+              if (grow < p.R && col < p.N) {
+                const size_t o = (size_t)(grow / 64) * p.N + col;
+                p.pmax[o] = mx; p.pmin[o] = mn; p.amax[o] = ax; p.amin[o] = an;
+              }
+            }
+          }
+        }
+      }
+      if constexpr ((POOL && RT == 2) || FIRST) {
         if (next_tile < ntiles) prefetch(next_tile, next_ks);
       }
     }
@@ -975,7 +1029,10 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     // pooled epilogue: 64-row wave tiles for ns = 64 (a group must live in one wave), 32-row ones
     // otherwise; at most 2 (resp. 4) column tiles per block so that the accumulators, the
     // prefetch and the epilogue's temporaries fit in 256 VGPRs - wider outputs go to blockIdx.y
-    const bool rt2 = a.ns == 64;
+    // ns = 64: 64-row wave tiles x <= 2 column tiles (column halves co-scheduled), or - when all the
+    // columns fit 4 tiles - 32-row wave tiles x 4 column tiles with the group merged across a wave pair
+    const bool half64 = a.ns == 64 && nt <= 4 && !env_int("DEMF_POOL_HALVES", 0);
+    const bool rt2 = a.ns == 64 && !half64;
     const int ntl = rt2 ? (nt < 2 ? nt : 2) : (nt < 4 ? nt : 4);
     const int ys = (nt + ntl - 1) / ntl;
     int gx = mlp_grid(a.R, rt2 ? 256 : 128);
