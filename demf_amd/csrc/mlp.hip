@@ -24,6 +24,7 @@
 // k in {k0+m, k0+4+m} on both operands consistently - four MFMAs consume the two float4.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace demf {
 
@@ -465,28 +466,62 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           first_store();                             // this half of Y_{l-1} through the wave's A slab
           if (nt + 1 < NT) first_load(nt + 1);
         }
+        // interior tiles of the pooled launches store unpredicated: a per-store bounds test costs an
+        // exec-mask branch each; only the last row tile / a ragged column tile takes the checked path
+        auto store_tile = [&](auto full_c) {
+          constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
+          for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = acc[rt][nt][r];
-            if (row < p.R && cofs + nt * 32 + lr < p.N)
-              p.Y[(size_t)row * p.ldy + cofs + nt * 32 + lr] = v;
-            if constexpr (RED) {
-              if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-              if (row < p.R && cofs + nt * 32 + lr < p.N) {
-                const float y = sa[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MLP_LD + lr];
-                const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? v : 0.f;
-                s1 += dz;
-                s2 = __builtin_fmaf(dz, (y - mu0) * is0, s2);
+            for (int r = 0; r < 16; ++r) {
+              const int row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              const float v = acc[rt][nt][r];
+              const bool ok = FULL || (row < p.R && cofs + nt * 32 + lr < p.N);
+              if (ok) p.Y[(size_t)row * p.ldy + cofs + nt * 32 + lr] = v;
+              if constexpr (RED) {
+                if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                if (ok) {
+                  const float y = sa[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MLP_LD + lr];
+                  const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? v : 0.f;
+                  s1 += dz;
+                  s2 = __builtin_fmaf(dz, (y - mu0) * is0, s2);
+                }
+              }
+              if constexpr (STATS) {
+                s1 += v;                   // rows >= R are exact zeros (their A rows are zero)
+                s2 = __builtin_fmaf(v, v, s2);
               }
             }
-            if constexpr (STATS) {
-              s1 += v;                     // rows >= R are exact zeros (their A rows are zero)
-              s2 = __builtin_fmaf(v, v, s2);
+        };
+        // (only in the pooled instantiations: duplicating the loop in the wide plain ones - up to
+        // 128 accumulators live - made them 30-90 % slower)
+        if constexpr (POOL) {
+          if (tile * BROWS + BROWS <= p.R && cofs + NT * 32 <= p.N) store_tile(std::true_type{});
+          else store_tile(std::false_type{});
+        } else {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = row0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              const float v = acc[rt][nt][r];
+              if (row < p.R && cofs + nt * 32 + lr < p.N)
+                p.Y[(size_t)row * p.ldy + cofs + nt * 32 + lr] = v;
+              if constexpr (RED) {
+                if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+                if (row < p.R && cofs + nt * 32 + lr < p.N) {
+                  const float y = sa[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MLP_LD + lr];
+                  const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? v : 0.f;
+                  s1 += dz;
+                  s2 = __builtin_fmaf(dz, (y - mu0) * is0, s2);
+                }
+              }
+              if constexpr (STATS) {
+                s1 += v;                   // rows >= R are exact zeros (their A rows are zero)
+                s2 = __builtin_fmaf(v, v, s2);
+              }
             }
-          }
+        }
         }
         cs1[nt] += s1;
         cs2[nt] += s2;
