@@ -19,9 +19,10 @@
  *   - Re-entrant; no global mutable state besides the thread-local error text and a device-side ring
  *     of self-resetting tile counters (256 KB) that the persistent shared-MLP GEMM launches claim
  *     their row tiles from: a launch is handed the next counter set of the ring and leaves it zeroed,
- *     so captured launches replay with the set they were given.  Launches that run CONCURRENTLY on
- *     different streams must not be more than 1024 shared-MLP launches apart (DEMF_STATIC_TILES=1
- *     switches the counters off).
+ *     so captured launches replay with the set they were given.  Two launches share a set only if
+ *     a multiple of 1024 counter-using launches lies between their enqueues; that matters only if
+ *     they also run concurrently on different streams (the path itself is single-stream;
+ *     DEMF_STATIC_TILES=1 switches the counters off).
  */
 #ifndef DEMF_HIP_H_
 #define DEMF_HIP_H_
