@@ -49,10 +49,10 @@ SIGNATURES = {
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,
-    "demf_pool_select": [_c_int] * 2 + [_ptr] * 8,
+    "demf_pool_select": [_c_int] * 2 + [_ptr] * 9,
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 6,
     "demf_bnrelu_maxpool_fwd": [_c_int] * 3 + [_ptr] * 5,
-    "demf_bn_bwd_reduce": [_c_int] * 3 + [_ptr] * 8,
+    "demf_bn_bwd_reduce": [_c_int] * 3 + [_ptr] * 9,
     "demf_bn_bwd_vectors": [_c_int, ctypes.c_longlong] + [_ptr] * 8,
     "demf_mlp_gemm_bwd_dx": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
     "demf_mlp_gemm_bwd_dx_first": [_c_int] * 3 + [_ptr] * 10,

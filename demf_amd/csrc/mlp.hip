@@ -697,7 +697,8 @@ __global__ __launch_bounds__(256) void pool_select_k(long long RC, int C,
                                                      const int* __restrict__ amin,
                                                      const float* __restrict__ ss,
                                                      float* __restrict__ out,
-                                                     int* __restrict__ arg) {
+                                                     int* __restrict__ arg,
+                                                     float* __restrict__ yraw) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; t < RC; t += stride) {
@@ -706,7 +707,12 @@ __global__ __launch_bounds__(256) void pool_select_k(long long RC, int C,
     const bool up = sc > 0.f;
     const float y = up ? pmax[t] : pmin[t];
     out[t] = fmaxf(0.f, __builtin_fmaf(y, sc, sh));
-    arg[t] = sc == 0.f ? 0 : (up ? amax[t] : amin[t]);      // constant activation: first slot wins
+    const int a = sc == 0.f ? 0 : (up ? amax[t] : amin[t]);  // constant activation: first slot wins
+    arg[t] = a;
+    // the raw output AT the selected row (what the sparse BN-backward reduce would otherwise gather
+    // from Y).  Zero scale: the selected row is slot 0, whose value is not among the extrema - NaN
+    // tells the consumer to gather it (dgamma = sum dZ*xhat needs it even though gamma is 0).
+    if (yraw) yraw[t] = sc == 0.f ? __builtin_nanf("") : y;
   }
 }
 
@@ -720,7 +726,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
                                                        const float* __restrict__ Y,
                                                        const float* __restrict__ ss,
                                                        const float* __restrict__ mi,
-                                                       double* __restrict__ g12) {
+                                                       double* __restrict__ g12,
+                                                       const float* __restrict__ yraw) {
   // thread -> one column, strided rows; columns are the fast index so reads coalesce
   __shared__ float red[2][256];
   const int cols_per_pass = N < 256 ? N : 256;
@@ -734,8 +741,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
       if constexpr (SPARSE) {
         const int Rp = R / ns;
         for (int rp = blockIdx.x * rows_par + r_in; rp < Rp; rp += gridDim.x * rows_par) {
-          const int s = arg[(size_t)rp * N + c];
-          const float y = Y[((size_t)rp * ns + s) * N + c];
+          // y at the arg-max row: handed over by demf_pool_select, else gathered from Y
+          float y = yraw ? yraw[(size_t)rp * N + c] : __builtin_nanf("");
+          if (y != y) y = Y[((size_t)rp * ns + arg[(size_t)rp * N + c]) * N + c];
           const float dz = __builtin_fmaf(y, sc, sh) > 0.f ? dP[(size_t)rp * N + c] : 0.f;
           a1 += dz;
           a2 = __builtin_fmaf(dz, (y - mu) * is, a2);
@@ -1177,7 +1185,7 @@ extern "C" int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float*
 
 extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,
                                 const int* amax, const int* amin, const float* scale_shift,
-                                float* out, int* arg, demf_stream_t stream) {
+                                float* out, int* arg, float* yraw, demf_stream_t stream) {
   DEMF_REQUIRE(Rp >= 0 && C >= 1, "pool_select: bad sizes");
   if (Rp == 0) return DEMF_OK;
   DEMF_REQUIRE(pmax && pmin && amax && amin && scale_shift && out && arg, "pool_select: null pointer");
@@ -1185,7 +1193,7 @@ extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* p
   long long g = (RC + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(pool_select_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, RC, C, pmax,
-                     pmin, amax, amin, scale_shift, out, arg);
+                     pmin, amax, amin, scale_shift, out, arg, yraw);
   return check_launch("pool_select");
 }
 
@@ -1217,8 +1225,9 @@ extern "C" int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y,
 }
 
 extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP,
-                                  const int* arg, const float* Y, const float* scale_shift,
-                                  const float* mean_invstd, double* g12, demf_stream_t stream) {
+                                  const int* arg, const float* Y, const float* yraw,
+                                  const float* scale_shift, const float* mean_invstd, double* g12,
+                                  demf_stream_t stream) {
   DEMF_REQUIRE(R >= 0 && N >= 1, "bn_bwd_reduce: bad sizes R=%d N=%d", R, N);
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
@@ -1241,10 +1250,10 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
   if (grid < 1) grid = 1;
   if (G)
     hipLaunchKernelGGL((bn_bwd_reduce_k<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12);
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, nullptr);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_k<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12);
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, yraw);
   return check_launch("bn_bwd_reduce");
 }
 

@@ -643,14 +643,19 @@ class _SharedMLPPool(Function):
         C = Ys[-1].shape[1]
         out = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
         arg = torch.empty((R // ns, C), dtype=torch.int32, device=dev)
+        yraw = None
         if fuse_pool:
+            # + the raw output at the selected rows: the sparse BN-backward reduce reads it
+            # instead of gathering 2 M scattered values from the (R x C) output
+            yraw = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
             _ffi.call("demf_pool_select", R // ns, C, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]),
-                      _p(sss[-1]), _p(out), _p(arg), st)
+                      _p(sss[-1]), _p(out), _p(arg), _p(yraw), st)
         else:
             _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
                       _p(arg), st)
         ctx.save_for_backward(x, arg, *Ys, *sss, *mis, *[tensors[7 * l] for l in range(L)],
-                              *[tensors[7 * l + 1] for l in range(L)])
+                              *[tensors[7 * l + 1] for l in range(L)],
+                              *([yraw] if yraw is not None else []))
         ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
@@ -670,6 +675,7 @@ class _SharedMLPPool(Function):
         x, arg = saved[0], saved[1]
         Ys, sss, mis = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]
         Ws, gammas = saved[2 + 3 * L:2 + 4 * L], saved[2 + 4 * L:2 + 5 * L]
+        yraw = saved[2 + 5 * L] if len(saved) > 2 + 5 * L else None
         dev, st = x.device, _stream()
         dP = grad_out.contiguous()
         G = None
@@ -697,8 +703,8 @@ class _SharedMLPPool(Function):
                 g12 = ws64[o64:o64 + 2 * N]
                 o64 += 2 * N
                 _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
-                          _p(arg if G is None else None), _p(Ys[l]), _p(sss[l]), _p(mis[l]), _p(g12),
-                          st)
+                          _p(arg if G is None else None), _p(Ys[l]),
+                          _p(yraw if G is None else None), _p(sss[l]), _p(mis[l]), _p(g12), st)
             vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
             dgamma = torch.empty(N, dtype=torch.float32, device=dev)
             dbeta = torch.empty(N, dtype=torch.float32, device=dev)

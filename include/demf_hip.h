@@ -233,9 +233,10 @@ int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float* X,
                            int ns, float* pmax, float* pmin, int* amax, int* amin,
                            demf_stream_t stream);
 
-/* out (Rp,C) = relu(scale*y*+shift), arg = row offset of y* (see demf_mlp_gemm_fwd_pool). */
+/* out (Rp,C) = relu(scale*y*+shift), arg = row offset of y* (see demf_mlp_gemm_fwd_pool);
+ * yraw (Rp,C) or NULL = y* itself, which spares demf_bn_bwd_reduce its gather from Y. */
 int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin, const int* amax,
-                     const int* amin, const float* scale_shift, float* out, int* arg,
+                     const int* amin, const float* scale_shift, float* out, int* arg, float* yraw,
                      demf_stream_t stream);
 
 /* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
@@ -253,10 +254,11 @@ int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y, const float* s
 
 /* BatchNorm backward reductions of one layer: g12[0:N] += sum dZ, g12[N:2N] += sum dZ*xhat
  * with dZ = dA * [act'(Y)].  Upstream gradient dA is either dense G (R,N) or, for the pooled
- * last layer, sparse: dP (R/ns,N) routed to slot arg (R/ns,N).                    */
+ * last layer, sparse: dP (R/ns,N) routed to slot arg (R/ns,N); yraw (R/ns,N) or NULL = Y at
+ * those slots (from demf_pool_select), read instead of gathering it.               */
 int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP, const int* arg,
-                       const float* Y, const float* scale_shift, const float* mean_invstd,
-                       double* g12, demf_stream_t stream);
+                       const float* Y, const float* yraw, const float* scale_shift,
+                       const float* mean_invstd, double* g12, demf_stream_t stream);
 
 /* g12 -> the five per-channel vectors the backward GEMM prologues consume (vec6: 5N floats:
  * scale, shift, gi = gamma*invstd, a, b with dY = gi*dZ + a*y + b) + dgamma, dbeta.  The

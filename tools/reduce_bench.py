@@ -9,12 +9,12 @@ for R, N in ((1048576, 64), (1048576, 128), (262144, 128), (262144, 256)):
     g12 = torch.zeros(2 * N, dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
-        _ffi.call("demf_bn_bwd_reduce", R, N, 1, p(G), None, None, p(Y), p(ss), p(mi), p(g12), st)
+        _ffi.call("demf_bn_bwd_reduce", R, N, 1, p(G), None, None, p(Y), None, p(ss), p(mi), p(g12), st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        _ffi.call("demf_bn_bwd_reduce", R, N, 1, p(G), None, None, p(Y), p(ss), p(mi), p(g12), st)
+        _ffi.call("demf_bn_bwd_reduce", R, N, 1, p(G), None, None, p(Y), None, p(ss), p(mi), p(g12), st)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     print(f"R={R} N={N}: {us:.1f} us  {2*R*N*4/us/1e3:.0f} GB/s")
