@@ -47,17 +47,27 @@ def rotation_z(angle):
 
 
 def augment_3d(points, boxes, meta, rng, flip_ratio=0.5, rot_range=(-np.pi / 6, np.pi / 6),
-               scale_range=(0.85, 1.15), translation_std=(0.0, 0.0, 0.0), sync_2d=True):
+               scale_range=(0.85, 1.15), translation_std=(0.0, 0.0, 0.0), sync_2d=False):
     """RandomFlip3D(sync_2d, flip_ratio_bev_horizontal) + GlobalRotScaleTrans (demf_votenet.py:
     198-206) on depth-coordinate points (N,>=3) and boxes (n,7); returns the augmented copies and
     ``meta`` extended with the fields the head's inverse reads: ``flip``, ``pcd_horizontal_flip``,
-    ``pcd_rotation``, ``pcd_scale_factor``, ``pcd_trans``, ``transformation_3d_flow``."""
+    ``pcd_rotation``, ``pcd_scale_factor``, ``pcd_trans``, ``transformation_3d_flow``.
+
+    Box yaw follows mmdet3d 0.18.1's depth convention (the one ``geometry.DepthBoxes.points_in_boxes``
+    and the head's target kernels use): ``DepthInstance3DBoxes.rotate`` turns the centres by +angle
+    and does ``yaw -= angle``; ``flip('horizontal')`` does ``yaw = pi - yaw``.  ``sync_2d`` defaults to
+    False as in the reference config (RandomFlip3D(sync_2d=False), image flip_ratio 0.0,
+    demf_votenet.py:198-202): the image is NOT mirrored with the cloud, so ``meta['flip']`` stays
+    whatever the 2-D pipeline wrote.  With ``sync_2d=True`` the caller must mirror the image (or its
+    feature pyramid) itself when ``meta['flip']`` comes back True."""
     pts, bx = points.copy(), boxes.copy()
     meta = dict(meta)
     flow = []
     flip = bool(rng.random() < flip_ratio)
     if sync_2d:
-        meta["flip"] = flip                      # the image is mirrored together with the cloud
+        meta["flip"] = flip                      # the caller mirrors the image together with the cloud
+    else:
+        meta.setdefault("flip", False)
     meta["pcd_horizontal_flip"] = flip
     meta["pcd_vertical_flip"] = False
     if flip:                                     # DepthPoints.flip('horizontal'): x -> -x
@@ -69,7 +79,7 @@ def augment_3d(points, boxes, meta, rng, flip_ratio=0.5, rot_range=(-np.pi / 6, 
     rot_t = rotation_z(angle).T                   # p @ rot_t rotates by +angle
     pts[:, :3] = pts[:, :3] @ rot_t
     bx[:, :3] = bx[:, :3] @ rot_t
-    bx[:, 6] += angle
+    bx[:, 6] -= angle                             # DepthInstance3DBoxes.rotate (0.18.1)
     meta["pcd_rotation"] = rot_t.astype(np.float32)
     flow.append("R")
     scale = rng.uniform(*scale_range)
@@ -106,10 +116,28 @@ def resize_meta(meta, ori_shape, img_scale, pad_divisor=32):
 
 
 def remap_checkpoint(state_dict):
-    """Released DeMF checkpoints keep the whole detector under mmdet3d names; the trainable hot path
-    of this package uses the same names for ``pts_backbone.*`` and ``pts_bbox_head.*`` and
-    ``img_backbone.* / img_neck.* / img_encoder.*`` for demf_amd.modules.ImageStream.  Returns
-    (hot_path_state, image_stream_state) split by prefix."""
-    hot = {k: v for k, v in state_dict.items() if k.startswith(("pts_backbone.", "pts_bbox_head."))}
-    img = {k: v for k, v in state_dict.items() if k.startswith(("img_backbone.", "img_neck.", "img_encoder."))}
+    """``DeMFVoteNet._load_from_state_dict`` (demf/modeling/detectors/demfnet.py:85-101) as a pure
+    function: a stage-1 checkpoint (the Deformable-DETR image detector of configs/deformdetr/*)
+    carries the image encoder under ``img_bbox_head.transformer.encoder.*`` and
+    ``img_bbox_head.transformer.level_embeds``; those keys move to ``img_encoder.*`` and EVERY other
+    ``img_bbox_head.*`` key (decoder, fc_cls, reg branches, query embedding ...) is dropped.  All
+    other keys pass through unchanged (``pts_backbone.* / pts_bbox_head.* / img_backbone.* /
+    img_neck.* / img_encoder.*`` use the reference's names in this package).  Like the reference the
+    test is a substring test on the whole key.  -> new dict (the input is not modified)."""
+    out = {}
+    for key, v in state_dict.items():
+        if not key.startswith("img_bbox_head"):
+            out[key] = v
+        elif "encoder" in key or "level_embeds" in key:
+            out[key.replace("img_bbox_head.transformer", "img_encoder")] = v
+    return out
+
+
+def split_checkpoint(state_dict):
+    """remap_checkpoint + split by consumer: (hot-path state for ``DeMFHotPath`` - ``pts_backbone.*``
+    / ``pts_bbox_head.*`` -, image-stream state for ``ImageStream`` - ``img_backbone.* / img_neck.* /
+    img_encoder.*``)."""
+    sd = remap_checkpoint(state_dict)
+    hot = {k: v for k, v in sd.items() if k.startswith(("pts_backbone.", "pts_bbox_head."))}
+    img = {k: v for k, v in sd.items() if k.startswith(("img_backbone.", "img_neck.", "img_encoder."))}
     return hot, img

@@ -119,15 +119,49 @@ class FlatAdamW:
                 p.data = self.flat[off:off + k].view_as(p)
                 off += k
             self.segments.append((start, off - start, float(g["lr"]), float(g["weight_decay"])))
+        self.params = params
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.betas, self.eps, self.t = betas, eps, 0
+        self.lr_factor = 1.0
+
+    def set_lr_factor(self, factor):
+        """Multiplies every group's base learning rate (the reference's step schedule:
+        lr_config step=[24, 32], x0.1 each - configs/_base_/schedules/schedule_3x.py:7-9)."""
+        self.lr_factor = float(factor)
+
+    def check_aliasing(self):
+        """Every parameter must still be a view of the flat buffer: ``model.to()`` / ``.float()`` /
+        ``.half()`` after the optimizer was built re-allocates ``p.data`` and would silently detach
+        the parameter from the update."""
+        lo = self.flat.data_ptr()
+        hi = lo + 4 * self.flat.numel()
+        for p in self.params:
+            if not (lo <= p.data_ptr() < hi):
+                raise RuntimeError("a parameter no longer lives in FlatAdamW's flat buffer (was the "
+                                   "model moved or cast after the Trainer was built?)")
+
+    def state_dict(self):
+        """Moments + step count + lr factor (resume: mmcv CheckpointHook saves the optimizer too)."""
+        return dict(exp_avg=self.exp_avg.clone(), exp_avg_sq=self.exp_avg_sq.clone(), t=self.t,
+                    lr_factor=self.lr_factor, numel=self.flat.numel())
+
+    def load_state_dict(self, sd):
+        if int(sd["numel"]) != self.flat.numel():
+            raise ValueError("optimizer state is for %d parameters, this model has %d"
+                             % (int(sd["numel"]), self.flat.numel()))
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.t = int(sd["t"])
+        self.lr_factor = float(sd.get("lr_factor", 1.0))
 
     def step(self, grad_norm=None, max_norm=0.0, grad_scale=1.0):
         from . import _ffi
+        self.check_aliasing()
         self.t += 1
         stream = torch.cuda.current_stream().cuda_stream
         for start, n, lr, wd in self.segments:
+            lr = lr * self.lr_factor
             o = 4 * start
             _ffi.call("demf_adamw_f32", n, self.flat.data_ptr() + o, self.grads.data_ptr() + o,
                       self.exp_avg.data_ptr() + o, self.exp_avg_sq.data_ptr() + o,
@@ -153,6 +187,27 @@ class Trainer:
         self.fused = self.flat.flat.is_cuda
         self.opt = FlatAdamW(groups, self.flat) if self.fused else \
             torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, foreach=True)
+        self._base_lrs = [float(g["lr"]) for g in groups]
+
+    def set_epoch(self, epoch, steps=(24, 32), gamma=0.1):
+        """The reference's step schedule (configs/_base_/schedules/schedule_3x.py:7-9:
+        lr_config = dict(policy='step', step=[24, 32]), 36 epochs): lr x gamma at each milestone."""
+        factor = gamma ** sum(1 for s in steps if epoch >= s)
+        if self.fused:
+            self.opt.set_lr_factor(factor)
+        else:
+            for g, base in zip(self.opt.param_groups, self._base_lrs):
+                g["lr"] = base * factor
+        return factor
+
+    def state_dict(self):
+        """Model + optimizer state for resume (mmcv CheckpointHook, cfg:280)."""
+        return dict(model=self.model.state_dict(), optimizer=self.opt.state_dict())
+
+    def load_state_dict(self, sd):
+        # copies INTO the existing (flat-buffer-resident) parameters: the views stay intact
+        self.model.load_state_dict(sd["model"])
+        self.opt.load_state_dict(sd["optimizer"])
 
     def _fwd(self, batch, geometry=None):
         kw = {} if geometry is None else dict(geometry=geometry)
@@ -241,6 +296,9 @@ class Trainer:
                                     if isinstance(feats, dict) else [f.clone() for f in feats]),
                       img_metas=batch["img_metas"], gt_bboxes_3d=gt, gt_labels_3d=lab)
         batch = static
+        head = getattr(self.model, "pts_bbox_head", None)
+        if head is not None and hasattr(head, "pin_metas"):
+            head.pin_metas(static["img_metas"])     # the graph holds raw pointers into its cache entry
         side = self.side_stream if getattr(self, "side_stream", None) is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -288,10 +346,18 @@ class Trainer:
             torch.cuda.synchronize()
         static_flat = flat_tensors(static_geo) if can_prefetch else None
 
+        # which cloud the static geometry buffers / the in-flight pre-pass belong to:
+        # (data_ptr, _version) of the tensor handed in; ``load`` checks it
+        tag = lambda t: (t.data_ptr(), t._version, tuple(t.shape))
+        state = dict(prefetched=None)
+
         def replay(next_points=None):
             main = torch.cuda.current_stream()
             if can_prefetch and next_points is not None:
                 static_pts.copy_(next_points)
+                state["prefetched"] = tag(next_points)
+            elif can_prefetch:
+                state["prefetched"] = None     # the pre-pass below recomputes the CURRENT cloud
             if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
                 graph.replay()
                 if graph_bwd is not None:
@@ -322,7 +388,21 @@ class Trainer:
             return loss
 
         def load(new):
-            """Copy another batch into the static input buffers of the captured step."""
+            """Copy another batch into the static input buffers of the captured step.  The
+            captured forward reads its FPS / ball-query / 3-NN indices from the static geometry
+            buffers: they hold the pre-pass of the cloud given as ``next_points`` to the previous
+            ``replay``; if ``new['points']`` is not that tensor (or nothing was prefetched), the
+            pre-pass is recomputed here for the new cloud, so geometry and targets can never
+            belong to different batches."""
+            if can_prefetch and state["prefetched"] != tag(new["points"]):
+                main = torch.cuda.current_stream()
+                static_pts.copy_(new["points"])
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    geo_graph.replay()
+                main.wait_stream(side)
+                torch._foreach_copy_(static_flat, fresh)
+            state["prefetched"] = None
             static["points"].copy_(new["points"])
             nf = new["img_features"]
             if isinstance(nf, dict):
@@ -337,7 +417,6 @@ class Trainer:
             else:
                 static["gt_bboxes_3d"].copy_(new["gt_bboxes_3d"])
                 static["gt_labels_3d"].copy_(new["gt_labels_3d"])
-            head = getattr(self.model, "pts_bbox_head", None)
             if head is not None and hasattr(head, "refresh_metas"):
                 head.refresh_metas(static["img_metas"], new["img_metas"])
 

@@ -194,13 +194,24 @@ class DeMFVoteHead(nn.Module):
         object; this overwrites them IN PLACE with the constants of ``new_metas`` (same batch size
         and padded image size), so the next replay sees the new batch's calibration / masks."""
         cache = self.__dict__.get("_meta_cache", {})
+        found = False
         for (mid, shapes, dev), entry in list(cache.items()):
             if mid != id(static_metas):
                 continue
+            found = True
             fresh = self._build_meta_tensors(new_metas, shapes, torch.device(dev), entry["M"].dtype)
             for k, v in fresh.items():
                 if torch.is_tensor(v) and torch.is_tensor(entry.get(k)):
                     entry[k].copy_(v)
+        if not found:
+            raise RuntimeError("refresh_metas: no cached device constants for this metas object "
+                               "(it was never used in a forward, or its entry was evicted)")
+
+    def pin_metas(self, img_metas):
+        """Entries of ``img_metas`` are never evicted from the cache: a captured hipGraph holds raw
+        pointers to their tensors (Trainer.capture calls this for its static metas)."""
+        self.__dict__.setdefault("_meta_pinned", set()).add(id(img_metas))
+        self.__dict__.setdefault("_meta_pinned_keep", []).append(img_metas)
 
     def _meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
         """Device-side constants derived from the (host) img_metas, cached per metas object:
@@ -208,10 +219,14 @@ class DeMFVoteHead(nn.Module):
         key = (id(img_metas), tuple(mlvl_shapes), str(dev))
         cache = self.__dict__.setdefault("_meta_cache", {})
         if key not in cache:
-            if len(cache) > 8:
-                cache.clear()
+            pinned = self.__dict__.get("_meta_pinned", ())
+            loose = [k for k in cache if k[0] not in pinned]
+            while len(loose) >= 8:           # LRU over the un-pinned entries (dict keeps use order)
+                del cache[loose.pop(0)]
             cache[key] = self._build_meta_tensors(img_metas, mlvl_shapes, dev, dt)
             cache[key]["keep"] = img_metas   # keep the keyed object alive so its id stays unique
+        else:
+            cache[key] = cache.pop(key)      # most recently used goes last
         return cache[key]
 
     def _build_meta_tensors(self, img_metas, mlvl_shapes, dev, dt):

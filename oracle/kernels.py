@@ -25,10 +25,16 @@ _i64p = ctypes.POINTER(ctypes.c_int64)
 
 def build(force=False):
     """Compile the C oracle with the committed Makefile (gcc, seconds)."""
+    import hashlib
     src = os.path.join(_HERE, "csrc", "demf_oracle.c")
-    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(src)
+    with open(src, "rb") as f, open(os.path.join(_HERE, "Makefile"), "rb") as m:
+        digest = hashlib.sha256(f.read() + m.read()).hexdigest()
+    stamp = _SO + ".sha256"
+    stale = not (os.path.exists(_SO) and os.path.exists(stamp)) or open(stamp).read().strip() != digest
     if force or stale:
         subprocess.run(["make", "-B", "-C", _HERE], check=True, capture_output=True)
+        with open(stamp, "w") as f:
+            f.write(digest)
     return _SO
 
 

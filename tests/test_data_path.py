@@ -48,7 +48,8 @@ def test_augmentation_metadata_is_undone_by_the_projection():
     uv0 = _project(pts, plain)
     flips = 0
     for _ in range(200):
-        apts, abox, meta = data.augment_3d(pts, boxes, base, rng, translation_std=(0.1, 0.1, 0.05))
+        apts, abox, meta = data.augment_3d(pts, boxes, base, rng, translation_std=(0.1, 0.1, 0.05),
+                                            sync_2d=True)
         uv = _project(apts, meta)
         want = uv0.copy()
         if meta["flip"]:                     # mirrored image: u -> (W - u) / (W - 1) in normalised form
@@ -74,10 +75,65 @@ def test_resize_meta_and_sampling():
     assert s.shape == (20000, 4)
 
 
-def test_remap_checkpoint_splits_by_prefix():
-    sd = {"pts_backbone.SA_modules.0.mlps.0.layer0.conv.weight": torch.zeros(1),
-          "pts_bbox_head.decoder.0.layer.norms.0.weight": torch.zeros(1),
-          "img_backbone.conv1.weight": torch.zeros(1), "img_encoder.level_embeds": torch.zeros(1),
-          "img_bbox_head.fc_cls.weight": torch.zeros(1)}
-    hot, img = data.remap_checkpoint(sd)
-    assert len(hot) == 2 and len(img) == 2
+def test_remap_checkpoint_follows_the_reference_rename():
+    """demf/modeling/detectors/demfnet.py:85-101 on a synthetic stage-1 key set: encoder /
+    level_embeds keys of img_bbox_head.transformer move to img_encoder, every other img_bbox_head key
+    is dropped, everything else passes through; the image-stream keys then load into ImageStream."""
+    t = lambda: torch.zeros(1)
+    sd = {"pts_backbone.SA_modules.0.mlps.0.layer0.conv.weight": t(),
+          "pts_bbox_head.decoder.0.layer.norms.0.weight": t(),
+          "img_backbone.conv1.weight": t(), "img_neck.convs.0.conv.weight": t(),
+          "img_bbox_head.transformer.encoder.layers.0.attentions.0.sampling_offsets.weight": t(),
+          "img_bbox_head.transformer.encoder.layers.5.ffns.0.layers.1.bias": t(),
+          "img_bbox_head.transformer.level_embeds": t(),
+          "img_bbox_head.transformer.decoder.layers.0.attentions.0.attn.in_proj_weight": t(),
+          "img_bbox_head.transformer.reference_points.weight": t(),
+          "img_bbox_head.cls_branches.0.weight": t(), "img_bbox_head.query_embedding.weight": t()}
+    keys_before = set(sd)
+    out = data.remap_checkpoint(sd)
+    assert set(sd) == keys_before                                  # input untouched
+    assert set(out) == {
+        "pts_backbone.SA_modules.0.mlps.0.layer0.conv.weight",
+        "pts_bbox_head.decoder.0.layer.norms.0.weight",
+        "img_backbone.conv1.weight", "img_neck.convs.0.conv.weight",
+        "img_encoder.encoder.layers.0.attentions.0.sampling_offsets.weight",
+        "img_encoder.encoder.layers.5.ffns.0.layers.1.bias", "img_encoder.level_embeds"}
+    hot, img = data.split_checkpoint(sd)
+    assert len(hot) == 2 and len(img) == 5
+    # a full stage-1-shaped state: ImageStream's own keys re-homed under img_bbox_head.transformer
+    from demf_amd.modules import ImageStream
+    stream = ImageStream(base=8, blocks=(1, 1, 1, 1), embed_dims=32, num_layers=2, num_heads=4,
+                         feedforward_channels=64, gn_groups=4)
+    stage1 = {}
+    for k, v in stream.state_dict().items():
+        if k.startswith("img_encoder."):
+            k = k.replace("img_encoder", "img_bbox_head.transformer")
+        stage1[k] = torch.full_like(v, 0.5) if v.is_floating_point() else v
+    stage1["img_bbox_head.fc_cls.weight"] = torch.zeros(3)
+    _, img = data.split_checkpoint(stage1)
+    missing, unexpected = stream.load_state_dict(img, strict=True)
+    assert not missing and not unexpected
+    assert float(stream.img_encoder.level_embeds.mean()) == 0.5
+
+
+def test_boxes_follow_their_points_under_augmentation():
+    """Membership of points in (elongated, rotated) boxes is invariant under augment_3d - flip,
+    rotation, scale and translation - with the box convention the target kernels use
+    (geometry.DepthBoxes.points_in_boxes, mmdet3d 0.18.1 depth boxes: rotate => yaw -= angle)."""
+    from demf_amd.geometry import DepthBoxes
+    rng = np.random.default_rng(3)
+    boxes = np.array([[0.2, 3.0, -0.5, 2.4, 0.5, 0.9, 0.3], [-1.0, 2.0, -1.0, 0.4, 1.9, 1.2, -1.1],
+                      [1.2, 4.2, 0.0, 1.0, 1.0, 0.6, 2.5]], np.float32)
+    pts = rng.uniform([-2.5, 0.8, -1.2], [2.5, 5.5, 1.0], size=(6000, 3)).astype(np.float32)
+    inside0 = DepthBoxes(torch.from_numpy(boxes)).points_in_boxes(torch.from_numpy(pts)).numpy()
+    assert inside0.sum(0).min() > 30
+    base = dict(depth2img=synthetic.depth2img())
+    flips = 0
+    for _ in range(50):
+        apts, abox, meta = data.augment_3d(pts, boxes, base, rng, translation_std=(0.1, 0.1, 0.05))
+        flips += meta["pcd_horizontal_flip"]
+        assert meta["flip"] is False          # sync_2d=False as demf_votenet.py:198-202
+        inside = DepthBoxes(torch.from_numpy(abox)).points_in_boxes(torch.from_numpy(apts)).numpy()
+        # fp32 round-off may move a point that sits on a face: allow 0.2 % of the memberships
+        assert (inside != inside0).sum() <= 0.002 * inside0.sum(), (inside != inside0).sum()
+    assert 10 < flips < 40
