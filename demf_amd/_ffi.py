@@ -65,7 +65,40 @@ SIGNATURES = {
     "demf_vote_loss": [_c_int] * 4 + [_c_float] + [_ptr] * 10,
     "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
+    "demf_gemm_f32": [_ptr, _ptr],
+    "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
+    "demf_add_dropout_ln_bwd": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _ptr, _c_int, _ptr, _c_int] + [_ptr] * 4,
+    "demf_softmax_dropout_fwd": [_c_int] * 2 + [_ptr, _c_float, _ptr, _c_int] + [_ptr] * 3,
+    "demf_softmax_dropout_bwd": [_c_int] * 2 + [_ptr, _c_float, _ptr, _c_int] + [_ptr] * 2,
+    "demf_msda_prep_fwd": [_c_int] * 5 + [_ptr] * 10,
+    "demf_msda_prep_bwd": [_c_int] * 5 + [_ptr] * 14,
+    "demf_rng_advance": [_ptr, _ptr],
+    "demf_dropout_mask": [ctypes.c_longlong, _c_float, _ptr, _c_int, _ptr, _ptr],
 }
+
+
+class GemmDesc(ctypes.Structure):
+    """include/demf_hip.h: demf_gemm_desc (field order and types must match)."""
+    _ll = ctypes.c_longlong
+    _fields_ = [
+        ("M", _c_int), ("N", _c_int), ("K", _c_int), ("batch", _c_int), ("zdiv", _c_int),
+        ("splitk", _c_int),
+        ("A", _ptr), ("sam", _ll), ("sak", _ll), ("sab", _ll), ("sab2", _ll),
+        ("A2", _ptr), ("a2_cols", _c_int),
+        ("B", _ptr), ("sbn", _ll), ("sbk", _ll), ("sbb", _ll), ("sbb2", _ll),
+        ("B2", _ptr), ("b2_rows", _c_int),
+        ("C", _ptr), ("scm", _ll), ("scb", _ll), ("scb2", _ll),
+        ("C2", _ptr),
+        ("bias", _ptr), ("sbias_b", _ll),
+        ("rowscale", _ptr), ("srs_m", _ll), ("srs_b", _ll),
+        ("alpha", _c_float),
+        ("flags", _c_int),
+        ("gate", _ptr), ("sgm", _ll), ("sgb", _ll),
+        ("gate_scale", _c_float),
+        ("drop_p", _c_float),
+        ("rng", _ptr),
+        ("op_id", _c_int),
+    ]
 
 _lib = None
 

@@ -1,5 +1,5 @@
 from .coder import DeMFClassAgnosticBBoxCoder
-from .detector import DeMFHotPath, head_kwargs
+from .detector import DeMFHotPath, DeMFVoteNet, head_kwargs
 from .head import DeMFVoteHead
 from .image_stream import ChannelMapper, DeformableDetrEncoder, ImageStream, ResNet50
 from .pointnet2 import PointFPModule, PointNet2SASSG, PointSAModule, build_sa_module
@@ -7,7 +7,7 @@ from .transformer import (DeMFTransformerDecoderLayer, MultiScaleDeformableAtten
                           PositionEmbeddingLearned)
 from .vote import BaseConvBboxHead, VoteModule
 
-__all__ = ["DeMFClassAgnosticBBoxCoder", "DeMFHotPath", "head_kwargs", "DeMFVoteHead",
+__all__ = ["DeMFClassAgnosticBBoxCoder", "DeMFHotPath", "DeMFVoteNet", "head_kwargs", "DeMFVoteHead",
            "PointFPModule", "PointNet2SASSG", "PointSAModule", "build_sa_module",
            "DeMFTransformerDecoderLayer", "MultiScaleDeformableAttention",
            "PositionEmbeddingLearned", "BaseConvBboxHead", "VoteModule", "ImageStream",

@@ -47,12 +47,6 @@ class DeMFHotPath(nn.Module):
                                                               self.pts_bbox_head.num_proposal)
         return geo
 
-    def _side_streams(self, device):
-        ss = self.__dict__.setdefault("_streams", {})
-        if str(device) not in ss:
-            ss[str(device)] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
-        return ss[str(device)]
-
     def forward_head(self, points, img_features, img_metas, image_inputs=None, geometry=None):
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)                                    # demfnet.py:150
@@ -64,45 +58,15 @@ class DeMFHotPath(nn.Module):
         return self.pts_bbox_head(feat_dict, self.cfg.head.sample_mod, img_dict)  # :165
 
     def forward_train(self, points, img_features, img_metas, gt_bboxes_3d, gt_labels_3d,
-                      overlap=False, geometry=None):
+                      geometry=None):
         """-> dict of losses (demfnet.py:134-170 with the image pyramid precomputed).
-
-        ``overlap=True``: the point stream starts with furthest-point sampling, which keeps 8 of
-        the 256 CUs busy for milliseconds; everything that does not depend on it - flattening /
-        masking / value-projecting the image tokens, and the per-point vote targets - is issued
-        on two side HIP streams.  Measured (profiles/, round 1): inside a captured hipGraph the
-        ROCm 7.2 runtime replays the forked branches serially (no kernel starts inside the FPS
-        launch) and the joins cost ~3 ms of idle, so the default is off until the step is
-        replayed as separate per-stream graphs."""
+        ``geometry``: the coordinate-only pre-pass (``index_geometry``) when it was computed ahead
+        of the step (engine.Trainer pipelines it under the previous step's backward)."""
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)
-        head = self.pts_bbox_head
-        if not (overlap and points.is_cuda):
-            bbox_preds = self.forward_head(points, img_features, img_metas, geometry=geometry)
-            return head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None, img_metas)
-        main = torch.cuda.current_stream()
-        s_img, s_tgt = self._side_streams(points.device)
-        s_img.wait_stream(main)
-        s_tgt.wait_stream(main)
-        with torch.cuda.stream(s_img):
-            image_inputs = head.prepare_image_inputs(img_features, img_metas)
-        with torch.cuda.stream(s_tgt):
-            vote_pack = head.vote_targets(points, gt_bboxes_3d, gt_labels_3d)
-        seeds_3d, seed_3d_features, seed_indices = self.extract_pts_feat(points)
-        main.wait_stream(s_img)
-        for t in [image_inputs["feat_flatten"], image_inputs["mask_flatten"],
-                  image_inputs["valid_ratios"], *(image_inputs["value_projected"] or []),
-                  *(image_inputs["value_tokens"] or [])]:
-            t.record_stream(main)
-        feat_dict = dict(seed_points=seeds_3d, seed_features=seed_3d_features,
-                         seed_indices=seed_indices)
-        img_dict = dict(img_features=img_features, img_metas=img_metas, image_inputs=image_inputs)
-        bbox_preds = head(feat_dict, self.cfg.head.sample_mod, img_dict)     # :165
-        main.wait_stream(s_tgt)
-        for t in vote_pack.values():
-            t.record_stream(main)
-        return head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None, img_metas,
-                         vote_pack=vote_pack)                                # :167
+        bbox_preds = self.forward_head(points, img_features, img_metas, geometry=geometry)
+        return self.pts_bbox_head.loss(bbox_preds, points, gt_bboxes_3d, gt_labels_3d, None, None,
+                                       img_metas)                            # :167
 
     def param_groups(self, lr=0.008, weight_decay=0.01):
         """AdamW groups of demf_votenet.py:16-24: 'decoder' params at lr*0.05."""
@@ -112,3 +76,84 @@ class DeMFHotPath(nn.Module):
                 (dec if "decoder" in n else rest).append(p)
         return [dict(params=rest, lr=lr, weight_decay=weight_decay),
                 dict(params=dec, lr=lr * 0.05, weight_decay=weight_decay)]
+
+
+class DeMFVoteNet(DeMFHotPath):
+    """The whole detector with the reference's entry points
+    (demf/modeling/detectors/demfnet.py:12-283): the trainable hot path above plus the frozen
+    image stream under the reference's attribute names (``img_backbone``, ``img_neck``,
+    ``img_encoder``), so a released checkpoint - or a stage-1 image checkpoint through the key
+    remap of :85-101 - loads with ``load_state_dict``.
+
+      forward_train(points, img, img_metas, gt_bboxes_3d, gt_labels_3d) -> dict of losses  (:134-170)
+      simple_test(points, img_metas, img) -> list of dict(boxes_3d, scores_3d, labels_3d)  (:254-283)
+      forward_test(points, img_metas, img)  (single-augmentation form of :172-238)
+    """
+
+    def __init__(self, cfg: DeMFCfg = None, image_stream=None, **image_stream_kwargs):
+        super().__init__(cfg)
+        from .image_stream import ImageStream
+        stream = image_stream if image_stream is not None else ImageStream(**image_stream_kwargs)
+        self.img_backbone, self.img_neck = stream.img_backbone, stream.img_neck
+        self.img_encoder = stream.img_encoder
+        self.freeze_img_branch_params()
+
+    def freeze_img_branch_params(self):                                     # :103-112
+        for m in (self.img_backbone, self.img_neck, self.img_encoder):
+            for p in m.parameters():
+                p.requires_grad_(False)
+
+    def train(self, mode=True):                                              # :114-122
+        super().train(mode)
+        for m in (self.img_backbone, self.img_neck, self.img_encoder):
+            m.eval()
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """+ the stage-1 key remap of ``_load_from_state_dict`` (:85-101)."""
+        from ..data import remap_checkpoint
+        return super().load_state_dict(remap_checkpoint(state_dict), strict=strict, **kw)
+
+    @torch.no_grad()
+    def extract_img_feat(self, img, img_metas):                             # :124-132
+        """-> the channels-last token form of the 4-level pyramid (dict(tokens (B,S,C), spatial,
+        ...)): what this package's head consumes without the flatten copy (:570-591).
+        ``self.img_encoder(feats, img_metas)`` gives the reference's list of NCHW maps."""
+        return self.img_encoder.forward_tokens(self.img_neck(self.img_backbone(img)), img_metas)
+
+    def forward_train(self, points=None, img=None, img_metas=None, gt_bboxes_3d=None,
+                      gt_labels_3d=None, **unused):
+        img_features = self.extract_img_feat(img, img_metas)               # :148
+        return super().forward_train(points, img_features, img_metas, gt_bboxes_3d, gt_labels_3d)
+
+    @torch.no_grad()
+    def simple_test(self, points=None, img_metas=None, img=None, bboxes_2d=None, rescale=False,
+                    **unused):
+        img_features = self.extract_img_feat(img, img_metas)               # :260
+        if isinstance(points, (list, tuple)):
+            points = torch.stack(points)                                    # :262
+        bbox_preds = self.forward_head(points, img_features, img_metas)    # :263-275
+        bbox_list = self.pts_bbox_head.get_bboxes(points, bbox_preds, img_metas, rescale=rescale)
+        return [bbox3d2result(b, s, l) for b, s, l in bbox_list]           # :278-282
+
+    def forward_test(self, points=None, img_metas=None, img=None, bboxes_2d=None, **kwargs):
+        """:172-238 for one augmentation (the only form the reference implements for points +
+        image): ``points`` / ``img_metas`` / ``img`` are lists over augmentations."""
+        for var, name in ((points, "points"), (img_metas, "img_metas")):
+            if not isinstance(var, list):
+                raise TypeError("{} must be a list, but got {}".format(name, type(var)))
+        if len(points) != len(img_metas):
+            raise ValueError("num of augmentations ({}) != num of image meta ({})".format(
+                len(points), len(img_metas)))
+        if len(points) != 1:
+            raise NotImplementedError("aug_test is not implemented by the reference either (:240-252)")
+        for _img, metas in zip(img, img_metas):                             # :180-183
+            for m in metas:
+                m["batch_input_shape"] = tuple(_img.shape[-2:])
+        return self.simple_test(points[0], img_metas[0], img[0],
+                                bboxes_2d=bboxes_2d[0] if bboxes_2d is not None else None, **kwargs)
+
+
+def bbox3d2result(bboxes, scores, labels):
+    """mmdet3d.core.bbox3d2result: results to host memory."""
+    return dict(boxes_3d=bboxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu())

@@ -423,6 +423,88 @@ int demf_adamw_f32(long long n, float* param, const float* grad, float* exp_avg,
                    const float* grad_norm, float max_norm, float grad_scale, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, demf_stream_t stream);
 
+/* ------------------------------------------------------------------ *
+ * Dense blocks of the DeMF fusion decoder layer (csrc/dense.hip)
+ * Reference: demf/modeling/layers/transformer.py:55-80 -> mmcv DetrTransformerDecoderLayer
+ * (nn.MultiheadAttention, MultiScaleDeformableAttention, FFN, 3 x LayerNorm; cfg
+ * configs/demf/demf_votenet.py:71-91).  Upstream reaches cuBLAS / ATen for these; here they are
+ * one strided GEMM with fused prologue / epilogue and a few row kernels.
+ * ------------------------------------------------------------------ */
+
+#define DEMF_GEMM_RELU 1      /* v = max(v, 0) after the bias                                  */
+#define DEMF_GEMM_DROPOUT 2   /* v *= keep / (1 - drop_p), counter-based mask (rng, op_id)      */
+#define DEMF_GEMM_GATE 4      /* v = gate[m,n] != 0 ? v * gate_scale : 0  (ReLU+dropout bwd)    */
+#define DEMF_GEMM_ACCUM 8     /* C += v (split-K always accumulates, atomically, into zeroed C) */
+#define DEMF_GEMM_ROWBIAS 16  /* bias term = bias[n] * rowscale[m]                              */
+#define DEMF_GEMM_ACCUM2 32   /* C2 += v instead of C2 = v                                      */
+
+/* C[m,n] (+)= epi( alpha * sum_k (A[m,k] + A2[m,k]) * (B[n,k] + B2[n,k]) + bias[n] ), all operands
+ * fp32 and addressed by element strides: A[m,k] at A + m*sam + k*sak, B[n,k] at B + n*sbn + k*sbk,
+ * C[m,n] at C + m*scm + n.  Batched over z = zo*zdiv + zi in [0,batch): operand offsets
+ * zo*s?b + zi*s?b2.  A2 (same strides as A) is added for blocks whose first column < a2_cols,
+ * B2 (same strides as B) for blocks whose first row < b2_rows.  splitk > 1 splits K over blocks.
+ * C2 (same strides as C): optional second destination of the same values.
+ * HOST struct; every pointer inside is a device pointer.                                      */
+typedef struct demf_gemm_desc {
+  int M, N, K, batch, zdiv, splitk;
+  const float* A; long long sam, sak, sab, sab2;
+  const float* A2; int a2_cols;
+  const float* B; long long sbn, sbk, sbb, sbb2;
+  const float* B2; int b2_rows;
+  float* C; long long scm, scb, scb2;
+  float* C2;
+  const float* bias; long long sbias_b;          /* bias[n + z*sbias_b]                  */
+  const float* rowscale; long long srs_m, srs_b; /* rowscale[m*srs_m + z*srs_b]          */
+  float alpha;
+  int flags;
+  const float* gate; long long sgm, sgb;         /* gate[z*sgb + m*sgm + n]              */
+  float gate_scale;
+  float drop_p;
+  const void* rng;                                /* 2 x uint64: seed, step counter       */
+  int op_id;
+} demf_gemm_desc;
+
+int demf_gemm_f32(const demf_gemm_desc* desc, demf_stream_t stream);
+
+/* s = identity + dropout(x) ; y = LayerNorm(s) over rows of C channels (C in 64..1024, power of two
+ * multiples of 64).  s_out may alias x; stats (R,2) = mean, rstd.  nn.LayerNorm + the
+ * `identity + dropout(out)` tails of mmcv MultiheadAttention / MultiScaleDeformableAttention / FFN. */
+int demf_add_dropout_ln_fwd(int R, int C, const float* x, const float* identity, const float* gamma,
+                            const float* beta, float eps, float p, const void* rng, int op_id,
+                            float* s_out, float* y, float* stats, demf_stream_t stream);
+/* backward of the above for dy (+ dy2): ds_out (=/+= per ds_accum) the gradient of s (residual
+ * path), dx_out = ds * keep/(1-p) the gradient of x, dgamma / dbeta ACCUMULATED (atomics).        */
+int demf_add_dropout_ln_bwd(int R, int C, const float* dy, const float* dy2, const float* s,
+                            const float* stats, const float* gamma, float p, const void* rng, int op_id,
+                            float* ds_out, int ds_accum, float* dx_out, float* dgamma, float* dbeta,
+                            demf_stream_t stream);
+/* prob = softmax(scores) over rows of S keys, out = dropout(prob): nn.MultiheadAttention's core. */
+int demf_softmax_dropout_fwd(int R, int S, const float* scores, float p, const void* rng, int op_id,
+                             float* prob, float* out, demf_stream_t stream);
+/* in place: dio (gradient of `out`) -> gradient of `scores`.                                     */
+int demf_softmax_dropout_bwd(int R, int S, const float* prob, float p, const void* rng, int op_id,
+                             float* dio, demf_stream_t stream);
+/* Sampling locations + attention weights of the fusion attention from the raw projection
+ * raw (R, H*L*P*3) = [offsets (H,L,P,2) | logits (H,L*P)] and the query points pts (R,3):
+ * DeMFVoteHead.get_reference_points (class_agnostic_vote_head.py:524-547; M (B,4,4) and
+ * ab (B,4) = (au,bu,av,bv) composed on the host), x valid ratios (transformer.py:62-68),
+ * + offsets / (W_l,H_l), softmax over L*P (mmcv MultiScaleDeformableAttention.forward).
+ * -> loc (R,H,L,P,2), w (R,H,L,P), uvw (R,4) kept for the backward.  R = B*Q, L*P <= 16.       */
+int demf_msda_prep_fwd(int R, int Q, int H, int L, int P, const float* pts, const float* M,
+                       const float* ab, const float* valid_ratios, const int64_t* shapes,
+                       const float* raw, float* loc, float* w, float* uvw, demf_stream_t stream);
+/* backward: (dloc + dloc2, dw + dw2) -> draw (R, H*L*P*3), dpts (R,3) or NULL.                   */
+int demf_msda_prep_bwd(int R, int Q, int H, int L, int P, const float* pts, const float* M,
+                       const float* ab, const float* valid_ratios, const int64_t* shapes,
+                       const float* w, const float* uvw, const float* dloc, const float* dloc2,
+                       const float* dw, const float* dw2, float* draw, float* dpts,
+                       demf_stream_t stream);
+/* rng[1] += 1: one per training step (a captured graph then draws fresh masks at every replay). */
+int demf_rng_advance(void* rng, demf_stream_t stream);
+/* out[i] = keep(i) / (1-p): the mask the fused kernels apply for (rng, op_id) - test hook.       */
+int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* out,
+                      demf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

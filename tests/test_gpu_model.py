@@ -1,15 +1,17 @@
 """GPU parity of the whole hot path (demf_amd.modules on libdemf_hip.so) against
 (1) golden vectors from the REAL reference head (tests/golden/ref_head_*.npz) and
-(2) the CPU oracle (oracle/model.py) at growing sizes up to the full reference config.
-Tolerance: 1e-4 (north-star), indices bit-exact."""
+(2) the CPU oracle (oracle/model.py) at growing sizes up to the full reference config at B=8.
+Forward: 1e-4 (north-star) up to the vote stage, fp32 noise floor beyond; indices bit-exact.
+Gradients: EVERY tensor within a stated bound of the fp64 oracle on ONE input per case, chosen by
+the oracle alone (tests/parity_tools.py: discrete-event margins) - no retry."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
+import parity_tools as P
 from oracle import fixtures
-from oracle.model import OracleDeMF
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +59,23 @@ def test_hot_path_vs_real_reference_goldens(name, seed, B, n_gt, golden_dir):
             if k.startswith("_"):       # private handles for the fused loss kernel
                 continue
             _close_to_gold(v.detach().cpu().numpy(), gold[f"decode{i}.{k}"], f"decode{i}.{k}")
-    losses = model.pts_bbox_head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
+    # the training targets the HIP kernels build (demf_vote_targets / demf_proposal_targets)
+    # against the REAL reference's get_targets (class_agnostic_vote_head.py:756-941)
+    head = model.pts_bbox_head
+    with torch.no_grad():
+        tg = head.get_targets(points, gb, gl, {k: v for k, v in preds.items() if k != "decode_res_all"})
+    names = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
+             "mask_targets", "objectness_targets", "objectness_weights", "box_loss_weights",
+             "distance_targets", "dir_targets", "size_targets", "center_targets")
+    for n, t in zip(names, tg):
+        want = gold["target." + n]
+        got = t.cpu().numpy()
+        if want.dtype.kind in "iu":
+            np.testing.assert_array_equal(got, want, err_msg="target." + n)
+        else:
+            # real-valued targets are functions of the aggregated points (1e-4 parity above)
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4, err_msg="target." + n)
+    losses = head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
     total = losses.pop("_total")            # what a training loop differentiates
     for k, v in losses.items():
         np.testing.assert_allclose(v.item(), gold["loss." + k], rtol=5e-4, err_msg=k)
@@ -78,63 +96,20 @@ def test_hot_path_vs_real_reference_goldens(name, seed, B, n_gt, golden_dir):
                    "grad " + small, tol=2e-3)
 
 
-def _ball_margin(xyz, center, r):
-    d2 = ((xyz[:, None, :, :].astype(np.float64) - center[:, :, None, :].astype(np.float64)) ** 2).sum(-1)
-    return np.abs(d2 - r * r).min() / (r * r)
-
-
-def _oracle_run(cfg, batch, gtb, gtl, seed, dtype):
-    ref = OracleDeMF(cfg)
-    fixtures.seed_weights(ref, seed)
-    ref.train().to(dtype)
-    pts = torch.from_numpy(batch["points"]).to(dtype)
-    feats = [torch.from_numpy(f).to(dtype) for f in batch["img_features"]]
-    losses, preds, _ = ref.forward_train(pts, feats, batch["img_metas"],
-                                         [torch.from_numpy(b).to(dtype) for b in gtb],
-                                         [torch.from_numpy(l) for l in gtl])
-    sum(losses.values()).backward()
-    return dict(model=ref, preds=preds, losses=losses)
-
-
-def _run_triple(cfg, B, N, pyramid, in_shape, img_shape, seed):
-    """fp64 CPU oracle (truth), fp32 CPU oracle (the reference-precision path) and the HIP
-    path on identical inputs / weights."""
+def _gpu_run(cfg, case):
     from demf_amd.modules import DeMFHotPath
-    batch = fixtures.make_scene_batch(B, N, pyramid, in_shape, cfg.head.embed_dims, seed=seed,
-                                      n_gt=5, img_shape=img_shape)
-    probe = OracleDeMF(cfg)
-    fixtures.seed_weights(probe, seed)
-    probe.train()
-    with torch.no_grad():
-        p0 = probe.forward_head(torch.from_numpy(batch["points"]),
-                                [torch.from_numpy(f) for f in batch["img_features"]],
-                                batch["img_metas"])
-    margin = _ball_margin(p0["vote_points"].numpy(), p0["aggregated_points"].numpy(),
-                          cfg.head.agg_radius)
-    if margin < 1e-5:
-        return None
-    # GT boxes: seeded in-room boxes + boxes dropped on a few proposals (so positives exist)
-    agg = p0["aggregated_points"].numpy()
-    rng = np.random.default_rng(seed)
-    gtb, gtl = [], []
-    ne = 3
-    for b in range(B):
-        pick = rng.choice(agg.shape[1], ne, replace=False)
-        dims = rng.uniform(0.6, 1.4, size=(ne, 3))
-        ctr = agg[b, pick] + rng.normal(0, 0.04, size=(ne, 3))
-        extra = np.concatenate([ctr - [0, 0, 1] * dims * 0.5, dims, rng.uniform(-3, 3, (ne, 1))], 1)
-        gtb.append(np.concatenate([batch["gt_boxes"][b], extra.astype(np.float32)], 0))
-        gtl.append(np.concatenate([batch["gt_labels"][b], rng.integers(0, 10, ne)]))
-    truth = _oracle_run(cfg, batch, gtb, gtl, seed, torch.float64)
-    cpu32 = _oracle_run(cfg, batch, gtb, gtl, seed, torch.float32)
     model = DeMFHotPath(cfg)
-    fixtures.seed_weights(model, seed)
+    fixtures.seed_weights(model, case["seed"])
     model.cuda().train()
-    points, f_d, gb, gl = _to_dev(batch, gtb, gtl)
-    preds = model.forward_head(points, f_d, batch["img_metas"])
-    losses = model.pts_bbox_head.loss(preds, points, gb, gl, None, None, batch["img_metas"])
+    points, f_d, gb, gl = _to_dev(case["batch"], case["gtb"], case["gtl"])
+    preds = model.forward_head(points, f_d, case["batch"]["img_metas"])
+    head = model.pts_bbox_head
+    with torch.no_grad():
+        tg = head.get_targets(points, gb, gl, {k: v for k, v in preds.items() if k != "decode_res_all"})
+    losses = head.loss(preds, points, gb, gl, None, None, case["batch"]["img_metas"])
     losses.pop("_total").backward()
-    return dict(truth=truth, cpu32=cpu32, gpu=dict(model=model, preds=preds, losses=losses))
+    grads = {n: p.grad.detach() for n, p in model.named_parameters() if p.grad is not None}
+    return dict(preds=preds, losses=losses, grads=grads, targets=tg)
 
 
 def _err(x, t):
@@ -149,8 +124,16 @@ def _check(name, e_gpu, e_cpu, scale, floor=2e-4, cap=2e-2):
     assert e_gpu <= cap * scale, f"{name}: gpu err {e_gpu:.2e} vs scale {scale:.2f}"
 
 
-def _compare(r):
-    T, C, G = r["truth"], r["cpu32"], r["gpu"]
+TARGET_NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
+                "mask_targets", "objectness_targets", "objectness_weights", "box_loss_weights",
+                "distance_targets", "dir_targets", "size_targets", "center_targets")
+
+
+def _parity(cfg, B, N, pyramid, in_shape, img_shape, seeds):
+    """One input (the first seed of ``seeds`` that the oracle qualifies), every check, no retry."""
+    case = P.qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=seeds)
+    T, C = case["truth"], case["cpu32"]
+    G = _gpu_run(cfg, case)
     for k in ("seed_indices", "aggregated_indices"):
         np.testing.assert_array_equal(G["preds"][k].cpu().numpy(), T["preds"][k].numpy())
     # up to the vote stage the arithmetic is shallow: hold the north-star 1e-4 outright
@@ -162,98 +145,64 @@ def _compare(r):
             eg, s = _err(G["preds"]["decode_res_all"][i][k], d[k])
             ec, _ = _err(C["preds"]["decode_res_all"][i][k], d[k])
             _check(f"decode{i}.{k}", eg, ec, s)
+    # training targets: the discrete ones exactly (the seed keeps every assignment threshold at a
+    # distance), the real-valued ones to 1e-4
+    for n, t in zip(TARGET_NAMES, G["targets"]):
+        want = T["targets"][n]
+        if want.dtype in (torch.int64, torch.int32, torch.bool):
+            assert torch.equal(t.cpu(), want), "target " + n
+        else:
+            e, s = _err(t, want)
+            assert e <= 1e-4 * s, f"target {n}: {e:.2e}"
     for k in T["losses"]:
         eg, s = _err(G["losses"][k], T["losses"][k])
         ec, _ = _err(C["losses"][k], T["losses"][k])
         _check("loss." + k, eg, ec, s, floor=1e-4)
-    return _compare_grads(T, C, G)
+    # gradients: EVERY tensor, rel-L2 vs fp64 <= max(1e-3, 4 x the CPU fp32 oracle's own error)
+    # + the seed's residual flip allowance: 2 x its worst per-layer flip risk (<= RISK_MAX; a flip
+    # can happen on either fp32 path and in more than one layer), printed with the seed
+    bad, rows = P.compare_grads(T, C, G["grads"], rtol=1e-3, mult=4.0, allowance=2.0 * case["risk"])
+    worst = sorted((r for r in rows if r[3] == r[3]), key=lambda r: -r[2])[:5]
+    print("[parity] worst gradient tensors (name, |g|, gpu rel err, cpu32 rel err):", worst)
+    assert not bad, "gradient parity (seed %d, allowance %.1e):\n  " % (case["seed"], 2.0 * case["risk"]) \
+        + "\n  ".join(bad)
 
 
-def _compare_grads(T, C, G):
-    """-> None if the gradients agree, else a message.  Box-loss gradients are carried by the
-    ~10 positive proposals, so ONE ReLU sign flip (|z| below the fp32 noise) on such a row
-    moves whole tensors by several % (traced with tools/loss_grad_debug2.py; the GPU backward
-    is exact to 5e-7 given its own inputs).  The caller may therefore retry another seed; the
-    forward checks above are never retried."""
-    pt, pc, pg = (dict(x["model"].named_parameters()) for x in (T, C, G))
-    assert sorted(pt) == sorted(pg)
-    cos_num = cos_g = cos_t = tot_g = tot_c = 0.0
-    n_all = n_tight = 0
-    gnorm_max = max(p.grad.double().norm().item() for p in pt.values() if p.grad is not None)
-    for n in sorted(pt):
-        gt_, gc_, gg_ = pt[n].grad, pc[n].grad, pg[n].grad
-        assert (gt_ is None) == (gg_ is None), n
-        if gt_ is None:
-            continue
-        # per-tensor relative L2 error vs the fp64 truth; gradients carry a larger fp32 noise
-        # floor than activations (ReLU / max-pool routing flips, 131k-row BN reductions)
-        nt = gt_.double().norm().item()
-        if nt < 1e-4 * gnorm_max:      # BN-shadowed conv biases: mathematically zero
-            continue
-        rg = (gg_.double().cpu() - gt_.double()).norm().item() / nt
-        rc = (gc_.double() - gt_.double()).norm().item() / nt
-        # per tensor only a loose sanity bound: these gradients are ill-conditioned sums
-        # (the CPU fp32 path itself is up to ~1 % off the fp64 truth on some of them)
-        # ... and box-loss gradients are carried by the ~10 positive proposals, so one ReLU
-        # sign flip (|z| below the fp32 noise) on such a row moves a tensor by several %
-        # (traced with tools/loss_grad_debug2.py: the GPU backward is exact to 5e-7 given
-        # its own inputs).  Hence: every tensor within 20 %, 90 % of them within 2 %.
-        if rg > 0.2:
-            return f"grad {n}: gpu {rg:.2e} cpu32 {rc:.2e}"
-        n_all += 1
-        n_tight += rg <= max(40 * rc, 2e-2)
-        tot_g += ((gg_.double().cpu() - gt_.double()) ** 2).sum().item()
-        tot_c += ((gc_.double() - gt_.double()) ** 2).sum().item()
-        a, b = gg_.double().cpu().flatten(), gt_.double().flatten()
-        cos_num += (a * b).sum().item()
-        cos_g += (a * a).sum().item()
-        cos_t += (b * b).sum().item()
-    if cos_num / np.sqrt(cos_g * cos_t) <= 0.999:  # whole-model gradient direction
-        return "gradient direction"
-    # whole-model relative L2 error vs fp64.  Measured (tools/bn_noise.py): the GPU BLAS
-    # weight-gradient GEMM reducing over ~1M rows is ~6x noisier in fp32 than the CPU one
-    # (7e-6 vs 1e-6 before cancellation); BN-normalised gradients cancel heavily, so the HIP
-    # path is allowed 4x the CPU fp32 path's own distance from the truth.
-    rel_g, rel_c = np.sqrt(tot_g / cos_t), np.sqrt(tot_c / cos_t)
-    # (tools/grad_table.py: at random init both fp32 paths sit 0.3-0.7 % from the fp64 truth)
-    if n_tight < 0.9 * n_all:
-        return f"only {n_tight}/{n_all} gradient tensors within 2 %"
-    if rel_g > max(4 * rel_c, 2e-2):
-        return f"global grad error gpu {rel_g:.2e} cpu32 {rel_c:.2e}"
-    return None
-
-
-def _seeded_check(cfg, B, N, pyramid, in_shape, img_shape):
-    # a neighbour within float round-off of the vote-aggregation ball boundary can land on
-    # either side in fp32 vs fp64 (vote_points come out of GEMMs): such seeds are skipped.
-    # Forward parity must hold on every seed tried; the gradient check may move on to the next
-    # seed once or twice (discrete ReLU flips, see _compare_grads).
-    tried, msgs = 0, []
-    for seed in range(1, 10):
-        r = _run_triple(cfg, B, N, pyramid, in_shape, img_shape, seed)
-        if r is None:
-            continue
-        tried += 1
-        msg = _compare(r)
-        if msg is None:
-            return
-        msgs.append(f"seed {seed}: {msg}")
-        if tried == 3:
-            break
-    if tried == 0:
-        pytest.skip("no boundary-safe seed found")
-    pytest.fail("gradient parity failed on every seed: " + "; ".join(msgs))
+MID = ((50, 70), (25, 35), (13, 18), (7, 9)), (400, 560), (400, 551)
 
 
 def test_hot_path_vs_oracle_mid_size():
     from demf_amd.config import BackboneCfg, DeMFCfg, HeadCfg
     cfg = DeMFCfg(backbone=BackboneCfg(num_points=(1024, 512, 256, 128)),
                   head=HeadCfg(num_proposal=128, attn_dropout=0.0, ffn_dropout=0.0))
-    _seeded_check(cfg, 2, 6000, ((50, 70), (25, 35), (13, 18), (7, 9)), (400, 560), (400, 551))
+    _parity(cfg, 2, 6000, *MID, seeds=SEEDS["mid"])
 
 
 def test_hot_path_vs_oracle_full_config():
     """configs/demf/demf_votenet.py sizes: 20 000 points, 800x1120 pyramid, 256 queries."""
     from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
     cfg = DeMFCfg(head=HeadCfg(attn_dropout=0.0, ffn_dropout=0.0))
-    _seeded_check(cfg, 2, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2])
+    _parity(cfg, 2, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2], seeds=SEEDS["full2"])
+
+
+def test_hot_path_vs_oracle_full_config_four_sampling_points():
+    """The whole path with P=4 sampling points per level (BASELINE.json's wording of configs[2];
+    the reference config has P=2) - bench.py --msda-points 4."""
+    from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
+    cfg = DeMFCfg(head=HeadCfg(attn_dropout=0.0, ffn_dropout=0.0, num_points=4))
+    _parity(cfg, 2, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2], seeds=SEEDS["full2p4"])
+
+
+def test_hot_path_vs_oracle_full_config_batch_8():
+    """BASELINE configs[2] as benchmarked: 8 scenes x 20 000 points x 18 609 image tokens."""
+    from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
+    cfg = DeMFCfg(head=HeadCfg(attn_dropout=0.0, ffn_dropout=0.0))
+    _parity(cfg, 8, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2], seeds=SEEDS["full8"])
+
+
+# Seeds to try, in order.  The first entries were found by running the (oracle-only) qualification
+# of tests/parity_tools.py in the build container - tools/qualify_seeds.py - so that the GPU tier
+# does not spend minutes of CPU time rejecting seeds; qualification is re-evaluated at test time
+# and the search simply continues if the host's BLAS rounds differently.
+SEEDS = dict(mid=tuple(range(1, 12)), full2=tuple(range(1, 12)), full2p4=tuple(range(1, 12)),
+             full8=tuple(range(1, 12)))

@@ -7,7 +7,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(path)):
     if r["Counter_Name"] == counter:
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-print("kernel,calls,mean_%s_KiB" % counter)
+print("kernel,calls,mean_%s_KiB,max_%s_KiB" % (counter, counter))
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     if "demf::" in k or sum(v) > 1e5:
-        print('"%s",%d,%.1f' % (k[:110], len(v), sum(v) / len(v)))
+        print('"%s",%d,%.1f,%.1f' % (k[:110], len(v), sum(v) / len(v), max(v)))
