@@ -49,56 +49,83 @@ enum {
 };
 using GemmArgs = demf_gemm_desc;
 
-constexpr int G_BM = 64, G_BN = 64, G_BK = 32, G_LD = G_BK + 4;
+constexpr int G_BM = 64, G_BN = 64, G_BK = 64, G_LD = G_BK + 4;
 
-// one 64 x 32 operand tile: rows r0.., reduction k0.. ; element (r,k) at P + r*sr + k*sk
+// One 64 x 64 operand tile (rows r0.., reduction k0..; element (r,k) at P + r*sr + k*sk) travels
+// global -> registers (gemm_fetch, issued one K step ahead so that the loads are in flight while the
+// MFMAs of the current step run) -> LDS (gemm_commit, + the optional second addend).
+struct GemmRegs {
+  float4 v[4], w[4];            // modes 1 / 2: four float4 per thread (+ second operand)
+};
+
 template <bool ADD2>
-__device__ __forceinline__ void gemm_stage(float* __restrict__ s, const float* __restrict__ P,
+__device__ __forceinline__ void gemm_fetch(GemmRegs& g, float (&sc)[16], const float* __restrict__ P,
                                            const float* __restrict__ P2, long long sr, long long sk,
                                            int r0, int R, int k0, int K1, int mode) {
   const int t = threadIdx.x;
   if (mode == 1) {                       // k-contiguous, 16-byte aligned rows: float4 along K
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = (t >> 3) + 32 * i, kq = (t & 7) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4; ++i) {
+      const int row = (t >> 4) + 16 * i, kq = (t & 15) * 4;
+      g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD2) g.w[i] = g.v[i];
       if (r0 + row < R && k0 + kq < K1) {    // K1 % 4 == 0 in this mode
         const size_t o = (size_t)(r0 + row) * sr + k0 + kq;
-        v = *reinterpret_cast<const float4*>(P + o);
-        if constexpr (ADD2) {
-          const float4 w = *reinterpret_cast<const float4*>(P2 + o);
-          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
+        g.v[i] = *reinterpret_cast<const float4*>(P + o);
+        if constexpr (ADD2) g.w[i] = *reinterpret_cast<const float4*>(P2 + o);
       }
-      *reinterpret_cast<float4*>(s + row * G_LD + kq) = v;
     }
   } else if (mode == 2) {                // row-contiguous (reduction strided): float4 along rows
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       const int k = (t >> 4) + 16 * i, rq = (t & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD2) g.w[i] = g.v[i];
       if (k0 + k < K1 && r0 + rq < R) {      // R % 4 == 0 in this mode
         const size_t o = (size_t)(k0 + k) * sk + r0 + rq;
-        v = *reinterpret_cast<const float4*>(P + o);
-        if constexpr (ADD2) {
-          const float4 w = *reinterpret_cast<const float4*>(P2 + o);
-          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-        }
+        g.v[i] = *reinterpret_cast<const float4*>(P + o);
+        if constexpr (ADD2) g.w[i] = *reinterpret_cast<const float4*>(P2 + o);
       }
-      float* d = s + rq * G_LD + k;
-      d[0] = v.x; d[G_LD] = v.y; d[2 * G_LD] = v.z; d[3 * G_LD] = v.w;
     }
   } else {                               // anything else: guarded scalar loads
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int e = t + 256 * i, row = e >> 5, k = e & 31;
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i, row = e >> 6, k = e & 63;
       float v = 0.f;
       if (r0 + row < R && k0 + k < K1) {
         const size_t o = (size_t)(r0 + row) * sr + (size_t)(k0 + k) * sk;
         v = P[o];
         if constexpr (ADD2) v += P2[o];
       }
-      s[row * G_LD + k] = v;
+      sc[i] = v;
+    }
+  }
+}
+
+template <bool ADD2>
+__device__ __forceinline__ void gemm_commit(float* __restrict__ s, const GemmRegs& g, const float (&sc)[16],
+                                            int mode) {
+  const int t = threadIdx.x;
+  if (mode == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = g.v[i];
+      if constexpr (ADD2) { v.x += g.w[i].x; v.y += g.w[i].y; v.z += g.w[i].z; v.w += g.w[i].w; }
+      *reinterpret_cast<float4*>(s + ((t >> 4) + 16 * i) * G_LD + (t & 15) * 4) = v;
+    }
+  } else if (mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = g.v[i];
+      if constexpr (ADD2) { v.x += g.w[i].x; v.y += g.w[i].y; v.z += g.w[i].z; v.w += g.w[i].w; }
+      float* d = s + (t & 15) * 4 * G_LD + (t >> 4) + 16 * i;
+      d[0] = v.x; d[G_LD] = v.y; d[2 * G_LD] = v.z; d[3 * G_LD] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i;
+      s[(e >> 6) * G_LD + (e & 63)] = sc[i];
     }
   }
 }
@@ -124,13 +151,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p, int modeA, int mo
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  GemmRegs ga, gb;
+  float sa16[16], sb16[16];
+  auto fetch = [&](int k0) {
+    if (A2 != nullptr) gemm_fetch<true>(ga, sa16, A, A2, p.sam, p.sak, m0, p.M, k0, kend, modeA);
+    else gemm_fetch<false>(ga, sa16, A, nullptr, p.sam, p.sak, m0, p.M, k0, kend, modeA);
+    if (B2 != nullptr) gemm_fetch<true>(gb, sb16, B, B2, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
+    else gemm_fetch<false>(gb, sb16, B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
+  };
+  if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += G_BK) {
+    __syncthreads();                                  // everyone is done reading the previous tiles
+    if (A2 != nullptr) gemm_commit<true>(s_a, ga, sa16, modeA); else gemm_commit<false>(s_a, ga, sa16, modeA);
+    if (B2 != nullptr) gemm_commit<true>(s_b, gb, sb16, modeB); else gemm_commit<false>(s_b, gb, sb16, modeB);
     __syncthreads();
-    if (A2 != nullptr) gemm_stage<true>(s_a, A, A2, p.sam, p.sak, m0, p.M, k0, kend, modeA);
-    else gemm_stage<false>(s_a, A, nullptr, p.sam, p.sak, m0, p.M, k0, kend, modeA);
-    if (B2 != nullptr) gemm_stage<true>(s_b, B, B2, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
-    else gemm_stage<false>(s_b, B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
-    __syncthreads();
+    if (k0 + G_BK < kend) fetch(k0 + G_BK);           // in flight during the MFMAs below
 #pragma unroll
     for (int c8 = 0; c8 < G_BK / 8; ++c8) {
       const float4 a4 = *reinterpret_cast<const float4*>(s_a + (wm * 32 + lr) * G_LD + c8 * 8 + 4 * lh);
@@ -291,28 +326,32 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_k(int R, int rows_per_
   }
 }
 
-// ---- attention softmax (+ dropout) over rows of S <= 1024 keys (S % 64 == 0) ----------------------
-// prob = softmax(scores) (kept for the backward) ; out = dropout(prob)
+// ---- attention softmax (+ dropout) over rows of S <= 1024 keys ------------------------------------
+// prob = softmax(scores) (kept for the backward) ; out = dropout(prob).  VPL = ceil(S/64).
 template <int VPL>
-__global__ __launch_bounds__(256) void softmax_dropout_fwd_k(int R, const float* __restrict__ sc,
+__global__ __launch_bounds__(256) void softmax_dropout_fwd_k(int R, int S, const float* __restrict__ sc,
                                                              float p, const unsigned long long* __restrict__ rng,
                                                              unsigned op, float* __restrict__ prob,
                                                              float* __restrict__ out) {
-  constexpr int S = 64 * VPL;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
   float v[VPL];
   float mx = -__builtin_inff();
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) { v[i] = sc[(size_t)row * S + lane + 64 * i]; mx = fmaxf(mx, v[i]); }
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < S ? sc[(size_t)row * S + c] : -__builtin_inff();
+    mx = fmaxf(mx, v[i]);
+  }
   mx = wave_allmax(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }
+  for (int i = 0; i < VPL; ++i) { v[i] = lane + 64 * i < S ? __expf(v[i] - mx) : 0.f; sum += v[i]; }
   const float inv = 1.0f / group_allsum<64>(sum);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
+    if (lane + 64 * i >= S) continue;
     const size_t o = (size_t)row * S + lane + 64 * i;
     const float pr = v[i] * inv;
     prob[o] = pr;
@@ -324,10 +363,9 @@ __global__ __launch_bounds__(256) void softmax_dropout_fwd_k(int R, const float*
 
 // dscores = prob * (dprob - sum(dprob * prob)),  dprob = dout * keep / (1-p)   (in place over dout)
 template <int VPL>
-__global__ __launch_bounds__(256) void softmax_dropout_bwd_k(int R, const float* __restrict__ prob,
+__global__ __launch_bounds__(256) void softmax_dropout_bwd_k(int R, int S, const float* __restrict__ prob,
                                                              float p, const unsigned long long* __restrict__ rng,
                                                              unsigned op, float* __restrict__ dio) {
-  constexpr int S = 64 * VPL;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const float inv_keep = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -335,6 +373,8 @@ __global__ __launch_bounds__(256) void softmax_dropout_bwd_k(int R, const float*
   float dot = 0.f;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
+    d[i] = pr[i] = 0.f;
+    if (lane + 64 * i >= S) continue;
     const size_t o = (size_t)row * S + lane + 64 * i;
     d[i] = dio[o];
     pr[i] = prob[o];
@@ -343,7 +383,8 @@ __global__ __launch_bounds__(256) void softmax_dropout_bwd_k(int R, const float*
   }
   dot = group_allsum<64>(dot);
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) dio[(size_t)row * S + lane + 64 * i] = pr[i] * (d[i] - dot);
+  for (int i = 0; i < VPL; ++i)
+    if (lane + 64 * i < S) dio[(size_t)row * S + lane + 64 * i] = pr[i] * (d[i] - dot);
 }
 
 // ---- sampling-location preparation of the fusion attention ----------------------------------------
@@ -493,6 +534,17 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
       return DEMF_EUNSUPPORTED;                    \
   }
 
+// softmax rows: any S <= 1024, VPL = ceil(S/64) rounded up to a power of two
+#define SM_DISPATCH(S, CALL)                       \
+  if ((S) <= 0 || (S) > 1024) {                    \
+    demf::set_error("softmax: %d keys unsupported (1..1024)", (S)); \
+    return DEMF_EUNSUPPORTED;                      \
+  } else if ((S) <= 64) { CALL(1); }               \
+  else if ((S) <= 128) { CALL(2); }                \
+  else if ((S) <= 256) { CALL(4); }                \
+  else if ((S) <= 512) { CALL(8); }                \
+  else { CALL(16); }
+
 extern "C" int demf_add_dropout_ln_fwd(int R, int C, const float* x, const float* identity,
                                        const float* gamma, const float* beta, float eps, float p,
                                        const void* rng, int op_id, float* s_out, float* y,
@@ -529,8 +581,8 @@ extern "C" int demf_softmax_dropout_fwd(int R, int S, const float* scores, float
   DEMF_REQUIRE(R > 0 && scores && prob && out, "softmax_dropout_fwd: bad arguments");
   DEMF_REQUIRE(p == 0.f || rng, "softmax_dropout_fwd: dropout needs the rng state");
 #define CALL(V) hipLaunchKernelGGL(softmax_dropout_fwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, \
-                                   R, scores, p, (const unsigned long long*)rng, (unsigned)op_id, prob, out)
-  LN_DISPATCH(S, CALL)
+                                   R, S, scores, p, (const unsigned long long*)rng, (unsigned)op_id, prob, out)
+  SM_DISPATCH(S, CALL)
 #undef CALL
   return check_launch("softmax_dropout_fwd_k");
 }
@@ -540,8 +592,8 @@ extern "C" int demf_softmax_dropout_bwd(int R, int S, const float* prob, float p
   DEMF_REQUIRE(R > 0 && prob && dio, "softmax_dropout_bwd: bad arguments");
   DEMF_REQUIRE(p == 0.f || rng, "softmax_dropout_bwd: dropout needs the rng state");
 #define CALL(V) hipLaunchKernelGGL(softmax_dropout_bwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, \
-                                   R, prob, p, (const unsigned long long*)rng, (unsigned)op_id, dio)
-  LN_DISPATCH(S, CALL)
+                                   R, S, prob, p, (const unsigned long long*)rng, (unsigned)op_id, dio)
+  SM_DISPATCH(S, CALL)
 #undef CALL
   return check_launch("softmax_dropout_bwd_k");
 }

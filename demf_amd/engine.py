@@ -185,6 +185,10 @@ class Trainer:
         # device path: flat fused AdamW (HIP); the torch optimizer serves the CPU/gloo host-logic
         # tests only
         self.fused = self.flat.flat.is_cuda
+        if self.fused:
+            from . import fused
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            fused.rng_state(self.flat.flat.device, seed=torch.initial_seed() + 7919 * rank)
         self.opt = FlatAdamW(groups, self.flat) if self.fused else \
             torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, foreach=True)
         self._base_lrs = [float(g["lr"]) for g in groups]
@@ -211,6 +215,12 @@ class Trainer:
 
     def _fwd(self, batch, geometry=None):
         kw = {} if geometry is None else dict(geometry=geometry)
+        if self.fused:
+            # counter-based dropout of the fused decoder layer: one advance per step, inside the
+            # (captured) forward, so that every replay draws fresh masks; the backward re-derives
+            # the masks of the same step
+            from . import fused
+            fused.advance_rng(self.flat.flat.device)
         losses = self.model.forward_train(batch["points"], batch["img_features"],
                                           batch["img_metas"], batch["gt_bboxes_3d"],
                                           batch["gt_labels_3d"], **kw)

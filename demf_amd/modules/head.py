@@ -156,6 +156,23 @@ class DeMFVoteHead(nn.Module):
         feat_flatten, mask_flatten = image_inputs["feat_flatten"], image_inputs["mask_flatten"]
         spatial_shapes = image_inputs["spatial_shapes"]
         level_start_index, valid_ratios = image_inputs["level_start_index"], image_inputs["valid_ratios"]
+        if features.is_cuda and image_inputs.get("value_tokens") is not None:
+            # device path: each fusion layer is one autograd node on batch-major rows
+            # (demf_amd/fused.py); the reference-point projection rides in its sampling kernel
+            B, E, Q = features.shape
+            mt = self._meta_tensors(img_metas, image_inputs["spatial"], features.device, features.dtype)
+            rows = features.transpose(1, 2).reshape(B * Q, E)
+            pts = aggregated_points.reshape(B * Q, 3)
+            for i in range(self.num_decoder_layers):
+                query_pos = torch.cat([decode_res["center"], decode_res["size"]], dim=-1).detach() \
+                    .reshape(B * Q, -1)
+                rows = self.decoder[i].forward_rows(
+                    rows, query_pos, pts, image_inputs["value_tokens"], spatial_shapes,
+                    level_start_index, (mt["M"], mt["ab"]), valid_ratios, B)
+                cls_p, reg_p = self.conv_preds[i + 1](rows.view(B, Q, E).transpose(1, 2))
+                decode_res = self._split(cls_p, reg_p, aggregated_points)
+                decode_res_all.append(decode_res)
+            return decode_res_all
         reference_points = self.get_reference_points(aggregated_points, img_metas,
                                                      image_inputs["spatial"])
         query = features.permute(2, 0, 1)

@@ -43,6 +43,20 @@ class PositionEmbeddingLearned(nn.Module):
         x = ops.linear(x, c1.weight.view(c1.out_channels, -1), c1.bias)
         return x.view(B, N, -1).transpose(1, 2)
 
+    def forward_rows(self, rows):
+        """(R,cin) -> (R,cpos) on the fused kernels: Conv1d+BN1d(train stats)+ReLU through the
+        shared-MLP GEMM (input rows zero-padded to a multiple of 4 columns), the second Conv1d through
+        the strided GEMM of csrc/dense.hip."""
+        c0, bn, _, c1 = self.position_embedding_head
+        R, cin = rows.shape
+        pad = (-cin) % 4
+        x = F.pad(rows, (0, pad)) if pad else rows.contiguous()
+        w0 = F.pad(c0.weight.view(c0.out_channels, cin), (0, pad)) if pad else c0.weight.view(c0.out_channels, cin)
+        h = ops.shared_mlp_pool(x, 1, [(w0.contiguous(), bn.weight, bn.bias, bn.running_mean,
+                                        bn.running_var, c0.bias, bn.num_batches_tracked)],
+                                training=bn.training, eps=bn.eps, momentum=bn.momentum)
+        return ops.linear(h, c1.weight.view(c1.out_channels, -1), c1.bias)
+
 
 class MultiheadAttention(nn.Module):
     """mmcv.cnn.bricks.transformer.MultiheadAttention (seq-first).  The deprecated
@@ -261,6 +275,40 @@ class DeMFTransformerDecoderLayer(nn.Module):
         for m in self.modules():
             if isinstance(m, MultiScaleDeformableAttention):
                 m.init_weights()
+
+    def forward_rows(self, x, query_pos, points, value_tokens, spatial_shapes, level_start_index,
+                     proj, valid_ratios, batch):
+        """The layer on batch-major rows through ONE autograd node (demf_amd/fused.py):
+        x (B*Q, E) query rows, query_pos (B*Q, 6), points (B*Q, 3) the 3-D query points (projected
+        into the image inside the sampling-location kernel: get_reference_points,
+        class_agnostic_vote_head.py:524-547, with ``proj`` = (M (B,4,4), ab (B,4)) composed on the
+        host), value_tokens = (tokens (B,S,C) padding-zeroed, keep4 (B,S,4)).  -> (B*Q, E).
+        Same mathematics as ``forward`` (self-attn, norm, deformable cross-attn with the value
+        projection applied after sampling, norm, FFN, norm)."""
+        from ..fused import FusedDecoderLayer
+        lyr = self.layer
+        mha, msda, ffn = lyr.attentions[0], lyr.attentions[1], lyr.ffns[0]
+        a = mha.attn
+        (fc0, _, drop0), fc1, _ = ffn.layers
+        n1, n2, n3 = lyr.norms
+        assert isinstance(mha.proj_drop, nn.Dropout) and mha.proj_drop.p == 0.0
+        p_attn = float(a.dropout)
+        assert (not isinstance(mha.dropout_layer, nn.Dropout) and p_attn == 0.0) or \
+            mha.dropout_layer.p == p_attn == msda.dropout.p, "one attention dropout rate (cfg:78,84)"
+        pos = self.posembed.forward_rows(query_pos)
+        tokens, keep4 = value_tokens
+        M, ab = proj
+        Q = x.shape[0] // batch
+        dims = (batch, Q, msda.num_heads, msda.num_levels, msda.num_points, p_attn, float(drop0.p),
+                float(n1.eps))
+        return FusedDecoderLayer.apply(
+            x.contiguous(), pos, points.contiguous(), tokens, keep4, spatial_shapes, level_start_index,
+            M, ab, valid_ratios, dims, self.training,
+            a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, n1.weight, n1.bias,
+            msda.sampling_offsets.weight, msda.sampling_offsets.bias, msda.attention_weights.weight,
+            msda.attention_weights.bias, msda.value_proj.weight, msda.value_proj.bias,
+            msda.output_proj.weight, msda.output_proj.bias, n2.weight, n2.bias,
+            fc0.weight, fc0.bias, fc1.weight, fc1.bias, n3.weight, n3.bias)
 
     def forward(self, query, query_pos, *args, reference_points=None, valid_ratios=None, **kwargs):
         if reference_points.shape[-1] == 4:

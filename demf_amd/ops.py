@@ -473,6 +473,18 @@ class _LinearRows(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, row_mask):
         ctx.has_bias = bias is not None
+        ctx.own = row_mask is None and x.shape[0] <= _OWN_GEMM_ROWS and x.stride(1) == 1 and \
+            (bias is None or bias.is_contiguous())
+        if ctx.own:
+            # few rows (heads, vote module, position embedding): the strided GEMM of csrc/dense.hip
+            from . import fused
+            R, K = x.shape
+            N = weight.shape[0]
+            y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+            fused.gemm(R, N, K, _p(x), (x.stride(0), 1), _p(weight), weight.stride(), _p(y), N,
+                       bias=_p(bias))
+            ctx.save_for_backward(x, weight)
+            return y
         y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
         if row_mask is not None:
             y.masked_fill_(row_mask.unsqueeze(-1), 0.0)
@@ -486,6 +498,25 @@ class _LinearRows(Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors[:2]
         g = g.contiguous()
+        if ctx.own:
+            from . import fused
+            R, K = x.shape
+            N = weight.shape[0]
+            gx = gw = gb = None
+            if ctx.needs_input_grad[0]:
+                gx = torch.empty((R, K), dtype=torch.float32, device=g.device)
+                fused.gemm(R, K, N, _p(g), (N, 1), _p(weight), (weight.stride(1), weight.stride(0)),
+                           _p(gx), K)
+            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+                # one zero-filled workspace for dW | db (split-K atomics, column sums)
+                ws = torch.zeros(N * K + N, dtype=torch.float32, device=g.device)
+                gw = ws[:N * K].view(N, K)
+                fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, x.stride(0)), _p(gw), K,
+                           splitk=fused._splitk(R))
+                if ctx.has_bias:
+                    gb = ws[N * K:]
+                    _ffi.call("demf_colsum_f32", R, N, N, _p(g), _p(gb), _stream())
+            return gx, gw, gb, None
         if len(ctx.saved_tensors) == 3:
             # the incoming gradient is a temporary of the producer (the MSDA backward's
             # grad_value); it is masked in place rather than cloned (152 MB at the bench size)
@@ -524,6 +555,7 @@ def linear(x, weight, bias=None, row_mask=None):
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------
 _ACCUM64 = {}
+_OWN_GEMM_ROWS = int(__import__('os').environ.get('DEMF_OWN_GEMM_ROWS', '65536'))    # A/B switch
 _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
 _NO_RED_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_RED_FUSE', '0')))        # A/B switch
 _NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
@@ -593,7 +625,9 @@ class _SharedMLPPool(Function):
                 ns in (16, 32, 64)
             if first_geo:
                 # reference column order [xyz(3) | feat(C)]: U = feat . Wf^T once per source point
-                U = torch.mm(x, W[:, 3:].t())
+                U = torch.empty((x.shape[0], N), dtype=torch.float32, device=dev)
+                from . import fused
+                fused.gemm(x.shape[0], N, ld, _p(x), (ld, 1), W.data_ptr() + 12, (K, 1), _p(U), N)
                 Wx = W[:, :3].t().contiguous()
                 stats = None
                 if training:
@@ -742,7 +776,9 @@ class _SharedMLPPool(Function):
                     grads[5] = ws32[o32:o32 + N].view(ctx.bias_shapes[0])
                     o32 += N
                 if ctx.needs_input_grad[0]:
-                    dx = torch.mm(dU, W[:, 3:])
+                    from . import fused
+                    dx = torch.empty((gB * gN, C0), dtype=torch.float32, device=dev)
+                    fused.gemm(gB * gN, C0, N, _p(dU), (N, 1), W.data_ptr() + 12, (1, K), _p(dx), C0)
                 break
             xprev = Ys[l - 1] if l > 0 else x
             ldx = xprev.shape[1]

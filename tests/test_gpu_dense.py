@@ -1,0 +1,299 @@
+"""csrc/dense.hip on the GPU: the strided GEMM in every operand form the decoder layer uses, the row
+kernels, and the fused decoder layer (demf_amd/fused.py) against a plain torch restatement of
+mmcv's DetrTransformerDecoderLayer mathematics (demf/modeling/layers/transformer.py:55-80;
+configs/demf/demf_votenet.py:71-91) - with dropout OFF and with dropout ON (the test pulls the
+counter-based masks out of the library and feeds them to the torch restatement)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _close(a, b, tol=1e-4, name=""):
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).abs().max().item()
+    assert err <= tol * max(1.0, b.abs().max().item()), f"{name}: max err {err:.3e} (scale {b.abs().max().item():.2f})"
+
+
+def test_gemm_operand_forms():
+    from demf_amd import fused
+    from demf_amd.fused import _p
+    # Y = X W^T + b  (both K-contiguous), odd sizes -> guarded tiles
+    for (M, N, K) in [(200, 96, 64), (70, 50, 6), (2048, 256, 256), (33, 7, 20)]:
+        x, w, b = _r(M, K, seed=1), _r(N, K, seed=2), _r(N, seed=3)
+        y = torch.empty(M, N, device="cuda")
+        fused.gemm(M, N, K, _p(x), (K, 1), _p(w), (K, 1), _p(y), N, bias=_p(b))
+        _close(y, x.double() @ w.double().t() + b.double(), name=f"NT {M}x{N}x{K}")
+    # dX = G W (B operand K-strided), relu + gate epilogues, A2 prologue on the first columns only
+    M, N, K = 300, 128, 192
+    g, w, a2 = _r(M, K, seed=4), _r(K, N, seed=5), _r(M, K, seed=6)
+    y = torch.empty(M, N, device="cuda")
+    fused.gemm(M, N, K, _p(g), (K, 1), _p(w), (1, N), _p(y), N, A2=_p(a2), a2_cols=64, flags=fused.RELU)
+    want = torch.cat([(g + a2).double() @ w.double()[:, :64], g.double() @ w.double()[:, 64:]], 1).clamp(min=0)
+    _close(y, want, name="NN + A2 + relu")
+    gate = (_r(M, N, seed=7) > 0).float() * 3.0
+    fused.gemm(M, N, K, _p(g), (K, 1), _p(w), (1, N), _p(y), N, flags=fused.GATE, gate=_p(gate), sg=(N, 0),
+               gate_scale=1.25)
+    _close(y, g.double() @ w.double() * (gate != 0).double() * 1.25, name="gate")
+    # dW = G^T X (+ X2 on the first rows), split-K atomics into a zeroed C, twice (accumulates)
+    R, N, K = 2048, 192, 256
+    g, x, x2 = _r(R, N, seed=8), _r(R, K, seed=9), _r(R, K, seed=10)
+    dw = torch.zeros(N, K, device="cuda")
+    for _ in range(2):
+        fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, K), _p(dw), K, B2=_p(x2), b2_rows=128, splitk=8)
+    want = torch.cat([g.double()[:, :128].t() @ (x + x2).double(), g.double()[:, 128:].t() @ x.double()], 0) * 2
+    _close(dw, want, name="TN split-K + B2")
+    # two-level batch (scene, head) over an interleaved (R, 3E) buffer + alpha, as the attention uses it
+    B, H, Q, Dh = 3, 4, 96, 16
+    E = H * Dh
+    qkv = _r(B * Q, 3 * E, seed=11)
+    sc = torch.empty(B * H, Q, Q, device="cuda")
+    zb = (Q * 3 * E, Dh)
+    fused.gemm(Q, Q, Dh, _p(qkv), (3 * E, 1), _p(qkv, E), (3 * E, 1), _p(sc), Q, batch=B * H, zdiv=H,
+               sab=zb, sbb=zb, scb=(H * Q * Q, Q * Q), alpha=0.25)
+    q = qkv[:, :E].view(B, Q, H, Dh).permute(0, 2, 1, 3).double()
+    k = qkv[:, E:2 * E].view(B, Q, H, Dh).permute(0, 2, 1, 3).double()
+    _close(sc.view(B, H, Q, Q), 0.25 * q @ k.transpose(-1, -2), name="batched scores")
+    # row-scaled bias (value projection after sampling) + second destination + accumulate
+    R, H2, C, D2 = 256, 4, 64, 16
+    z, wv, bv, ks = _r(R * H2, C, seed=12), _r(H2 * D2, C, seed=13), _r(H2 * D2, seed=14), _r(R * H2, 4, seed=15)
+    mo, mo2 = torch.ones(R, H2 * D2, device="cuda"), torch.ones(R, H2 * D2, device="cuda")
+    fused.gemm(R, D2, C, _p(z), (H2 * C, 1), _p(wv), (C, 1), _p(mo), H2 * D2, batch=H2, sab=(C, 0),
+               sbb=(D2 * C, 0), scb=(D2, 0), bias=_p(bv), sbias_b=D2, rowscale=_p(ks), srs=(4 * H2, 4),
+               flags=fused.ROWBIAS | fused.ACCUM, C2=_p(mo2))
+    want = torch.einsum("rhc,hdc->rhd", z.view(R, H2, C).double(), wv.view(H2, D2, C).double()) + \
+        bv.view(1, H2, D2).double() * ks.view(R, H2, 4)[..., :1].double()
+    _close(mo, want.reshape(R, -1) + 1.0, name="rowbias + accum")
+    _close(mo2, want.reshape(R, -1), name="second destination")
+
+
+def test_gemm_dropout_epilogue_matches_the_mask_hook():
+    from demf_amd import fused
+    from demf_amd.fused import _p
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=5)
+    M, N, K = 300, 192, 64
+    x, w, b = _r(M, K, seed=1), _r(N, K, seed=2), _r(N, seed=3)
+    y = torch.empty(M, N, device="cuda")
+    fused.gemm(M, N, K, _p(x), (K, 1), _p(w), (K, 1), _p(y), N, bias=_p(b), flags=fused.RELU | fused.DROPOUT,
+               drop_p=0.1, rng=fused.rng_state(dev).data_ptr(), op_id=4)
+    mask = fused.dropout_mask(M * N, 0.1, 4, dev).view(M, N)
+    _close(y, torch.relu(x.double() @ w.double().t() + b.double()) * mask.double(), name="relu+dropout")
+
+
+def test_dropout_mask_statistics_and_step():
+    from demf_amd import fused
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=1234)
+    m1 = fused.dropout_mask(1 << 20, 0.4, 3, dev)
+    vals = torch.unique(m1).tolist()
+    assert len(vals) == 2 and vals[0] == 0.0 and abs(vals[1] - 1 / 0.6) < 1e-6
+    assert abs((m1 != 0).float().mean().item() - 0.6) < 3e-3
+    assert torch.equal(m1, fused.dropout_mask(1 << 20, 0.4, 3, dev))           # reproducible
+    m_other = fused.dropout_mask(1 << 20, 0.4, 4, dev)                          # another stream
+    assert 0.3 < ((m1 != 0) == (m_other != 0)).float().mean().item() < 0.7
+    fused.advance_rng(dev)
+    m2 = fused.dropout_mask(1 << 20, 0.4, 3, dev)                               # next step: new mask
+    agree = ((m1 != 0) == (m2 != 0)).float().mean().item()
+    assert abs(agree - (0.36 + 0.16)) < 5e-3
+
+
+@pytest.mark.parametrize("p", [0.0, 0.4])
+def test_add_dropout_layernorm(p):
+    from demf_amd import _ffi, fused
+    from demf_amd.fused import _p
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=7)
+    R, C = 517, 256
+    x, idn, gm, bt, dy = _r(R, C, seed=1), _r(R, C, seed=2), 1 + 0.1 * _r(C, seed=3), _r(C, seed=4), _r(R, C, seed=5)
+    rng, st = fused.rng_state(dev).data_ptr(), torch.cuda.current_stream().cuda_stream
+    s, y, stats = torch.empty_like(x), torch.empty_like(x), torch.empty(R, 2, device="cuda")
+    _ffi.call("demf_add_dropout_ln_fwd", R, C, _p(x), _p(idn), _p(gm), _p(bt), 1e-5, p, rng, 9, _p(s), _p(y), _p(stats), st)
+    mask = fused.dropout_mask(R * C, p, 9, dev).view(R, C) if p > 0 else torch.ones(R, C, device="cuda")
+    xr, ir, gr, br = (t.double().requires_grad_() for t in (x, idn, gm, bt))
+    sr = ir + xr * mask.double()
+    yr = F.layer_norm(sr, (C,), gr, br, 1e-5)
+    _close(s, sr, 1e-6, "s")
+    _close(y, yr, 1e-5, "y")
+    yr.backward(dy.double())
+    ds, dx = torch.full_like(x, 1.0), torch.empty_like(x)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    _ffi.call("demf_add_dropout_ln_bwd", R, C, _p(dy), None, _p(s), _p(stats), _p(gm), p, rng, 9, _p(ds), 1,
+              _p(dx), _p(dg), _p(db), st)
+    _close(ds - 1.0, ir.grad, 1e-5, "ds (accumulated)")
+    _close(dx, xr.grad, 1e-5, "dx")
+    _close(dg, gr.grad, 1e-5, "dgamma")
+    _close(db, br.grad, 1e-5, "dbeta")
+
+
+@pytest.mark.parametrize("S,p", [(256, 0.0), (256, 0.4), (32, 0.4), (100, 0.0)])
+def test_softmax_dropout(S, p):
+    from demf_amd import _ffi, fused
+    from demf_amd.fused import _p
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=11)
+    R = 333
+    sc, dout = _r(R, S, seed=1, scale=3.0), _r(R, S, seed=2)
+    rng, st = fused.rng_state(dev).data_ptr(), torch.cuda.current_stream().cuda_stream
+    prob, out = torch.empty_like(sc), torch.empty_like(sc)
+    _ffi.call("demf_softmax_dropout_fwd", R, S, _p(sc), p, rng, 1, _p(prob), _p(out), st)
+    mask = fused.dropout_mask(R * S, p, 1, dev).view(R, S) if p > 0 else torch.ones(R, S, device="cuda")
+    sr = sc.double().requires_grad_()
+    pr = torch.softmax(sr, -1)
+    _close(prob, pr, 1e-6, "prob")
+    _close(out, pr * mask.double(), 1e-6, "out")
+    (pr * mask.double()).backward(dout.double())
+    dio = dout.clone()
+    _ffi.call("demf_softmax_dropout_bwd", R, S, _p(prob), p, rng, 1, _p(dio), st)
+    _close(dio, sr.grad, 1e-5, "dscores")
+
+
+def _make_case(B, Q, H, L, P, E, Fd, shapes, seed):
+    rng = np.random.default_rng(seed)
+    S = sum(h * w for h, w in shapes)
+    R = B * Q
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32)).cuda()
+    x, pos = t(rng.standard_normal((R, E))), t(rng.standard_normal((R, E)) * 0.5)
+    pts = t(rng.uniform([-2, 1.0, -1], [2, 5, 1], size=(R, 3)))
+    keep = rng.uniform(size=(B, S)) > 0.15
+    tokens = t(rng.standard_normal((B, S, E)) * keep[..., None])
+    keep4 = t(np.stack([keep, np.zeros_like(keep), np.zeros_like(keep), np.zeros_like(keep)], -1))
+    shp = torch.tensor(shapes, dtype=torch.int64).cuda()
+    sizes = [h * w for h, w in shapes]
+    lsi = torch.tensor([0] + list(np.cumsum(sizes)[:-1]), dtype=torch.int64).cuda()
+    # a pinhole-ish projection per scene; some points fall outside [0,1] -> clamp branch
+    M = np.tile(np.eye(4, dtype=np.float32), (B, 1, 1))
+    for b in range(B):
+        M[b, 0] = [1.0, 0.2 * b, 0.0, 0.3]
+        M[b, 1] = [0.0, 0.1, -1.0, 0.8]
+        M[b, 2] = [0.0, 1.0, 0.0, 0.5]
+    ab = np.tile(np.array([[0.45, 0.5, 0.4, 0.45]], np.float32), (B, 1)) * (1 + 0.1 * np.arange(B)[:, None])
+    vr = rng.uniform(0.7, 1.0, size=(B, L, 2)).astype(np.float32)
+    HLP = H * L * P
+    prm = dict(
+        in_w=rng.standard_normal((3 * E, E)) / math.sqrt(E), in_b=rng.standard_normal(3 * E) * 0.1,
+        out_w=rng.standard_normal((E, E)) / math.sqrt(E), out_b=rng.standard_normal(E) * 0.1,
+        g1=1 + 0.1 * rng.standard_normal(E), b1=0.1 * rng.standard_normal(E),
+        off_w=rng.standard_normal((2 * HLP, E)) * 0.05, off_b=rng.standard_normal(2 * HLP) * 1.5,
+        aw_w=rng.standard_normal((HLP, E)) * 0.1, aw_b=rng.standard_normal(HLP) * 0.1,
+        vp_w=rng.standard_normal((E, E)) / math.sqrt(E), vp_b=rng.standard_normal(E) * 0.1,
+        op_w=rng.standard_normal((E, E)) / math.sqrt(E), op_b=rng.standard_normal(E) * 0.1,
+        g2=1 + 0.1 * rng.standard_normal(E), b2=0.1 * rng.standard_normal(E),
+        f0_w=rng.standard_normal((Fd, E)) / math.sqrt(E), f0_b=rng.standard_normal(Fd) * 0.1,
+        f1_w=rng.standard_normal((E, Fd)) / math.sqrt(Fd), f1_b=rng.standard_normal(E) * 0.1,
+        g3=1 + 0.1 * rng.standard_normal(E), b3=0.1 * rng.standard_normal(E))
+    prm = {k: t(v) for k, v in prm.items()}
+    return dict(x=x, pos=pos, pts=pts, tokens=tokens, keep4=keep4, shapes=shp, lsi=lsi, M=t(M), ab=t(ab),
+                vr=t(vr), prm=prm)
+
+
+PARAM_ORDER = ("in_w", "in_b", "out_w", "out_b", "g1", "b1", "off_w", "off_b", "aw_w", "aw_b", "vp_w", "vp_b",
+               "op_w", "op_b", "g2", "b2", "f0_w", "f0_b", "f1_w", "f1_b", "g3", "b3")
+
+
+def _torch_layer(c, prm, dims, masks):
+    """mmcv's decoder layer spelled out on batch-major rows with explicit dropout masks; the
+    deformable sampling in the reference order (project the tokens, then sample) through the
+    operator that is pinned to the oracle in test_gpu_ops.py."""
+    from demf_amd import ops
+    B, Q, H, L, P, p_attn, p_ffn, eps = dims
+    x, pos, pts = c["x"], c["pos"], c["pts"]
+    R, E = x.shape
+    Dh = E // H
+    qk = (x + pos) @ prm["in_w"][:2 * E].t() + prm["in_b"][:2 * E]
+    v = x @ prm["in_w"][2 * E:].t() + prm["in_b"][2 * E:]
+    hd = lambda t_: t_.view(B, Q, H, Dh).permute(0, 2, 1, 3)
+    sc = hd(qk[:, :E]) @ hd(qk[:, E:]).transpose(-1, -2) / math.sqrt(Dh)
+    pd = torch.softmax(sc, -1) * masks["attn"].view(B, H, Q, Q)
+    att = (pd @ hd(v)).permute(0, 2, 1, 3).reshape(R, E)
+    s1 = x + (att @ prm["out_w"].t() + prm["out_b"]) * masks["ln1"].view(R, E)
+    x1 = F.layer_norm(s1, (E,), prm["g1"], prm["b1"], eps)
+    qp = x1 + pos
+    off = (qp @ prm["off_w"].t() + prm["off_b"]).view(B, Q, H, L, P, 2)
+    aw = torch.softmax((qp @ prm["aw_w"].t() + prm["aw_b"]).view(B, Q, H, L * P), -1).view(B, Q, H, L, P)
+    p4 = torch.cat([pts, torch.ones_like(pts[:, :1])], -1).view(B, Q, 4) @ c["M"].transpose(1, 2)
+    uv = p4[..., :2] / p4[..., 2:3]
+    uv = torch.clamp(uv * c["ab"][:, None, 0::2] + c["ab"][:, None, 1::2], 0, 1)
+    ref = uv[:, :, None] * c["vr"][:, None]                                       # (B,Q,L,2)
+    norm = torch.stack([c["shapes"][:, 1], c["shapes"][:, 0]], -1).float()
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    value = (c["tokens"] @ prm["vp_w"].t() + prm["vp_b"]) * c["keep4"][..., :1]
+    mo = ops.MultiScaleDeformableAttnFunction.apply(value.view(B, -1, H, Dh).contiguous(), c["shapes"],
+                                                    c["lsi"], loc.contiguous(), aw.contiguous(), 64)
+    s2 = x1 + (mo.view(R, E) @ prm["op_w"].t() + prm["op_b"]) * masks["ln2"].view(R, E)
+    x2 = F.layer_norm(s2, (E,), prm["g2"], prm["b2"], eps)
+    z0 = x2 @ prm["f0_w"].t() + prm["f0_b"]
+    masks["_relu_margin"] = z0.detach().abs()[masks["ffn"].view(R, -1) != 0].min().item()
+    hid = torch.relu(z0) * masks["ffn"].view(R, -1)
+    s3 = x2 + (hid @ prm["f1_w"].t() + prm["f1_b"]) * masks["ln3"].view(R, E)
+    return F.layer_norm(s3, (E,), prm["g3"], prm["b3"], eps)
+
+
+@pytest.mark.parametrize("B,Q,H,L,P,E,Fd,shapes,p_attn,p_ffn", [
+    (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.0, 0.0),
+    (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.4, 0.0),
+    (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.0, 0.1),
+    (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.4, 0.1),
+    (3, 256, 8, 4, 2, 256, 1024, ((50, 70), (25, 35), (13, 18), (7, 9)), 0.4, 0.1),
+    (2, 128, 8, 4, 4, 256, 512, ((25, 35), (13, 18), (7, 9), (4, 5)), 0.0, 0.0),
+])
+def test_fused_decoder_layer_vs_torch(B, Q, H, L, P, E, Fd, shapes, p_attn, p_ffn):
+    from demf_amd import fused
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=99)
+    c = _make_case(B, Q, H, L, P, E, Fd, shapes, seed=B * 100 + Q)
+    dims = (B, Q, H, L, P, p_attn, p_ffn, 1e-5)
+    R = B * Q
+    ones = lambda n: torch.ones(n, device="cuda")
+    masks = dict(
+        attn=fused.dropout_mask(B * H * Q * Q, p_attn, fused.OP_ATTN, dev) if p_attn else ones(B * H * Q * Q),
+        ln1=fused.dropout_mask(R * E, p_attn, fused.OP_LN1, dev) if p_attn else ones(R * E),
+        ln2=fused.dropout_mask(R * E, p_attn, fused.OP_LN2, dev) if p_attn else ones(R * E),
+        ffn=fused.dropout_mask(R * Fd, p_ffn, fused.OP_FFN, dev) if p_ffn else ones(R * Fd),
+        ln3=fused.dropout_mask(R * E, p_ffn, fused.OP_LN3, dev) if p_ffn else ones(R * E))
+    leaves = [c["x"], c["pos"], c["pts"]] + [c["prm"][k] for k in PARAM_ORDER]
+    gout = _r(R, E, seed=5)
+
+    def run(fn):
+        ins = [t.detach().clone().requires_grad_() for t in leaves]
+        cc = dict(c, x=ins[0], pos=ins[1], pts=ins[2])
+        prm = dict(zip(PARAM_ORDER, ins[3:]))
+        out = fn(cc, prm)
+        out.backward(gout)
+        return out.detach(), [t.grad for t in ins]
+
+    want, gw = run(lambda cc, prm: _torch_layer(cc, prm, dims, masks))
+    got, gg = run(lambda cc, prm: fused.FusedDecoderLayer.apply(
+        cc["x"], cc["pos"], cc["pts"], c["tokens"], c["keep4"], c["shapes"], c["lsi"], c["M"], c["ab"],
+        c["vr"], dims, True, *[prm[k] for k in PARAM_ORDER]))
+    _close(got, want, 2e-4, "output")
+    # The FFN's ReLU is the one discontinuity inside the layer: a pre-activation within the two
+    # GEMMs' round-off of zero (~1e-6; there are R x F = up to 786 k of them) may resolve
+    # differently, and that single element then shifts every upstream gradient by ~1e-3 relative
+    # (traced with tools/debug_fused.py).  Element-wise agreement is therefore asserted when the
+    # reference's smallest |pre-activation| keeps its distance, and the relative L2 error always.
+    strict = masks["_relu_margin"] > 2e-5
+    bad = []
+    for name, a, b in zip(("x", "pos", "pts") + PARAM_ORDER, gg, gw):
+        assert a is not None and b is not None, name
+        a, b = a.double(), b.double()
+        err, rel = (a - b).abs().max().item(), ((a - b).norm() / b.norm()).item()
+        if rel > 5e-3 or (strict and err > 5e-4 * max(1.0, b.abs().max().item())):
+            bad.append(f"{name}: max {err:.2e} (scale {b.abs().max().item():.2f}) rel-l2 {rel:.2e}")
+    assert not bad, (masks["_relu_margin"], bad)
+    # eval mode: no dropout whatever the rates
+    with torch.no_grad():
+        ev = fused.FusedDecoderLayer.apply(c["x"], c["pos"], c["pts"], c["tokens"], c["keep4"], c["shapes"],
+                                           c["lsi"], c["M"], c["ab"], c["vr"], dims, False,
+                                           *[c["prm"][k] for k in PARAM_ORDER])
+        nomask = {k: torch.ones_like(v) for k, v in masks.items()}
+        _close(ev, _torch_layer(c, c["prm"], dims, nomask), 2e-4, "eval output")

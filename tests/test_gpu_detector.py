@@ -111,12 +111,16 @@ def test_forward_train_is_the_hot_path_on_the_streams_tokens():
     gtl = [torch.from_numpy(l).cuda() for l in batch["gt_labels"]]
     x = torch.from_numpy(img).cuda()
     sd0 = {k: v.clone() for k, v in det.state_dict().items()}
-    losses = det.forward_train(pts, x, batch["img_metas"], gtb, gtl)
+    from demf_amd import fused
+    fused.rng_state(pts.device, seed=3)
+    with torch.no_grad():
+        losses = det.forward_train(pts, x, batch["img_metas"], gtb, gtl)
     det.load_state_dict(sd0)                       # undo the BN running-stat update
     from demf_amd.modules import DeMFHotPath
     tokens = det.extract_img_feat(x, batch["img_metas"])
     want = DeMFHotPath.forward_train(det, pts, tokens, batch["img_metas"], gtb, gtl)
     for k in want:
         np.testing.assert_allclose(losses[k].item(), want[k].item(), rtol=1e-5)
-    losses["_total"].backward()
+    want["_total"].backward()
     assert all(p.grad is not None for n, p in det.named_parameters() if n.startswith("pts_") and p.requires_grad)
+    assert all(p.grad is None for n, p in det.named_parameters() if n.startswith("img_"))

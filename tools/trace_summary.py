@@ -21,3 +21,16 @@ small = sum(v[0] for v in agg.values() if v[0] / v[1] < 10000)
 print(f"kernels with avg < 10 us: {small/K/1e6:.2f} ms/step")
 for name, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(sys.argv[3]) if len(sys.argv) > 3 else 25]:
     print(f"  {t/K/1e6:7.3f} ms/step  x{n/K:6.1f}  avg {t/n/1e3:8.1f} us  {name}")
+
+import os
+if os.environ.get("DETAIL"):
+    # per launch-shape breakdown of one kernel family (grid size + duration)
+    sub = os.environ["DETAIL"]
+    det = collections.defaultdict(lambda: [0, 0])
+    for r in sel:
+        if sub in r["Kernel_Name"]:
+            key = (r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+            d = det[key]; d[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); d[1] += 1
+    print(f"--- {sub}: per grid shape")
+    for k, (t, n) in sorted(det.items(), key=lambda kv: -kv[1][0]):
+        print(f"  {t/K/1e3:8.1f} us/step  x{n/K:5.1f}  avg {t/n/1e3:7.1f} us  grid {k}")
