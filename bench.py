@@ -215,6 +215,10 @@ def main():
     ap.add_argument("--msda-points", type=int, default=2,
                     help="sampling points per level of the fusion attention: 2 = reference config "
                          "(demf_votenet.py:83), 4 = BASELINE.json's wording; secondary figure only")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="compute dtype of the dense MFMA kernels: f32 = the reference's precision "
+                         "(headline, BASELINE configs[2]); bf16 = configs[3] (bf16 MFMA, fp32 accumulate, "
+                         "fp32 storage / statistics / indices / losses)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -234,6 +238,7 @@ def main():
 
     from demf_amd import ops
     from demf_amd.modules import DeMFHotPath
+    ops.set_compute_dtype(args.dtype)
     torch.manual_seed(0)
     cfg = DeMFCfg()
     if args.msda_points != cfg.head.num_points:
@@ -309,11 +314,13 @@ def main():
             "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: full DeMF fusion hot path fwd+loss+bwd+"
                                    "allreduce+AdamW, %d scenes/GPU x (20000 pts, 800x1120 -> "
-                                   "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=%d, fp32"
-                                   % (args.batch, args.msda_points),
+                                   "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=%d, %s"
+                                   % (args.batch, args.msda_points,
+                                      "fp32" if args.dtype == "f32" else
+                                      "bf16 MFMA / fp32 accumulate+storage (BASELINE configs[3] per GPU)"),
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else "hipGraphs(fwd+loss | bwd) + eager allreduce/AdamW; "
                                  "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
@@ -325,6 +332,7 @@ def main():
         # runs underneath the step on a side stream).  Algorithmic bytes of that GEMM = read the
         # (R,64) input rows once, write the (R,128) raw output once, write pooled max/min + their
         # row offsets (4 x (R/64,128) words); weights < 1 %.
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 4 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
@@ -335,18 +343,19 @@ def main():
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,
             "avg_launch_ms": mlp_ms,
-            "mfma_frac": mlp_flop / (mlp_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-            "note": "also %.1f GFLOP fp32 MFMA per launch (mfma_frac = of the 157.3 TF/s dense fp32 peak)"
-                    % (mlp_flop / 1e9)}
+            "mfma_frac": mlp_flop / (mlp_ms * 1e-3) / 1e12 / mfma_peak,
+            "note": "also %.1f GFLOP of MFMA per launch (mfma_frac = of the %.1f TF/s dense %s peak)"
+                    % (mlp_flop / 1e9, mfma_peak, args.dtype)}
         # ---- step level: what the metric asks for ("as achieved fraction of HBM roofline")
         step_bytes = ALGO_BYTES_PER_SCENE * args.batch
         step_flop = ALGO_FLOP_PER_SCENE * args.batch
         out["roofline_step"] = {
-            "bound": "mfma", "algorithmic_bytes": step_bytes, "algorithmic_flop": step_flop,
+            "bound": "mfma" if args.dtype == "f32" else "hbm", "algorithmic_bytes": step_bytes,
+            "algorithmic_flop": step_flop,
             "hbm": {"achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "mfma": {"achieved": step_flop / (ms_step * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": step_flop / (ms_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS},
+            "mfma": {"achieved": step_flop / (ms_step * 1e-3) / 1e12, "peak": mfma_peak,
+                     "unit": "TFLOP/s", "frac": step_flop / (ms_step * 1e-3) / 1e12 / mfma_peak},
             "note": "SURVEY 8(d) per-scene algorithmic figures (190 MB, 46 GFLOP fwd+bwd) x scenes/GPU "
                     "over the measured step time, per GPU; the path is fp32-MFMA / latency bound, "
                     "not HBM bound"}

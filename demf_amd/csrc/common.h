@@ -85,4 +85,7 @@ __device__ __forceinline__ int lane_id() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// compute dtype switch (demf_set_compute_dtype, csrc/mlp.hip): true = bf16 MFMA, fp32 accumulate
+bool compute_bf16();
+
 }  // namespace demf

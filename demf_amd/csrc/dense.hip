@@ -20,6 +20,8 @@
 namespace demf {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
 
 // ---- counter-based dropout mask: stateless, reproducible in the backward -------------------------
 // keep(seed, step, op, idx) ; murmur3-style finaliser over the four words.  The step counter lives
@@ -46,6 +48,7 @@ __device__ __forceinline__ bool dropout_keep(const unsigned long long* __restric
 enum {
   GEMM_RELU = DEMF_GEMM_RELU, GEMM_DROPOUT = DEMF_GEMM_DROPOUT, GEMM_GATE = DEMF_GEMM_GATE,
   GEMM_ACCUM = DEMF_GEMM_ACCUM, GEMM_ROWBIAS = DEMF_GEMM_ROWBIAS, GEMM_ACCUM2 = DEMF_GEMM_ACCUM2,
+  GEMM_FP32 = DEMF_GEMM_FP32,
 };
 using GemmArgs = demf_gemm_desc;
 
@@ -58,12 +61,12 @@ struct GemmRegs {
   float4 v[4], w[4];            // modes 1 / 2: four float4 per thread (+ second operand)
 };
 
-template <bool ADD2>
+template <int mode, bool ADD2>
 __device__ __forceinline__ void gemm_fetch(GemmRegs& g, float (&sc)[16], const float* __restrict__ P,
                                            const float* __restrict__ P2, long long sr, long long sk,
-                                           int r0, int R, int k0, int K1, int mode) {
+                                           int r0, int R, int k0, int K1) {
   const int t = threadIdx.x;
-  if (mode == 1) {                       // k-contiguous, 16-byte aligned rows: float4 along K
+  if constexpr (mode == 1) {                       // k-contiguous, 16-byte aligned rows: float4 along K
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (t >> 4) + 16 * i, kq = (t & 15) * 4;
@@ -75,7 +78,7 @@ __device__ __forceinline__ void gemm_fetch(GemmRegs& g, float (&sc)[16], const f
         if constexpr (ADD2) g.w[i] = *reinterpret_cast<const float4*>(P2 + o);
       }
     }
-  } else if (mode == 2) {                // row-contiguous (reduction strided): float4 along rows
+  } else if constexpr (mode == 2) {      // row-contiguous (reduction strided): float4 along rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = (t >> 4) + 16 * i, rq = (t & 15) * 4;
@@ -102,18 +105,55 @@ __device__ __forceinline__ void gemm_fetch(GemmRegs& g, float (&sc)[16], const f
   }
 }
 
-template <bool ADD2>
-__device__ __forceinline__ void gemm_commit(float* __restrict__ s, const GemmRegs& g, const float (&sc)[16],
-                                            int mode) {
+constexpr int G_LDB = 2 * (G_BK + 8);      // bf16 tiles: bytes per row
+
+__device__ __forceinline__ float4 add4(float4 v, const float4& w) {
+  v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  return v;
+}
+
+// bf16 flavour of gemm_commit: element (row, k) at byte row * G_LDB + 2k
+template <int mode, bool ADD2>
+__device__ __forceinline__ void gemm_commit_bf16(char* __restrict__ s, const GemmRegs& g, const float (&sc)[16]) {
   const int t = threadIdx.x;
-  if (mode == 1) {
+  if constexpr (mode == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = ADD2 ? add4(g.v[i], g.w[i]) : g.v[i];
+      bf16x4 b;
+      b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+      *reinterpret_cast<bf16x4*>(s + ((t >> 4) + 16 * i) * G_LDB + 2 * (t & 15) * 4) = b;
+    }
+  } else if constexpr (mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = ADD2 ? add4(g.v[i], g.w[i]) : g.v[i];
+      char* d = s + (t & 15) * 4 * G_LDB + 2 * ((t >> 4) + 16 * i);
+      *reinterpret_cast<__bf16*>(d) = (__bf16)v.x;
+      *reinterpret_cast<__bf16*>(d + G_LDB) = (__bf16)v.y;
+      *reinterpret_cast<__bf16*>(d + 2 * G_LDB) = (__bf16)v.z;
+      *reinterpret_cast<__bf16*>(d + 3 * G_LDB) = (__bf16)v.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = t + 256 * i;
+      *reinterpret_cast<__bf16*>(s + (e >> 6) * G_LDB + 2 * (e & 63)) = (__bf16)sc[i];
+    }
+  }
+}
+
+template <int mode, bool ADD2>
+__device__ __forceinline__ void gemm_commit(float* __restrict__ s, const GemmRegs& g, const float (&sc)[16]) {
+  const int t = threadIdx.x;
+  if constexpr (mode == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = g.v[i];
       if constexpr (ADD2) { v.x += g.w[i].x; v.y += g.w[i].y; v.z += g.w[i].z; v.w += g.w[i].w; }
       *reinterpret_cast<float4*>(s + ((t >> 4) + 16 * i) * G_LD + (t & 15) * 4) = v;
     }
-  } else if (mode == 2) {
+  } else if constexpr (mode == 2) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = g.v[i];
@@ -130,7 +170,9 @@ __device__ __forceinline__ void gemm_commit(float* __restrict__ s, const GemmReg
   }
 }
 
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p, int modeA, int modeB) {
+// MA / MB: staging mode of the A / B operand (stage_mode); ADD = a second addend on either operand
+template <int MA, int MB, bool ADD, bool BF16>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float s_a[G_BM * G_LD];
   __shared__ __attribute__((aligned(16))) float s_b[G_BN * G_LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -154,16 +196,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p, int modeA, int mo
   GemmRegs ga, gb;
   float sa16[16], sb16[16];
   auto fetch = [&](int k0) {
-    if (A2 != nullptr) gemm_fetch<true>(ga, sa16, A, A2, p.sam, p.sak, m0, p.M, k0, kend, modeA);
-    else gemm_fetch<false>(ga, sa16, A, nullptr, p.sam, p.sak, m0, p.M, k0, kend, modeA);
-    if (B2 != nullptr) gemm_fetch<true>(gb, sb16, B, B2, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
-    else gemm_fetch<false>(gb, sb16, B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend, modeB);
+    if (ADD && A2 != nullptr) gemm_fetch<MA, ADD>(ga, sa16, A, A2, p.sam, p.sak, m0, p.M, k0, kend);
+    else gemm_fetch<MA, false>(ga, sa16, A, nullptr, p.sam, p.sak, m0, p.M, k0, kend);
+    if (ADD && B2 != nullptr) gemm_fetch<MB, ADD>(gb, sb16, B, B2, p.sbn, p.sbk, n0, p.N, k0, kend);
+    else gemm_fetch<MB, false>(gb, sb16, B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend);
   };
   if (kbeg < kend) fetch(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += G_BK) {
     __syncthreads();                                  // everyone is done reading the previous tiles
-    if (A2 != nullptr) gemm_commit<true>(s_a, ga, sa16, modeA); else gemm_commit<false>(s_a, ga, sa16, modeA);
-    if (B2 != nullptr) gemm_commit<true>(s_b, gb, sb16, modeB); else gemm_commit<false>(s_b, gb, sb16, modeB);
+    if constexpr (BF16) {
+      char* ca = reinterpret_cast<char*>(s_a);
+      char* cb = reinterpret_cast<char*>(s_b);
+      if (ADD && A2 != nullptr) gemm_commit_bf16<MA, ADD>(ca, ga, sa16); else gemm_commit_bf16<MA, false>(ca, ga, sa16);
+      if (ADD && B2 != nullptr) gemm_commit_bf16<MB, ADD>(cb, gb, sb16); else gemm_commit_bf16<MB, false>(cb, gb, sb16);
+      __syncthreads();
+      if (k0 + G_BK < kend) fetch(k0 + G_BK);
+#pragma unroll
+      for (int c16 = 0; c16 < G_BK / 16; ++c16) {
+        const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(ca + (wm * 32 + lr) * G_LDB + 2 * (c16 * 16 + 8 * lh));
+        const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(cb + (wn * 32 + lr) * G_LDB + 2 * (c16 * 16 + 8 * lh));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+      }
+      continue;
+    }
+    if (ADD && A2 != nullptr) gemm_commit<MA, ADD>(s_a, ga, sa16); else gemm_commit<MA, false>(s_a, ga, sa16);
+    if (ADD && B2 != nullptr) gemm_commit<MB, ADD>(s_b, gb, sb16); else gemm_commit<MB, false>(s_b, gb, sb16);
     __syncthreads();
     if (k0 + G_BK < kend) fetch(k0 + G_BK);           // in flight during the MFMAs below
 #pragma unroll
@@ -213,14 +270,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p, int modeA, int mo
   }
 }
 
-static inline bool aligned16(const void* q) { return ((uintptr_t)q & 15) == 0; }
-
-// staging mode of an operand with rows R, reduction K, strides (sr, sk)
-static int stage_mode(const float* P, const float* P2, long long sr, long long sk, long long sb,
-                      long long sb2, int R, int K) {
-  const bool al = aligned16(P) && (P2 == nullptr || aligned16(P2)) && sb % 4 == 0 && sb2 % 4 == 0;
-  if (sk == 1 && sr % 4 == 0 && K % 4 == 0 && al) return 1;
-  if (sr == 1 && sk % 4 == 0 && R % 4 == 0 && al) return 2;
+// staging mode of an operand with rows R, reduction K, strides (sr, sk).  Global dwordx4 loads only
+// need 4-byte alignment on gfx9 (parameters live at arbitrary float offsets of the flat optimizer
+// buffer), so contiguity and a length that is a multiple of 4 are the only requirements.
+static int stage_mode(long long sr, long long sk, int R, int K) {
+  if (sk == 1 && K % 4 == 0) return 1;
+  if (sr == 1 && R % 4 == 0) return 2;
   return 0;
 }
 
@@ -515,10 +570,33 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
   DEMF_REQUIRE(p.splitk == 1 || !(p.flags & (GEMM_RELU | GEMM_DROPOUT | GEMM_GATE)),
                "gemm: split-K cannot carry a non-linear epilogue");
   DEMF_REQUIRE((long long)p.batch * p.splitk <= 65535, "gemm: batch*splitk too large");
-  const int modeA = stage_mode(p.A, p.A2, p.sam, p.sak, p.sab, p.sab2, p.M, p.K);
-  const int modeB = stage_mode(p.B, p.B2, p.sbn, p.sbk, p.sbb, p.sbb2, p.N, p.K);
+  const int modeA = stage_mode(p.sam, p.sak, p.M, p.K);
+  const int modeB = stage_mode(p.sbn, p.sbk, p.N, p.K);
   dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), p.batch * p.splitk);
-  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, modeA, modeB);
+  const bool add = p.A2 != nullptr || p.B2 != nullptr;
+  const bool bf = compute_bf16() && !(p.flags & GEMM_FP32);
+#define GEMM_LAUNCH(MA_, MB_)                                                                          \
+  do {                                                                                                 \
+    if (bf) {                                                                                          \
+      if (add) hipLaunchKernelGGL((gemm_kernel<MA_, MB_, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);   \
+      else hipLaunchKernelGGL((gemm_kernel<MA_, MB_, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);      \
+    } else {                                                                                           \
+      if (add) hipLaunchKernelGGL((gemm_kernel<MA_, MB_, true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);  \
+      else hipLaunchKernelGGL((gemm_kernel<MA_, MB_, false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);     \
+    }                                                                                                  \
+  } while (0)
+  switch (modeA * 3 + modeB) {
+    case 0: GEMM_LAUNCH(0, 0); break;
+    case 1: GEMM_LAUNCH(0, 1); break;
+    case 2: GEMM_LAUNCH(0, 2); break;
+    case 3: GEMM_LAUNCH(1, 0); break;
+    case 4: GEMM_LAUNCH(1, 1); break;
+    case 5: GEMM_LAUNCH(1, 2); break;
+    case 6: GEMM_LAUNCH(2, 0); break;
+    case 7: GEMM_LAUNCH(2, 1); break;
+    default: GEMM_LAUNCH(2, 2); break;
+  }
+#undef GEMM_LAUNCH
   return check_launch("gemm_kernel");
 }
 

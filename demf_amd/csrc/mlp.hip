@@ -29,6 +29,22 @@
 namespace demf {
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+
+// Compute dtype of the dense kernels (demf_set_compute_dtype): 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32,
+// the reference's precision), 1 = bf16 MFMA with fp32 accumulate (v_mfma_f32_32x32x16_bf16):
+// operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS, AFTER the fp32
+// prologue (BN + ReLU / BN-backward); everything stored to memory, every statistic, index and loss
+// stays fp32.  BASELINE.json configs[3].
+static std::atomic<int> g_compute_bf16{0};
+bool compute_bf16() { return g_compute_bf16.load(std::memory_order_relaxed) != 0; }
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
+  bf16x4 r;
+  r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+  return r;
+}
 
 constexpr int MLP_BK = 32;        // K step staged per iteration
 constexpr int SCHED_GROUPS = 16;  // counters per dynamically scheduled persistent launch
@@ -239,7 +255,11 @@ __device__ __forceinline__ void pool_half_reduce(const f32x16 (&acc)[1][NT], int
         make_float4(mx, mn, __builtin_bit_cast(float, ax), __builtin_bit_cast(float, an));
 }
 
-template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false>
+// BF16: the A / B slabs hold bf16 (same byte row stride as the fp32 layout, so the slab doubles as
+// fp32 staging for the FIRST / RED epilogues unchanged) and a K step of 32 is two
+// v_mfma_f32_32x32x16_bf16 per tile instead of sixteen v_mfma_f32_32x32x2_f32.
+template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false,
+          bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   static_assert(!(STATS && RED) && !(FIRST && RED), "one column-sum epilogue at a time");
   constexpr int WROWS = 32 * RT;          // rows per wave
@@ -349,6 +369,26 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
     }
     __syncthreads();                                  // everyone is done reading the old Bt slab
+    if constexpr (BF16) {
+      // bf16 element (row, k) lives at byte row * 4*MLP_LD + 2*k of the slab
+      char* sab = reinterpret_cast<char*>(sa);
+      char* sbb = reinterpret_cast<char*>(sb);
+#pragma unroll
+      for (int it = 0; it < 4 * RT; ++it)
+        *reinterpret_cast<bf16x4*>(sab + (it * 8 + pr) * (4 * MLP_LD) + 2 * pc) =
+            to_bf16x4(mlp_xform<PRO>(p, s_vec, k0 + pc, pok[it], pre[it]));
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (p.ldb > 0) {
+          char* d = sbb + (32 * i + pc) * (4 * MLP_LD) + 2 * br;
+          *reinterpret_cast<__bf16*>(d) = (__bf16)preb[i].x;
+          *reinterpret_cast<__bf16*>(d + 4 * MLP_LD) = (__bf16)preb[i].y;
+          *reinterpret_cast<__bf16*>(d + 8 * MLP_LD) = (__bf16)preb[i].z;
+          *reinterpret_cast<__bf16*>(d + 12 * MLP_LD) = (__bf16)preb[i].w;
+        } else {
+          *reinterpret_cast<bf16x4*>(sbb + (br + 32 * i) * (4 * MLP_LD) + 2 * pc) = to_bf16x4(preb[i]);
+        }
+    } else {
 #pragma unroll
     for (int it = 0; it < 4 * RT; ++it)
       *reinterpret_cast<float4*>(sa + (it * 8 + pr) * MLP_LD + pc) =
@@ -361,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       } else {
         *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
       }
+    }
     __syncthreads();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
@@ -400,6 +441,24 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           xq = *reinterpret_cast<const float4*>(p.fX + (size_t)(row0 + lane) * 4);
       }
     }
+    if constexpr (BF16) {
+      const char* sab = reinterpret_cast<const char*>(sa);
+      const char* sbb = reinterpret_cast<const char*>(sb);
+      const int kch = min(MLP_BK / 16, (p.K - k0 + 15) / 16);
+      for (int c16 = 0; c16 < kch; ++c16) {
+        bf16x8 a8[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          a8[rt] = *reinterpret_cast<const bf16x8*>(sab + (rt * 32 + lr) * (4 * MLP_LD) + 2 * (c16 * 16 + 8 * lh));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(sbb + (nt * 32 + lr) * (4 * MLP_LD) + 2 * (c16 * 16 + 8 * lh));
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[rt], b8, acc[rt][nt], 0, 0, 0);
+        }
+      }
+    } else {
     const int kchunks = min(MLP_BK / 8, (p.K - k0 + 7) / 8);
     for (int c8 = 0; c8 < kchunks; ++c8) {
       float4 a4[RT];
@@ -417,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
           acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[rt].w, b4.w, acc[rt][nt], 0, 0, 0);
         }
       }
+    }
     }
     if (last_ks) {
       // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -1052,8 +1112,17 @@ static int mlp_grid(int R, int brows) {
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
+template <int PRO, bool STATS, bool POOL, bool RED, bool BF16>
+static int launch_gemm_t(const MlpArgs& a, hipStream_t s);
+
 template <int PRO, bool STATS, bool POOL = false, bool RED = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
+  return compute_bf16() ? launch_gemm_t<PRO, STATS, POOL, RED, true>(a, s)
+                        : launch_gemm_t<PRO, STATS, POOL, RED, false>(a, s);
+}
+
+template <int PRO, bool STATS, bool POOL, bool RED, bool BF16>
+static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
   // in 256 VGPRs: up to 4 column tiles for the forward prologues, up to 2 for the backward ones
@@ -1086,7 +1155,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
       a2.halves = 2;
       grid = dim3(2 * gx, 1);
     }
-#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true>), grid, block, 0, s, a2)
+#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true, false, false, BF16>), grid, block, 0, s, a2)
     if (rt2) { if (ntl == 1) PGO(1, 2); else PGO(2, 2); }
     else if (ntl == 1) PGO(1, 1);
     else if (ntl == 2) PGO(2, 1);
@@ -1103,7 +1172,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     const dim3 grid(tiles1, (nt + ntl - 1) / ntl);
     switch (ntl) {
 #define SPLIT(NTv)                                                                              \
-      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS, POOL, false, RED>), grid, block, 0, s, a); break;
+      case NTv: hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO, STATS, POOL, false, RED, BF16>), grid, block, 0, s, a); break;
       SPLIT(1) SPLIT(2) SPLIT(3) SPLIT(4)
 #undef SPLIT
       default: break;
@@ -1116,7 +1185,7 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
     const int gxv = mlp_grid(a.R, 128 * RTv);                                                   \
     const int tilesv = (a.R + 128 * RTv - 1) / (128 * RTv);                                     \
     if (tilesv > gxv && a.K > MLP_BK && gxv % (8 * SCHED_GROUPS) == 0) a3.sched = sched_slot();                                \
-    hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL, false, RED>), dim3(gxv), block, 0, s, a3); \
+    hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, POOL, false, RED, BF16>), dim3(gxv), block, 0, s, a3); \
   } while (0)
 #define CASE(NTv)                                                                               \
   case NTv:                                                                                     \
@@ -1144,6 +1213,12 @@ static int mlp_check(int R, int K, int N, int ldx) {
 
 using namespace demf;
 
+
+extern "C" int demf_set_compute_dtype(int bf16) {
+  DEMF_REQUIRE(bf16 == 0 || bf16 == 1, "set_compute_dtype: 0 = fp32, 1 = bf16");
+  g_compute_bf16.store(bf16);
+  return DEMF_OK;
+}
 
 extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,
                                  const float* pro_scale_shift, const float* Wt, float* Y,
@@ -1385,8 +1460,14 @@ extern "C" int demf_mlp_gemm_bwd_dx_first(int R, int N, int K0, const float* G, 
   const int tiles = (R + 127) / 128;
   if (tiles > gx && a.K > MLP_BK && gx % (8 * SCHED_GROUPS) == 0) a.sched = sched_slot();
   if (K0 <= 32)
+    if (compute_bf16())
+      hipLaunchKernelGGL((mlp_gemm_kernel<1, 1, PRO_DY_DENSE, false, false, true, false, true>), dim3(gx), dim3(256), 0, s, a);
+    else
     hipLaunchKernelGGL((mlp_gemm_kernel<1, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
   else
+    if (compute_bf16())
+      hipLaunchKernelGGL((mlp_gemm_kernel<2, 1, PRO_DY_DENSE, false, false, true, false, true>), dim3(gx), dim3(256), 0, s, a);
+    else
     hipLaunchKernelGGL((mlp_gemm_kernel<2, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
   return check_launch("mlp_gemm_bwd_dx_first");
 }

@@ -13,7 +13,7 @@ from torch.autograd.function import once_differentiable
 from . import _ffi
 
 __all__ = [
-    "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
+    "set_compute_dtype", "get_compute_dtype", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
     "three_nn", "three_interpolate", "MultiScaleDeformableAttnFunction",
     "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns", "shared_mlp_pool",
 ]
@@ -21,6 +21,26 @@ __all__ = [
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+_COMPUTE_DTYPE = "f32"
+
+
+def set_compute_dtype(name):
+    """"f32" (the reference's precision: fp32 MFMA) or "bf16" (BASELINE.json configs[3]): the dense
+    MFMA kernels - shared-MLP GEMMs forward / input-gradient, the decoder layer's GEMMs, the linear
+    heads - round their operands to bf16 on the way into LDS and run v_mfma_f32_32x32x16_bf16 with
+    fp32 accumulation.  Tensors in memory, BN statistics, weight-gradient reductions, indices,
+    sampling and losses stay fp32.  Process-wide (demf_set_compute_dtype)."""
+    global _COMPUTE_DTYPE
+    if name not in ("f32", "bf16"):
+        raise ValueError("compute dtype must be 'f32' or 'bf16'")
+    _ffi.call("demf_set_compute_dtype", 1 if name == "bf16" else 0)
+    _COMPUTE_DTYPE = name
+
+
+def get_compute_dtype():
+    return _COMPUTE_DTYPE
 
 
 def _chk(t, name, dtype=torch.float32):

@@ -437,6 +437,7 @@ int demf_adamw_f32(long long n, float* param, const float* grad, float* exp_avg,
 #define DEMF_GEMM_ACCUM 8     /* C += v (split-K always accumulates, atomically, into zeroed C) */
 #define DEMF_GEMM_ROWBIAS 16  /* bias term = bias[n] * rowscale[m]                              */
 #define DEMF_GEMM_ACCUM2 32   /* C2 += v instead of C2 = v                                      */
+#define DEMF_GEMM_FP32 64     /* keep this launch on the fp32 MFMA path in bf16 compute mode    */
 
 /* C[m,n] (+)= epi( alpha * sum_k (A[m,k] + A2[m,k]) * (B[n,k] + B2[n,k]) + bias[n] ), all operands
  * fp32 and addressed by element strides: A[m,k] at A + m*sam + k*sak, B[n,k] at B + n*sbn + k*sbk,
@@ -465,6 +466,13 @@ typedef struct demf_gemm_desc {
 } demf_gemm_desc;
 
 int demf_gemm_f32(const demf_gemm_desc* desc, demf_stream_t stream);
+
+/* Compute dtype of the dense MFMA kernels (demf_mlp_gemm_*, demf_gemm_f32): 0 = fp32 MFMA (the
+ * reference's precision, class_agnostic_vote_head.py:384 fp16_enabled=False), 1 = bf16 MFMA with
+ * fp32 accumulation (BASELINE.json configs[3]): operands are rounded to bf16 on their way into LDS,
+ * after the fp32 prologues; stored tensors, BN statistics, indices and losses stay fp32.
+ * Process-wide setting (the one piece of host-side mutable state besides the counter ring).     */
+int demf_set_compute_dtype(int bf16);
 
 /* s = identity + dropout(x) ; y = LayerNorm(s) over rows of C channels (C in 64..1024, power of two
  * multiples of 64).  s_out may alias x; stats (R,2) = mean, rstd.  nn.LayerNorm + the
