@@ -34,7 +34,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
 # the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
-DOMINANT_KERNEL = "mlp_gemm_kernel<4, 1, 1, true, true, false, false>"
+DOMINANT_KERNEL = {"f32": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, false>",
+                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, true>"}
 # FPS: per round one barrier phase (~450 cycles with 16 waves) + 20 points/lane x 8 VALU ops
 FPS_FLOOR_CYCLES = 900.0
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
@@ -336,9 +337,10 @@ def main():
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 4 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
-        traffic, src = pmc_per_launch(DOMINANT_KERNEL) if args.batch == 8 else (None, None)
+        dom = DOMINANT_KERNEL[args.dtype]
+        traffic, src = pmc_per_launch(dom) if args.batch == 8 else (None, None)
         out["roofline"] = {
-            "kernel": "%s (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (DOMINANT_KERNEL, sa1_rows),
+            "kernel": "%s (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (dom, sa1_rows),
             "bound": "hbm", "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,

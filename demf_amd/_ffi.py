@@ -67,6 +67,7 @@ SIGNATURES = {
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
     "demf_gemm_f32": [_ptr, _ptr],
     "demf_set_compute_dtype": [_c_int],
+    "demf_multi_copy": [_c_int, _ptr, _c_int, _ptr],
     "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
     "demf_add_dropout_ln_bwd": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _ptr, _c_int, _ptr, _c_int] + [_ptr] * 4,
     "demf_softmax_dropout_fwd": [_c_int] * 2 + [_ptr, _c_float, _ptr, _c_int] + [_ptr] * 3,

@@ -65,9 +65,39 @@ __global__ __launch_bounds__(256) void adamw_flat_k(AdamWArgs a) {
   }
 }
 
+// n segments copied (src != null) or zero-filled (src == null) in ONE launch: blockIdx.y = segment,
+// blockIdx.x strides over its 4-byte words.  table (device, 3 x n int64): src | dst | words.
+__global__ __launch_bounds__(256) void multi_copy_k(int n, const long long* __restrict__ table) {
+  const int seg = blockIdx.y;
+  const unsigned* src = reinterpret_cast<const unsigned*>(table[seg]);
+  unsigned* dst = reinterpret_cast<unsigned*>(table[n + seg]);
+  const long long words = table[2 * n + seg];
+  const bool vec = ((table[seg] | table[n + seg]) & 15) == 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const long long q = words >> 2;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (long long j = i; j < q; j += stride) d4[j] = src != nullptr ? s4[j] : make_uint4(0, 0, 0, 0);
+    for (long long j = 4 * q + i; j < words; j += stride) dst[j] = src != nullptr ? src[j] : 0u;
+  } else {
+    for (long long j = i; j < words; j += stride) dst[j] = src != nullptr ? src[j] : 0u;
+  }
+}
+
 }  // namespace demf
 
 using namespace demf;
+
+extern "C" int demf_multi_copy(int n, const void* table, int blocks_per_segment, demf_stream_t stream) {
+  DEMF_REQUIRE(n >= 0 && blocks_per_segment >= 1, "multi_copy: bad arguments");
+  if (n == 0) return DEMF_OK;
+  DEMF_REQUIRE(table != nullptr, "multi_copy: null table");
+  hipLaunchKernelGGL(multi_copy_k, dim3(blocks_per_segment, n), dim3(256), 0, (hipStream_t)stream, n,
+                     (const long long*)table);
+  return check_launch("multi_copy");
+}
 
 extern "C" int demf_adamw_f32(long long n, float* param, const float* grad, float* exp_avg,
                               float* exp_avg_sq, const float* grad_norm, float max_norm,

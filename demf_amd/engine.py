@@ -227,9 +227,22 @@ class Trainer:
         # the head hands out the sum of its losses directly (one node instead of 8 selects)
         return losses["_total"] if "_total" in losses else torch.stack(list(losses.values())).sum()
 
+    def _arena(self, begin):
+        """Bracket forward + backward with the step's zero arena (ops._ZeroArena) on the device path."""
+        if self.fused:
+            from . import ops
+            if begin:
+                ops.ARENA.begin(self.flat.flat.device)
+            else:
+                ops.ARENA.end()
+
     def _fwd_bwd(self, batch, geometry=None):
-        total = self._fwd(batch, geometry)
-        self.flat.backward_into(total)
+        self._arena(True)
+        try:
+            total = self._fwd(batch, geometry)
+            self.flat.backward_into(total)
+        finally:
+            self._arena(False)
         return total.detach()
 
     def _update(self):
@@ -326,11 +339,15 @@ class Trainer:
             # started in between: it then runs underneath the backward, whose long persistent
             # kernels take their tiles dynamically and lose less to the resident FPS chain than the
             # forward does (measured 9.26 -> 9.11 ms/step; DEMF_GEO_AT_FWD=1 restores the old order)
-            with torch.cuda.graph(graph):
-                total = self._fwd(batch, static_geo)
-            graph_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_bwd, pool=graph.pool()):
-                self.flat.backward_into(total)
+            try:
+                with torch.cuda.graph(graph):
+                    self._arena(True)            # the arena's single fill is the graph's first node
+                    total = self._fwd(batch, static_geo)
+                graph_bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_bwd, pool=graph.pool()):
+                    self.flat.backward_into(total)
+            finally:
+                self._arena(False)
             loss = total.detach()
         else:
             with torch.cuda.graph(graph):
@@ -355,6 +372,12 @@ class Trainer:
                 fresh = flat_tensors(self.model.index_geometry(static_pts))
             torch.cuda.synchronize()
         static_flat = flat_tensors(static_geo) if can_prefetch else None
+        refresh = None
+        if can_prefetch:
+            # one launch instead of one copy per index tensor (~30 of them)
+            from . import ops
+            pairs = [(d, s) for d, s in zip(static_flat, fresh) if d.numel()]
+            refresh = ops.MultiCopy([d for d, _ in pairs], [s for _, s in pairs])
 
         # which cloud the static geometry buffers / the in-flight pre-pass belong to:
         # (data_ptr, _version) of the tensor handed in; ``load`` checks it
@@ -382,7 +405,7 @@ class Trainer:
                 graph_bwd.replay()
                 self._update()
                 main.wait_stream(side)
-                torch._foreach_copy_(static_flat, fresh)
+                refresh()
                 return loss
             if can_prefetch:
                 # the pre-pass goes first: enqueueing the ~900-node step graph takes the host
@@ -394,7 +417,7 @@ class Trainer:
             self._update()
             if can_prefetch:
                 main.wait_stream(side)
-                torch._foreach_copy_(static_flat, fresh)
+                refresh()
             return loss
 
         def load(new):
@@ -411,7 +434,7 @@ class Trainer:
                 with torch.cuda.stream(side):
                     geo_graph.replay()
                 main.wait_stream(side)
-                torch._foreach_copy_(static_flat, fresh)
+                refresh()
             state["prefetched"] = None
             static["points"].copy_(new["points"])
             nf = new["img_features"]

@@ -219,7 +219,8 @@ class FusedDecoderLayer(Function):
         shp = [(3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (2 * HLP, E), (2 * HLP,), (HLP, E), (HLP,),
                (E, Ct), (E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,), (E,), (E,)]
         sizes = [math.prod(s) for s in shp]
-        ws = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        from . import ops
+        ws = ops.zeros(sum(sizes), dev)
         gr, o = [], 0
         for s_, n in zip(shp, sizes):
             gr.append(ws[o:o + n].view(s_))
@@ -244,7 +245,7 @@ class FusedDecoderLayer(Function):
         dmo = new(R, E)
         gemm(R, E, E, _p(dco), (E, 1), _p(op_w), (1, E), _p(dmo), E)
         # per-head value projection applied after sampling: mo[:, h] = z_h Wv_h^T + bv_h * ksum_h
-        dz, dks4 = new(R * H, Ct), torch.zeros((R * H, 4), dtype=torch.float32, device=dev)
+        dz, dks4 = new(R * H, Ct), ops.zeros((R * H, 4), dev)
         gemm(R, Ct, Dh, _p(dmo), (E, 1), _p(vp_w), (1, Ct), _p(dz), H * Ct, batch=H, sab=(Dh, 0),
              sbb=(Dh * Ct, 0), scb=(Ct, 0))
         gemm(Dh, Ct, R, _p(dmo), (1, E), _p(z), (1, H * Ct), _p(d_vp_w), Ct, batch=H, sab=(Dh, 0),

@@ -23,6 +23,80 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class MultiCopy:
+    """dst[i].copy_(src[i]) (src[i] None: dst[i].zero_()) for a FIXED list of contiguous tensor pairs
+    as one kernel launch (demf_multi_copy); the address table is built once."""
+
+    def __init__(self, dst, src):
+        assert len(dst) == len(src) and len(dst) > 0
+        tab = [[], [], []]
+        for d, s in zip(dst, src):
+            assert d.is_contiguous() and d.is_cuda and (d.numel() * d.element_size()) % 4 == 0
+            if s is not None:
+                assert s.is_contiguous() and s.dtype == d.dtype and s.numel() == d.numel()
+            tab[0].append(0 if s is None else s.data_ptr())
+            tab[1].append(d.data_ptr())
+            tab[2].append(d.numel() * d.element_size() // 4)
+        self.keep = (list(dst), list(src))             # the table holds raw addresses
+        self.n = len(dst)
+        self.table = torch.tensor(tab, dtype=torch.int64, device=dst[0].device)
+        self.blocks = max(1, min(64, max(tab[2]) // 4096))
+
+    def __call__(self):
+        _ffi.call("demf_multi_copy", self.n, self.table.data_ptr(), self.blocks, _stream())
+
+
+class _ZeroArena:
+    """Zero-filled fp32 scratch for ONE training step, handed out by a bump pointer and re-zeroed
+    by a single fill at the start of the next step - instead of one memset launch per accumulated
+    output (weight-gradient workspaces of every fused stack, scatter targets of the gather /
+    interpolation backwards, loss accumulators: ~30 per step).  Only active between ``begin`` and
+    ``end`` (engine.Trainer brackets forward + backward with it); outside, ``zeros`` is torch.zeros."""
+
+    def __init__(self):
+        self.buf, self.off, self.high, self.active = None, 0, 0, False
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("zero arena must be sized by an eager warm-up step before capture")
+            self.buf = torch.zeros(1 << 22, dtype=torch.float32, device=device)
+        elif self.high:
+            self.buf[:self.high].zero_()
+        self.off, self.active = 0, True
+
+    def end(self):
+        self.active = False
+
+    def take(self, numel):
+        n = (numel + 63) // 64 * 64                   # 256-byte aligned pieces
+        if self.off + n > self.buf.numel():
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("zero arena overflow during capture")
+            # grow: pieces already handed out stay valid views of the old buffer (still zero-filled)
+            self.buf = torch.zeros(max(2 * self.buf.numel(), self.off + n), dtype=torch.float32,
+                                   device=self.buf.device)
+        out = self.buf[self.off:self.off + numel]
+        self.off += n
+        self.high = max(self.high, self.off)
+        return out
+
+
+ARENA = _ZeroArena()
+
+
+def zeros(shape, device):
+    """fp32 zeros: a piece of the step's zero arena when one is open, else torch.zeros."""
+    if isinstance(shape, int):
+        shape = (shape,)
+    if ARENA.active and ARENA.buf is not None and ARENA.buf.device == torch.device(device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return ARENA.take(n).view(*shape)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 _COMPUTE_DTYPE = "f32"
 
 
@@ -397,7 +471,7 @@ class _GatherRowsCL(Function):
         (idx,) = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         B, M, C = grad_out.shape
-        g = torch.zeros((B, ctx.N, C), dtype=grad_out.dtype, device=grad_out.device)
+        g = zeros((B, ctx.N, C), grad_out.device)
         _ffi.call("demf_gather_rows_cl_bwd", B, ctx.N, M, C, _p(grad_out), _p(idx), _p(g),
                   _stream())
         return g, None
@@ -429,7 +503,7 @@ class _ThreeInterpolateCL(Function):
         idx, weight = ctx.saved_tensors
         grad_out = grad_out.contiguous()
         B, n, C = grad_out.shape
-        g = torch.zeros((B, ctx.m, C), dtype=grad_out.dtype, device=grad_out.device)
+        g = zeros((B, ctx.m, C), grad_out.device)
         _ffi.call("demf_three_interpolate_cl_bwd", B, ctx.m, n, C, C, 0, _p(grad_out), _p(idx),
                   _p(weight), _p(g), _stream())
         return g, None, None
@@ -529,7 +603,7 @@ class _LinearRows(Function):
                            _p(gx), K)
             if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
                 # one zero-filled workspace for dW | db (split-K atomics, column sums)
-                ws = torch.zeros(N * K + N, dtype=torch.float32, device=g.device)
+                ws = zeros(N * K + N, g.device)
                 gw = ws[:N * K].view(N, K)
                 fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, x.stride(0)), _p(gw), K,
                            splitk=fused._splitk(R))
@@ -745,7 +819,7 @@ class _SharedMLPPool(Function):
         ws64 = _accum64(n64, dev)
         # (+ room for the exact-zero gradients of conv biases shadowed by BatchNorm)
         nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
-        ws32 = torch.zeros(sum(W.numel() for W in Ws) + nbias, dtype=torch.float32, device=dev)
+        ws32 = zeros(sum(W.numel() for W in Ws) + nbias, dev)
         o64 = o32 = 0
         g12_ready = None      # layer l's sums already taken by the dx GEMM of layer l+1 (RED epilogue)
         for l in range(L - 1, -1, -1):
@@ -781,7 +855,7 @@ class _SharedMLPPool(Function):
                     # the coordinates carry a gradient too (vote aggregation)
                     Wx = W[:, :3].t().contiguous()
                     dxyz = torch.empty((gB, gN, 3), dtype=torch.float32, device=dev)
-                    dcenter = torch.zeros((gB, gM, 3), dtype=torch.float32, device=dev)
+                    dcenter = zeros((gB, gM, 3), dev)
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
                           _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
                           _p(dWx), _p(Wx), _p(dxyz), _p(dcenter), st)
@@ -909,7 +983,7 @@ class _HeadLoss(Function):
         R = cls_rows.shape[0]
         assert cls_rows.shape[1] == 12 and reg_rows.shape[1] == 30
         hp = (_ct.c_float * 12)(*hyper)
-        out = torch.zeros(7, dtype=torch.float32, device=cls_rows.device)
+        out = zeros(7, cls_rows.device)
         _ffi.call("demf_head_loss_fwd", R, 12, 10, hp, _p(cls_rows), _p(reg_rows), _p(base),
                   _p(center_t), _p(size_t), _p(dir_class_t), _p(dir_res_t), _p(sem_t), _p(obj_t),
                   _p(obj_w), _p(box_w), _p(out), _stream())
@@ -951,7 +1025,7 @@ class _VoteLoss(Function):
         B, S, _ = seed_points.shape
         N = masks.shape[1]
         msum = torch.gather(masks, 1, seed_indices).sum().to(torch.float32).reshape(1)
-        out = torch.zeros(1, dtype=torch.float32, device=vote_points.device)
+        out = zeros(1, vote_points.device)
         _ffi.call("demf_vote_loss", B, S, N, int(gt_per_seed), float(dst_weight), _p(seed_points),
                   _p(vote_points), _p(seed_indices), _p(masks), _p(vote_targets), _p(msum), None,
                   _p(out), None, _stream())

@@ -513,6 +513,12 @@ int demf_rng_advance(void* rng, demf_stream_t stream);
 int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* out,
                       demf_stream_t stream);
 
+/* n device-to-device copies (or zero fills where src == 0) in one launch.  `table` is a DEVICE
+ * array of 3*n int64: n source addresses (0 = fill with zeros), n destination addresses, n lengths in
+ * 4-byte words.  Replaces the per-tensor copy / memset launches of a training step: the refresh of
+ * the step's static index buffers from the pipelined pre-pass, the zeroing of accumulated outputs. */
+int demf_multi_copy(int n, const void* table, int blocks_per_segment, demf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

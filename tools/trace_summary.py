@@ -34,3 +34,11 @@ if os.environ.get("DETAIL"):
     print(f"--- {sub}: per grid shape")
     for k, (t, n) in sorted(det.items(), key=lambda kv: -kv[1][0]):
         print(f"  {t/K/1e3:8.1f} us/step  x{n/K:5.1f}  avg {t/n/1e3:7.1f} us  grid {k}")
+
+if os.environ.get("TOPN"):
+    n = int(os.environ["TOPN"])
+    one = rows[marks[-2 - SKIP]:marks[-1 - SKIP]]
+    t0 = int(one[0]["Start_Timestamp"])
+    print(f"--- the {n} longest launches of one step (start offset us, duration us, name)")
+    for r in sorted(one, key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))[:n]:
+        print(f"  @{(int(r['Start_Timestamp'])-t0)/1e3:8.1f}  {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:7.1f} us  {r['Kernel_Name'][:110]}")
