@@ -83,6 +83,13 @@ __device__ __forceinline__ int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt,
+// i.e. stalls until every outstanding global STORE of the wave has been acknowledged by memory - in a
+// GEMM whose epilogue has just issued 64 stores per lane that is microseconds per tile.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // compute dtype switch (demf_set_compute_dtype, csrc/mlp.hip): true = bf16 MFMA, fp32 accumulate

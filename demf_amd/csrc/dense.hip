@@ -16,6 +16,8 @@
 // tiles, 4 waves x one 32x32 MFMA accumulator, K staged in steps of 32 through LDS (fragment trick
 // of mlp.hip: a lane feeds component m of its float4 along K to MFMA m).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace demf {
 
@@ -170,6 +172,35 @@ __device__ __forceinline__ void gemm_commit(float* __restrict__ s, const GemmReg
   }
 }
 
+// one output element through the fused epilogue
+__device__ __forceinline__ void gemm_store(const GemmArgs& p, int z, size_t oc, int sp, int m, int n,
+                                           float bias, float accv) {
+  float v = p.alpha * accv;
+  if (p.flags & GEMM_ROWBIAS) {
+    if (sp == 0) v = __builtin_fmaf(bias, p.rowscale[(size_t)m * p.srs_m + (size_t)z * p.srs_b], v);
+  } else {
+    v += bias;
+  }
+  if (p.flags & GEMM_RELU) v = fmaxf(v, 0.f);
+  if (p.flags & GEMM_DROPOUT) {
+    const unsigned long long idx = ((unsigned long long)z * p.M + m) * p.N + n;
+    v = dropout_keep((const unsigned long long*)p.rng, (unsigned)p.op_id, idx, p.drop_p)
+            ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+  }
+  if (p.flags & GEMM_GATE)
+    v = p.gate[(size_t)z * p.sgb + (size_t)m * p.sgm + n] != 0.f ? v * p.gate_scale : 0.f;
+  float* dst = p.C + oc + (size_t)m * p.scm + n;
+  if (p.splitk > 1) atomicAdd(dst, v);
+  else if (p.flags & GEMM_ACCUM) *dst += v;
+  else *dst = v;
+  if (p.C2 != nullptr) {                          // same values to a second consumer
+    float* d2 = p.C2 + oc + (size_t)m * p.scm + n;
+    if (p.splitk > 1) atomicAdd(d2, v);
+    else if (p.flags & GEMM_ACCUM2) *d2 += v;
+    else *d2 = v;
+  }
+}
+
 // MA / MB: staging mode of the A / B operand (stage_mode); ADD = a second addend on either operand
 template <int MA, int MB, bool ADD, bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
@@ -193,44 +224,65 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  GemmRegs ga, gb;
-  float sa16[16], sb16[16];
-  auto fetch = [&](int k0) {
-    if (ADD && A2 != nullptr) gemm_fetch<MA, ADD>(ga, sa16, A, A2, p.sam, p.sak, m0, p.M, k0, kend);
-    else gemm_fetch<MA, false>(ga, sa16, A, nullptr, p.sam, p.sak, m0, p.M, k0, kend);
-    if (ADD && B2 != nullptr) gemm_fetch<MB, ADD>(gb, sb16, B, B2, p.sbn, p.sbk, n0, p.N, k0, kend);
-    else gemm_fetch<MB, false>(gb, sb16, B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend);
+  // Register prefetch ring, NS K-steps deep: with a few hundred rows there is one workgroup per CU
+  // and nothing else to hide the global-load latency (~2 us) behind, so the loads of the next NS
+  // steps are all in flight while a step's tiles go through LDS and the MFMAs (K = 256: the whole
+  // reduction is requested up front; measured 19 -> 11 us per 2048 x 256 x 256 launch).
+  constexpr int NS = ADD ? 2 : 3;
+  GemmRegs ga[NS], gb[NS];
+  float sa16[NS][16], sb16[NS][16];
+  auto fetch = [&](auto stage, int k0) {
+    constexpr int S = decltype(stage)::value;
+    if (ADD && A2 != nullptr) gemm_fetch<MA, ADD>(ga[S], sa16[S], A, A2, p.sam, p.sak, m0, p.M, k0, kend);
+    else gemm_fetch<MA, false>(ga[S], sa16[S], A, nullptr, p.sam, p.sak, m0, p.M, k0, kend);
+    if (ADD && B2 != nullptr) gemm_fetch<MB, ADD>(gb[S], sb16[S], B, B2, p.sbn, p.sbk, n0, p.N, k0, kend);
+    else gemm_fetch<MB, false>(gb[S], sb16[S], B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend);
   };
-  if (kbeg < kend) fetch(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += G_BK) {
-    __syncthreads();                                  // everyone is done reading the previous tiles
+  auto step = [&](auto stage, int k0) {
+    constexpr int S = decltype(stage)::value;
+    lds_barrier();                                    // everyone is done reading the previous tiles
     if constexpr (BF16) {
       char* ca = reinterpret_cast<char*>(s_a);
       char* cb = reinterpret_cast<char*>(s_b);
-      if (ADD && A2 != nullptr) gemm_commit_bf16<MA, ADD>(ca, ga, sa16); else gemm_commit_bf16<MA, false>(ca, ga, sa16);
-      if (ADD && B2 != nullptr) gemm_commit_bf16<MB, ADD>(cb, gb, sb16); else gemm_commit_bf16<MB, false>(cb, gb, sb16);
-      __syncthreads();
-      if (k0 + G_BK < kend) fetch(k0 + G_BK);
+      if (ADD && A2 != nullptr) gemm_commit_bf16<MA, ADD>(ca, ga[S], sa16[S]); else gemm_commit_bf16<MA, false>(ca, ga[S], sa16[S]);
+      if (ADD && B2 != nullptr) gemm_commit_bf16<MB, ADD>(cb, gb[S], sb16[S]); else gemm_commit_bf16<MB, false>(cb, gb[S], sb16[S]);
+      lds_barrier();
+      if (k0 + NS * G_BK < kend) fetch(stage, k0 + NS * G_BK);
 #pragma unroll
       for (int c16 = 0; c16 < G_BK / 16; ++c16) {
         const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(ca + (wm * 32 + lr) * G_LDB + 2 * (c16 * 16 + 8 * lh));
         const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(cb + (wn * 32 + lr) * G_LDB + 2 * (c16 * 16 + 8 * lh));
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
       }
-      continue;
-    }
-    if (ADD && A2 != nullptr) gemm_commit<MA, ADD>(s_a, ga, sa16); else gemm_commit<MA, false>(s_a, ga, sa16);
-    if (ADD && B2 != nullptr) gemm_commit<MB, ADD>(s_b, gb, sb16); else gemm_commit<MB, false>(s_b, gb, sb16);
-    __syncthreads();
-    if (k0 + G_BK < kend) fetch(k0 + G_BK);           // in flight during the MFMAs below
+    } else {
+      if (ADD && A2 != nullptr) gemm_commit<MA, ADD>(s_a, ga[S], sa16[S]); else gemm_commit<MA, false>(s_a, ga[S], sa16[S]);
+      if (ADD && B2 != nullptr) gemm_commit<MB, ADD>(s_b, gb[S], sb16[S]); else gemm_commit<MB, false>(s_b, gb[S], sb16[S]);
+      lds_barrier();
+      if (k0 + NS * G_BK < kend) fetch(stage, k0 + NS * G_BK);   // in flight during the next NS steps
 #pragma unroll
-    for (int c8 = 0; c8 < G_BK / 8; ++c8) {
-      const float4 a4 = *reinterpret_cast<const float4*>(s_a + (wm * 32 + lr) * G_LD + c8 * 8 + 4 * lh);
-      const float4 b4 = *reinterpret_cast<const float4*>(s_b + (wn * 32 + lr) * G_LD + c8 * 8 + 4 * lh);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      for (int c8 = 0; c8 < G_BK / 8; ++c8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(s_a + (wm * 32 + lr) * G_LD + c8 * 8 + 4 * lh);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_b + (wn * 32 + lr) * G_LD + c8 * 8 + 4 * lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, NS - 1>;
+  if (kbeg < kend) fetch(S0{}, kbeg);
+  if (kbeg + G_BK < kend) fetch(S1{}, kbeg + G_BK);
+  if constexpr (NS == 3) {
+    if (kbeg + 2 * G_BK < kend) fetch(S2{}, kbeg + 2 * G_BK);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += NS * G_BK) {
+    step(S0{}, k0);
+    if (k0 + G_BK < kend) step(S1{}, k0 + G_BK);
+    if constexpr (NS == 3) {
+      if (k0 + 2 * G_BK < kend) step(S2{}, k0 + 2 * G_BK);
     }
   }
   // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -239,40 +291,202 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   float bias = 0.f;
   if (p.bias != nullptr && sp == 0) bias = p.bias[(size_t)z * p.sbias_b + n];
   const size_t oc = (size_t)zo * p.scb + (size_t)zi * p.scb2;
-  float* C = p.C + oc;
-  const float inv_keep = (p.flags & GEMM_DROPOUT) ? 1.0f / (1.0f - p.drop_p) : 1.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (m >= p.M) continue;
-    float v = p.alpha * acc[r];
-    if (p.flags & GEMM_ROWBIAS) {
-      if (sp == 0) v = __builtin_fmaf(bias, p.rowscale[(size_t)m * p.srs_m + (size_t)z * p.srs_b], v);
+    if (m < p.M) gemm_store(p, z, oc, sp, m, n, bias, acc[r]);
+  }
+}
+
+// ---- few-tile launches: 32 x 32 output tiles, the K step of 64 split over the 4 waves ---------------
+// A 2048 x 256 output is 128 tiles of 64 x 64 - half the CUs, one workgroup each, every K step a
+// serial load -> LDS -> MFMA round.  Here a workgroup owns a 32 x 32 tile (4x as many workgroups,
+// several per CU) and its 4 waves each contract a quarter of the staged K range; the four partial
+// accumulators are folded through LDS and each wave applies the epilogue to 8 of the 32 rows.
+struct GemmRegsS {
+  float4 v[2], w[2];
+};
+
+template <int mode, bool ADD2>
+__device__ __forceinline__ void gemm_fetch_s(GemmRegsS& g, float (&sc)[8], const float* __restrict__ P,
+                                             const float* __restrict__ P2, long long sr, long long sk,
+                                             int r0, int R, int k0, int K1) {
+  const int t = threadIdx.x;
+  if constexpr (mode == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (t >> 4) + 16 * i, kq = (t & 15) * 4;
+      g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD2) g.w[i] = g.v[i];
+      if (r0 + row < R && k0 + kq < K1) {
+        const size_t o = (size_t)(r0 + row) * sr + k0 + kq;
+        g.v[i] = *reinterpret_cast<const float4*>(P + o);
+        if constexpr (ADD2) g.w[i] = *reinterpret_cast<const float4*>(P2 + o);
+      }
     }
-    else v += bias;
-    if (p.flags & GEMM_RELU) v = fmaxf(v, 0.f);
-    if (p.flags & GEMM_DROPOUT) {
-      const unsigned long long idx = ((unsigned long long)z * p.M + m) * p.N + n;
-      v = dropout_keep((const unsigned long long*)p.rng, (unsigned)p.op_id, idx, p.drop_p) ? v * inv_keep : 0.f;
+  } else if constexpr (mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = (t >> 3) + 32 * i, rq = (t & 7) * 4;
+      g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD2) g.w[i] = g.v[i];
+      if (k0 + k < K1 && r0 + rq < R) {
+        const size_t o = (size_t)(k0 + k) * sk + r0 + rq;
+        g.v[i] = *reinterpret_cast<const float4*>(P + o);
+        if constexpr (ADD2) g.w[i] = *reinterpret_cast<const float4*>(P2 + o);
+      }
     }
-    if (p.flags & GEMM_GATE)
-      v = p.gate[(size_t)z * p.sgb + (size_t)m * p.sgm + n] != 0.f ? v * p.gate_scale : 0.f;
-    float* dst = C + (size_t)m * p.scm + n;
-    if (p.splitk > 1) atomicAdd(dst, v);
-    else if (p.flags & GEMM_ACCUM) *dst += v;
-    else *dst = v;
-    if (p.C2 != nullptr) {                          // same values to a second consumer
-      float* d2 = p.C2 + oc + (size_t)m * p.scm + n;
-      if (p.splitk > 1) atomicAdd(d2, v);
-      else if (p.flags & GEMM_ACCUM2) *d2 += v;
-      else *d2 = v;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i, row = e >> 6, k = e & 63;
+      float v = 0.f;
+      if (r0 + row < R && k0 + k < K1) {
+        const size_t o = (size_t)(r0 + row) * sr + (size_t)(k0 + k) * sk;
+        v = P[o];
+        if constexpr (ADD2) v += P2[o];
+      }
+      sc[i] = v;
     }
+  }
+}
+
+template <int mode, bool ADD2, bool BF16>
+__device__ __forceinline__ void gemm_commit_s(float* __restrict__ s, const GemmRegsS& g, const float (&sc)[8]) {
+  const int t = threadIdx.x;
+  char* sb = reinterpret_cast<char*>(s);
+  if constexpr (mode == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = ADD2 ? add4(g.v[i], g.w[i]) : g.v[i];
+      const int row = (t >> 4) + 16 * i, kq = (t & 15) * 4;
+      if constexpr (BF16) {
+        bf16x4 b;
+        b[0] = (__bf16)v.x; b[1] = (__bf16)v.y; b[2] = (__bf16)v.z; b[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4*>(sb + row * G_LDB + 2 * kq) = b;
+      } else {
+        *reinterpret_cast<float4*>(s + row * G_LD + kq) = v;
+      }
+    }
+  } else if constexpr (mode == 2) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = ADD2 ? add4(g.v[i], g.w[i]) : g.v[i];
+      const int k = (t >> 3) + 32 * i, rq = (t & 7) * 4;
+      if constexpr (BF16) {
+        char* d = sb + rq * G_LDB + 2 * k;
+        *reinterpret_cast<__bf16*>(d) = (__bf16)v.x;
+        *reinterpret_cast<__bf16*>(d + G_LDB) = (__bf16)v.y;
+        *reinterpret_cast<__bf16*>(d + 2 * G_LDB) = (__bf16)v.z;
+        *reinterpret_cast<__bf16*>(d + 3 * G_LDB) = (__bf16)v.w;
+      } else {
+        float* d = s + rq * G_LD + k;
+        d[0] = v.x; d[G_LD] = v.y; d[2 * G_LD] = v.z; d[3 * G_LD] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = t + 256 * i;
+      if constexpr (BF16) *reinterpret_cast<__bf16*>(sb + (e >> 6) * G_LDB + 2 * (e & 63)) = (__bf16)sc[i];
+      else s[(e >> 6) * G_LD + (e & 63)] = sc[i];
+    }
+  }
+}
+
+template <int MA, int MB, bool ADD, bool BF16>
+__global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
+  __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
+  __shared__ float s_red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int z = blockIdx.z / p.splitk, sp = blockIdx.z - z * p.splitk;
+  const int kchunk = ((p.K + p.splitk - 1) / p.splitk + G_BK - 1) / G_BK * G_BK;
+  const int kbeg = sp * kchunk, kend = min(p.K, kbeg + kchunk);
+  const int zo = z / p.zdiv, zi = z - zo * p.zdiv;
+  const size_t oa = (size_t)zo * p.sab + (size_t)zi * p.sab2, ob = (size_t)zo * p.sbb + (size_t)zi * p.sbb2;
+  const float* A = p.A + oa;
+  const float* A2 = (p.A2 != nullptr && n0 < p.a2_cols) ? p.A2 + oa : nullptr;
+  const float* B = p.B + ob;
+  const float* B2 = (p.B2 != nullptr && m0 < p.b2_rows) ? p.B2 + ob : nullptr;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int NS = 3;
+  GemmRegsS ga[NS], gb[NS];
+  float sa8[NS][8], sb8[NS][8];
+  auto fetch = [&](auto stage, int k0) {
+    constexpr int S = decltype(stage)::value;
+    if (ADD && A2 != nullptr) gemm_fetch_s<MA, ADD>(ga[S], sa8[S], A, A2, p.sam, p.sak, m0, p.M, k0, kend);
+    else gemm_fetch_s<MA, false>(ga[S], sa8[S], A, nullptr, p.sam, p.sak, m0, p.M, k0, kend);
+    if (ADD && B2 != nullptr) gemm_fetch_s<MB, ADD>(gb[S], sb8[S], B, B2, p.sbn, p.sbk, n0, p.N, k0, kend);
+    else gemm_fetch_s<MB, false>(gb[S], sb8[S], B, nullptr, p.sbn, p.sbk, n0, p.N, k0, kend);
+  };
+  auto step = [&](auto stage, int k0) {
+    constexpr int S = decltype(stage)::value;
+    lds_barrier();
+    if (ADD && A2 != nullptr) gemm_commit_s<MA, ADD, BF16>(s_a, ga[S], sa8[S]); else gemm_commit_s<MA, false, BF16>(s_a, ga[S], sa8[S]);
+    if (ADD && B2 != nullptr) gemm_commit_s<MB, ADD, BF16>(s_b, gb[S], sb8[S]); else gemm_commit_s<MB, false, BF16>(s_b, gb[S], sb8[S]);
+    lds_barrier();
+    if (k0 + NS * G_BK < kend) fetch(stage, k0 + NS * G_BK);
+    // this wave's quarter of the K step: k = 16*wave .. 16*wave + 15
+    if constexpr (BF16) {
+      const char* ca = reinterpret_cast<const char*>(s_a);
+      const char* cb = reinterpret_cast<const char*>(s_b);
+      const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(ca + lr * G_LDB + 2 * (wave * 16 + 8 * lh));
+      const bf16x8 b8 = *reinterpret_cast<const bf16x8*>(cb + lr * G_LDB + 2 * (wave * 16 + 8 * lh));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {
+        const float4 a4 = *reinterpret_cast<const float4*>(s_a + lr * G_LD + wave * 16 + c8 * 8 + 4 * lh);
+        const float4 b4 = *reinterpret_cast<const float4*>(s_b + lr * G_LD + wave * 16 + c8 * 8 + 4 * lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      }
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  if (kbeg < kend) fetch(S0{}, kbeg);
+  if (kbeg + G_BK < kend) fetch(S1{}, kbeg + G_BK);
+  if (kbeg + 2 * G_BK < kend) fetch(S2{}, kbeg + 2 * G_BK);
+  for (int k0 = kbeg; k0 < kend; k0 += NS * G_BK) {
+    step(S0{}, k0);
+    if (k0 + G_BK < kend) step(S1{}, k0 + G_BK);
+    if (k0 + 2 * G_BK < kend) step(S2{}, k0 + 2 * G_BK);
+  }
+  // fold the 4 partial tiles; wave q finishes registers 4q..4q+3 = rows 8q + (0..3) + 4*lh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
+  lds_barrier();
+  const int n = n0 + lr;
+  if (n >= p.N) return;
+  float bias = 0.f;
+  if (p.bias != nullptr && sp == 0) bias = p.bias[(size_t)z * p.sbias_b + n];
+  const size_t oc = (size_t)zo * p.scb + (size_t)zi * p.scb2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * wave + q;
+    const int m = m0 + q + 8 * wave + 4 * lh;
+    const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+    if (m < p.M) gemm_store(p, z, oc, sp, m, n, bias, v);
   }
 }
 
 // staging mode of an operand with rows R, reduction K, strides (sr, sk).  Global dwordx4 loads only
 // need 4-byte alignment on gfx9 (parameters live at arbitrary float offsets of the flat optimizer
 // buffer), so contiguity and a length that is a multiple of 4 are the only requirements.
+static int env_tiles() {
+  static const int v = getenv("DEMF_GEMM_SMALL_TILES") ? atoi(getenv("DEMF_GEMM_SMALL_TILES")) : 1024;
+  return v;
+}
+
 static int stage_mode(long long sr, long long sk, int R, int K) {
   if (sk == 1 && K % 4 == 0) return 1;
   if (sr == 1 && R % 4 == 0) return 2;
@@ -575,6 +789,34 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
   dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), p.batch * p.splitk);
   const bool add = p.A2 != nullptr || p.B2 != nullptr;
   const bool bf = compute_bf16() && !(p.flags & GEMM_FP32);
+  // few 64 x 64 tiles (or a narrow output): 32 x 32 tiles with the K step split over the waves
+  const bool small = (long long)grid.x * grid.y * grid.z <= env_tiles() || p.N <= 32;
+  if (small) {
+    grid = dim3(cdiv(p.N, 32), cdiv(p.M, 32), p.batch * p.splitk);
+#define GEMM_LAUNCH_S(MA_, MB_)                                                                        \
+  do {                                                                                                 \
+    if (bf) {                                                                                          \
+      if (add) hipLaunchKernelGGL((gemm_ks_kernel<MA_, MB_, true, true>), grid, dim3(256), 0, (hipStream_t)stream, p);   \
+      else hipLaunchKernelGGL((gemm_ks_kernel<MA_, MB_, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p);      \
+    } else {                                                                                           \
+      if (add) hipLaunchKernelGGL((gemm_ks_kernel<MA_, MB_, true, false>), grid, dim3(256), 0, (hipStream_t)stream, p);  \
+      else hipLaunchKernelGGL((gemm_ks_kernel<MA_, MB_, false, false>), grid, dim3(256), 0, (hipStream_t)stream, p);     \
+    }                                                                                                  \
+  } while (0)
+    switch (modeA * 3 + modeB) {
+      case 0: GEMM_LAUNCH_S(0, 0); break;
+      case 1: GEMM_LAUNCH_S(0, 1); break;
+      case 2: GEMM_LAUNCH_S(0, 2); break;
+      case 3: GEMM_LAUNCH_S(1, 0); break;
+      case 4: GEMM_LAUNCH_S(1, 1); break;
+      case 5: GEMM_LAUNCH_S(1, 2); break;
+      case 6: GEMM_LAUNCH_S(2, 0); break;
+      case 7: GEMM_LAUNCH_S(2, 1); break;
+      default: GEMM_LAUNCH_S(2, 2); break;
+    }
+#undef GEMM_LAUNCH_S
+    return check_launch("gemm_ks_kernel");
+  }
 #define GEMM_LAUNCH(MA_, MB_)                                                                          \
   do {                                                                                                 \
     if (bf) {                                                                                          \

@@ -79,9 +79,6 @@ __device__ __forceinline__ float row16_max_dpp(float v) {
   return v;
 }
 
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 using f2 = float __attribute__((ext_vector_type(2)));
 

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0.f;
     }
-    __syncthreads();                                  // everyone is done reading the old Bt slab
+    lds_barrier();                                    // everyone is done reading the old Bt slab (LDS-only
+                                                      // wait: the previous tile's output stores stay in flight)
     if constexpr (BF16) {
       // bf16 element (row, k) lives at byte row * 4*MLP_LD + 2*k of the slab
       char* sab = reinterpret_cast<char*>(sa);
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
     constexpr bool DEFER = (POOL && RT == 2) || FIRST;   // epilogues that need the prefetch registers
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       }
       if constexpr (POOL && RT == 1) {
         if (p.ns == 64) {                       // merge the two half groups of each wave pair
-          __syncthreads();
+          lds_barrier();                        // (LDS-only: the tile's output stores keep draining)
           if ((wave & 1) == 0 && lh == 0) {
             const int grow = row0;              // first row of this wave pair's group
 #pragma unroll
