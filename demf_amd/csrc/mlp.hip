@@ -695,6 +695,223 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   }
 }
 
+// ---- forward GEMM with the A rows streamed global -> LDS directly (global_load_lds_dwordx4) ---------
+// The register-staged kernel above keeps ONE K step of A per wave in flight (16 VGPRs; its 255 VGPRs
+// leave no room for a second) and a CU holds two such workgroups: ~32 KB in flight per CU, and
+// nothing is issued during a wave's 1.7 us MFMA burst - the memory system idles ~40 % of the time and
+// MFMA time adds serially to memory time (262 us = 178 + 84 at SA1's last layer).  Here the raw A rows
+// never pass through VGPRs: each wave owns a 3-stage LDS ring of its 32-row x 32-k slabs (4 KB each)
+// filled by LDS-direct loads issued two K steps ahead, so 2 x 4 KB per wave = 64 KB per CU are always
+// in flight (+ the weight slab), waves never wait for each other's A rows (the ring is wave-private:
+// no barrier for A), and the previous tile's output stores drain underneath the next tile's MFMAs:
+// every load a step needs is OLDER than those stores, so the step waits with s_waitcnt vmcnt(N>0)
+// instead of the vmcnt(0) the compiler emits for register prefetches in a loop.
+// The BN + ReLU prologue is applied on the LDS -> fragment read (8 VALU per float4).  16-byte chunks
+// of a row are XOR-swizzled by the row (chunk c of row r at position c ^ (r & 7)): LDS-direct places a
+// lane's 16 bytes at lane*16, so padding is impossible; the swizzle makes the fragment reads (same
+// chunk, 32 consecutive rows) 4-way instead of 32-way conflicted.
+// One 512-thread workgroup (8 waves x 32 rows = 256-row tiles) per CU; K % 32 == 0, N <= 128.
+constexpr int FL_NW = 8, FL_STG = 3;
+
+__device__ __forceinline__ void lds_dma16(const float* __restrict__ g, float* __restrict__ lds_base) {
+  // every lane's 16 bytes land at lds_base + lane * 16 (M0 = wave-uniform LDS byte address).  Inline
+  // asm on purpose: the compiler would otherwise guard every later ds_read with s_waitcnt vmcnt(0),
+  // i.e. wait for the stages that were just requested; the waits are placed by hand (wait_vm).
+  const unsigned m0 = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory", "m0");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int NT, bool PROBN, bool POOL>
+__global__ __launch_bounds__(512, 1) void mlp_fwd_lds_kernel(MlpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float fl_smem[];
+  float* s_ring = fl_smem;                                   // [8 waves][3 stages][32 rows x 32 k]
+  float* s_w = s_ring + FL_NW * FL_STG * 1024;               // 2 x [NT*32 rows x 32 k], swizzled like A
+  float* s_vec = s_w + 2 * NT * 32 * 32;                     // [scale | shift] (2K)
+  float4* s_pool = reinterpret_cast<float4*>(s_vec + 2 * MLP_MAXK);     // [8*NT*32]
+  float* s_red = s_ring;                                     // [8][NT][64]: after the last step only
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  constexpr int BROWS = FL_NW * 32;
+  constexpr int W_INST = NT * 4;                             // wave-instructions per weight slab
+  constexpr int W_OPS = (W_INST + FL_NW - 1) / FL_NW;        // per wave (duplicates pad the last waves)
+  constexpr int NSTORE = 16 * NT;                            // unconditional output stores of a full tile
+  const int ntiles = (p.R + BROWS - 1) / BROWS;
+  const int ksteps = p.K / MLP_BK;
+  if constexpr (PROBN) {
+    for (int i = threadIdx.x; i < 2 * p.K; i += 512) s_vec[i] = p.vec[i];
+  }
+  float* ring = s_ring + wave * FL_STG * 1024;
+  auto issue_a = [&](int tile, int ks, int stage) {
+    const int row0 = tile * BROWS + wave * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pos = i * 64 + lane;                         // 16-byte position inside the stage
+      const int r = pos >> 3, c = (pos & 7) ^ (r & 7);       // row, global chunk (swizzle)
+      int row = row0 + r;
+      row = row < p.R ? row : p.R - 1;                       // ragged tail: valid address, masked at use
+      lds_dma16(p.X + (size_t)row * p.ldx + ks * MLP_BK + 4 * c, ring + stage * 1024 + i * 256);
+    }
+  };
+  auto issue_w = [&](int ks, int buf) {
+#pragma unroll
+    for (int i = 0; i < W_OPS; ++i) {
+      const int inst = (wave * W_OPS + i) % W_INST;          // identical rewrites pad the tail waves
+      const int pos = inst * 64 + lane;
+      const int r = pos >> 3, c = (pos & 7) ^ (r & 7);
+      const int n = r < p.N ? r : p.N - 1;
+      lds_dma16(p.Bt + (size_t)n * p.K + ks * MLP_BK + 4 * c, s_w + buf * NT * 1024 + inst * 256);
+    }
+  };
+  float cs1[NT], cs2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
+  f32x16 acc[1][NT];
+  int tile = blockIdx.x;
+  // Issue order per wave:  A(0) W(0) A(1) | step 0: W(1) A(2) | step 1: W(2) A(3) | ...
+  // Step s waits for W(s) (and thereby A(s)); younger than W(s) are A(s+1) [4 ops, if it exists] and
+  // the output stores of step s-1's epilogue [NSTORE, if it was the full-tile path].
+  int t1 = tile, k1 = 0;                                     // (tile, ks) of step s+1
+  bool a1 = false;                                           // A(s+1) was issued
+  if (tile < ntiles) {
+    issue_a(tile, 0, 0);
+    issue_w(0, 0);
+    k1 = ksteps > 1 ? 1 : 0;
+    t1 = ksteps > 1 ? tile : tile + (int)gridDim.x;
+    a1 = t1 < ntiles;
+    if (a1) issue_a(t1, k1, 1);
+  }
+  int seq = 0, ks = 0;
+  bool stores_behind = false;
+  while (tile < ntiles) {
+    const int row0 = tile * BROWS + wave * 32;
+    const bool last_ks = ks == ksteps - 1;
+    if (a1) { if (stores_behind) wait_vm<(4 + NSTORE > 63 ? 63 : 4 + NSTORE)>(); else wait_vm<4>(); }
+    else { if (stores_behind) wait_vm<(NSTORE > 63 ? 63 : NSTORE)>(); else wait_vm<0>(); }
+    lds_barrier();        // W(s) landed for every wave; everyone is past step s-1's MFMAs (s_vec visible)
+    int t2 = t1, k2 = k1 + 1;                                // (tile, ks) of step s+2
+    if (k2 == ksteps) { k2 = 0; t2 = t1 + (int)gridDim.x; }
+    if (a1) issue_w(k1, (seq + 1) & 1);                      // W(s+1): the buffer step s-1 read
+    const bool a2 = a1 && t2 < ntiles;
+    if (a2) issue_a(t2, k2, (seq + 2) % FL_STG);
+    if (ks == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.f;
+    }
+    const float* sa = ring + (seq % FL_STG) * 1024;
+    const float* sw = s_w + (seq & 1) * NT * 1024;
+    const bool row_ok = row0 + lr < p.R;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+      const int c = c8 * 2 + lh;                             // 16-byte chunk of the K step
+      float4 a4 = *reinterpret_cast<const float4*>(sa + lr * 32 + 4 * (c ^ (lr & 7)));
+      if constexpr (PROBN) {
+        const float4 sc = *reinterpret_cast<const float4*>(s_vec + ks * MLP_BK + 4 * c);
+        const float4 sh = *reinterpret_cast<const float4*>(s_vec + p.K + ks * MLP_BK + 4 * c);
+        a4.x = fmaxf(0.f, __builtin_fmaf(a4.x, sc.x, sh.x));
+        a4.y = fmaxf(0.f, __builtin_fmaf(a4.y, sc.y, sh.y));
+        a4.z = fmaxf(0.f, __builtin_fmaf(a4.z, sc.z, sh.z));
+        a4.w = fmaxf(0.f, __builtin_fmaf(a4.w, sc.w, sh.w));
+      }
+      if (!row_ok) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + lr;
+        float4 b4 = *reinterpret_cast<const float4*>(sw + n * 32 + 4 * (c ^ (n & 7)));
+        if (n >= p.N) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[0][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[0][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[0][nt], 0, 0, 0);
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[0][nt], 0, 0, 0);
+      }
+    }
+    stores_behind = false;
+    if (last_ks) {
+      const bool full = tile * BROWS + BROWS <= p.R && NT * 32 <= p.N;
+      stores_behind = full;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float s1 = 0.f, s2 = 0.f;
+        const int col = nt * 32 + lr;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            p.Y[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * p.ldy + col] = acc[0][nt][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = acc[0][nt][r];
+          if (!full && row < p.R && col < p.N) p.Y[(size_t)row * p.ldy + col] = v;
+          s1 += v;                                           // rows >= R are exact zeros
+          s2 = __builtin_fmaf(v, v, s2);
+        }
+        cs1[nt] += s1;
+        cs2[nt] += s2;
+        if constexpr (POOL) {
+          if (p.ns == 16) pool_epilogue<1, NT, 16>(p, acc, nt, row0, col, lh);
+          else if (p.ns == 32) pool_epilogue<1, NT, 32>(p, acc, nt, row0, col, lh);
+          else pool_half_reduce<NT>(acc, nt, wave, lr, lh, s_pool);
+        }
+      }
+      if constexpr (POOL) {
+        if (p.ns == 64) {                                    // merge the two half groups of each wave pair
+          lds_barrier();
+          if ((wave & 1) == 0 && lh == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int col = nt * 32 + lr;
+              const float4 a = s_pool[(wave * NT + nt) * 32 + lr];
+              const float4 b = s_pool[((wave + 1) * NT + nt) * 32 + lr];
+              float mx = a.x, mn = a.y;
+              int ax = __builtin_bit_cast(int, a.z), an = __builtin_bit_cast(int, a.w);
+              if (b.x > mx) { mx = b.x; ax = __builtin_bit_cast(int, b.z); }
+              if (b.y < mn) { mn = b.y; an = __builtin_bit_cast(int, b.w); }
+              if (row0 < p.R && col < p.N) {
+                const size_t o = (size_t)(row0 / 64) * p.N + col;
+                p.pmax[o] = mx; p.pmin[o] = mn; p.amax[o] = ax; p.amin[o] = an;
+              }
+            }
+          }
+        }
+      }
+    }
+    // advance the sequence
+    ++seq;
+    if (last_ks) { ks = 0; tile += (int)gridDim.x; } else { ++ks; }
+    t1 = t2; k1 = k2; a1 = a2;
+  }
+  // column statistics: lanes l and l+32 hold the same column; fold, the 8 waves, one fp64 atomic
+  if (p.stats != nullptr) {
+    wait_vm<0>();
+    lds_barrier();                                           // the ring is free: s_red aliases it
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      cs1[nt] += __shfl_xor(cs1[nt], 32);
+      cs2[nt] += __shfl_xor(cs2[nt], 32);
+      if (lh == 0) {
+        s_red[(wave * NT + nt) * 64 + lr] = cs1[nt];
+        s_red[(wave * NT + nt) * 64 + 32 + lr] = cs2[nt];
+      }
+    }
+    lds_barrier();
+    for (int i = threadIdx.x; i < NT * 64; i += 512) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < FL_NW; ++w) v += s_red[w * NT * 64 + i];
+      const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
+      if (nt * 32 + c < p.N) atomicAdd(p.stats + which * p.N + nt * 32 + c, (double)v);
+    }
+  }
+}
+
 // ---- BN statistics -> per-channel scale/shift (+ running stats, saved mean/invstd) -----------
 __global__ void bn_finalize_kernel(int N, double count, double* __restrict__ stats,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1122,8 +1339,41 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
                         : launch_gemm_t<PRO, STATS, POOL, RED, false>(a, s);
 }
 
+// forward launches that qualify for the LDS-direct kernel (mlp_fwd_lds_kernel)
+template <int NT, bool PROBN, bool POOL>
+static int launch_fwd_lds(const MlpArgs& a, hipStream_t s) {
+  const size_t bytes = sizeof(float) * (FL_NW * FL_STG * 1024 + 2 * NT * 1024 + 2 * MLP_MAXK) +
+                       (POOL ? sizeof(float4) * FL_NW * NT * 32 : 0);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_lds_kernel<NT, PROBN, POOL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      set_error("mlp_fwd_lds: cannot reserve %zu bytes of LDS", bytes);
+      return DEMF_ELAUNCH;
+    }
+    configured = true;
+  }
+  const int tiles = (a.R + FL_NW * 32 - 1) / (FL_NW * 32);
+  const int gx = tiles < 256 ? tiles : 256;                 // one 512-thread workgroup per CU
+  hipLaunchKernelGGL((mlp_fwd_lds_kernel<NT, PROBN, POOL>), dim3(gx), dim3(512), bytes, s, a);
+  return check_launch("mlp_fwd_lds");
+}
+
 template <int PRO, bool STATS, bool POOL, bool RED, bool BF16>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
+  if constexpr (!BF16 && !RED && STATS && (PRO == PRO_NONE || PRO == PRO_BNRELU)) {
+    const int ntl = (a.N + 31) / 32;
+    if (env_int("DEMF_FWD_LDS", 0) && a.K % MLP_BK == 0 && a.K >= MLP_BK && ntl <= 4 && a.ldb == 0 &&
+        a.ldy == a.N && a.R >= 256 * 128 && (!POOL || a.R % (FL_NW * 32) == 0)) {
+      constexpr bool PB = PRO == PRO_BNRELU;
+      switch (ntl) {
+        case 1: return launch_fwd_lds<1, PB, POOL>(a, s);
+        case 2: return launch_fwd_lds<2, PB, POOL>(a, s);
+        case 3: return launch_fwd_lds<3, PB, POOL>(a, s);
+        default: return launch_fwd_lds<4, PB, POOL>(a, s);
+      }
+    }
+  }
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
   // in 256 VGPRs: up to 4 column tiles for the forward prologues, up to 2 for the backward ones

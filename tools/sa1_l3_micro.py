@@ -1,0 +1,23 @@
+"""The dominant kernel alone: demf_mlp_gemm_fwd_pool at SA1's last layer (R = 8*2048*64 rows, 64 -> 128,
+ns = 64), N launches back to back; DEMF_FWD_LDS=0/1 selects the register-staged / LDS-direct kernel.
+Used under rocprofv3 --pmc for pipe-utilisation counters."""
+import sys, os, torch
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R_)
+from demf_amd import _ffi
+R, K, N, ns = 8 * 2048 * 64, 64, 128, 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") / 8
+pro = torch.cat([torch.ones(K), torch.zeros(K)]).cuda()
+y = torch.empty(R, N, device="cuda"); stats = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+pm = torch.empty(2, R // ns, N, device="cuda"); am = torch.empty(2, R // ns, N, dtype=torch.int32, device="cuda")
+st = torch.cuda.current_stream().cuda_stream
+def run():
+    _ffi.call("demf_mlp_gemm_fwd_pool", R, K, N, K, x.data_ptr(), pro.data_ptr(), w.data_ptr(), y.data_ptr(),
+              stats.data_ptr(), ns, pm[0].data_ptr(), pm[1].data_ptr(), am[0].data_ptr(), am[1].data_ptr(), st)
+for _ in range(3): run()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(n): run()
+e.record(); torch.cuda.synchronize()
+print("DEMF_FWD_LDS=%s  avg %.1f us" % (os.environ.get("DEMF_FWD_LDS", "1"), s.elapsed_time(e) * 1e3 / n))
