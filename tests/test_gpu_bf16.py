@@ -73,8 +73,8 @@ def _mlp_case(seed, R, ns, chans):
 
 class _BfMatmul(torch.autograd.Function):
     """y = q(x) q(w)^T with q = round-to-bf16 and fp32 accumulation - what the bf16 MFMA kernels
-    compute; backward: dx = q(g) q(w) (the input-gradient GEMM also runs on bf16 MFMA), dw = g^T x in
-    fp32 (the weight-gradient kernel stays fp32)."""
+    compute; backward: dx = q(g) q(w), dw = q(g)^T q(x) (input- and weight-gradient GEMMs run on
+    bf16 MFMA as well, fp32 accumulation)."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -86,7 +86,7 @@ class _BfMatmul(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         q = lambda t: t.bfloat16().double()
-        return (q(g) @ q(w)).float(), (g.double().t() @ x.double()).float()
+        return (q(g) @ q(w)).float(), (q(g).t() @ q(x)).float()
 
 
 def _emulated_stack(x, weights, gammas, betas, ns, eps=1e-5):
