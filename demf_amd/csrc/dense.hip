@@ -760,6 +760,42 @@ __global__ void msda_prep_bwd_k(int R, int Q, int H, int L, int P, const float* 
   dpts[3 * row + 2] = gx * m[2] + gy * m[6] + gw * m[10];
 }
 
+// ---- row L2 normalisation (VoteModule norm_feats) -------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_fwd_k(int R, const float* __restrict__ x,
+                                                    float* __restrict__ y, float* __restrict__ norm) {
+  constexpr int C = 64 * VPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float v[VPL], sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) { v[i] = x[(size_t)row * C + lane + 64 * i]; sq = __builtin_fmaf(v[i], v[i], sq); }
+  const float n = sqrtf(group_allsum<64>(sq));
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) y[(size_t)row * C + lane + 64 * i] = v[i] / n;
+  if (lane == 0) norm[row] = n;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void l2norm_bwd_k(int R, const float* __restrict__ y,
+                                                    const float* __restrict__ norm,
+                                                    const float* __restrict__ dy, float* __restrict__ dx) {
+  constexpr int C = 64 * VPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float yv[VPL], g[VPL], dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    yv[i] = y[(size_t)row * C + lane + 64 * i];
+    g[i] = dy[(size_t)row * C + lane + 64 * i];
+    dot = __builtin_fmaf(yv[i], g[i], dot);
+  }
+  dot = group_allsum<64>(dot);
+  const float inv = 1.0f / norm[row];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) dx[(size_t)row * C + lane + 64 * i] = (g[i] - yv[i] * dot) * inv;
+}
+
 __global__ void rng_advance_k(unsigned long long* rng) { rng[1] += 1; }
 
 __global__ void dropout_mask_k(long long n, float p, const unsigned long long* __restrict__ rng,
@@ -941,6 +977,24 @@ extern "C" int demf_msda_prep_bwd(int R, int Q, int H, int L, int P, const float
   hipLaunchKernelGGL(msda_prep_bwd_k, dim3(cdiv(R * H, 256)), dim3(256), 0, (hipStream_t)stream, R, Q, H, L,
                      P, pts, M, ab, valid_ratios, (const long long*)shapes, w, uvw, dloc, dloc2, dw, dw2, draw, dpts);
   return check_launch("msda_prep_bwd_k");
+}
+
+extern "C" int demf_l2norm_rows_fwd(int R, int C, const float* x, float* y, float* norm,
+                                    demf_stream_t stream) {
+  DEMF_REQUIRE(R > 0 && x && y && norm, "l2norm_rows_fwd: bad arguments");
+#define CALL(V) hipLaunchKernelGGL(l2norm_fwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, R, x, y, norm)
+  LN_DISPATCH(C, CALL)
+#undef CALL
+  return check_launch("l2norm_fwd_k");
+}
+
+extern "C" int demf_l2norm_rows_bwd(int R, int C, const float* y, const float* norm, const float* dy,
+                                    float* dx, demf_stream_t stream) {
+  DEMF_REQUIRE(R > 0 && y && norm && dy && dx, "l2norm_rows_bwd: bad arguments");
+#define CALL(V) hipLaunchKernelGGL(l2norm_bwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, R, y, norm, dy, dx)
+  LN_DISPATCH(C, CALL)
+#undef CALL
+  return check_launch("l2norm_bwd_k");
 }
 
 extern "C" int demf_rng_advance(void* rng, demf_stream_t stream) {

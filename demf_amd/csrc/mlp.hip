@@ -918,7 +918,8 @@ __global__ void bn_finalize_kernel(int N, double count, double* __restrict__ sta
                                    float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var,
                                    long long* __restrict__ num_batches_tracked,
-                                   float* __restrict__ ss, float* __restrict__ mi) {
+                                   float* __restrict__ ss, float* __restrict__ mi,
+                                   const float* __restrict__ conv_bias) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (c >= N) return;
@@ -935,7 +936,9 @@ __global__ void bn_finalize_kernel(int N, double count, double* __restrict__ sta
   mi[N + c] = (float)invstd;
   if (running_mean != nullptr) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    // a conv bias in front of a train-mode BN cancels in the output; it only shifts the batch mean
+    const double bm = mean + (conv_bias != nullptr ? (double)conv_bias[c] : 0.0);
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * bm);
     running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
   }
 }
@@ -1695,12 +1698,12 @@ extern "C" int demf_bn_finalize(int N, long long count, double* stats, const flo
                                 const float* beta, float eps, float momentum,
                                 float* running_mean, float* running_var,
                                 long long* num_batches_tracked, float* scale_shift,
-                                float* mean_invstd, demf_stream_t stream) {
+                                float* mean_invstd, const float* conv_bias, demf_stream_t stream) {
   DEMF_REQUIRE(N >= 1 && count >= 1 && stats && gamma && beta && scale_shift && mean_invstd,
                "bn_finalize: bad arguments");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N,
                      (double)count, stats, gamma, beta, eps, momentum, running_mean, running_var,
-                     num_batches_tracked, scale_shift, mean_invstd);
+                     num_batches_tracked, scale_shift, mean_invstd, conv_bias);
   return check_launch("bn_finalize");
 }
 

@@ -65,15 +65,17 @@ class DeMFClassAgnosticBBoxCoder:
         reg_t = reg_preds.transpose(2, 1)
         with_sem = cls_t.shape[-1] > 2
         nb = self.num_dir_bins
-        results["center"] = base_xyz + reg_t[..., 0:3].contiguous()
-        results["size"] = reg_t[..., 3:6].contiguous()
-        results["dir_class"] = reg_t[..., 6:6 + nb].contiguous()
-        dir_res_norm = reg_t[..., 6 + nb:6 + 2 * nb].contiguous()
+        # (the reference materialises every slice with .contiguous(); here they stay views of the
+        # raw conv rows - same values, no copy kernels; consumers that need dense memory copy)
+        results["center"] = base_xyz + reg_t[..., 0:3]
+        results["size"] = reg_t[..., 3:6]
+        results["dir_class"] = reg_t[..., 6:6 + nb]
+        dir_res_norm = reg_t[..., 6 + nb:6 + 2 * nb]
         results["dir_res_norm"] = dir_res_norm
         results["dir_res"] = dir_res_norm * (np.pi / nb)
-        results["obj_scores"] = cls_t[..., 0:2].contiguous()
+        results["obj_scores"] = cls_t[..., 0:2]
         if with_sem:
-            results["sem_scores"] = cls_t[..., 2:].contiguous()
+            results["sem_scores"] = cls_t[..., 2:]
         return results
 
     # ---- coder.py:242-251 ----

@@ -39,7 +39,11 @@ class VoteModule(nn.Module):
         vote_points = (seed_points + offset).contiguous()
         vote_feats = rows + votes[:, 3:]
         if self.norm_feats:
-            vote_feats = vote_feats / torch.norm(vote_feats, p=2, dim=1, keepdim=True)
+            C = vote_feats.shape[1]
+            if vote_feats.is_cuda and C % 64 == 0 and C <= 1024 and (C // 64) & (C // 64 - 1) == 0:
+                vote_feats = ops.l2norm_rows(vote_feats.contiguous())
+            else:
+                vote_feats = vote_feats / torch.norm(vote_feats, p=2, dim=1, keepdim=True)
         vote_feats = vote_feats.view(B, N, -1).transpose(1, 2)  # (B,C,N) view of point-major
         return vote_points, vote_feats, offset.transpose(2, 1)
 

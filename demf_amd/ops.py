@@ -732,7 +732,7 @@ class _SharedMLPPool(Function):
                           _p(Y), _p(stats), st)
                 if training:
                     _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
+                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
                 else:
                     invstd = torch.rsqrt(rvar + eps)
                     ss[:N] = gamma * invstd
@@ -748,14 +748,14 @@ class _SharedMLPPool(Function):
                 _ffi.call("demf_mlp_gemm_fwd_pool", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           _p(stats), ns, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]), st)
                 _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
+                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
             elif training:
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           _p(stats), st)
                 _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), st)
+                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
             else:
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           None, st)
@@ -953,13 +953,34 @@ def shared_mlp_pool(x, ns, layers, training=True, eps=1e-5, momentum=0.1, geo=No
     if geo is not None and torch.is_grad_enabled():
         gx = geo[0] if geo[0].requires_grad else None
         gc = geo[1] if geo[1].requires_grad else None
-    out = _SharedMLPPool.apply(x, ns, training, eps, momentum, geo, gx, gc, *flat)
-    if training:
-        with torch.no_grad():
-            for layer in layers:
-                if len(layer) > 5 and layer[5] is not None:
-                    layer[3].add_(layer[5], alpha=momentum)
-    return out
+    # (a conv bias in front of the BN only shifts the running mean: folded into demf_bn_finalize)
+    return _SharedMLPPool.apply(x, ns, training, eps, momentum, geo, gx, gc, *flat)
+
+
+class _L2NormRows(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _chk(x, "x")
+        R, C = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(R, dtype=torch.float32, device=x.device)
+        _ffi.call("demf_l2norm_rows_fwd", R, C, _p(x), _p(y), _p(norm), _stream())
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        _ffi.call("demf_l2norm_rows_bwd", y.shape[0], y.shape[1], _p(y), _p(norm), _p(dy), _p(dx), _stream())
+        return dx
+
+
+def l2norm_rows(x):
+    """x (R,C) -> x / ||x||_2 per row (VoteModule norm_feats), one kernel each way."""
+    return _L2NormRows.apply(x)
 
 
 # --------------------------------------------------------------------------

@@ -242,11 +242,19 @@ int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin, const 
 /* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
  * running statistics (momentum, unbiased variance) and increments *num_batches_tracked when
  * they are non-NULL (BatchNorm's train-mode bookkeeping).  The consumed accumulator is left
- * ZEROED, so a persistent stats buffer needs no per-step clearing.                */
+ * ZEROED, so a persistent stats buffer needs no per-step clearing.  conv_bias (N) or NULL: the bias
+ * of the convolution in front of the BatchNorm - it cancels in the normalised output and never
+ * reaches the GEMM; it only shifts the batch mean that enters the running mean.              */
 int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,
                      const float* beta, float eps, float momentum, float* running_mean,
                      float* running_var, long long* num_batches_tracked, float* scale_shift,
-                     float* mean_invstd, demf_stream_t stream);
+                     float* mean_invstd, const float* conv_bias, demf_stream_t stream);
+
+/* y = x / ||x||_2 over rows of C channels (VoteModule norm_feats, class_agnostic_vote_head.py:413-414 ->
+ * mmdet3d VoteModule.forward); norm (R) kept for the backward dx = (dy - y (y . dy)) / norm.  */
+int demf_l2norm_rows_fwd(int R, int C, const float* x, float* y, float* norm, demf_stream_t stream);
+int demf_l2norm_rows_bwd(int R, int C, const float* y, const float* norm, const float* dy, float* dx,
+                         demf_stream_t stream);
 
 /* out (R,C) = max over s of act(Y (R,ns,C)); arg = first maximising s.           */
 int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y, const float* scale_shift,
