@@ -303,8 +303,9 @@ class Trainer:
         the backbone ball queries, 3-NN - ``DeMFHotPath.index_geometry``) is issued on a side
         HIP stream between the forward and the backward graph of the current batch, so the
         latency-bound FPS chain (B workgroups on 256 CUs) runs underneath the current step's
-        backward instead of in front of the next step.  Every step still computes one full pre-pass; the graph reads it from
-        static buffers that are refreshed by a ~6 MB device copy at the step boundary."""
+        backward instead of in front of the next step.  Every step still computes one full
+        pre-pass; the graph reads it from static buffers that are refreshed by ONE ~6 MB multi-copy
+        launch at the step boundary."""
         dev = batch["points"].device
         gt_list = isinstance(batch["gt_bboxes_3d"], (list, tuple))
         if gt_list and dev.type == "cuda":
@@ -379,63 +380,86 @@ class Trainer:
             pairs = [(d, s) for d, s in zip(static_flat, fresh) if d.numel()]
             refresh = ops.MultiCopy([d for d, _ in pairs], [s for _, s in pairs])
 
-        # which cloud the static geometry buffers / the in-flight pre-pass belong to:
-        # (data_ptr, _version) of the tensor handed in; ``load`` checks it
+        # Which cloud the static geometry buffers hold and which cloud's pre-pass sits in `fresh`
+        # (in flight or finished): tags = (data_ptr, _version, shape) of the tensors handed in.
         tag = lambda t: (t.data_ptr(), t._version, tuple(t.shape))
-        state = dict(prefetched=None)
+        state = dict(static="captured", fresh=None, pts="captured")   # static_pts holds the captured cloud
+        one_deep = not os.environ.get("DEMF_GEO_TWO_DEEP")         # A/B: see replay()
+
+        def take_fresh(main):
+            """fresh -> static (one launch), after the pre-pass that filled `fresh` has finished."""
+            main.wait_stream(side)
+            refresh()
+            state["static"], state["fresh"] = state["fresh"], None
+
+        def launch_prepass(main, next_points):
+            if next_points is not None:
+                static_pts.copy_(next_points)
+                state["pts"] = tag(next_points)
+            side.wait_stream(main)                # the cloud is in place, `fresh` has been consumed
+            with torch.cuda.stream(side):
+                geo_graph.replay()
+            state["fresh"] = state["pts"]
 
         def replay(next_points=None):
+            """One training step.  Default (one-deep): ``next_points`` is the cloud of the NEXT batch;
+            its coordinate pre-pass is launched on the side stream between the forward and the
+            backward graph and runs underneath the backward, whose long persistent kernels claim
+            their tiles dynamically and lose least to the 8 CUs the FPS chain occupies; the result
+            is moved into the static buffers at the end of the call.
+            ``DEMF_GEO_TWO_DEEP=1``: ``next_points`` is the cloud of the batch AFTER the next one;
+            the pre-pass is launched after the backward and runs underneath the optimizer update and
+            the first layers of the next forward (measured: 7.80 vs 7.67 ms/step - the forward's
+            statically striped pooled GEMMs lose more to the occupied CUs than the backward does;
+            the step alone is 7.03 ms).  Any other usage stays correct: ``load`` checks the tags and
+            waits for / recomputes the geometry it needs.  ``next_points=None`` recomputes the
+            pre-pass of the cloud last given (every step still pays for one full pre-pass)."""
             main = torch.cuda.current_stream()
-            if can_prefetch and next_points is not None:
-                static_pts.copy_(next_points)
-                state["prefetched"] = tag(next_points)
-            elif can_prefetch:
-                state["prefetched"] = None     # the pre-pass below recomputes the CURRENT cloud
             if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
                 graph.replay()
                 if graph_bwd is not None:
                     graph_bwd.replay()
                 self._update()
                 return loss
-            if graph_bwd is not None:
+            if graph_bwd is not None and one_deep:
                 graph.replay()
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    geo_graph.replay()
+                launch_prepass(main, next_points)
                 graph_bwd.replay()
                 self._update()
-                main.wait_stream(side)
-                refresh()
+                take_fresh(main)
+                return loss
+            if graph_bwd is not None:
+                graph.replay()
+                graph_bwd.replay()
+                if state["fresh"] is not None:
+                    take_fresh(main)              # no stall: that pre-pass had a whole step
+                launch_prepass(main, next_points)
+                self._update()
                 return loss
             if can_prefetch:
-                # the pre-pass goes first: enqueueing the ~900-node step graph takes the host
-                # about a millisecond, which would otherwise delay the start of the FPS chain
-                side.wait_stream(main)            # inputs of the next batch are in place
-                with torch.cuda.stream(side):
-                    geo_graph.replay()
+                # single-graph step (DEMF_GEO_AT_FWD): the pre-pass goes first - enqueueing the
+                # ~900-node step graph takes the host about a millisecond
+                launch_prepass(main, next_points)
             graph.replay()
             self._update()
             if can_prefetch:
-                main.wait_stream(side)
-                refresh()
+                take_fresh(main)
             return loss
 
         def load(new):
-            """Copy another batch into the static input buffers of the captured step.  The
-            captured forward reads its FPS / ball-query / 3-NN indices from the static geometry
-            buffers: they hold the pre-pass of the cloud given as ``next_points`` to the previous
-            ``replay``; if ``new['points']`` is not that tensor (or nothing was prefetched), the
-            pre-pass is recomputed here for the new cloud, so geometry and targets can never
-            belong to different batches."""
-            if can_prefetch and state["prefetched"] != tag(new["points"]):
+            """Copy another batch into the static input buffers of the captured step.  The captured
+            forward reads its FPS / ball-query / 3-NN indices from the static geometry buffers; if
+            they do not hold THIS cloud's geometry, it is fetched from the finished / in-flight
+            pre-pass (waiting for it) or recomputed here, so geometry and targets can never belong
+            to different batches."""
+            if can_prefetch and state["static"] != tag(new["points"]):
                 main = torch.cuda.current_stream()
-                static_pts.copy_(new["points"])
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    geo_graph.replay()
-                main.wait_stream(side)
-                refresh()
-            state["prefetched"] = None
+                if state["fresh"] is not None and state["fresh"] == tag(new["points"]):
+                    take_fresh(main)
+                else:
+                    # (an unrelated pre-pass in flight is left to finish; its result is dropped)
+                    launch_prepass(main, new["points"])
+                    take_fresh(main)
             static["points"].copy_(new["points"])
             nf = new["img_features"]
             if isinstance(nf, dict):

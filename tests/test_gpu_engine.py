@@ -134,10 +134,14 @@ def _tiny_batch(seed, n_gt):
                 gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]])
 
 
-def test_replay_with_changing_batches_matches_eager():
+@pytest.mark.parametrize("ahead", [2, 1, 0])
+def test_replay_with_changing_batches_matches_eager(ahead):
     """The captured step fed through its static input buffers (load()) with the pipelined
-    pre-pass of the NEXT batch: three different batches (points, image features, metas, GT counts)
-    cycled through the graph give the same losses and parameters as eager steps on them."""
+    pre-pass: three different batches (points, image features, metas, GT counts) cycled through
+    the graph give the same losses and parameters as eager steps on them - with next_points = the
+    next batch (the default one-deep contract), = the batch after the next (the DEMF_GEO_TWO_DEEP
+    contract; under the default placement load() then recomputes) and with no prefetch at all
+    (load() recomputes the geometry): the tags keep every usage correct, only the overlap differs."""
     batches = [_tiny_batch(11, 4), _tiny_batch(12, 2), _tiny_batch(13, 5)]
     # a small learning rate keeps the two runs from drifting apart through the (legitimately
     # nondeterministic) fp32 atomics: the losses then mainly reflect WHICH batch was consumed
@@ -152,7 +156,7 @@ def test_replay_with_changing_batches_matches_eager():
     for k, i in enumerate(order):
         if k:
             replay.load(batches[i])
-        nxt = batches[order[k + 1]]["points"] if k + 1 < len(order) else None
+        nxt = batches[order[k + ahead]]["points"] if ahead and k + ahead < len(order) else None
         got.append(float(replay(next_points=nxt)))
     torch.cuda.synchronize()
     assert eager == pytest.approx(got, rel=2e-3), (eager, got)
