@@ -20,7 +20,7 @@ TOL = dict(rtol=1e-4, atol=1e-4)
 
 def _close_to_gold(a, g, name, tol=5e-4):
     """fp32 CPU golden vs fp32 GPU: both carry the network's fp32 noise floor (measured
-    ~1.5e-4 abs at the decode outputs of the tiny config, tools/noise_floor.py)."""
+    ~1.5e-4 abs at the decode outputs of the tiny config: fp32 vs fp64 oracle)."""
     err = np.abs(a.astype(np.float64) - g.astype(np.float64)).max()
     assert err <= tol * max(1.0, np.abs(g).max()), f"{name}: max err {err:.2e}"
 
