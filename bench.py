@@ -34,8 +34,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
 # the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
-DOMINANT_KERNEL = {"f32": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, false>",
-                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, true>"}
+DOMINANT_KERNEL = {"f32": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0>",
+                   "f32x3": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 2>",
+                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 1>"}
 # FPS: per round one barrier phase (~450 cycles with 16 waves) + 20 points/lane x 8 VALU ops
 FPS_FLOOR_CYCLES = 900.0
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
@@ -216,7 +217,7 @@ def main():
     ap.add_argument("--msda-points", type=int, default=2,
                     help="sampling points per level of the fusion attention: 2 = reference config "
                          "(demf_votenet.py:83), 4 = BASELINE.json's wording; secondary figure only")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16"), default="f32",
                     help="compute dtype of the dense MFMA kernels: f32 = the reference's precision "
                          "(headline, BASELINE configs[2]); bf16 = configs[3] (bf16 MFMA, fp32 accumulate, "
                          "fp32 storage / statistics / indices / losses)")

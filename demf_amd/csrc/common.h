@@ -94,5 +94,6 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // compute dtype switch (demf_set_compute_dtype, csrc/mlp.hip): true = bf16 MFMA, fp32 accumulate
 bool compute_bf16();
+int compute_mode();   // 0 fp32 MFMA, 1 bf16 MFMA, 2 fp32 as three bf16 terms (mlp.hip)
 
 }  // namespace demf

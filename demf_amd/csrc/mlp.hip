@@ -32,18 +32,60 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
 using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
 
-// Compute dtype of the dense kernels (demf_set_compute_dtype): 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32,
-// the reference's precision), 1 = bf16 MFMA with fp32 accumulate (v_mfma_f32_32x32x16_bf16):
-// operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS, AFTER the fp32
-// prologue (BN + ReLU / BN-backward); everything stored to memory, every statistic, index and loss
-// stays fp32.  BASELINE.json configs[3].
-static std::atomic<int> g_compute_bf16{0};
-bool compute_bf16() { return g_compute_bf16.load(std::memory_order_relaxed) != 0; }
+// Compute mode of the dense kernels (demf_set_compute_dtype):
+//   0 = fp32 MFMA (v_mfma_f32_32x32x2_f32, the reference's precision);
+//   1 = bf16 MFMA with fp32 accumulate (v_mfma_f32_32x32x16_bf16): operands are rounded to bf16 (RNE,
+//       v_cvt_pk_bf16_f32) on their way into LDS, AFTER the fp32 prologue (BN + ReLU / BN-backward);
+//       everything stored to memory, every statistic, index and loss stays fp32.  BASELINE configs[3];
+//   2 = fp32 operands split into three bf16 terms each (x = h + m + l exactly: 3 x 8 significand
+//       bits) and the six products h.h, h.m, m.h, m.m, h.l, l.h accumulated in fp32 on the bf16 MFMA
+//       (the dropped m.l, l.m, l.l terms are <= 2^-23 relative - the rounding of one fp32 FMA).
+//       On gfx950 the bf16 MFMA runs 16x the fp32 one, so six of them cost 3/8 of the native fp32
+//       issue time at fp32-grade results (tests/test_gpu_split.py measures both against fp64).
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// Until demf_set_compute_dtype is called the mode is 2, or 0 with DEMF_F32_NATIVE=1 in the environment.
+static std::atomic<int> g_compute_mode{-1};
+int compute_mode() {
+  int m = g_compute_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* v = getenv("DEMF_F32_NATIVE");
+    m = (v && atoi(v)) ? 0 : 2;
+    g_compute_mode.store(m);
+  }
+  return m;
+}
+bool compute_bf16() { return compute_mode() == 1; }
 
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
   bf16x4 r;
   r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
   return r;
+}
+
+// x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m); both differences are exact in
+// fp32 and the last one fits bf16's 8 bits, so the three terms carry all 24 significand bits.
+__device__ __forceinline__ float4 bf16x4_to_f32(const bf16x4& h) {
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void split3(const float4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = to_bf16x4(v);
+  const float4 hf = bf16x4_to_f32(h);
+  const float4 r = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
+  m = to_bf16x4(r);
+  const float4 mf = bf16x4_to_f32(m);
+  l = to_bf16x4(make_float4(r.x - mf.x, r.y - mf.y, r.z - mf.z, r.w - mf.w));
+}
+__device__ __forceinline__ void split3(const float4& v0, const float4& v1, bf16x8& h, bf16x8& m, bf16x8& l) {
+  bf16x4 h0, m0, l0, h1, m1, l1;
+  split3(v0, h0, m0, l0);
+  split3(v1, h1, m1, l1);
+  h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+  m = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+  l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 constexpr int MLP_BK = 32;        // K step staged per iteration
@@ -52,6 +94,7 @@ constexpr int DW_CHUNK = 16;      // 32-row slabs per claim of the weight-gradie
 constexpr int DW_MAX_SUB = 32;    // blockIdx.y columns with their own counter
 constexpr int SCHED_INTS = 2 * DW_MAX_SUB;   // ints per counter set (>= 2*SCHED_GROUPS + 1)
 constexpr int MLP_LD = MLP_BK + 4;  // LDS row stride (floats), +16 B pad
+constexpr int MLP_LD3 = 3 * (MLP_BK / 2) + 4;   // Bt row stride of compute mode 2: three bf16 terms
 
 enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
 
@@ -255,18 +298,25 @@ __device__ __forceinline__ void pool_half_reduce(const f32x16 (&acc)[1][NT], int
         make_float4(mx, mn, __builtin_bit_cast(float, ax), __builtin_bit_cast(float, an));
 }
 
-// BF16: the A / B slabs hold bf16 (same byte row stride as the fp32 layout, so the slab doubles as
-// fp32 staging for the FIRST / RED epilogues unchanged) and a K step of 32 is two
+// CM = 1 (bf16): the A / B slabs hold bf16 (same byte row stride as the fp32 layout, so the slab
+// doubles as fp32 staging for the FIRST / RED epilogues unchanged) and a K step of 32 is two
 // v_mfma_f32_32x32x16_bf16 per tile instead of sixteen v_mfma_f32_32x32x2_f32.
+// CM = 2 (three-term split): the A slab stays fp32 - each wave splits the 8 floats of its own
+// fragment in registers after the LDS read (its rows are private to it, so nothing is split twice) -
+// and the Bt slab, which all four waves share, is split once on its way into LDS: row stride
+// MLP_LD3 floats = [32 h | 32 m | 32 l] bf16 + 16 B pad (52 dwords: 8 consecutive rows still cover
+// the 32 banks with their 16-byte reads).  Six bf16 MFMAs per tile and 16 columns of K.
 template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false,
-          bool BF16 = false>
+          int CM = 0>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   static_assert(!(STATS && RED) && !(FIRST && RED), "one column-sum epilogue at a time");
+  constexpr bool BF16 = CM == 1, X3 = CM == 2;
+  constexpr int LDB = X3 ? MLP_LD3 : MLP_LD;
   constexpr int WROWS = 32 * RT;          // rows per wave
   constexpr int BROWS = 4 * WROWS;        // rows per block tile
   constexpr int NVEC = PRO == PRO_NONE ? 0 : (PRO == PRO_BNRELU ? 2 : 5);
   __shared__ __attribute__((aligned(16))) float s_a[4][WROWS * MLP_LD];
-  __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * MLP_LD];
+  __shared__ __attribute__((aligned(16))) float s_b[NT * 32 * LDB];
   __shared__ __attribute__((aligned(16))) float s_vec[NVEC ? NVEC * MLP_MAXK : 4];
   __shared__ float s_red[(STATS || RED) ? 4 * NT * 32 * 2 : (FIRST ? 4 * NT * 32 * 10 + 16 : 1)];
   __shared__ float4 s_pool[(POOL && RT == 1) ? 4 * NT * 32 : 1];
@@ -389,6 +439,32 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         } else {
           *reinterpret_cast<bf16x4*>(sbb + (br + 32 * i) * (4 * MLP_LD) + 2 * pc) = to_bf16x4(preb[i]);
         }
+    } else if constexpr (X3) {
+#pragma unroll
+      for (int it = 0; it < 4 * RT; ++it)
+        *reinterpret_cast<float4*>(sa + (it * 8 + pr) * MLP_LD + pc) =
+            mlp_xform<PRO>(p, s_vec, k0 + pc, pok[it], pre[it]);
+      // term t of element (n, k) lives at byte n * 4*MLP_LD3 + 64*t + 2*k of the Bt slab
+      char* sbb = reinterpret_cast<char*>(sb);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        bf16x4 h, m, l;
+        split3(preb[i], h, m, l);
+        if (p.ldb > 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            char* d = sbb + (32 * i + pc + e) * (4 * MLP_LD3) + 2 * br;
+            *reinterpret_cast<__bf16*>(d) = h[e];
+            *reinterpret_cast<__bf16*>(d + 64) = m[e];
+            *reinterpret_cast<__bf16*>(d + 128) = l[e];
+          }
+        } else {
+          char* d = sbb + (br + 32 * i) * (4 * MLP_LD3) + 2 * pc;
+          *reinterpret_cast<bf16x4*>(d) = h;
+          *reinterpret_cast<bf16x4*>(d + 64) = m;
+          *reinterpret_cast<bf16x4*>(d + 128) = l;
+        }
+      }
     } else {
 #pragma unroll
     for (int it = 0; it < 4 * RT; ++it)
@@ -457,6 +533,35 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
             acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[rt], b8, acc[rt][nt], 0, 0, 0);
+        }
+      }
+    } else if constexpr (X3) {
+      const char* sbb = reinterpret_cast<const char*>(sb);
+      const int kch = min(MLP_BK / 16, (p.K - k0 + 15) / 16);
+      for (int c16 = 0; c16 < kch; ++c16) {
+        bf16x8 ah[RT], am[RT], al[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const float* src = sa + (rt * 32 + lr) * MLP_LD + c16 * 16 + 8 * lh;
+          split3(*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4),
+                 ah[rt], am[rt], al[rt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const char* src = sbb + (nt * 32 + lr) * (4 * MLP_LD3) + 2 * (c16 * 16 + 8 * lh);
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(src);
+          const bf16x8 bm = *reinterpret_cast<const bf16x8*>(src + 64);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(src + 128);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            // small terms first
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bm, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[rt], bh, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bm, acc[rt][nt], 0, 0, 0);
+            acc[rt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][nt], 0, 0, 0);
+          }
         }
       }
     } else {
@@ -1472,11 +1577,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_bf16_kernel(DwArgs p) {
     }
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 // Counter sets {next tile per group, finished blocks} of the dynamically scheduled persistent
 // launches.  A launch takes the next set of a ring; the last block of the launch leaves it zeroed, so
 // a captured launch can be replayed with the set it was given.  Launches that share a set are
@@ -1501,13 +1601,21 @@ static int mlp_grid(int R, int brows) {
   return tiles < cap ? (tiles > 0 ? tiles : 1) : cap;
 }
 
-template <int PRO, bool STATS, bool POOL, bool RED, bool BF16>
+template <int PRO, bool STATS, bool POOL, bool RED, int CM>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s);
 
 template <int PRO, bool STATS, bool POOL = false, bool RED = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
-  return compute_bf16() ? launch_gemm_t<PRO, STATS, POOL, RED, true>(a, s)
-                        : launch_gemm_t<PRO, STATS, POOL, RED, false>(a, s);
+  switch (compute_mode()) {
+    case 1: return launch_gemm_t<PRO, STATS, POOL, RED, 1>(a, s);
+    case 2: {
+      // A/B switch: DEMF_X3_MASK bit 0 = forward launches, bit 1 = input-gradient launches
+      static const int mask = env_int("DEMF_X3_MASK", 3);
+      if (mask & (PRO >= PRO_DY_DENSE ? 2 : 1)) return launch_gemm_t<PRO, STATS, POOL, RED, 2>(a, s);
+      return launch_gemm_t<PRO, STATS, POOL, RED, 0>(a, s);
+    }
+    default: return launch_gemm_t<PRO, STATS, POOL, RED, 0>(a, s);
+  }
 }
 
 // forward launches that qualify for the LDS-direct kernel (mlp_fwd_lds_kernel)
@@ -1530,9 +1638,9 @@ static int launch_fwd_lds(const MlpArgs& a, hipStream_t s) {
   return check_launch("mlp_fwd_lds");
 }
 
-template <int PRO, bool STATS, bool POOL, bool RED, bool BF16>
+template <int PRO, bool STATS, bool POOL, bool RED, int BF16>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
-  if constexpr (!BF16 && !RED && STATS && (PRO == PRO_NONE || PRO == PRO_BNRELU)) {
+  if constexpr (BF16 == 0 && !RED && STATS && (PRO == PRO_NONE || PRO == PRO_BNRELU)) {
     const int ntl = (a.N + 31) / 32;
     if (env_int("DEMF_FWD_LDS", 0) && a.K % MLP_BK == 0 && a.K >= MLP_BK && ntl <= 4 && a.ldb == 0 &&
         a.ldy == a.N && a.R >= 256 * 128 && (!POOL || a.R % (FL_NW * 32) == 0)) {
@@ -1611,10 +1719,14 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
   } while (0)
 #define CASE(NTv)                                                                               \
   case NTv:                                                                                     \
-    if constexpr (NTv <= NT_MAX) {                                                              \
+    if constexpr (NTv <= NT_MAX && (BF16 != 2 || NTv <= 4)) {                                   \
       if constexpr (NTv <= RT2_MAX && !RED) GO(NTv, 2); else GO(NTv, 1);                        \
     }                                                                                           \
     break;
+  // the split Bt slab of more than 4 column tiles would not leave room for two blocks per CU
+  if constexpr (BF16 == 2) {
+    if (nt > 4) return launch_gemm_t<PRO, STATS, POOL, RED, 0>(a, s);
+  }
   switch (nt) {
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
   }
@@ -1636,9 +1748,9 @@ static int mlp_check(int R, int K, int N, int ldx) {
 using namespace demf;
 
 
-extern "C" int demf_set_compute_dtype(int bf16) {
-  DEMF_REQUIRE(bf16 == 0 || bf16 == 1, "set_compute_dtype: 0 = fp32, 1 = bf16");
-  g_compute_bf16.store(bf16);
+extern "C" int demf_set_compute_dtype(int mode) {
+  DEMF_REQUIRE(mode >= 0 && mode <= 2, "set_compute_dtype: 0 = fp32, 1 = bf16, 2 = fp32 as three bf16 terms");
+  g_compute_mode.store(mode);
   return DEMF_OK;
 }
 
@@ -1881,16 +1993,15 @@ extern "C" int demf_mlp_gemm_bwd_dx_first(int R, int N, int K0, const float* G, 
   const int gx = mlp_grid(R, 128);
   const int tiles = (R + 127) / 128;
   if (tiles > gx && a.K > MLP_BK && gx % (8 * SCHED_GROUPS) == 0) a.sched = sched_slot();
-  if (K0 <= 32)
-    if (compute_bf16())
-      hipLaunchKernelGGL((mlp_gemm_kernel<1, 1, PRO_DY_DENSE, false, false, true, false, true>), dim3(gx), dim3(256), 0, s, a);
-    else
-    hipLaunchKernelGGL((mlp_gemm_kernel<1, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
-  else
-    if (compute_bf16())
-      hipLaunchKernelGGL((mlp_gemm_kernel<2, 1, PRO_DY_DENSE, false, false, true, false, true>), dim3(gx), dim3(256), 0, s, a);
-    else
-    hipLaunchKernelGGL((mlp_gemm_kernel<2, 1, PRO_DY_DENSE, false, false, true>), dim3(gx), dim3(256), 0, s, a);
+#define FIRSTGO(NTv, CMv) \
+  hipLaunchKernelGGL((mlp_gemm_kernel<NTv, 1, PRO_DY_DENSE, false, false, true, false, CMv>), dim3(gx), dim3(256), 0, s, a)
+  const int cm = compute_mode();
+  if (K0 <= 32) {
+    if (cm == 1) FIRSTGO(1, 1); else if (cm == 2) FIRSTGO(1, 2); else FIRSTGO(1, 0);
+  } else {
+    if (cm == 1) FIRSTGO(2, 1); else if (cm == 2) FIRSTGO(2, 2); else FIRSTGO(2, 0);
+  }
+#undef FIRSTGO
   return check_launch("mlp_gemm_bwd_dx_first");
 }
 

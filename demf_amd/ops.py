@@ -6,6 +6,8 @@ reference calls (cited per function); tensors stay PyTorch-ROCm tensors and only
 raw device pointers + the current HIP stream cross the C ABI.  There is no CPU or
 eager fallback: a CPU tensor or a missing library raises.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -100,16 +102,29 @@ def zeros(shape, device):
 _COMPUTE_DTYPE = "f32"
 
 
+_COMPUTE_MODES = {"f32_native": 0, "bf16": 1, "f32x3": 2}
+
+
 def set_compute_dtype(name):
-    """"f32" (the reference's precision: fp32 MFMA) or "bf16" (BASELINE.json configs[3]): the dense
-    MFMA kernels - shared-MLP GEMMs forward / input-gradient, the decoder layer's GEMMs, the linear
-    heads - round their operands to bf16 on the way into LDS and run v_mfma_f32_32x32x16_bf16 with
-    fp32 accumulation.  Tensors in memory, BN statistics, weight-gradient reductions, indices,
-    sampling and losses stay fp32.  Process-wide (demf_set_compute_dtype)."""
+    """"f32" (default), "f32_native", "f32x3" or "bf16" (BASELINE.json configs[3]).
+    f32x3: the shared-MLP GEMMs (forward / input-gradient) split every fp32 operand EXACTLY into
+    three bf16 terms and accumulate the six significant products in fp32 on the bf16 MFMA, which
+    gfx950 runs 16x faster than its fp32 MFMA: fp32-grade results (error against fp64 measured equal
+    to the fp32 MFMA's, tests/test_gpu_split.py) at 3/8 of the issue time.  f32_native: the same
+    kernels on v_mfma_f32_32x32x2_f32.  "f32" = f32x3, or f32_native with DEMF_F32_NATIVE=1.
+    bf16: the dense MFMA kernels - shared-MLP GEMMs forward / input-gradient / weight-gradient, the
+    decoder layer's GEMMs, the linear heads - round their operands to bf16 on the way into LDS and
+    run v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    Tensors in memory, BN statistics, indices, sampling and losses stay fp32 in every mode.
+    Process-wide (demf_set_compute_dtype)."""
     global _COMPUTE_DTYPE
-    if name not in ("f32", "bf16"):
-        raise ValueError("compute dtype must be 'f32' or 'bf16'")
-    _ffi.call("demf_set_compute_dtype", 1 if name == "bf16" else 0)
+    if name == "f32":
+        mode = 0 if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else 2
+    elif name in _COMPUTE_MODES:
+        mode = _COMPUTE_MODES[name]
+    else:
+        raise ValueError("compute dtype must be 'f32' or one of %s" % sorted(_COMPUTE_MODES))
+    _ffi.call("demf_set_compute_dtype", mode)
     _COMPUTE_DTYPE = name
 
 

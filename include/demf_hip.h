@@ -478,9 +478,12 @@ int demf_gemm_f32(const demf_gemm_desc* desc, demf_stream_t stream);
 /* Compute dtype of the dense MFMA kernels (demf_mlp_gemm_*, demf_gemm_f32): 0 = fp32 MFMA (the
  * reference's precision, class_agnostic_vote_head.py:384 fp16_enabled=False), 1 = bf16 MFMA with
  * fp32 accumulation (BASELINE.json configs[3]): operands are rounded to bf16 on their way into LDS,
- * after the fp32 prologues; stored tensors, BN statistics, indices and losses stay fp32.
+ * after the fp32 prologues; stored tensors, BN statistics, indices and losses stay fp32;
+ * 2 = fp32 emulated on the bf16 MFMA in the demf_mlp_gemm_* kernels: each fp32 operand is split
+ * exactly into three bf16 terms (3 x 8 significand bits) and the six products of weight >= 2^-16
+ * are accumulated in fp32 (dropped terms <= 2^-23 relative); demf_gemm_f32 stays on the fp32 MFMA.
  * Process-wide setting (the one piece of host-side mutable state besides the counter ring).     */
-int demf_set_compute_dtype(int bf16);
+int demf_set_compute_dtype(int mode);
 
 /* s = identity + dropout(x) ; y = LayerNorm(s) over rows of C channels (C in 64..1024, power of two
  * multiples of 64).  s_out may alias x; stats (R,2) = mean, rstd.  nn.LayerNorm + the

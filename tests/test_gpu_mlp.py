@@ -1,6 +1,15 @@
 """Fused shared-MLP kernels (csrc/mlp.hip) against a plain PyTorch fp64 reference of the same
 op chain: (linear -> train-mode batch_norm -> relu) x L -> max over ns.  fp32 tolerance 1e-4
-relative to each tensor's scale (forward) / 1e-3 (gradients: long fp32 reductions)."""
+relative to each tensor's scale (forward) / 1e-3 (gradients: long fp32 reductions).
+Gradients are compared ON THE BRANCH THE KERNELS TOOK: with ~10^7 pre-activations per case about
+one lies within fp32 round-off of its ReLU threshold (or two pooled neighbours within round-off of
+each other) and resolves differently in fp32 than in fp64; that single element moves an O(1)
+gradient, which reaches every earlier layer's dW at ~3e-3 of its scale.  Which element it is
+depends on the last bit of the GEMM - on the kernel variant and the seed (a 6-seed sweep fails a
+plain fp64 comparison in ~10 % of the cases in either fp32 MFMA mode).  So the reference backward
+uses the kernels' own ReLU masks and pooled rows (read from the tensors the autograd node saved),
+after checking that those decisions differ from the fp64 reference's only where the pre-activation
+is at round-off level; on that common branch the 1e-3 bar holds for every seed."""
 import numpy as np
 import pytest
 import torch
@@ -49,10 +58,7 @@ def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
     layers64[-1][1][2] = 0.0        # ... and a zero scale (constant activation)
     go = torch.randn(Rp, chans[-1], dtype=torch.float64)
 
-    xr = x.clone().requires_grad_(xgrad)
-    lr = [tuple(t.clone().requires_grad_() for t in l) for l in layers64]
-    out_r = _ref(xr, ns, lr)
-    out_r.backward(go)
+    out_r = _ref(x, ns, layers64)
 
     xg = x.float().cuda().requires_grad_(xgrad)
     lg = []
@@ -62,7 +68,6 @@ def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
                    b.float().cuda().requires_grad_(), torch.zeros(n, device="cuda"),
                    torch.ones(n, device="cuda")))
     out = ops.shared_mlp_pool(xg, ns, lg, training=True)
-    out.backward(go.float().cuda())
 
     def close(a, b, tol, name):
         a, b = a.detach().double().cpu(), b.detach().double()
@@ -70,19 +75,46 @@ def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
         bad = torch.nonzero((a - b).abs().reshape(a.shape[0], -1).max(0).values > tol * max(1.0, b.abs().max().item())).flatten().tolist()
         assert err <= tol * max(1.0, b.abs().max().item()), f"{name}: err {err:.3e}, bad columns {bad[:8]}"
 
+    # ---- the kernels' discrete decisions, from what the autograd node saved (ops._SharedMLPPool:
+    # x, arg, Y_0..Y_{L-1} raw conv outputs, [scale|shift]_0.., ...)
+    L = len(chans)
+    saved = out.grad_fn.saved_tensors
+    arg_g = saved[1].long().cpu()
+    masks_g = []
+    for l in range(L):
+        Yg, ssg = saved[2 + l].double().cpu(), saved[2 + L + l].double().cpu()
+        n = Yg.shape[1]
+        masks_g.append(Yg * ssg[:n] + ssg[n:] > 0)        # exact sign of the kernels' one fma
+    # they may differ from the fp64 reference's only at round-off-level pre-activations
+    h = x
+    for l, (W, g, b) in enumerate(layers64):
+        z = F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, 1e-5)
+        diff = masks_g[l] != (z > 0)
+        assert int(diff.sum()) <= 4 + z.numel() // 10 ** 6, f"layer {l}: {int(diff.sum())} ReLU masks differ"
+        assert not bool(diff.any()) or z[diff].abs().max().item() < 2e-5, f"layer {l}: mask differs at |z| = {z[diff].abs().max().item():.2e}"
+        h = F.relu(z)
+    top = h.view(Rp, ns, -1)
+    picked = top.gather(1, arg_g.view(Rp, 1, -1)).squeeze(1)
+    assert (top.max(1).values - picked).abs().max().item() < 2e-5, "pooled row is not (within round-off) the maximum"
+
+    def ref_on_branch(xr, lr):
+        h = xr
+        for (W, g, b), m in zip(lr, masks_g):
+            h = F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, 1e-5) * m
+        return h.view(Rp, ns, -1).gather(1, arg_g.view(Rp, 1, -1)).squeeze(1)
+
+    xr = x.clone().requires_grad_(xgrad)
+    lr = [tuple(t.clone().requires_grad_() for t in l) for l in layers64]
+    ref_on_branch(xr, lr).backward(go)
+    out.backward(go.float().cuda())
+
     close(out, out_r, 1e-4, "out")
     for i, (gl, rl) in enumerate(zip(lg, lr)):
         close(gl[0].grad, rl[0].grad, 1e-3, f"dW{i}")
         close(gl[1].grad, rl[1].grad, 1e-3, f"dgamma{i}")
         close(gl[2].grad, rl[2].grad, 1e-3, f"dbeta{i}")
     if xgrad:
-        # the arg-max of a group can legitimately differ between the fp32 path and the fp64
-        # reference when two neighbours are within round-off (about one group per 10^7): the
-        # gradient then lands on another row.  Allow a handful of such rows, none elsewhere.
-        a, b = xg.grad.detach().double().cpu(), xr.grad.detach()
-        row_err = (a - b).abs().max(1).values
-        bad = torch.nonzero(row_err > 1e-3 * max(1.0, b.abs().max().item())).flatten()
-        assert len(bad) <= 4, f"dx: {len(bad)} rows off, e.g. {bad[:6].tolist()}"
+        close(xg.grad, xr.grad, 1e-3, "dx")
     # running statistics follow nn.BatchNorm semantics (momentum 0.1, unbiased variance)
     h = x
     for i, (W, g, b) in enumerate(layers64):
