@@ -1274,7 +1274,10 @@ struct DwArgs {
 // Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
 // tiles tn = wn + 2i (i < TN), tk = wk + 2j (j < TK), so per row pair it reads TN + TK LDS
 // values for TN*TK MFMAs.
-template <int TN, int TK, bool SPARSE>
+// X3 (compute mode 2): the slab stays fp32 in LDS; per 16 rows a lane gathers its 8 rows of one column
+// (8 ds_read_b32, conflict-free: consecutive lanes read consecutive columns), splits them into three
+// bf16 terms and issues the six significant products on v_mfma_f32_32x32x16_bf16.
+template <int TN, int TK, bool SPARSE, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
   constexpr int PROY = SPARSE ? PRO_DY_SPARSE : PRO_DY_DENSE;
   {  // this block's (<= 2TN x 2TK tiles) corner of the N x K output
@@ -1368,6 +1371,34 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
     const int next_chunk = last ? (dyn ? s_next : chunk + (int)gridDim.x) : chunk;
     const int next_si = last ? 0 : si + 1;
     if (next_chunk < nchunk) prefetch(next_chunk * p.chunk + next_si);
+    if constexpr (X3) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        // lane supplies rows 16c + 8lh .. +7 of column lr of its tiles
+        bf16x8 ah[TN], am[TN], al[TN];
+        auto gather = [&](const float* col, int ld, bf16x8& h, bf16x8& m, bf16x8& l) {
+          const float* q = col + (16 * c + 8 * lh) * ld;
+          split3(make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]),
+                 make_float4(q[4 * ld], q[5 * ld], q[6 * ld], q[7 * ld]), h, m, l);
+        };
+#pragma unroll
+        for (int i = 0; i < TN; ++i) gather(s_dy + (wn + 2 * i) * 32 + lr, ldn, ah[i], am[i], al[i]);
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          bf16x8 bh, bm, bl;
+          gather(s_a + (wk + 2 * j) * 32 + lr, ldk, bh, bm, bl);
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    } else
     // A-op: dY^T -> lane supplies dY[r = 2m + lh][n = tn*32 + lr]; B-op: A[r][k = tk*32 + lr]
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) {
@@ -1609,8 +1640,8 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   switch (compute_mode()) {
     case 1: return launch_gemm_t<PRO, STATS, POOL, RED, 1>(a, s);
     case 2: {
-      // A/B switch: DEMF_X3_MASK bit 0 = forward launches, bit 1 = input-gradient launches
-      static const int mask = env_int("DEMF_X3_MASK", 3);
+      // A/B switch: DEMF_X3_MASK bit 0 = forward launches, bit 1 = input-gradient, bit 2 = weight-gradient
+      static const int mask = env_int("DEMF_X3_MASK", 7);
       if (mask & (PRO >= PRO_DY_DENSE ? 2 : 1)) return launch_gemm_t<PRO, STATS, POOL, RED, 2>(a, s);
       return launch_gemm_t<PRO, STATS, POOL, RED, 0>(a, s);
     }
@@ -2065,6 +2096,18 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
     else { DWB(2, 2); }
 #undef DWB
     return check_launch("mlp_gemm_bwd_dw(bf16)");
+  }
+  static const int x3mask = env_int("DEMF_X3_MASK", 7);          // bit 2: weight-gradient launches
+  if (compute_mode() == 2 && (x3mask & 4)) {
+#define DWX(TNv, TKv)                                                                            \
+  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, true>), grid, dim3(256), lds, s, a); \
+  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, true>), grid, dim3(256), lds, s, a)
+    if (tn == 1 && tk == 1) { DWX(1, 1); }
+    else if (tn == 1) { DWX(1, 2); }
+    else if (tk == 1) { DWX(2, 1); }
+    else { DWX(2, 2); }
+#undef DWX
+    return check_launch("mlp_gemm_bwd_dw(x3)");
   }
 #define DW(TNv, TKv)                                                                             \
   if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), grid, dim3(256), lds, s, a);       \

@@ -3,7 +3,7 @@ every fp32 operand is split exactly into three bf16 terms and the six significan
 accumulated in fp32 on v_mfma_f32_32x32x16_bf16.  What is asserted: (1) against an fp64 product the
 split kernels are as accurate as the same kernels on the native fp32 MFMA (rms within 1.5x, max
 within 2.5x, both at the 1e-7 level - NOT the 1e-3 level of bf16), for the forward and
-pooled-forward launches in their tilings (the input-gradient launches: (3)); (2) operands whose three terms exercise the whole
+pooled-forward, input-gradient and weight-gradient launches in their tilings; (2) operands whose three terms exercise the whole
 24-bit significand (values with non-zero low mantissa bits, huge dynamic range across K) stay at
 that level; (3) a whole shared-MLP stack, forward + backward, agrees between the two fp32 modes to
 1e-6 relative L2 forward / flip-level backward; (4) the whole hot path in "f32_native" mode meets the same golden vectors of the
@@ -176,6 +176,52 @@ def test_input_gradient_split_is_as_accurate_as_fp32_mfma(R, N, K, ns, sparse):
     for mode in ("f32_native", "f32x3"):
         err = (g12s[mode] - want).abs().max().item()
         assert err <= 1e-5 * max(1.0, want.abs().max().item()), (mode, err)
+
+
+@pytest.mark.parametrize("R,N,K,ns", [(65536, 128, 64, 16), (32768, 256, 128, 32), (5008, 64, 64, 16),
+                                      (3000, 96, 36, 8), (40000, 32, 128, 16)])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_weight_gradient_split_is_as_accurate_as_fp32_mfma(R, N, K, ns, sparse):
+    """dW (N, K) = dY^T @ relu(bn(Xprev)), dY formed in the prologue - the reduction runs over the
+    ROWS, so the split terms are gathered column-wise from the staged slab - against fp64."""
+    from demf_amd import _ffi
+    R = (R // ns) * ns
+    y, g, xp = _r(R, N, seed=1), _r(R, N, seed=2), _r(R, K, seed=3)
+    vec = torch.stack([torch.rand(N) + 0.5, torch.randn(N) * 0.3, torch.rand(N) + 0.5,
+                       torch.randn(N) * 0.1, torch.randn(N) * 0.1, torch.zeros(N)]).cuda().contiguous()
+    sc, sh, gi, a, b = [vec[i] for i in range(5)]
+    pss = torch.cat([torch.rand(K) + 0.5, torch.randn(K) * 0.3]).cuda()
+    dP = _r(R // ns, N, seed=4)
+    arg = torch.randint(0, ns, (R // ns, N), dtype=torch.int32, device="cuda")
+    if sparse:
+        gfull = torch.zeros(R // ns, ns, N, device="cuda")
+        gfull.scatter_(1, arg.long().unsqueeze(1), dP.unsqueeze(1))
+        gfull = gfull.view(R, N)
+    else:
+        gfull = g
+    dz = torch.where(y.double() * sc.double() + sh.double() > 0, gfull, torch.zeros_like(gfull))
+    dY = torch.addcmul(torch.addcmul(b, a, y), gi, dz).double()
+    act = torch.relu(torch.addcmul(pss[K:], xp, pss[:K])).double()
+    ref = dY.t() @ act
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        dW = torch.zeros(N, K, device="cuda")
+        _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, K, 0 if sparse else g.data_ptr(),
+                  dP.data_ptr() if sparse else 0, arg.data_ptr() if sparse else 0, ns, y.data_ptr(),
+                  vec.data_ptr(), xp.data_ptr(), pss.data_ptr(), dW.data_ptr(), st)
+        torch.cuda.synchronize()
+        return dW
+    out = _modes(run)
+    # long fp32 reductions (R rows, atomics in arrival order): fp32-grade means ~1e-6 of the scale here
+    mx_n, rms_n = _errs(out["f32_native"], ref)
+    mx_s, rms_s = _errs(out["f32x3"], ref)
+    _, rms_b = _errs(out["bf16"], ref)
+    scale = ref.pow(2).mean().sqrt().item()
+    assert rms_s <= 1.5 * rms_n + 1e-7 * scale, (rms_s, rms_n)
+    assert mx_s <= 2.5 * mx_n + 1e-6 * scale, (mx_s, mx_n)
+    assert rms_s <= 1e-5 * scale, (rms_s, scale)
+    assert rms_b >= 20 * rms_s, ("bf16 should be visibly coarser", rms_b, rms_s)
 
 
 def _mlp_case(seed, R, ns, chans):
