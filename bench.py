@@ -34,9 +34,17 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
 # the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
-DOMINANT_KERNEL = {"f32": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0>",
+DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0>",
                    "f32x3": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 2>",
                    "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 1>"}
+DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
+    "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
+MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
+             "f32x3": "fp32 operands split exactly into 3 bf16 terms, 6 products on "
+                      "v_mfma_f32_32x32x16_bf16, fp32 accumulate (error vs fp64 = the fp32 MFMA's, "
+                      "tests/test_gpu_split.py)",
+             "bf16": "operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
+MFMA_PATH["f32"] = MFMA_PATH["f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
 # FPS: per round one barrier phase (~450 cycles with 16 waves) + 20 points/lane x 8 VALU ops
 FPS_FLOOR_CYCLES = 900.0
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
@@ -217,10 +225,13 @@ def main():
     ap.add_argument("--msda-points", type=int, default=2,
                     help="sampling points per level of the fusion attention: 2 = reference config "
                          "(demf_votenet.py:83), 4 = BASELINE.json's wording; secondary figure only")
-    ap.add_argument("--dtype", choices=("f32", "f32x3", "bf16"), default="f32",
-                    help="compute dtype of the dense MFMA kernels: f32 = the reference's precision "
-                         "(headline, BASELINE configs[2]); bf16 = configs[3] (bf16 MFMA, fp32 accumulate, "
-                         "fp32 storage / statistics / indices / losses)")
+    ap.add_argument("--dtype", choices=("f32", "f32_native", "f32x3", "bf16"), default="f32",
+                    help="compute mode of the dense MFMA kernels.  f32 = the reference's precision "
+                         "(headline, BASELINE configs[2]): fp32 results; the shared-MLP GEMMs split each "
+                         "fp32 operand exactly into three bf16 terms and run the six significant "
+                         "products on the bf16 MFMA (= f32x3; DEMF_F32_NATIVE=1 or f32_native: the "
+                         "fp32 MFMA itself).  bf16 = configs[3] (operands rounded to bf16, fp32 "
+                         "accumulate, fp32 storage / statistics / indices / losses)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -316,13 +327,15 @@ def main():
             "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: full DeMF fusion hot path fwd+loss+bwd+"
                                    "allreduce+AdamW, %d scenes/GPU x (20000 pts, 800x1120 -> "
                                    "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=%d, %s"
                                    % (args.batch, args.msda_points,
-                                      "fp32" if args.dtype == "f32" else
+                                      "fp32" if args.dtype != "bf16" else
                                       "bf16 MFMA / fp32 accumulate+storage (BASELINE configs[3] per GPU)"),
+                       "compute_mode": args.dtype, "mfma_path": MFMA_PATH[args.dtype],
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "launch": "eager" if args.no_graph else "hipGraphs(fwd+loss | bwd) + eager allreduce/AdamW; "
                                  "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
@@ -334,7 +347,7 @@ def main():
         # runs underneath the step on a side stream).  Algorithmic bytes of that GEMM = read the
         # (R,64) input rows once, write the (R,128) raw output once, write pooled max/min + their
         # row offsets (4 x (R/64,128) words); weights < 1 %.
-        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "f32" else MFMA_BF16_PEAK_TFLOPS
+        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype != "bf16" else MFMA_BF16_PEAK_TFLOPS
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 4 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
@@ -347,13 +360,14 @@ def main():
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,
             "avg_launch_ms": mlp_ms,
             "mfma_frac": mlp_flop / (mlp_ms * 1e-3) / 1e12 / mfma_peak,
-            "note": "also %.1f GFLOP of MFMA per launch (mfma_frac = of the %.1f TF/s dense %s peak)"
-                    % (mlp_flop / 1e9, mfma_peak, args.dtype)}
+            "note": "also %.1f algorithmic GFLOP per launch (mfma_frac = of the %.1f TF/s dense %s MFMA "
+                    "peak; in the f32x3 mode each product is issued as 6 bf16 MFMAs = 3/8 of the fp32 "
+                    "MFMA's issue time)" % (mlp_flop / 1e9, mfma_peak, "bf16" if args.dtype == "bf16" else "fp32")}
         # ---- step level: what the metric asks for ("as achieved fraction of HBM roofline")
         step_bytes = ALGO_BYTES_PER_SCENE * args.batch
         step_flop = ALGO_FLOP_PER_SCENE * args.batch
         out["roofline_step"] = {
-            "bound": "mfma" if args.dtype == "f32" else "hbm", "algorithmic_bytes": step_bytes,
+            "bound": "mfma" if args.dtype != "bf16" else "hbm", "algorithmic_bytes": step_bytes,
             "algorithmic_flop": step_flop,
             "hbm": {"achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

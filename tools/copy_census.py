@@ -1,5 +1,5 @@
-"""aten::copy_ / cat / add launches of one eager training step, by input shapes (where do the
-remaining library launches come from)."""
+"""Library (non-demf) launches of one eager training step, by op, input shapes and the innermost
+demf_amd call site (where do the remaining glue launches come from)."""
 import sys, os, collections, torch
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R_)
 import bench
@@ -16,7 +16,7 @@ geo = model.index_geometry(batch["points"])
 for _ in range(2):
     tr._fwd_bwd(batch, geo); tr._update()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     tr._fwd_bwd(batch, geo); tr._update()
     torch.cuda.synchronize()
 cnt = collections.Counter()
@@ -24,6 +24,7 @@ for e in prof.events():
     if e.device_type != torch.autograd.DeviceType.CPU or not e.kernels: continue
     if any(c.kernels for c in e.cpu_children): continue
     if all("demf::" in k.name for k in e.kernels): continue
-    cnt[(e.name, str(e.input_shapes)[:110])] += len(e.kernels)
-for (n, sh), c in cnt.most_common(60):
-    print(f"{c:3d} {n:28s} {sh}")
+    site = next((f.split("/root/repo/")[-1] for f in (e.stack or []) if "demf_amd/" in f), "?")
+    cnt[(e.name, str(e.input_shapes)[:70], site[:60])] += len(e.kernels)
+for (n, sh, site), c in cnt.most_common(80):
+    print(f"{c:3d} {n:24s} {site:60s} {sh}")

@@ -1,9 +1,11 @@
 """The dominant kernel alone: demf_mlp_gemm_fwd_pool at SA1's last layer (R = 8*2048*64 rows, 64 -> 128,
-ns = 64), N launches back to back; DEMF_FWD_LDS=0/1 selects the register-staged / LDS-direct kernel.
+ns = 64), N launches back to back; DEMF_FWD_LDS=0/1 selects the register-staged / LDS-direct kernel,
+DEMF_MODE=f32|f32_native|f32x3|bf16 the compute mode.
 Used under rocprofv3 --pmc for pipe-utilisation counters."""
 import sys, os, torch
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R_)
-from demf_amd import _ffi
+from demf_amd import _ffi, ops
+ops.set_compute_dtype(os.environ.get("DEMF_MODE", "f32"))
 R, K, N, ns = 8 * 2048 * 64, 64, 128, 64
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 x = torch.randn(R, K, device="cuda"); w = torch.randn(N, K, device="cuda") / 8
@@ -20,4 +22,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(n): run()
 e.record(); torch.cuda.synchronize()
-print("DEMF_FWD_LDS=%s  avg %.1f us" % (os.environ.get("DEMF_FWD_LDS", "1"), s.elapsed_time(e) * 1e3 / n))
+print("DEMF_MODE=%s DEMF_FWD_LDS=%s  avg %.1f us" % (os.environ.get("DEMF_MODE", "f32"), os.environ.get("DEMF_FWD_LDS", "0"), s.elapsed_time(e) * 1e3 / n))
