@@ -42,6 +42,8 @@ SIGNATURES = {
     "demf_box_extent_count": [_c_int] * 4 + [_ptr] * 8,
     "demf_aligned_nms": [_c_int, _c_int, _c_float] + [_ptr] * 6,
     "demf_proposal_targets": [_c_int] * 4 + [_c_float] * 3 + [_ptr] * 18,
+    "demf_gt_prep": [_c_int] * 3 + [_ptr] * 10,
+    "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
     "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 8,

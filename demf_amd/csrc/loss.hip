@@ -355,6 +355,76 @@ __global__ __launch_bounds__(256) void proposal_targets_k(PropTargetArgs a) {
   a.obj_mask[r] = (euc < a.pos_thr || euc > a.neg_thr) ? 1.f : 0.f;
 }
 
+// ---- ground-truth preparation: everything the two target kernels need that depends on the GT boxes
+// alone, in one launch instead of ~20 element-wise ones on (B, G) tensors:
+//   cos / sin(-yaw); angle2class(yaw) (PartialBinBasedBBoxCoder: class = bin of the angle shifted
+//   by half a bin, residual = offset from the bin centre), in torch's fp32 remainder / floor-divide
+//   semantics; valid = label >= 0, label clamped at 0; gravity centre (x, y, z + dz/2).
+__device__ __forceinline__ float torch_remainder(float a, float b) {
+  float m = fmodf(a, b);
+  if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+  return m;
+}
+__device__ __forceinline__ float torch_floor_divide(float a, float b) {   // ATen div_floor_floating
+  float m = fmodf(a, b);
+  float d = (a - m) / b;
+  if (m != 0.f && ((b < 0.f) != (m < 0.f))) d -= 1.f;
+  if (d != 0.f) {
+    float f = floorf(d);
+    if (d - f > 0.5f) f += 1.f;
+    return f;
+  }
+  return copysignf(0.f, a / b);
+}
+
+__global__ void gt_prep_k(int n, int nbins, const float* __restrict__ gt,
+                          const long long* __restrict__ labels, float* __restrict__ cs,
+                          float* __restrict__ sn, long long* __restrict__ dir_cls,
+                          float* __restrict__ dir_res, unsigned char* __restrict__ valid,
+                          long long* __restrict__ lab, float* __restrict__ center) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* t = gt + (size_t)i * 7;
+  const float yaw = t[6];
+  cs[i] = cosf(-yaw);
+  sn[i] = sinf(-yaw);
+  const float two_pi = (float)(2.0 * 3.14159265358979323846);
+  const float per = (float)(2.0 * 3.14159265358979323846 / (double)nbins);
+  const float half = (float)(2.0 * 3.14159265358979323846 / (double)nbins / 2.0);
+  const float ang = torch_remainder(yaw, two_pi);
+  const float shifted = torch_remainder(ang + half, two_pi);
+  const float c = torch_floor_divide(shifted, per);
+  dir_cls[i] = (long long)c;
+  dir_res[i] = shifted - (c * per + half);
+  const long long l = labels[i];
+  valid[i] = l >= 0 ? 1 : 0;
+  lab[i] = l < 0 ? 0 : l;
+  center[(size_t)i * 3] = t[0];
+  center[(size_t)i * 3 + 1] = t[1];
+  center[(size_t)i * 3 + 2] = t[2] + t[5] * 0.5f;
+}
+
+// objectness_weights = masks / (sum(masks) + 1e-6); box_loss_weights = obj / (sum(obj) + 1e-6)
+// (class_agnostic_vote_head.py:797-816), R <= a few thousand proposals: one workgroup.
+__global__ __launch_bounds__(1024) void target_weights_k(int R, const float* __restrict__ obj_mask,
+                                                         const long long* __restrict__ obj_t,
+                                                         float* __restrict__ obj_w,
+                                                         float* __restrict__ box_w) {
+  __shared__ float s_m[16], s_o[16];
+  float m = 0.f, o = 0.f;
+  for (int i = threadIdx.x; i < R; i += 1024) { m += obj_mask[i]; o += (float)obj_t[i]; }
+  for (int d = 32; d >= 1; d >>= 1) { m += __shfl_xor(m, d); o += __shfl_xor(o, d); }
+  if ((threadIdx.x & 63) == 0) { s_m[threadIdx.x >> 6] = m; s_o[threadIdx.x >> 6] = o; }
+  __syncthreads();
+  m = 0.f; o = 0.f;
+  for (int w = 0; w < 16; ++w) { m += s_m[w]; o += s_o[w]; }
+  const float im = m + 1e-6f, io = o + 1e-6f;
+  for (int i = threadIdx.x; i < R; i += 1024) {
+    obj_w[i] = obj_mask[i] / im;
+    box_w[i] = (float)obj_t[i] / io;
+  }
+}
+
 }  // namespace demf
 
 using namespace demf;
@@ -470,4 +540,32 @@ extern "C" int demf_proposal_targets(int B, int Q, int G, int with_rot, float po
   a.obj_t = (long long*)objectness_targets;
   hipLaunchKernelGGL(proposal_targets_k, dim3(cdiv(Q, 256), B), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("proposal_targets");
+}
+
+extern "C" int demf_gt_prep(int B, int G, int num_dir_bins, const float* gt_boxes,
+                            const int64_t* labels_padded, float* cos_neg_yaw, float* sin_neg_yaw,
+                            int64_t* gt_dir_class, float* gt_dir_res, unsigned char* valid,
+                            int64_t* labels_clamped, float* gravity_center, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && G >= 1 && num_dir_bins >= 1, "gt_prep: bad sizes B=%d G=%d", B, G);
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(gt_boxes && labels_padded && cos_neg_yaw && sin_neg_yaw && gt_dir_class && gt_dir_res &&
+                   valid && labels_clamped && gravity_center, "gt_prep: null pointer");
+  const int n = B * G;
+  hipLaunchKernelGGL(gt_prep_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, num_dir_bins,
+                     gt_boxes, (const long long*)labels_padded, cos_neg_yaw, sin_neg_yaw,
+                     (long long*)gt_dir_class, gt_dir_res, valid, (long long*)labels_clamped,
+                     gravity_center);
+  return check_launch("gt_prep");
+}
+
+extern "C" int demf_target_weights(int R, const float* objectness_masks,
+                                   const int64_t* objectness_targets, float* objectness_weights,
+                                   float* box_loss_weights, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0, "target_weights: bad size");
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(objectness_masks && objectness_targets && objectness_weights && box_loss_weights,
+               "target_weights: null pointer");
+  hipLaunchKernelGGL(target_weights_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, R, objectness_masks,
+                     (const long long*)objectness_targets, objectness_weights, box_loss_weights);
+  return check_launch("target_weights");
 }

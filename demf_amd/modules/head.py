@@ -538,6 +538,16 @@ class DeMFVoteHead(nn.Module):
         else:
             # already padded (B,G,7) / (B,G): label -1 marks a padding slot (static-shape loops)
             gt = gt_bboxes_3d
+            if gt.is_cuda and gt.is_contiguous() and gt_labels_3d.is_contiguous() and \
+                    gt_labels_3d.dtype == torch.int64 and points.is_contiguous() and gt.shape[1] <= 64:
+                # device path of the captured step: the GT-only quantities (cos / sin(-yaw),
+                # angle2class, valid, clamped labels, gravity centres) in one launch, then
+                # vote_targets_k; the torch code below is the specification of both
+                prep = ops.gt_prep(gt, gt_labels_3d, self.num_dir_bins)
+                vote_targets, masks = ops.vote_targets(points, gt, prep["valid"], prep=prep)
+                return dict(gt=gt, lab=prep["lab"], valid=prep["valid"], center=prep["center"],
+                            dims=gt[..., 3:6], yaw=gt[..., 6], vote_targets=vote_targets,
+                            vote_target_masks=masks, prep=prep)
             valid = gt_labels_3d >= 0
             lab = gt_labels_3d.clamp(min=0)
         B, G = gt.shape[:2]
@@ -582,17 +592,21 @@ class DeMFVoteHead(nn.Module):
         agg = bbox_preds["aggregated_points"]
 
         # -- proposal targets (:877-934)
-        dir_class_t, dir_res_t = self.bbox_coder.angle2class(yaw)
+        prep = vp.get("prep")
+        if prep is not None:
+            dir_class_t, dir_res_t = prep["dir_class"], prep["dir_res"]
+        else:
+            dir_class_t, dir_res_t = self.bbox_coder.angle2class(yaw)
         pos_thr = self.train_cfg["pos_distance_thr"]
         neg_thr = self.train_cfg["neg_distance_thr"]
         if agg.is_cuda and "gt" in vp and vp["gt"].is_contiguous():
             # one kernel (csrc/loss.hip: proposal_targets_k); the torch code below is its spec
             t = ops.proposal_targets(agg.contiguous(), vp["gt"], lab, valid, dir_class_t, dir_res_t,
                                      self.bbox_coder.with_rot, pos_thr, neg_thr,
-                                     np.pi / self.num_dir_bins)
+                                     np.pi / self.num_dir_bins, prep=prep)
             objectness_masks, objectness_targets = t["objectness_masks"], t["objectness"]
-            objectness_weights = objectness_masks / (objectness_masks.sum() + 1e-6)
-            box_loss_weights = objectness_targets.float() / (objectness_targets.sum().float() + 1e-6)
+            objectness_weights, box_loss_weights = ops.target_weights(objectness_masks,
+                                                                      objectness_targets)
             return (vote_targets, vote_target_masks, t["dir_class"], t["dir_res"], t["mask"],
                     objectness_targets, objectness_weights, box_loss_weights, t["distance"],
                     t["dir"], t["size"], t["center"])

@@ -15,7 +15,7 @@ from torch.autograd.function import once_differentiable
 from . import _ffi
 
 __all__ = [
-    "set_compute_dtype", "get_compute_dtype", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
+    "set_compute_dtype", "get_compute_dtype", "gt_prep", "target_weights", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
     "three_nn", "three_interpolate", "MultiScaleDeformableAttnFunction",
     "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns", "shared_mlp_pool",
 ]
@@ -1090,16 +1090,52 @@ def vote_loss(vote_points, seed_points, seed_indices, vote_target_masks, vote_ta
                            dst_weight)
 
 
-def vote_targets(points, gt, valid):
+def gt_prep(gt, labels_padded, num_dir_bins):
+    """Everything the target kernels need from the padded ground truth alone - gt (B,G,7), labels
+    (B,G) int64 with -1 on padding slots - in ONE launch (demf_gt_prep) instead of ~20 element-wise
+    ones: dict(cs, sn = cos / sin(-yaw); dir_class, dir_res = bbox_coder.angle2class(yaw);
+    valid (bool view of valid_u8), lab = labels clamped at 0, center = gravity centres (B,G,3))."""
+    _chk(gt, "gt")
+    _chk(labels_padded, "labels", torch.int64)
+    B, G = gt.shape[:2]
+    dev = gt.device
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    out = dict(cs=f(B, G), sn=f(B, G), dir_class=torch.empty((B, G), dtype=torch.int64, device=dev),
+               dir_res=f(B, G), valid_u8=torch.empty((B, G), dtype=torch.uint8, device=dev),
+               lab=torch.empty((B, G), dtype=torch.int64, device=dev), center=f(B, G, 3))
+    _ffi.call("demf_gt_prep", B, G, int(num_dir_bins), _p(gt), _p(labels_padded), _p(out["cs"]),
+              _p(out["sn"]), _p(out["dir_class"]), _p(out["dir_res"]), _p(out["valid_u8"]),
+              _p(out["lab"]), _p(out["center"]), _stream())
+    out["valid"] = out["valid_u8"].view(torch.bool)
+    return out
+
+
+def target_weights(objectness_masks, objectness_targets):
+    """-> (objectness_weights, box_loss_weights): each tensor divided by (its sum + 1e-6)
+    (class_agnostic_vote_head.py:797-816), one launch."""
+    _chk(objectness_masks, "objectness_masks")
+    _chk(objectness_targets, "objectness_targets", torch.int64)
+    ow = torch.empty_like(objectness_masks)
+    bw = torch.empty_like(objectness_masks)
+    _ffi.call("demf_target_weights", objectness_masks.numel(), _p(objectness_masks),
+              _p(objectness_targets), _p(ow), _p(bw), _stream())
+    return ow, bw
+
+
+def vote_targets(points, gt, valid, prep=None):
     """points (B,N,>=3), gt (B,G,7), valid (B,G) bool -> (vote_targets (B,N,9), masks (B,N) int64):
-    the per-point half of DeMFVoteHead.get_targets (class_agnostic_vote_head.py:828-858)."""
+    the per-point half of DeMFVoteHead.get_targets (class_agnostic_vote_head.py:828-858).
+    ``prep``: the result of ``gt_prep`` on the same boxes (saves the element-wise launches)."""
     _chk(points, "points")
     _chk(gt, "gt")
     B, N, stride = points.shape
     G = gt.shape[1]
-    yaw = gt[..., 6]
-    cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
-    v = valid.to(torch.uint8).contiguous()
+    if prep is not None:
+        cs, sn, v = prep["cs"], prep["sn"], prep["valid_u8"]
+    else:
+        yaw = gt[..., 6]
+        cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
+        v = valid.to(torch.uint8).contiguous()
     vt = torch.empty((B, N, 9), dtype=torch.float32, device=points.device)
     mask = torch.empty((B, N), dtype=torch.int64, device=points.device)
     _ffi.call("demf_vote_targets", B, N, stride, G, _p(points), _p(gt), _p(cs), _p(sn), _p(v),
@@ -1107,7 +1143,8 @@ def vote_targets(points, gt, valid):
     return vt, mask
 
 
-def proposal_targets(agg, gt, lab, valid, dir_class, dir_res, with_rot, pos_thr, neg_thr, res_scale):
+def proposal_targets(agg, gt, lab, valid, dir_class, dir_res, with_rot, pos_thr, neg_thr, res_scale,
+                     prep=None):
     """The per-proposal half of DeMFVoteHead.get_targets (class_agnostic_vote_head.py:877-934) in
     one kernel.  agg (B,Q,3), gt (B,G,7), lab / valid (B,G), dir_class / dir_res = angle2class(yaw).
     -> dict(center, size, dir_class, dir_res, dir, mask, distance, objectness, objectness_masks)"""
@@ -1116,15 +1153,19 @@ def proposal_targets(agg, gt, lab, valid, dir_class, dir_res, with_rot, pos_thr,
     B, Q, _ = agg.shape
     G = gt.shape[1]
     dev = agg.device
-    yaw = gt[..., 6]
-    cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
+    if prep is not None:
+        cs, sn, valid_u8 = prep["cs"], prep["sn"], prep["valid_u8"]
+    else:
+        yaw = gt[..., 6]
+        cs, sn = torch.cos(-yaw).contiguous(), torch.sin(-yaw).contiguous()
+        valid_u8 = valid.to(torch.uint8).contiguous()
     f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
     l = lambda *s: torch.empty(s, dtype=torch.int64, device=dev)
     out = dict(center=f(B, Q, 3), size=f(B, Q, 3), dir_class=l(B, Q), dir_res=f(B, Q), dir=f(B, Q),
                mask=l(B, Q), distance=f(B, Q, 6), objectness=l(B, Q), objectness_masks=f(B, Q))
     _ffi.call("demf_proposal_targets", B, Q, G, int(bool(with_rot)), float(pos_thr), float(neg_thr),
               float(res_scale), _p(agg), _p(gt), _p(cs), _p(sn), _p(dir_class.contiguous()),
-              _p(dir_res.contiguous()), _p(lab.contiguous()), _p(valid.to(torch.uint8).contiguous()),
+              _p(dir_res.contiguous()), _p(lab.contiguous()), _p(valid_u8),
               _p(out["center"]), _p(out["size"]), _p(out["dir_class"]), _p(out["dir_res"]),
               _p(out["dir"]), _p(out["mask"]), _p(out["distance"]), _p(out["objectness"]),
               _p(out["objectness_masks"]), _stream())

@@ -401,6 +401,20 @@ int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, floa
                           float* distance_targets, int64_t* objectness_targets,
                           float* objectness_masks, demf_stream_t stream);
 
+/* Everything the two target kernels need that depends on the padded ground truth alone (label -1 =
+ * padding slot), one launch: cos/sin(-yaw), PartialBinBasedBBoxCoder.angle2class(yaw) in torch's
+ * fp32 remainder / floor-divide semantics (class_agnostic_vote_head.py:877-883 via
+ * bbox_coder.encode), valid = label >= 0, labels clamped at 0, gravity centres (B,G,3).           */
+int demf_gt_prep(int B, int G, int num_dir_bins, const float* gt_boxes, const int64_t* labels_padded,
+                 float* cos_neg_yaw, float* sin_neg_yaw, int64_t* gt_dir_class, float* gt_dir_res,
+                 unsigned char* valid, int64_t* labels_clamped, float* gravity_center,
+                 demf_stream_t stream);
+
+/* objectness_weights = masks / (sum + 1e-6), box_loss_weights = objectness / (sum + 1e-6) over all
+ * R = B*Q proposals (class_agnostic_vote_head.py:797-816).                                          */
+int demf_target_weights(int R, const float* objectness_masks, const int64_t* objectness_targets,
+                        float* objectness_weights, float* box_loss_weights, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Test-time post-processing: DeMFVoteHead.get_bboxes (class_agnostic_vote_head.py:714-754) +
  * the inherited mmdet3d VoteHead.multiclass_nms_single / aligned_3d_nms.

@@ -138,3 +138,46 @@ def test_proposal_targets_kernel_matches_spec(B, Q, G, seed):
             np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6, err_msg=n)
         else:
             np.testing.assert_array_equal(a, b, err_msg=n)
+
+
+def test_gt_prep_matches_the_torch_specification():
+    """demf_gt_prep against the host code it replaces in the captured step: cos / sin(-yaw),
+    bbox_coder.angle2class(yaw) (class exact, residual bit-exact: same fp32 remainder /
+    floor-divide arithmetic), valid mask, clamped labels, gravity centres."""
+    from demf_amd import ops
+    from demf_amd.modules.coder import DeMFClassAgnosticBBoxCoder
+    g = torch.Generator().manual_seed(5)
+    B, G, nb = 8, 11, 12
+    gt = torch.randn(B, G, 7, generator=g)
+    gt[..., 3:6] = gt[..., 3:6].abs() + 0.1
+    gt[..., 6] = (torch.rand(B, G, generator=g) - 0.5) * 4 * np.pi       # beyond one period, both signs
+    per = 2 * np.pi / nb
+    gt[0, :6, 6] = torch.tensor([0.0, per / 2, -per / 2, np.pi, -np.pi, 2 * np.pi - 1e-7])  # bin edges
+    lab = torch.randint(0, 10, (B, G), generator=g)
+    lab[:, 7:] = -1
+    lab[3] = -1
+    gt, lab = gt.cuda(), lab.cuda()
+    p = ops.gt_prep(gt, lab, nb)
+    yaw = gt[..., 6]
+    cls, res = DeMFClassAgnosticBBoxCoder(nb).angle2class(yaw)
+    assert torch.equal(p["dir_class"], cls)
+    assert torch.equal(p["dir_res"], res)
+    assert torch.equal(p["cs"], torch.cos(-yaw)) and torch.equal(p["sn"], torch.sin(-yaw))
+    assert torch.equal(p["valid"], lab >= 0) and p["valid"].dtype == torch.bool
+    assert torch.equal(p["lab"], lab.clamp(min=0))
+    center = torch.cat([gt[..., :2], gt[..., 2:3] + gt[..., 5:6] * 0.5], dim=-1)
+    assert torch.equal(p["center"], center)
+
+
+def test_target_weights_match_the_torch_specification():
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for R in (2048, 1000, 7):
+        m = (torch.rand(R, generator=g) < 0.6).float().cuda()
+        o = (torch.rand(R, generator=g) < 0.1).long().cuda()
+        ow, bw = ops.target_weights(m, o)
+        np.testing.assert_allclose(ow.cpu().numpy(), (m / (m.sum() + 1e-6)).cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(bw.cpu().numpy(), (o.float() / (o.sum().float() + 1e-6)).cpu().numpy(), rtol=1e-6)
+    z = torch.zeros(64, device="cuda")
+    ow, bw = ops.target_weights(z, z.long())
+    assert float(ow.abs().max()) == 0.0 and float(bw.abs().max()) == 0.0
