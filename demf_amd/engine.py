@@ -64,6 +64,9 @@ class FlatGrads:
         dev, dt = self.params[0].device, self.params[0].dtype
         self.flat = torch.zeros(n, dtype=dt, device=dev)
         self.views = []
+        self._pending_tables, self._tables = [], []     # address tables of captured pack launches
+        self.captured_pack = False      # set by Trainer.capture around its captures (it calls finish_capture)
+        self._reserved_table = None
         off = 0
         for p in self.params:
             k = p.numel()
@@ -79,7 +82,38 @@ class FlatGrads:
         src = [g for g in grads if g is not None]
         if len(src) != len(grads):
             self.flat.zero_()
+        if self.captured_pack and self.flat.is_cuda and torch.cuda.is_current_stream_capturing() and src:
+            # Under capture the gradients live at fixed addresses of the graph's pool: one
+            # demf_multi_copy launch over an address table (two multi-tensor launches of 37 us each
+            # otherwise).  The table cannot be uploaded while capturing; the recorded launch only
+            # holds its device address, ``finish_capture`` fills it before the first replay.
+            from . import _ffi
+            src = [g if g.is_contiguous() else g.contiguous() for g in src]
+            tab = [[g.data_ptr() for g in src], [d.data_ptr() for d in dst],
+                   [d.numel() for d in dst]]
+            # (allocated by Trainer.capture BEFORE capturing: memory of the graphs' shared pool is
+            # scratch that the forward graph rewrites on every replay)
+            table = self._reserved_table.view(-1)[:3 * len(src)].view(3, len(src))
+            blocks = max(1, min(64, max(tab[2]) // 4096))
+            _ffi.call("demf_multi_copy", len(src), table.data_ptr(), blocks,
+                      torch.cuda.current_stream().cuda_stream)
+            self._pending_tables.append((table, tab))
+            return
         torch._foreach_copy_(dst, src)
+
+    def reserve_table(self):
+        """Room for the address table of one captured pack launch, from the ordinary allocator."""
+        self._reserved_table = torch.empty((3, len(self.params)), dtype=torch.int64,
+                                           device=self.flat.device)
+
+    def finish_capture(self):
+        """Upload the address tables of the pack launches recorded while capturing (call once the
+        capture has ended, before the first replay)."""
+        for table, tab in self._pending_tables:
+            table.copy_(torch.tensor(tab, dtype=torch.int64))
+            self._tables.append(table)                 # the graphs hold its address
+        self._reserved_table = None
+        self._pending_tables = []
 
     def zero_(self):
         self.flat.zero_()
@@ -333,6 +367,7 @@ class Trainer:
         can_prefetch = prefetch_geometry and hasattr(self.model, "index_geometry")
         static_geo = self.model.index_geometry(batch["points"]) if can_prefetch else None
         torch.cuda.synchronize()
+        self.flat.reserve_table()
         graph = torch.cuda.CUDAGraph()
         graph_bwd = None
         if can_prefetch and not os.environ.get("DEMF_GEO_AT_FWD"):
@@ -340,6 +375,7 @@ class Trainer:
             # started in between: it then runs underneath the backward, whose long persistent
             # kernels take their tiles dynamically and lose less to the resident FPS chain than the
             # forward does (measured 9.26 -> 9.11 ms/step; DEMF_GEO_AT_FWD=1 restores the old order)
+            self.flat.captured_pack = True
             try:
                 with torch.cuda.graph(graph):
                     self._arena(True)            # the arena's single fill is the graph's first node
@@ -349,10 +385,16 @@ class Trainer:
                     self.flat.backward_into(total)
             finally:
                 self._arena(False)
+                self.flat.captured_pack = False
             loss = total.detach()
         else:
-            with torch.cuda.graph(graph):
-                loss = self._fwd_bwd(batch, static_geo)
+            self.flat.captured_pack = True
+            try:
+                with torch.cuda.graph(graph):
+                    loss = self._fwd_bwd(batch, static_geo)
+            finally:
+                self.flat.captured_pack = False
+        self.flat.finish_capture()
 
         def flat_tensors(g):
             """Every tensor of the (nested) geometry structure, in a deterministic order."""

@@ -48,6 +48,23 @@ def test_graph_replay_matches_eager():
     assert all(torch.isfinite(torch.tensor(l1)))
 
 
+def test_captured_gradient_pack_equals_eager():
+    """Trainer.capture packs the gradients with ONE demf_multi_copy launch over an address table
+    (uploaded after the capture): with lr = 0 the weights stay put, so the flat gradient buffer
+    after a replay must equal the eager one - every entry rewritten."""
+    ta, _, batch = _setup(lr=0.0)
+    tb, _, _ = _setup(lr=0.0)
+    ta._fwd_bwd(batch)
+    replay = tb.capture(batch, warmup=1)
+    for _ in range(2):
+        tb.flat.flat.fill_(123.0)
+        replay()
+        torch.cuda.synchronize()
+        ga, gb = ta.flat.flat.double(), tb.flat.flat.double()
+        assert not bool((tb.flat.flat == 123.0).any())
+        assert ((ga - gb).norm() / ga.norm()).item() < 1e-3
+
+
 def test_steps_reduce_the_loss():
     """Small steps on one fixed batch (small enough that the discrete target assignment
     stays put) must walk the loss down."""
