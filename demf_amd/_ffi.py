@@ -51,10 +51,14 @@ SIGNATURES = {
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,
+    "demf_mlp_gemm_fwd_bn": [_c_int] * 4 + [_ptr] * 7 + [_c_float, _c_float] + [_ptr] * 7,
+    "demf_mlp_gemm_fwd_pool_bn": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 6 + [_c_float, _c_float] + [_ptr] * 7,
     "demf_pool_select": [_c_int] * 2 + [_ptr] * 9,
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 7,
     "demf_l2norm_rows_fwd": [_c_int] * 2 + [_ptr] * 4,
     "demf_l2norm_rows_bwd": [_c_int] * 2 + [_ptr] * 5,
+    "demf_vote_combine_fwd": [_c_int] * 2 + [_ptr] * 7,
+    "demf_vote_combine_bwd": [_c_int] * 2 + [_ptr] * 7,
     "demf_bnrelu_maxpool_fwd": [_c_int] * 3 + [_ptr] * 5,
     "demf_bn_bwd_reduce": [_c_int] * 3 + [_ptr] * 9,
     "demf_bn_bwd_vectors": [_c_int, ctypes.c_longlong] + [_ptr] * 8,

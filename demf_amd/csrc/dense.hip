@@ -796,6 +796,62 @@ __global__ __launch_bounds__(256) void l2norm_bwd_k(int R, const float* __restri
   for (int i = 0; i < VPL; ++i) dx[(size_t)row * C + lane + 64 * i] = (g[i] - yv[i] * dot) * inv;
 }
 
+// ---- VoteModule tail as one pass each way (class_agnostic_vote_head.py:394-403 -> mmdet3d VoteModule
+// with vote_per_seed = 1, with_res_feat, norm_feats): votes (R, 3 + C) = conv_out's output rows;
+//   vote_xyz = seed_xyz + votes[:, :3];   s = rows + votes[:, 3:];   y = s / |s|
+template <int VPL>
+__global__ __launch_bounds__(256) void vote_combine_fwd_k(int R, const float* __restrict__ rows,
+                                                          const float* __restrict__ votes,
+                                                          const float* __restrict__ seed_xyz,
+                                                          float* __restrict__ vote_xyz,
+                                                          float* __restrict__ y, float* __restrict__ norm) {
+  constexpr int C = 64 * VPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* vr = votes + (size_t)row * (C + 3);
+  float v[VPL], sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i] = rows[(size_t)row * C + lane + 64 * i] + vr[3 + lane + 64 * i];
+    sq = __builtin_fmaf(v[i], v[i], sq);
+  }
+  const float n = sqrtf(group_allsum<64>(sq));
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) y[(size_t)row * C + lane + 64 * i] = v[i] / n;
+  if (lane == 0) norm[row] = n;
+  if (lane < 3) vote_xyz[(size_t)row * 3 + lane] = seed_xyz[(size_t)row * 3 + lane] + vr[lane];
+}
+
+// dvotes (R, 3 + C) is written completely: [:, :3] = dxyz (or 0), [:, 3:] = drows = the gradient of s
+template <int VPL>
+__global__ __launch_bounds__(256) void vote_combine_bwd_k(int R, const float* __restrict__ y,
+                                                          const float* __restrict__ norm,
+                                                          const float* __restrict__ dy,
+                                                          const float* __restrict__ dxyz,
+                                                          float* __restrict__ dvotes,
+                                                          float* __restrict__ drows) {
+  constexpr int C = 64 * VPL;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float yv[VPL], g[VPL], dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    yv[i] = y[(size_t)row * C + lane + 64 * i];
+    g[i] = dy != nullptr ? dy[(size_t)row * C + lane + 64 * i] : 0.f;
+    dot = __builtin_fmaf(yv[i], g[i], dot);
+  }
+  dot = group_allsum<64>(dot);
+  const float inv = 1.0f / norm[row];
+  float* dv = dvotes + (size_t)row * (C + 3);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float d = (g[i] - yv[i] * dot) * inv;
+    dv[3 + lane + 64 * i] = d;
+    drows[(size_t)row * C + lane + 64 * i] = d;
+  }
+  if (lane < 3) dv[lane] = dxyz != nullptr ? dxyz[(size_t)row * 3 + lane] : 0.f;
+}
+
 __global__ void rng_advance_k(unsigned long long* rng) { rng[1] += 1; }
 
 __global__ void dropout_mask_k(long long n, float p, const unsigned long long* __restrict__ rng,
@@ -995,6 +1051,27 @@ extern "C" int demf_l2norm_rows_bwd(int R, int C, const float* y, const float* n
   LN_DISPATCH(C, CALL)
 #undef CALL
   return check_launch("l2norm_bwd_k");
+}
+
+extern "C" int demf_vote_combine_fwd(int R, int C, const float* rows, const float* votes,
+                                     const float* seed_xyz, float* vote_xyz, float* vote_feats,
+                                     float* norm, demf_stream_t stream) {
+  DEMF_REQUIRE(R > 0 && rows && votes && seed_xyz && vote_xyz && vote_feats && norm,
+               "vote_combine_fwd: bad arguments");
+#define CALL(V) hipLaunchKernelGGL(vote_combine_fwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, R, rows, votes, seed_xyz, vote_xyz, vote_feats, norm)
+  LN_DISPATCH(C, CALL)
+#undef CALL
+  return check_launch("vote_combine_fwd_k");
+}
+
+extern "C" int demf_vote_combine_bwd(int R, int C, const float* vote_feats, const float* norm,
+                                     const float* d_vote_feats, const float* d_vote_xyz,
+                                     float* d_votes, float* d_rows, demf_stream_t stream) {
+  DEMF_REQUIRE(R > 0 && vote_feats && norm && d_votes && d_rows, "vote_combine_bwd: bad arguments");
+#define CALL(V) hipLaunchKernelGGL(vote_combine_bwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, R, vote_feats, norm, d_vote_feats, d_vote_xyz, d_votes, d_rows)
+  LN_DISPATCH(C, CALL)
+#undef CALL
+  return check_launch("vote_combine_bwd_k");
 }
 
 extern "C" int demf_rng_advance(void* rng, demf_stream_t stream) {

@@ -101,6 +101,45 @@ enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
 // per-channel vectors of the backward prologue ("vec5"), struct-of-arrays of length n each:
 //   [0] scale  [1] shift  (z = y*scale + shift, ReLU mask)   [2] gi = gamma*invstd
 //   [3] a = -gi*invstd*mean(dZ*xhat)   [4] b = -gi*mean(dZ) - a*mean     (dY = gi*dZ + a*y + b)
+// Train-mode BatchNorm bookkeeping of a forward launch (demf_bn_finalize's arguments).  With
+// ss != null the LAST workgroup of a STATS launch turns the column sums into scale / shift, saved
+// mean / invstd and the running statistics itself and leaves the sums zeroed - the separate ~5 us
+// finalize launch behind every forward GEMM disappears.
+constexpr int FIN_OFF = 40;    // ints [FIN_OFF, FIN_OFF + 17) of a counter set: exit counts of the finalize
+struct BnFin {
+  double count;
+  const float *gamma, *beta, *conv_bias;
+  float eps, momentum;
+  float *rmean, *rvar;
+  long long* nbt;
+  float *ss, *mi;
+  int* ticket;                 // counter set (sched_slot) or null
+};
+
+__device__ __forceinline__ void bn_finalize_channel(int c, int N, double count, double s1, double s2,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps,
+                                                    float momentum, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var,
+                                                    float* __restrict__ ss, float* __restrict__ mi,
+                                                    const float* __restrict__ conv_bias) {
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;            // biased, as BN normalises with
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  ss[c] = (float)((double)gamma[c] * invstd);                                   // scale
+  ss[N + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);      // shift
+  mi[c] = (float)mean;
+  mi[N + c] = (float)invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    // a conv bias in front of a train-mode BN cancels in the output; it only shifts the batch mean
+    const double bm = mean + (conv_bias != nullptr ? (double)conv_bias[c] : 0.0);
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * bm);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
 struct MlpArgs {
   int R, K, N;                 // rows, reduction length, output columns
   int ldx;                     // row stride of X (floats)
@@ -135,6 +174,7 @@ struct MlpArgs {
   // l-1 operands are addressed with row stride / vector length fld and column offset fc0
   int fld, fc0;
   int* sched;                  // persistent launches: SCHED_GROUPS tile counters, 1 + SCHED_GROUPS exit counters, or null
+  BnFin fin;                   // STATS launches: in-kernel finalize when fin.ss != null
 };
 
 // Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
@@ -798,6 +838,42 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         atomicAdd(p.stats + which * (RED ? p.fld : p.N) + (RED ? p.fc0 : 0) + cofs + nt * 32 + c, (double)v);
     }
   }
+  if constexpr (STATS) {
+    if (p.fin.ss != nullptr) {
+      // Only atomics touch the sums and the counters, and __syncthreads() waits for this block's own
+      // to be acknowledged, so no fence is needed.  Two-level exit count as above.
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int total = (int)(gridDim.x * gridDim.y);
+        const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+        const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
+        const int g = lin % SCHED_GROUPS;
+        const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
+        int* t = p.fin.ticket + FIN_OFF;
+        int last = 0;
+        if (atomicAdd(t + 1 + g, 1) == members - 1) {
+          atomicExch(t + 1 + g, 0);
+          if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }
+        }
+        s_next = last;
+      }
+      __syncthreads();
+      if (s_next) {
+        const BnFin& f = p.fin;
+        if (threadIdx.x == 0 && f.nbt != nullptr) *f.nbt += 1;
+        for (int c = threadIdx.x; c < p.N; c += 256) {
+          // read through the atomic unit (the sums were produced by device-scope atomics) and leave
+          // the accumulator zeroed, in one exchange each
+          const double s1 = __builtin_bit_cast(
+              double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+          const double s2 = __builtin_bit_cast(
+              double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + p.N + c), 0ull));
+          bn_finalize_channel(c, p.N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean,
+                              f.rvar, f.ss, f.mi, f.conv_bias);
+        }
+      }
+    }
+  }
 }
 
 // ---- forward GEMM with the A rows streamed global -> LDS directly (global_load_lds_dwordx4) ---------
@@ -1028,24 +1104,11 @@ __global__ void bn_finalize_kernel(int N, double count, double* __restrict__ sta
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches_tracked != nullptr) *num_batches_tracked += 1;
   if (c >= N) return;
-  const double mean = stats[c] / count;
-  double var = stats[N + c] / count - mean * mean;  // biased, as BN normalises with
+  const double s1 = stats[c], s2 = stats[N + c];
   stats[c] = 0.0;                                   // consumed: the accumulator is left zeroed
   stats[N + c] = 0.0;
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  const float sc = (float)((double)gamma[c] * invstd);
-  ss[c] = sc;                                        // scale
-  ss[N + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);  // shift
-  mi[c] = (float)mean;
-  mi[N + c] = (float)invstd;
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    // a conv bias in front of a train-mode BN cancels in the output; it only shifts the batch mean
-    const double bm = mean + (conv_bias != nullptr ? (double)conv_bias[c] : 0.0);
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * bm);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
+  bn_finalize_channel(c, N, count, s1, s2, gamma, beta, eps, momentum, running_mean, running_var, ss,
+                      mi, conv_bias);
 }
 
 // ---- tail: out[r,c] = max_s max(0, y[r,s,c]*scale+shift), first maximum wins -----------------
@@ -1821,6 +1884,75 @@ extern "C" int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float*
   a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
   a.Y = Y; a.stats = stats; a.ns = ns; a.pmax = pmax; a.pmin = pmin; a.amax = amax; a.amin = amin;
   return launch_gemm<PRO_BNRELU, true, true>(a, (hipStream_t)stream);
+}
+
+// forward launch + train-mode BN bookkeeping: in the kernel's last workgroup when a counter set is
+// available, as a separate launch otherwise (DEMF_STATIC_TILES=1, DEMF_FWD_LDS=1, DEMF_NO_FIN=1)
+template <typename Launch>
+static int launch_with_finalize(MlpArgs& a, BnFin fin, Launch launch, hipStream_t s) {
+  static const int off = env_int("DEMF_NO_FIN", 0) || env_int("DEMF_FWD_LDS", 0);
+  fin.ticket = off ? nullptr : sched_slot();
+  if (fin.ticket != nullptr) {
+    a.fin = fin;
+    return launch(a);
+  }
+  if (int e = launch(a)) return e;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.N, 256)), dim3(256), 0, s, a.N, fin.count, a.stats,
+                     fin.gamma, fin.beta, fin.eps, fin.momentum, fin.rmean, fin.rvar, fin.nbt, fin.ss,
+                     fin.mi, fin.conv_bias);
+  return check_launch("bn_finalize");
+}
+
+static int fin_check(long long count, const float* gamma, const float* beta, const float* ss,
+                     const float* mi, const double* stats) {
+  DEMF_REQUIRE(count >= 1 && gamma && beta && ss && mi && stats, "mlp_gemm_fwd_bn: bad BN arguments");
+  return DEMF_OK;
+}
+
+extern "C" int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X,
+                                    const float* pro_scale_shift, const float* Wt, float* Y,
+                                    double* stats, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* scale_shift,
+                                    float* mean_invstd, const float* conv_bias, demf_stream_t stream) {
+  if (int e = mlp_check(R, K, N, ldx)) return e;
+  DEMF_REQUIRE(R >= 1 && X && Wt && Y, "mlp_gemm_fwd_bn: null pointer / no rows");
+  if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
+  MlpArgs a{};
+  a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
+  a.Y = Y; a.stats = stats;
+  hipStream_t s = (hipStream_t)stream;
+  BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+            num_batches_tracked, scale_shift, mean_invstd, nullptr};
+  if (pro_scale_shift)
+    return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_BNRELU, true>(b, s); }, s);
+  return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_NONE, true>(b, s); }, s);
+}
+
+extern "C" int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const float* X,
+                                         const float* pro_scale_shift, const float* Wt, float* Y,
+                                         double* stats, int ns, float* pmax, float* pmin, int* amax,
+                                         int* amin, const float* gamma, const float* beta, float eps,
+                                         float momentum, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float* scale_shift,
+                                         float* mean_invstd, const float* conv_bias,
+                                         demf_stream_t stream) {
+  if (int e = mlp_check(R, K, N, ldx)) return e;
+  const bool ok = (ns == 16 || ns == 32 || ns == 64) && R % ns == 0 && R >= 1;
+  if (!ok) {
+    set_error("mlp_gemm_fwd_pool_bn: ns=%d with R=%d N=%d is not fused", ns, R, N);
+    return DEMF_EUNSUPPORTED;
+  }
+  DEMF_REQUIRE(X && Wt && Y && pro_scale_shift && pmax && pmin && amax && amin,
+               "mlp_gemm_fwd_pool_bn: null pointer");
+  if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
+  MlpArgs a{};
+  a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
+  a.Y = Y; a.stats = stats; a.ns = ns; a.pmax = pmax; a.pmin = pmin; a.amax = amax; a.amin = amin;
+  hipStream_t s = (hipStream_t)stream;
+  BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+            num_batches_tracked, scale_shift, mean_invstd, nullptr};
+  return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_BNRELU, true, true>(b, s); }, s);
 }
 
 extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,

@@ -36,6 +36,14 @@ class VoteModule(nn.Module):
         votes = ops.linear(x, self.conv_out.weight.view(self.conv_out.out_channels, -1),
                          self.conv_out.bias)
         offset = votes[:, 0:3].view(B, N, 3)
+        C = rows.shape[1]
+        if self.norm_feats and rows.is_cuda and C % 64 == 0 and C <= 1024 and \
+                (C // 64) & (C // 64 - 1) == 0:
+            # seed + offset, residual add and row normalisation in one kernel each way
+            # (csrc/dense.hip: vote_combine_*); the lines below are its specification
+            vote_points, vote_feats = ops.vote_combine(rows, votes, seed_points)
+            vote_feats = vote_feats.view(B, N, -1).transpose(1, 2)
+            return vote_points, vote_feats, offset.transpose(2, 1)
         vote_points = (seed_points + offset).contiguous()
         vote_feats = rows + votes[:, 3:]
         if self.norm_feats:

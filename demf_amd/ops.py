@@ -15,7 +15,7 @@ from torch.autograd.function import once_differentiable
 from . import _ffi
 
 __all__ = [
-    "set_compute_dtype", "get_compute_dtype", "gt_prep", "target_weights", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
+    "set_compute_dtype", "get_compute_dtype", "gt_prep", "target_weights", "vote_combine", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
     "three_nn", "three_interpolate", "MultiScaleDeformableAttnFunction",
     "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns", "shared_mlp_pool",
 ]
@@ -760,17 +760,17 @@ class _SharedMLPPool(Function):
                 woff += 2 * N
                 pm = torch.empty((2, R // ns, N), dtype=torch.float32, device=dev)
                 am = torch.empty((2, R // ns, N), dtype=torch.int32, device=dev)
-                _ffi.call("demf_mlp_gemm_fwd_pool", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
-                          _p(stats), ns, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]), st)
-                _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
+                # (+ the BN bookkeeping, in the GEMM's last workgroup)
+                _ffi.call("demf_mlp_gemm_fwd_pool_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                          _p(stats), ns, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]), _p(gamma),
+                          _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss),
+                          _p(mi), _p(tensors[7 * l + 5]), st)
             elif training:
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
-                _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
-                          _p(stats), st)
-                _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
+                _ffi.call("demf_mlp_gemm_fwd_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                          _p(stats), _p(gamma), _p(beta), float(eps), float(momentum), _p(rmean),
+                          _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
             else:
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           None, st)
@@ -996,6 +996,42 @@ class _L2NormRows(Function):
 def l2norm_rows(x):
     """x (R,C) -> x / ||x||_2 per row (VoteModule norm_feats), one kernel each way."""
     return _L2NormRows.apply(x)
+
+
+class _VoteCombine(Function):
+    @staticmethod
+    def forward(ctx, rows, votes, seed_xyz):
+        _chk(rows, "rows")
+        _chk(votes, "votes")
+        _chk(seed_xyz, "seed_xyz")
+        R, C = rows.shape
+        assert votes.shape == (R, C + 3) and seed_xyz.numel() == 3 * R
+        vote_xyz = torch.empty_like(seed_xyz)
+        y = torch.empty_like(rows)
+        norm = torch.empty(R, dtype=torch.float32, device=rows.device)
+        _ffi.call("demf_vote_combine_fwd", R, C, _p(rows), _p(votes), _p(seed_xyz), _p(vote_xyz), _p(y),
+                  _p(norm), _stream())
+        ctx.save_for_backward(y, norm)
+        return vote_xyz, y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dxyz, dy):
+        y, norm = ctx.saved_tensors
+        R, C = y.shape
+        dxyz = None if dxyz is None else dxyz.contiguous()
+        dy = None if dy is None else dy.contiguous()
+        dvotes = torch.empty((R, C + 3), dtype=torch.float32, device=y.device)
+        drows = torch.empty_like(y)
+        _ffi.call("demf_vote_combine_bwd", R, C, _p(y), _p(norm), _p(dy), _p(dxyz), _p(dvotes),
+                  _p(drows), _stream())
+        return drows, dvotes, (dxyz if ctx.needs_input_grad[2] else None)
+
+
+def vote_combine(rows, votes, seed_xyz):
+    """VoteModule tail in one kernel each way: rows (R,C) seed features, votes (R,3+C) conv_out rows,
+    seed_xyz (B,N,3) -> (vote_xyz = seed_xyz + votes[:, :3], l2-normalised rows of rows + votes[:, 3:])."""
+    return _VoteCombine.apply(rows.contiguous(), votes.contiguous(), seed_xyz.contiguous())
 
 
 # --------------------------------------------------------------------------

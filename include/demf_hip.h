@@ -233,6 +233,23 @@ int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float* X,
                            int ns, float* pmax, float* pmin, int* amax, int* amin,
                            demf_stream_t stream);
 
+/* demf_mlp_gemm_fwd / demf_mlp_gemm_fwd_pool followed by demf_bn_finalize(N, count = R, stats, ...)
+ * as ONE launch: the last workgroup of the GEMM turns the column sums into scale_shift,
+ * mean_invstd and the running statistics (torch.nn.BatchNorm semantics, see demf_bn_finalize) and
+ * leaves `stats` zeroed.  The following layer's launch reads scale_shift as its prologue.         */
+int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X, const float* pro_scale_shift,
+                         const float* Wt, float* Y, double* stats, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* scale_shift,
+                         float* mean_invstd, const float* conv_bias, demf_stream_t stream);
+int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const float* X,
+                              const float* pro_scale_shift, const float* Wt, float* Y, double* stats,
+                              int ns, float* pmax, float* pmin, int* amax, int* amin,
+                              const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var,
+                              long long* num_batches_tracked, float* scale_shift,
+                              float* mean_invstd, const float* conv_bias, demf_stream_t stream);
+
 /* out (Rp,C) = relu(scale*y*+shift), arg = row offset of y* (see demf_mlp_gemm_fwd_pool);
  * yraw (Rp,C) or NULL = y* itself, which spares demf_bn_bwd_reduce its gather from Y. */
 int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin, const int* amax,
@@ -255,6 +272,17 @@ int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,
 int demf_l2norm_rows_fwd(int R, int C, const float* x, float* y, float* norm, demf_stream_t stream);
 int demf_l2norm_rows_bwd(int R, int C, const float* y, const float* norm, const float* dy, float* dx,
                          demf_stream_t stream);
+
+/* VoteModule tail (mmdet3d VoteModule.forward with vote_per_seed = 1, with_res_feat, norm_feats; built at
+ * class_agnostic_vote_head.py:382) as one pass each way.  votes (R, 3 + C) = conv_out's rows:
+ *   vote_xyz = seed_xyz + votes[:, :3];  vote_feats = l2-normalised rows of (rows + votes[:, 3:]).
+ * Backward writes d_votes (R, 3 + C) completely and d_rows (R, C); d_vote_feats / d_vote_xyz may be
+ * null (= zero).  C in {64, 128, 256, 512, 1024}.                                                  */
+int demf_vote_combine_fwd(int R, int C, const float* rows, const float* votes, const float* seed_xyz,
+                          float* vote_xyz, float* vote_feats, float* norm, demf_stream_t stream);
+int demf_vote_combine_bwd(int R, int C, const float* vote_feats, const float* norm,
+                          const float* d_vote_feats, const float* d_vote_xyz, float* d_votes,
+                          float* d_rows, demf_stream_t stream);
 
 /* out (R,C) = max over s of act(Y (R,ns,C)); arg = first maximising s.           */
 int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y, const float* scale_shift,

@@ -297,3 +297,35 @@ def test_fused_decoder_layer_vs_torch(B, Q, H, L, P, E, Fd, shapes, p_attn, p_ff
                                            *[c["prm"][k] for k in PARAM_ORDER])
         nomask = {k: torch.ones_like(v) for k, v in masks.items() if torch.is_tensor(v)}
         _close(ev, _torch_layer(c, c["prm"], dims, nomask), 2e-4, "eval output")
+
+
+def test_vote_combine_matches_the_torch_specification():
+    """VoteModule tail (seed + offset, residual add, row l2-normalisation) as one kernel each way
+    against the torch composition it replaces, forward and all three gradients."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for (B, N, C) in [(8, 1024, 256), (3, 100, 64)]:
+        rows = torch.randn(B * N, C, generator=g).cuda().requires_grad_()
+        votes = torch.randn(B * N, C + 3, generator=g).cuda().requires_grad_()
+        seed = torch.randn(B, N, 3, generator=g).cuda().requires_grad_()
+        gx = torch.randn(B, N, 3, generator=g).cuda()
+        gf = torch.randn(B * N, C, generator=g).cuda()
+        vx, vf = ops.vote_combine(rows, votes, seed)
+        (vx * gx).sum().add((vf * gf).sum()).backward()
+        got = [vx.detach(), vf.detach(), rows.grad, votes.grad, seed.grad]
+        r2, v2, s2 = [t.detach().double().requires_grad_() for t in (rows, votes, seed)]
+        wx = s2 + v2[:, :3].view(B, N, 3)
+        s = r2 + v2[:, 3:]
+        wf = s / torch.norm(s, p=2, dim=1, keepdim=True)
+        (wx * gx.double()).sum().add((wf * gf.double()).sum()).backward()
+        want = [wx.detach(), wf.detach(), r2.grad, v2.grad, s2.grad]
+        for a, b, name in zip(got, want, ("vote_xyz", "vote_feats", "d_rows", "d_votes", "d_seed")):
+            err = (a.double() - b).abs().max().item()
+            assert err <= 1e-5 * max(1.0, b.abs().max().item()), (name, err)
+    # only one of the two outputs carries a gradient
+    rows = torch.randn(64, 64, generator=g).cuda().requires_grad_()
+    votes = torch.randn(64, 67, generator=g).cuda().requires_grad_()
+    vx, vf = ops.vote_combine(rows, votes, torch.zeros(1, 64, 3, device="cuda"))
+    vx.sum().backward()
+    assert float(rows.grad.abs().max()) == 0.0 and float(votes.grad[:, 3:].abs().max()) == 0.0
+    assert torch.equal(votes.grad[:, :3], torch.ones(64, 3, device="cuda"))
