@@ -46,8 +46,8 @@ SIGNATURES = {
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
-    "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 8,
-    "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 13,
+    "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 5 + [_c_int] + [_ptr] * 3,
+    "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 9 + [_c_int, _ptr, _c_int] + [_ptr] * 3,
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,
@@ -68,6 +68,7 @@ SIGNATURES = {
     "demf_mlp_gemm_bwd_dx_red": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 9,
     "demf_mlp_gemm_bwd_dx_w": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
     "demf_mlp_gemm_bwd_dw": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 6,
+    "demf_mlp_gemm_bwd_dw_ld": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5 + [_c_int, _ptr],
     "demf_head_loss_fwd": [_c_int] * 3 + [_ptr] * 14,
     "demf_head_loss_bwd": [_c_int] * 3 + [_ptr] * 17,
     "demf_vote_loss": [_c_int] * 4 + [_c_float] + [_ptr] * 10,

@@ -29,20 +29,28 @@ __device__ __forceinline__ float grp_bcast(float v, int src) { return __shfl(v, 
 template <int LPR>
 __device__ __forceinline__ int grp_bcast(int v, int src) { return __shfl(v, src, LPR); }
 
+// coordinate weights of 4 consecutive output channels c..c+3 for input column j: from the transposed
+// (3, C1) copy (wld == 0) or in place from the layer's weight W (C1 x wld row-major, columns 0..2)
+__device__ __forceinline__ float4 load_wx(const float* __restrict__ Wx, int wld, int C1, int c, int j) {
+  if (wld == 0) return *reinterpret_cast<const float4*>(Wx + j * C1 + c);
+  return make_float4(Wx[(size_t)c * wld + j], Wx[(size_t)(c + 1) * wld + j],
+                     Wx[(size_t)(c + 2) * wld + j], Wx[(size_t)(c + 3) * wld + j]);
+}
+
 template <int LPR>
 __global__ __launch_bounds__(512) void group_first_fwd_k(
     int N, int M, int ns, float div, const float* __restrict__ xyz,
     const float* __restrict__ center, const int* __restrict__ idx, const float* __restrict__ U,
-    const float* __restrict__ Wx, float* __restrict__ Y, double* __restrict__ stats,
+    const float* __restrict__ Wx, int wld, float* __restrict__ Y, double* __restrict__ stats,
     long long rows) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 512 / LPR;
   constexpr int UNR = 8;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int c = sub * 4;
-  const float4 w0 = *reinterpret_cast<const float4*>(Wx + c);
-  const float4 w1 = *reinterpret_cast<const float4*>(Wx + C1 + c);
-  const float4 w2 = *reinterpret_cast<const float4*>(Wx + 2 * C1 + c);
+  const float4 w0 = load_wx(Wx, wld, C1, c, 0);
+  const float4 w1 = load_wx(Wx, wld, C1, c, 1);
+  const float4 w2 = load_wx(Wx, wld, C1, c, 2);
   float4 s = f4_zero(), q = f4_zero();
   const long long chunks = (rows + LPR - 1) / LPR;
   for (long long ch = (long long)blockIdx.x * GPB + grp; ch < chunks;
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     int N, int M, int ns, int ns_shift, float inv_div, const float* __restrict__ xyz,
     const float* __restrict__ center, const float* __restrict__ G, const float* __restrict__ Yl,
     const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
-    float* __restrict__ dU, float* __restrict__ dWx, long long points,
-    const float* __restrict__ Wx, float* __restrict__ dxyz, float* __restrict__ dcenter) {
+    float* __restrict__ dU, float* __restrict__ dWx, int dwld, long long points,
+    const float* __restrict__ Wx, int wld, float* __restrict__ dxyz, float* __restrict__ dcenter) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 256 / LPR;
   constexpr int UNR = 8;
@@ -139,9 +147,9 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
   float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();  // sum (p - q)_k * dY, scaled at the end
   float4 wx0 = f4_zero(), wx1 = f4_zero(), wx2 = f4_zero();
   if constexpr (XG) {
-    wx0 = *reinterpret_cast<const float4*>(Wx + c);
-    wx1 = *reinterpret_cast<const float4*>(Wx + C1 + c);
-    wx2 = *reinterpret_cast<const float4*>(Wx + 2 * C1 + c);
+    wx0 = load_wx(Wx, wld, C1, c, 0);
+    wx1 = load_wx(Wx, wld, C1, c, 1);
+    wx2 = load_wx(Wx, wld, C1, c, 2);
   }
   for (long long pt = (long long)blockIdx.x * GPB + grp; pt < points;
        pt += (long long)gridDim.x * GPB) {
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     float tot = 0.f;
 #pragma unroll
     for (int g = 0; g < GPB; ++g) tot += base[g * C1];
-    atomicAdd(dWx + which * C1 + col, tot * inv_div);
+    atomicAdd(dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which, tot * inv_div);
   }
 }
 
@@ -243,8 +251,8 @@ using namespace demf;
 
 extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius,
                                     int normalize_xyz, const float* xyz, const float* center,
-                                    const int* idx, const float* U, const float* Wx, float* Y,
-                                    double* stats, demf_stream_t stream) {
+                                    const int* idx, const float* U, const float* Wx, int w_ld,
+                                    float* Y, double* stats, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_fwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0 || M == 0) return DEMF_OK;
@@ -259,7 +267,7 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
   const dim3 grid((unsigned)blocks);
 #define GF_FWD(L)                                                                          \
   hipLaunchKernelGGL(group_first_fwd_k<L>, grid, dim3(512), 0, s, N, M, ns, div, xyz, center, \
-                     idx, U, Wx, Y, stats, rows)
+                     idx, U, Wx, w_ld, Y, stats, rows)
   if (lpr == 64) GF_FWD(64);
   else if (lpr == 32) GF_FWD(32);
   else GF_FWD(16);
@@ -271,8 +279,8 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
                                     int normalize_xyz, const float* xyz, const float* center,
                                     const float* G, const float* Y, const float* vec6,
                                     const int* inv_off, const int* inv_rows, float* dU,
-                                    float* dWx, const float* Wx, float* dxyz, float* dcenter,
-                                    demf_stream_t stream) {
+                                    float* dWx, int dw_ld, const float* Wx, int w_ld, float* dxyz,
+                                    float* dcenter, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_bwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0) return DEMF_OK;
@@ -293,11 +301,11 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   do {                                                                                     \
   if (dxyz)                                                                                \
     hipLaunchKernelGGL((group_first_bwd_k<L, true>), grid, dim3(256), 0, s, N, M, ns, ns_shift,    \
-                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, points, Wx, \
+                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, \
                        dxyz, dcenter);                                                     \
   else                                                                                     \
     hipLaunchKernelGGL((group_first_bwd_k<L, false>), grid, dim3(256), 0, s, N, M, ns, ns_shift,   \
-                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, points, Wx, \
+                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, \
                        dxyz, dcenter);                                                     \
   } while (0)
   if (lpr == 64) GF_BWD(64);

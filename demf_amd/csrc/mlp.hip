@@ -1328,6 +1328,7 @@ struct DwArgs {
   const float* Xp;     // (R x K) previous layer's pre-BN output, or the raw input
   const float* pvec;   // [scale|shift] of the previous layer (2K) or null (raw input)
   float* dW;           // (N x K), accumulated
+  int lddw;            // row stride of dW (>= K)
   int n0, k0, NTn, NTk;  // output sub-block of a block (derived from blockIdx.y inside the kernel)
   int nsub_k;            // sub-blocks along K
   int chunk;             // 32-row slabs per claim
@@ -1497,7 +1498,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
         for (int r = 0; r < 16; ++r) {
           const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int k = (p.k0 + tk) * 32 + lr;
-          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
+          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.lddw + k, acc[i][j][r]);
         }
       }
     }
@@ -1665,7 +1666,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_bf16_kernel(DwArgs p) {
         for (int r = 0; r < 16; ++r) {
           const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int k = (p.k0 + tk) * 32 + lr;
-          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.K + k, acc[i][j][r]);
+          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.lddw + k, acc[i][j][r]);
         }
       }
     }
@@ -2178,12 +2179,25 @@ extern "C" int demf_mlp_first_finish(int N0, long long count, double* sums, cons
   return check_launch("mlp_first_finish");
 }
 
+extern "C" int demf_mlp_gemm_bwd_dw_ld(int, int, int, int, const float*, const float*, const int*, int,
+                                       const float*, const float*, const float*, const float*, float*,
+                                       int, demf_stream_t);
+
 extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,
                                     const int* arg, int ns, const float* Y, const float* vec6,
                                     const float* Xprev, const float* prev_scale_shift, float* dW,
                                     demf_stream_t stream) {
-  DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 4 && K % 4 == 0 && ldx >= K && ldx % 4 == 0,
-               "mlp_gemm_bwd_dw: bad sizes R=%d N=%d K=%d", R, N, K);
+  return demf_mlp_gemm_bwd_dw_ld(R, N, K, ldx, G, dP, arg, ns, Y, vec6, Xprev, prev_scale_shift, dW, K,
+                                 stream);
+}
+
+extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float* G, const float* dP,
+                                       const int* arg, int ns, const float* Y, const float* vec6,
+                                       const float* Xprev, const float* prev_scale_shift, float* dW,
+                                       int lddw, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 4 && K % 4 == 0 && ldx >= K && ldx % 4 == 0 &&
+                   lddw >= K,
+               "mlp_gemm_bwd_dw: bad sizes R=%d N=%d K=%d lddw=%d", R, N, K, lddw);
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && vec6 && Xprev && dW && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dw: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -2193,7 +2207,7 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
   const int tn = TNt > 2 ? 2 : 1, tk = TKt > 2 ? 2 : 1;
   DwArgs a{};
   a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
-  a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW;
+  a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW; a.lddw = lddw;
   const int nsub_n = cdiv(TNt, 2 * tn);
   a.nsub_k = cdiv(TKt, 2 * tk);
   const int nsub = nsub_n * a.nsub_k;

@@ -737,13 +737,13 @@ class _SharedMLPPool(Function):
                 U = torch.empty((x.shape[0], N), dtype=torch.float32, device=dev)
                 from . import fused
                 fused.gemm(x.shape[0], N, ld, _p(x), (ld, 1), W.data_ptr() + 12, (K, 1), _p(U), N)
-                Wx = W[:, :3].t().contiguous()
                 stats = None
                 if training:
                     stats = ws[woff:woff + 2 * N]
                     woff += 2 * N
+                # (the xyz columns of W are read in place: w_ld = K)
                 _ffi.call("demf_group_first_fwd", gB, gN, gM, ns, N, float(g_radius),
-                          int(bool(g_norm)), _p(g_xyz), _p(g_center), _p(g_idx), _p(U), _p(Wx),
+                          int(bool(g_norm)), _p(g_xyz), _p(g_center), _p(g_idx), _p(U), _p(W), K,
                           _p(Y), _p(stats), st)
                 if training:
                     _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
@@ -863,23 +863,23 @@ class _SharedMLPPool(Function):
                 gB, gN, _ = g_xyz.shape
                 gM = g_center.shape[1]
                 dU = torch.empty((gB * gN, N), dtype=torch.float32, device=dev)
-                dWx = ws32[o32:o32 + 3 * N]
+                # both halves of dW0 (N, K) = [xyz columns | feature columns] land in place in the
+                # zero-filled workspace: no transposed copies, no concatenation
+                dW0 = ws32[o32:o32 + N * K].view(N, K)
                 o32 += N * K
-                dxyz = dcenter = Wx = None
+                dxyz = dcenter = None
                 if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
                     # the coordinates carry a gradient too (vote aggregation)
-                    Wx = W[:, :3].t().contiguous()
                     dxyz = torch.empty((gB, gN, 3), dtype=torch.float32, device=dev)
                     dcenter = zeros((gB, gM, 3), dev)
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
                           _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
-                          _p(dWx), _p(Wx), _p(dxyz), _p(dcenter), st)
+                          _p(dW0), K, _p(W), K, _p(dxyz), _p(dcenter), st)
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3
-                dWf = ws32[o32 - N * K + 3 * N:o32].view(N, C0)
-                _ffi.call("demf_mlp_gemm_bwd_dw", gB * gN, N, C0, C0, _p(dU), None, None, 1, _p(dU),
-                          _p(_identity_dy_vectors(N, dev)), _p(x), None, _p(dWf), st)
-                grads[0] = torch.cat([dWx.view(3, N).t(), dWf], dim=1)
+                _ffi.call("demf_mlp_gemm_bwd_dw_ld", gB * gN, N, C0, C0, _p(dU), None, None, 1, _p(dU),
+                          _p(_identity_dy_vectors(N, dev)), _p(x), None, dW0.data_ptr() + 12, K, st)
+                grads[0] = dW0
                 grads[1], grads[2] = dgamma, dbeta
                 if ctx.bias_shapes[0] is not None:
                     grads[5] = ws32[o32:o32 + N].view(ctx.bias_shapes[0])

@@ -180,7 +180,9 @@ int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int fea
  * C1 in {64,128,256}. */
 int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
                          const float* xyz, const float* center, const int* idx, const float* U,
-                         const float* Wx, float* Y, double* stats, demf_stream_t stream);
+                         const float* Wx, int w_ld /* 0: Wx is the (3, C1) copy; > 0: Wx is the layer's
+                         weight (C1 x w_ld row-major) itself, columns 0..2 read in place */,
+                         float* Y, double* stats, demf_stream_t stream);
 /* Backward of the above through the inverse lists of demf_invert_index: with dY the BN-backward
  * transform of (G, Y) by vec6 (demf_bn_bwd_vectors; same formula as demf_mlp_gemm_bwd_dx),
  *   dU[b,j,:]  = sum of dY over the rows that gathered point j        (fully written, no atomics)
@@ -190,7 +192,9 @@ int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius, int 
 int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
                          const float* xyz, const float* center, const float* G, const float* Y,
                          const float* vec6, const int* inv_off, const int* inv_rows, float* dU,
-                         float* dWx, const float* Wx /* needed with dxyz */,
+                         float* dWx, int dw_ld /* 0: (3, C1) layout; > 0: dWx[c*dw_ld + k], i.e. columns
+                         0..2 of the (C1 x dw_ld) weight gradient */,
+                         const float* Wx /* needed with dxyz */, int w_ld /* as in the forward */,
                          float* dxyz /* (B,N,3) fully written, or NULL */,
                          float* dcenter /* (B,M,3) accumulated: arrives zeroed, or NULL */,
                          demf_stream_t stream);
@@ -343,6 +347,12 @@ int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const flo
                          const int* arg, int ns, const float* Y, const float* vec6,
                          const float* Xprev, const float* prev_scale_shift, float* dW,
                          demf_stream_t stream);
+/* Same with an explicit row stride of dW (>= K): the (N x K) result lands inside a wider weight
+ * gradient (the feature columns 3.. of a set-abstraction level's first layer).                  */
+int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float* G, const float* dP,
+                            const int* arg, int ns, const float* Y, const float* vec6,
+                            const float* Xprev, const float* prev_scale_shift, float* dW, int lddw,
+                            demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Fused head losses: DeMFVoteHead._loss (class_agnostic_vote_head.py:622-712)
