@@ -34,9 +34,9 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
 # the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
-DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0>",
-                   "f32x3": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 2>",
-                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 1>"}
+DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0, true>",
+                   "f32x3": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 2, true>",
+                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 1, true>"}
 DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
     "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
 MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
@@ -267,7 +267,7 @@ def main():
     # BN statistics and the max-pool fused into its epilogue
     from demf_amd import _ffi
     sa1_rows = args.batch * 2048 * 64
-    mlp_timer = FfiTimer(_ffi, "demf_mlp_gemm_fwd_pool", (sa1_rows, 64, 128))
+    mlp_timer = FfiTimer(_ffi, "demf_mlp_gemm_fwd_pool_bn", (sa1_rows, 64, 128))
 
     def sync():
         if world > 1:
@@ -349,7 +349,7 @@ def main():
         # row offsets (4 x (R/64,128) words); weights < 1 %.
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype != "bf16" else MFMA_BF16_PEAK_TFLOPS
         mlp_ms = mlp_timer.mean_ms()
-        mlp_bytes = sa1_rows * (64 + 128) * 4 + 4 * (sa1_rows // 64) * 128 * 4
+        mlp_bytes = sa1_rows * (64 + 128) * 4 + 2 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
         dom = DOMINANT_KERNEL[args.dtype]
         traffic, src = pmc_per_launch(dom) if args.batch == 8 else (None, None)

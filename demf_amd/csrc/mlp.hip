@@ -338,6 +338,65 @@ __device__ __forceinline__ void pool_half_reduce(const f32x16 (&acc)[1][NT], int
         make_float4(mx, mn, __builtin_bit_cast(float, ax), __builtin_bit_cast(float, an));
 }
 
+// SEL: the sign of the BN scale is the sign of gamma, which IS known before the statistics: only the
+// extremum the consumer will pick is tracked - the maximum of v for gamma >= 0, of -v otherwise
+// (``flip`` = the lane's sign-bit mask) - at half the compare / select work and half the pooled stores.
+__device__ __forceinline__ float flip_sign(float v, unsigned flip) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ flip);
+}
+
+template <int RT, int NT, int NS>
+__device__ __forceinline__ void pool_epilogue_sel(const MlpArgs& p, const f32x16 (&acc)[RT][NT], int nt,
+                                                  int row0, int col, int lh, unsigned flip) {
+  constexpr int GROUPS = (32 * RT) / NS;
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) {
+    float mx = -__builtin_inff();
+    int ax = 0;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rho_w = rt * 32 + (r & 3) + 8 * (r >> 2);
+        if (rho_w / NS != g) continue;
+        const int rho = rho_w % NS + 4 * lh;
+        const float v = flip_sign(acc[rt][nt][r], flip);
+        const bool up = v > mx;
+        mx = up ? v : mx; ax = up ? rho : ax;
+      }
+    const float omx = __shfl_xor(mx, 32);
+    const int oax = __shfl_xor(ax, 32);
+    if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+    const int row = row0 + g * NS;
+    if (lh == 0 && row < p.R && col < p.N) {
+      const size_t o = (size_t)(row / NS) * p.N + col;
+      p.pmax[o] = flip_sign(mx, flip); p.amax[o] = ax;
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void pool_half_reduce_sel(const f32x16 (&acc)[1][NT], int nt, int wave, int lr,
+                                                     int lh, float4* __restrict__ s_pool, unsigned flip) {
+  float mx = -__builtin_inff();
+  int ax = 0;
+  const int base = (wave & 1) * 32 + 4 * lh;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rho = base + (r & 3) + 8 * (r >> 2);
+    const float v = flip_sign(acc[0][nt][r], flip);
+    const bool up = v > mx;
+    mx = up ? v : mx; ax = up ? rho : ax;
+  }
+  const float omx = __shfl_xor(mx, 32);
+  const int oax = __shfl_xor(ax, 32);
+  if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+  if (lh == 0) {
+    float2* sp = reinterpret_cast<float2*>(s_pool);
+    sp[(wave * NT + nt) * 32 + lr] = make_float2(mx, __builtin_bit_cast(float, ax));
+  }
+}
+
 // CM = 1 (bf16): the A / B slabs hold bf16 (same byte row stride as the fp32 layout, so the slab
 // doubles as fp32 staging for the FIRST / RED epilogues unchanged) and a K step of 32 is two
 // v_mfma_f32_32x32x16_bf16 per tile instead of sixteen v_mfma_f32_32x32x2_f32.
@@ -347,8 +406,9 @@ __device__ __forceinline__ void pool_half_reduce(const f32x16 (&acc)[1][NT], int
 // MLP_LD3 floats = [32 h | 32 m | 32 l] bf16 + 16 B pad (52 dwords: 8 consecutive rows still cover
 // the 32 banks with their 16-byte reads).  Six bf16 MFMAs per tile and 16 columns of K.
 template <int NT, int RT, int PRO, bool STATS, bool POOL = false, bool FIRST = false, bool RED = false,
-          int CM = 0>
+          int CM = 0, bool SEL = false>
 __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
+  static_assert(!SEL || POOL, "SEL is a mode of the pooled epilogue");
   static_assert(!(STATS && RED) && !(FIRST && RED), "one column-sum epilogue at a time");
   constexpr bool BF16 = CM == 1, X3 = CM == 2;
   constexpr int LDB = X3 ? MLP_LD3 : MLP_LD;
@@ -409,6 +469,14 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       for (int q = 0; q < 10; ++q) fs[nt][q] = 0.f;
   }
   f32x16 acc[RT][NT];
+  unsigned selbits = 0;                            // SEL: bit nt = this lane's column of tile nt has gamma < 0
+  if constexpr (SEL) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = cofs + nt * 32 + lr;
+      if (col < p.N && p.fin.gamma[col] < 0.f) selbits |= 1u << nt;
+    }
+  }
 
   const int pr = lane >> 3, pc = (lane & 7) * 4;   // this lane's slot in a 32 x BK slab
   const int br = threadIdx.x >> 3;                  // Bt slab: row br + 32*i, cols pc..pc+3
@@ -734,10 +802,18 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         if constexpr (POOL) {
           {
             const int col = cofs + nt * 32 + lr;
+            if constexpr (SEL) {
+              const unsigned flip = ((selbits >> nt) & 1u) << 31;
+              if (p.ns == 16) pool_epilogue_sel<RT, NT, 16>(p, acc, nt, row0, col, lh, flip);
+              else if (p.ns == 32) pool_epilogue_sel<RT, NT, 32>(p, acc, nt, row0, col, lh, flip);
+              else if constexpr (RT == 2) pool_epilogue_sel<RT, NT, 64>(p, acc, nt, row0, col, lh, flip);
+              else pool_half_reduce_sel<NT>(acc, nt, wave, lr, lh, s_pool, flip);
+            } else {
             if (p.ns == 16) pool_epilogue<RT, NT, 16>(p, acc, nt, row0, col, lh);
             else if (p.ns == 32) pool_epilogue<RT, NT, 32>(p, acc, nt, row0, col, lh);
             else if constexpr (RT == 2) pool_epilogue<RT, NT, 64>(p, acc, nt, row0, col, lh);
             else pool_half_reduce<NT>(acc, nt, wave, lr, lh, s_pool);
+            }
           }
         }
       }
@@ -749,6 +825,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
               const int col = cofs + nt * 32 + lr;
+              if constexpr (SEL) {
+                const float2* sp = reinterpret_cast<const float2*>(s_pool);
+                const float2 a = sp[(wave * NT + nt) * 32 + lr];
+                const float2 b = sp[((wave + 1) * NT + nt) * 32 + lr];
+                const bool take_b = b.x > a.x;          // the even wave's offsets are the smaller ones
+                if (grow < p.R && col < p.N) {
+                  const unsigned flip = ((selbits >> nt) & 1u) << 31;
+                  const size_t o = (size_t)(grow / 64) * p.N + col;
+                  p.pmax[o] = flip_sign(take_b ? b.x : a.x, flip);
+                  p.amax[o] = __builtin_bit_cast(int, take_b ? b.y : a.y);
+                }
+                continue;
+              }
               const float4 a = s_pool[(wave * NT + nt) * 32 + lr];
               const float4 b = s_pool[((wave + 1) * NT + nt) * 32 + lr];
               float mx = a.x, mn = a.y;
@@ -1780,7 +1869,13 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
       a2.halves = 2;
       grid = dim3(2 * gx, 1);
     }
-#define PGO(NTv, RTv) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true, false, false, BF16>), grid, block, 0, s, a2)
+    // SEL: only the extremum the sign of gamma selects (pmin / amin not given, gamma known)
+    const bool sel = a.pmin == nullptr && a.fin.gamma != nullptr;
+#define PGO(NTv, RTv)                                                                                       \
+    do {                                                                                                    \
+      if (sel) hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true, false, false, BF16, true>), grid, block, 0, s, a2); \
+      else hipLaunchKernelGGL((mlp_gemm_kernel<NTv, RTv, PRO, STATS, true, false, false, BF16>), grid, block, 0, s, a2);           \
+    } while (0)
     if (rt2) { if (ntl == 1) PGO(1, 2); else PGO(2, 2); }
     else if (ntl == 1) PGO(1, 1);
     else if (ntl == 2) PGO(2, 1);
@@ -1893,10 +1988,9 @@ template <typename Launch>
 static int launch_with_finalize(MlpArgs& a, BnFin fin, Launch launch, hipStream_t s) {
   static const int off = env_int("DEMF_NO_FIN", 0) || env_int("DEMF_FWD_LDS", 0);
   fin.ticket = off ? nullptr : sched_slot();
-  if (fin.ticket != nullptr) {
-    a.fin = fin;
-    return launch(a);
-  }
+  a.fin = fin;
+  if (fin.ticket != nullptr) return launch(a);
+  a.fin.ss = nullptr;                     // (gamma stays: the pooled epilogue selects by its sign)
   if (int e = launch(a)) return e;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.N, 256)), dim3(256), 0, s, a.N, fin.count, a.stats,
                      fin.gamma, fin.beta, fin.eps, fin.momentum, fin.rmean, fin.rvar, fin.nbt, fin.ss,
@@ -1944,7 +2038,7 @@ extern "C" int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const flo
     set_error("mlp_gemm_fwd_pool_bn: ns=%d with R=%d N=%d is not fused", ns, R, N);
     return DEMF_EUNSUPPORTED;
   }
-  DEMF_REQUIRE(X && Wt && Y && pro_scale_shift && pmax && pmin && amax && amin,
+  DEMF_REQUIRE(X && Wt && Y && pro_scale_shift && pmax && amax && (pmin == nullptr) == (amin == nullptr),
                "mlp_gemm_fwd_pool_bn: null pointer");
   if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
   MlpArgs a{};

@@ -758,11 +758,12 @@ class _SharedMLPPool(Function):
                 # last layer: the max over the ns neighbours rides in the GEMM epilogue
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
-                pm = torch.empty((2, R // ns, N), dtype=torch.float32, device=dev)
-                am = torch.empty((2, R // ns, N), dtype=torch.int32, device=dev)
+                # only the extremum the sign of gamma selects (pmin / amin = NULL)
+                pm = torch.empty((R // ns, N), dtype=torch.float32, device=dev)
+                am = torch.empty((R // ns, N), dtype=torch.int32, device=dev)
                 # (+ the BN bookkeeping, in the GEMM's last workgroup)
                 _ffi.call("demf_mlp_gemm_fwd_pool_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
-                          _p(stats), ns, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]), _p(gamma),
+                          _p(stats), ns, _p(pm), None, _p(am), None, _p(gamma),
                           _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss),
                           _p(mi), _p(tensors[7 * l + 5]), st)
             elif training:
@@ -791,7 +792,7 @@ class _SharedMLPPool(Function):
             # + the raw output at the selected rows: the sparse BN-backward reduce reads it
             # instead of gathering 2 M scattered values from the (R x C) output
             yraw = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
-            _ffi.call("demf_pool_select", R // ns, C, _p(pm[0]), _p(pm[1]), _p(am[0]), _p(am[1]),
+            _ffi.call("demf_pool_select", R // ns, C, _p(pm), _p(pm), _p(am), _p(am),
                       _p(sss[-1]), _p(out), _p(arg), _p(yraw), st)
         else:
             _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),

@@ -240,7 +240,11 @@ int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float* X,
 /* demf_mlp_gemm_fwd / demf_mlp_gemm_fwd_pool followed by demf_bn_finalize(N, count = R, stats, ...)
  * as ONE launch: the last workgroup of the GEMM turns the column sums into scale_shift,
  * mean_invstd and the running statistics (torch.nn.BatchNorm semantics, see demf_bn_finalize) and
- * leaves `stats` zeroed.  The following layer's launch reads scale_shift as its prologue.         */
+ * leaves `stats` zeroed.  The following layer's launch reads scale_shift as its prologue.
+ * demf_mlp_gemm_fwd_pool_bn with pmin == amin == NULL: the sign of the BN scale is the sign of gamma,
+ * so only the extremum the consumer will select is reduced - pmax / amax then hold, per group and
+ * column, the maximum of y for gamma >= 0 and the minimum otherwise (pass them to demf_pool_select
+ * as both the max and the min operands).                                                            */
 int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X, const float* pro_scale_shift,
                          const float* Wt, float* Y, double* stats, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean,

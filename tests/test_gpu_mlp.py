@@ -280,3 +280,52 @@ def test_factored_first_layer_coordinate_gradients():
     close(xyz_g.grad, xr.grad, 1e-3, "dxyz")
     close(lg[0][0].grad, lr[0][0].grad, 1e-3, "dW0")
     close(fg.grad, fr.grad.view(B * N, C), 1e-3, "dfeat")
+
+
+@pytest.mark.parametrize("R,K,N,ns", [(2048 * 64, 64, 128, 64), (1024 * 32, 128, 256, 32),
+                                      (600 * 16, 36, 72, 16), (130 * 64, 64, 256, 64)])
+def test_pooled_forward_with_bn_bookkeeping_equals_the_separate_launches(R, K, N, ns):
+    """demf_mlp_gemm_fwd_pool_bn (statistics finalised by the GEMM's last workgroup, only the
+    extremum that the sign of gamma selects) against demf_mlp_gemm_fwd_pool + demf_bn_finalize:
+    same Y, scale / shift, mean / invstd, running statistics, counters left zeroed, and the selected
+    value / row offset = the max (gamma >= 0) or min (gamma < 0) of the 4-output form."""
+    from demf_amd import _ffi
+    g = torch.Generator().manual_seed(R + N)
+    x = torch.randn(R, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    pro = torch.cat([torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3]).cuda()
+    gamma = (1.0 + 0.3 * torch.randn(N, generator=g))
+    gamma[1], gamma[2] = -0.5, 0.0
+    gamma, beta = gamma.cuda(), (0.1 * torch.randn(N, generator=g)).cuda()
+    bias = (0.1 * torch.randn(N, generator=g)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    f = lambda *s: torch.empty(s, device="cuda")
+    # reference: two launches
+    y0, stats0 = f(R, N), torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+    pm, am = f(2, R // ns, N), torch.empty(2, R // ns, N, dtype=torch.int32, device="cuda")
+    ss0, mi0, rm0, rv0 = f(2 * N), f(2 * N), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    nbt0 = torch.zeros((), dtype=torch.int64, device="cuda")
+    _ffi.call("demf_mlp_gemm_fwd_pool", R, K, N, K, x.data_ptr(), pro.data_ptr(), w.data_ptr(),
+              y0.data_ptr(), stats0.data_ptr(), ns, pm[0].data_ptr(), pm[1].data_ptr(),
+              am[0].data_ptr(), am[1].data_ptr(), st)
+    _ffi.call("demf_bn_finalize", N, R, stats0.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1,
+              rm0.data_ptr(), rv0.data_ptr(), nbt0.data_ptr(), ss0.data_ptr(), mi0.data_ptr(),
+              bias.data_ptr(), st)
+    for rep in range(2):                     # twice: the exit counters must re-arm themselves
+        y1, stats1 = f(R, N), torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+        ps, as_ = f(R // ns, N), torch.empty(R // ns, N, dtype=torch.int32, device="cuda")
+        ss1, mi1, rm1, rv1 = f(2 * N), f(2 * N), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+        nbt1 = torch.zeros((), dtype=torch.int64, device="cuda")
+        _ffi.call("demf_mlp_gemm_fwd_pool_bn", R, K, N, K, x.data_ptr(), pro.data_ptr(), w.data_ptr(),
+                  y1.data_ptr(), stats1.data_ptr(), ns, ps.data_ptr(), 0, as_.data_ptr(), 0,
+                  gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm1.data_ptr(), rv1.data_ptr(),
+                  nbt1.data_ptr(), ss1.data_ptr(), mi1.data_ptr(), bias.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y0)
+        assert float(stats1.abs().max()) == 0.0 and int(nbt1) == 1
+        for a, b, name in ((ss1, ss0, "scale_shift"), (mi1, mi0, "mean_invstd"), (rm1, rm0, "running_mean"),
+                           (rv1, rv0, "running_var")):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=name)
+        neg = (gamma < 0)[None, :]
+        assert torch.equal(ps, torch.where(neg, pm[1], pm[0]))
+        assert torch.equal(as_, torch.where(neg, am[1], am[0]))
