@@ -761,11 +761,23 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
                   s2 = __builtin_fmaf(dz, (y - mu0) * is0, s2);
                 }
               }
-              if constexpr (STATS) {
-                s1 += v;                   // rows >= R are exact zeros (their A rows are zero)
-                s2 = __builtin_fmaf(v, v, s2);
-              }
             }
+          if constexpr (STATS) {
+            // column statistics on register pairs: v_pk_add_f32 / v_pk_fma_f32 take two accumulators
+            // per instruction (rows >= R are exact zeros: their A rows are zero)
+            using f32x2 = float __attribute__((ext_vector_type(2)));
+            f32x2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                const f32x2 v = {acc[rt][nt][r], acc[rt][nt][r + 1]};
+                a1 += v;
+                a2 = __builtin_elementwise_fma(v, v, a2);
+              }
+            s1 += a1.x + a1.y;
+            s2 += a2.x + a2.y;
+          }
         };
         // (only in the pooled instantiations: duplicating the loop in the wide plain ones - up to
         // 128 accumulators live - made them 30-90 % slower)
