@@ -345,8 +345,8 @@ def main():
         }
         # ---- headline roofline: the dominant kernel ON the step's critical path (the FPS chain
         # runs underneath the step on a side stream).  Algorithmic bytes of that GEMM = read the
-        # (R,64) input rows once, write the (R,128) raw output once, write pooled max/min + their
-        # row offsets (4 x (R/64,128) words); weights < 1 %.
+        # (R,64) input rows once, write the (R,128) raw output once, write the pooled extremum that
+        # the sign of gamma selects + its row offset (2 x (R/64,128) words); weights < 1 %.
         mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype != "bf16" else MFMA_BF16_PEAK_TFLOPS
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 2 * (sa1_rows // 64) * 128 * 4
