@@ -1442,7 +1442,7 @@ struct DwArgs {
 // X3 (compute mode 2): the slab stays fp32 in LDS; per 16 rows a lane gathers its 8 rows of one column
 // (8 ds_read_b32, conflict-free: consecutive lanes read consecutive columns), splits them into three
 // bf16 terms and issues the six significant products on v_mfma_f32_32x32x16_bf16.
-template <int TN, int TK, bool SPARSE, bool X3 = false>
+template <int TN, int TK, bool SPARSE, int X3 = 0>   // 0 fp32 MFMA, 1 three-term split, 2 one bf16 term
 __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
   constexpr int PROY = SPARSE ? PRO_DY_SPARSE : PRO_DY_DENSE;
   {  // this block's (<= 2TN x 2TK tiles) corner of the N x K output
@@ -1536,7 +1536,28 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
     const int next_chunk = last ? (dyn ? s_next : chunk + (int)gridDim.x) : chunk;
     const int next_si = last ? 0 : si + 1;
     if (next_chunk < nchunk) prefetch(next_chunk * p.chunk + next_si);
-    if constexpr (X3) {
+    if constexpr (X3 == 2) {
+      // compute dtype bf16: the same column gather, operands rounded to bf16, one MFMA per tile pair
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        auto gather1 = [&](const float* col, int ld) {
+          const float* q = col + (16 * c + 8 * lh) * ld;
+          const bf16x4 lo = to_bf16x4(make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]));
+          const bf16x4 hi = to_bf16x4(make_float4(q[4 * ld], q[5 * ld], q[6 * ld], q[7 * ld]));
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8 a8[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) a8[i] = gather1(s_dy + (wn + 2 * i) * 32 + lr, ldn);
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const bf16x8 b8 = gather1(s_a + (wk + 2 * j) * 32 + lr, ldk);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (X3 == 1) {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         // lane supplies rows 16c + 8lh .. +7 of column lr of its tiles
@@ -1588,174 +1609,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
       atomicExch(done + blockIdx.y, 0);
       atomicExch(p.sched + blockIdx.y, 0);
     }
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int tn = wn + 2 * i, tk = wk + 2 * j;
-      if (tn < p.NTn && tk < p.NTk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int k = (p.k0 + tk) * 32 + lr;
-          if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.lddw + k, acc[i][j][r]);
-        }
-      }
-    }
-}
-
-// ---- the same reduction on bf16 MFMA (compute dtype bf16) -------------------------------------------
-// v_mfma_f32_32x32x16_bf16 contracts 16 ROWS per instruction and wants a lane's 8 reduction elements
-// contiguous, i.e. the slab transposed ([column][row]) in LDS.  The transposition is done by the load
-// pattern instead of by LDS scatter: lane <-> column (64 consecutive columns per wave-load: coalesced
-// 256-byte dword loads), wave <-> row octet; a thread applies the prologue to its 8 rows of one
-// column (per-column vectors are per-lane constants), packs them to 8 bf16 and writes ONE 16-byte
-// LDS word.  Column stride 80 bytes (64 + 16 pad): the 16-byte fragment reads of 32 consecutive
-// columns are 4-way conflicted, like any b128 access.  16x fewer MFMA issue cycles than the fp32
-// kernel above; raw values of the next slab are prefetched into registers.
-template <int TN, int TK, bool SPARSE>
-__global__ __launch_bounds__(256, 2) void mlp_dw_bf16_kernel(DwArgs p) {
-  {
-    const int TNt = (p.N + 31) / 32, TKt = (p.K + 31) / 32;
-    p.n0 = ((int)blockIdx.y / p.nsub_k) * 2 * TN;
-    p.k0 = ((int)blockIdx.y % p.nsub_k) * 2 * TK;
-    p.NTn = TNt - p.n0 < 2 * TN ? TNt - p.n0 : 2 * TN;
-    p.NTk = TKt - p.k0 < 2 * TK ? TKt - p.k0 : 2 * TK;
-  }
-  constexpr int WN = 2 * TN * 32, WK = 2 * TK * 32;
-  constexpr int PN = WN / 64, PK = WK / 64;            // 64-column passes per operand
-  constexpr int LDC = 80;                              // bytes per staged column
-  extern __shared__ __attribute__((aligned(16))) char dwb_smem[];
-  char* s_dy = dwb_smem;                               // [WN][LDC]
-  char* s_a = s_dy + WN * LDC;                         // [WK][LDC]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lr = lane & 31, lh = lane >> 5;
-  const int wn = wave >> 1, wk = wave & 1;
-  // per-lane column constants
-  float v_sc[PN], v_sh[PN], v_gi[PN], v_a[PN], v_b[PN], x_sc[PK], x_sh[PK];
-  bool okn[PN], okk[PK];
-  int coln[PN], colk[PK];
-#pragma unroll
-  for (int q = 0; q < PN; ++q) {
-    coln[q] = p.n0 * 32 + q * 64 + lane;
-    okn[q] = coln[q] < p.N;
-    const int c = okn[q] ? coln[q] : 0;
-    v_sc[q] = p.vec[c]; v_sh[q] = p.vec[p.N + c]; v_gi[q] = p.vec[2 * p.N + c];
-    v_a[q] = p.vec[3 * p.N + c]; v_b[q] = p.vec[4 * p.N + c];
-  }
-#pragma unroll
-  for (int q = 0; q < PK; ++q) {
-    colk[q] = p.k0 * 32 + q * 64 + lane;
-    okk[q] = colk[q] < p.K;
-    const int c = okk[q] ? colk[q] : 0;
-    x_sc[q] = p.pvec ? p.pvec[c] : 1.f;
-    x_sh[q] = p.pvec ? p.pvec[p.K + c] : 0.f;
-  }
-  f32x16 acc[TN][TK];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const bool group8 = SPARSE && (p.ns % 8 == 0);       // an 8-row octet lies inside one pooled group
-  float ry[PN][8], rg[PN][8], rx[PK][8];
-  int rarg[PN][8];
-  auto prefetch = [&](int slab) {
-    const int rbase = slab * 32 + 8 * wave;
-#pragma unroll
-    for (int q = 0; q < PN; ++q) {
-      if constexpr (SPARSE) {
-        if (group8) {
-          const int rp = rbase / p.ns;
-          const bool ok = okn[q] && rbase < p.R;
-          rg[q][0] = ok ? p.dP[(size_t)rp * p.N + coln[q]] : 0.f;
-          rarg[q][0] = ok ? p.arg[(size_t)rp * p.N + coln[q]] : -1;
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = rbase + t;
-        const bool ok = okn[q] && row < p.R;
-        ry[q][t] = ok ? p.Yl[(size_t)row * p.N + coln[q]] : 0.f;
-        if constexpr (SPARSE) {
-          if (!group8) {
-            const int rp = row / p.ns;
-            rg[q][t] = ok ? p.dP[(size_t)rp * p.N + coln[q]] : 0.f;
-            rarg[q][t] = ok ? p.arg[(size_t)rp * p.N + coln[q]] : -1;
-          }
-        } else {
-          rg[q][t] = ok ? p.G[(size_t)row * p.N + coln[q]] : 0.f;
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < PK; ++q)
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = rbase + t;
-        rx[q][t] = (okk[q] && row < p.R) ? p.Xp[(size_t)row * p.ldx + colk[q]] : 0.f;
-      }
-  };
-  const int nslab = (p.R + 31) / 32;
-  int slab = blockIdx.x;
-  if (slab < nslab) prefetch(slab);
-  while (slab < nslab) {
-    const int rbase = slab * 32 + 8 * wave;
-    lds_barrier();                                     // previous slab fully consumed
-#pragma unroll
-    for (int q = 0; q < PN; ++q) {
-      bf16x8 pk;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int row = rbase + t;
-        const float y = ry[q][t];
-        float g;
-        if constexpr (SPARSE) {
-          const int slot = row - (row / p.ns) * p.ns;
-          g = group8 ? (rarg[q][0] == slot ? rg[q][0] : 0.f) : (rarg[q][t] == slot ? rg[q][t] : 0.f);
-        } else {
-          g = rg[q][t];
-        }
-        const float dz = __builtin_fmaf(y, v_sc[q], v_sh[q]) > 0.f ? g : 0.f;
-        float dy = __builtin_fmaf(v_gi[q], dz, __builtin_fmaf(v_a[q], y, v_b[q]));
-        if (!(okn[q] && row < p.R)) dy = 0.f;
-        pk[t] = (__bf16)dy;
-      }
-      *reinterpret_cast<bf16x8*>(s_dy + (q * 64 + lane) * LDC + 16 * wave) = pk;
-    }
-#pragma unroll
-    for (int q = 0; q < PK; ++q) {
-      bf16x8 pk;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        float x = rx[q][t];
-        if (p.pvec) x = fmaxf(0.f, __builtin_fmaf(x, x_sc[q], x_sh[q]));
-        if (!(okk[q] && rbase + t < p.R)) x = 0.f;
-        pk[t] = (__bf16)x;
-      }
-      *reinterpret_cast<bf16x8*>(s_a + (q * 64 + lane) * LDC + 16 * wave) = pk;
-    }
-    lds_barrier();
-    const int next = slab + (int)gridDim.x;
-    if (next < nslab) prefetch(next);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      bf16x8 a8[TN], b8[TK];
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-        a8[i] = *reinterpret_cast<const bf16x8*>(s_dy + ((wn + 2 * i) * 32 + lr) * LDC + 2 * (16 * h + 8 * lh));
-#pragma unroll
-      for (int j = 0; j < TK; ++j)
-        b8[j] = *reinterpret_cast<const bf16x8*>(s_a + ((wk + 2 * j) * 32 + lr) * LDC + 2 * (16 * h + 8 * lh));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8[j], acc[i][j], 0, 0, 0);
-    }
-    slab = next;
   }
 #pragma unroll
   for (int i = 0; i < TN; ++i)
@@ -2336,24 +2189,21 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
   }
   const dim3 grid(gx, nsub);
   if (compute_bf16() && !env_int("DEMF_DW_F32", 0)) {
-    a.chunk = 1;
-    a.sched = nullptr;
-    const size_t ldsb = 80 * (size_t)(2 * tn * 32 + 2 * tk * 32);
-#define DWB(TNv, TKv)                                                                            \
-  if (G) hipLaunchKernelGGL((mlp_dw_bf16_kernel<TNv, TKv, false>), grid, dim3(256), ldsb, s, a); \
-  else hipLaunchKernelGGL((mlp_dw_bf16_kernel<TNv, TKv, true>), grid, dim3(256), ldsb, s, a)
-    if (tn == 1 && tk == 1) { DWB(1, 1); }
-    else if (tn == 1) { DWB(1, 2); }
-    else if (tk == 1) { DWB(2, 1); }
-    else { DWB(2, 2); }
-#undef DWB
-    return check_launch("mlp_gemm_bwd_dw(bf16)");
+#define DWG(TNv, TKv)                                                                            \
+  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, 2>), grid, dim3(256), lds, s, a);    \
+  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, 2>), grid, dim3(256), lds, s, a)
+    if (tn == 1 && tk == 1) { DWG(1, 1); }
+    else if (tn == 1) { DWG(1, 2); }
+    else if (tk == 1) { DWG(2, 1); }
+    else { DWG(2, 2); }
+#undef DWG
+    return check_launch("mlp_gemm_bwd_dw(bf16 gather)");
   }
   static const int x3mask = env_int("DEMF_X3_MASK", 7);          // bit 2: weight-gradient launches
   if (compute_mode() == 2 && (x3mask & 4)) {
 #define DWX(TNv, TKv)                                                                            \
-  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, true>), grid, dim3(256), lds, s, a); \
-  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, true>), grid, dim3(256), lds, s, a)
+  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, 1>), grid, dim3(256), lds, s, a); \
+  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, 1>), grid, dim3(256), lds, s, a)
     if (tn == 1 && tk == 1) { DWX(1, 1); }
     else if (tn == 1) { DWX(1, 2); }
     else if (tk == 1) { DWX(2, 1); }
