@@ -1734,6 +1734,15 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
       a2.halves = 2;
       grid = dim3(2 * gx, 1);
     }
+    // persistent pooled launches take their tiles dynamically too (not the interleaved-halves form,
+    // whose block -> (tile, half) mapping is static)
+    {
+      const int brows = rt2 ? 256 : 128;
+      const int tiles = (a.R + brows - 1) / brows;
+      static const int pool_dyn = env_int("DEMF_POOL_DYN", 1);
+      if (pool_dyn && ys == 1 && tiles > gx && a.K > MLP_BK && gx % (8 * SCHED_GROUPS) == 0)
+        a2.sched = sched_slot();
+    }
     // SEL: only the extremum the sign of gamma selects (pmin / amin not given, gamma known)
     const bool sel = a.pmin == nullptr && a.fin.gamma != nullptr;
 #define PGO(NTv, RTv)                                                                                       \
