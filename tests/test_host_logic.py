@@ -101,3 +101,28 @@ def test_targets_empty_scene_and_padding():
     # a point in exactly one box carries that vote in all three slots (reference :852-854)
     i = int(torch.nonzero(vm[0])[0])
     assert torch.equal(vt[0, i, 0:3], vt[0, i, 3:6]) and torch.equal(vt[0, i, 0:3], vt[0, i, 6:9])
+
+
+def test_compute_dtype_names_and_native_override(monkeypatch):
+    """ops.set_compute_dtype: 'f32' is the three-term split (mode 2) unless DEMF_F32_NATIVE=1 asks for
+    the fp32 MFMA (mode 0); unknown names are rejected; the C entry refuses modes outside 0..2.
+    (demf_set_compute_dtype only stores the mode: no GPU needed.)"""
+    from demf_amd import _ffi, ops
+    seen = []
+    real = _ffi.call
+    monkeypatch.setattr(_ffi, "call", lambda name, *a: seen.append((name, a)) or real(name, *a))
+    try:
+        monkeypatch.delenv("DEMF_F32_NATIVE", raising=False)
+        for name, mode in (("f32", 2), ("f32x3", 2), ("f32_native", 0), ("bf16", 1)):
+            ops.set_compute_dtype(name)
+            assert seen[-1] == ("demf_set_compute_dtype", (mode,)) and ops.get_compute_dtype() == name
+        monkeypatch.setenv("DEMF_F32_NATIVE", "1")
+        ops.set_compute_dtype("f32")
+        assert seen[-1] == ("demf_set_compute_dtype", (0,))
+        with pytest.raises(ValueError):
+            ops.set_compute_dtype("fp8")
+        with pytest.raises(Exception):
+            real("demf_set_compute_dtype", 3)
+    finally:
+        monkeypatch.delenv("DEMF_F32_NATIVE", raising=False)
+        ops.set_compute_dtype("f32")
