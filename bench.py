@@ -82,6 +82,13 @@ def pmc_per_launch(kernel_substr, which="max"):
     return None, None
 
 
+def pmc_per_step():
+    """HBM bytes of one whole training step (every kernel of it) from the newest committed PMC passes:
+    the __TOTAL_PER_STEP__ row tools/pmc_summary.py writes (FETCH doubled as above).
+    -> (bytes | None, source | None)"""
+    return pmc_per_launch("__TOTAL_PER_STEP__", which="mean")
+
+
 def make_batch(B, seed, device):
     raw = synthetic.make_scene_batch(B, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, 256, seed=seed,
                                      n_gt=8, img_shape=IMG_SHAPE[:2], scale_factor=1.5094)
@@ -147,7 +154,9 @@ def cpu_baseline(seconds_budget=20.0):
     """The CPU oracle (oracle/model.py: a port of the reference path, checker-only code) timed
     on this host, ONE full-size scene per pass: leg (a) SA backbone forward,
     leg (b) full hot-path forward, leg (c) fwd + loss + bwd = the figure `value` reports.
-    Thread count: the faster of min(32, cores) and all cores on a warm-up pass of leg (c)."""
+    Threads: min(32, host cores) - on the 256-thread GPU-box host 32 threads measured faster than
+    all of them (round 2: the probe that found that out cost ~200 s per run and is gone);
+    `host_cores` in the result states what the machine has."""
     from oracle import fixtures
     from oracle.model import OracleDeMF
     host = os.cpu_count() or 1
@@ -179,17 +188,7 @@ def cpu_baseline(seconds_budget=20.0):
         torch.set_num_threads(n)
         os.environ["OMP_NUM_THREADS"] = str(n)
 
-    cands = sorted({min(32, host), host})
-    best = None
-    for n in cands:
-        set_threads(n)
-        leg_c()                                   # warm-up at this thread count
-        t0 = time.perf_counter()
-        leg_c()
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, n)
-    set_threads(best[1])
+    set_threads(min(32, host))
 
     def timed(fn, budget, max_n):
         fn()
@@ -242,7 +241,25 @@ def main():
     ap.add_argument("--cu-mask", action="store_true",
                     help="pin the FPS pre-pass to its own CUs (hipExtStreamCreateWithCUMask); measured: "
                          "no effect under hipGraph replay, off by default")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (bf16 / P=4 step times, the replay.load() input-path leg)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: launch the ranks ourselves, the way the reference's
+        # tools/dist_train.sh:8-9 does (python -m torch.distributed.launch --nproc_per_node=$GPUS),
+        # one process per GPU over RCCL; rank 0 of the children prints the JSON line
+        import socket
+        import subprocess
+        port = os.environ.get("MASTER_PORT")
+        if not port:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = str(sk.getsockname()[1])
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     rank, local, world = engine.init_distributed()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -314,6 +331,54 @@ def main():
         trainer.step(batch)
     torch.cuda.synchronize()
     fps_timer.enabled = mlp_timer.enabled = False
+
+    def time_steps(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1000.0 * (time.perf_counter() - t1) / n
+
+    secondary = {}
+    if world == 1 and not args.no_secondary and not args.no_graph:
+        # (a) the per-step input path: two DISTINCT batches cycled through replay.load() (target
+        # padding's host round trip, meta refresh, the H2D of the static buffers) with the next
+        # cloud handed to the pipelined pre-pass - what a real training loop pays per step
+        batch_b, _ = make_batch(args.batch, seed=2000 + rank, device=device)
+        pair = [batch, batch_b]
+        k = [0]
+
+        def step_with_load():
+            k[0] += 1
+            cur, nxt = pair[k[0] & 1], pair[(k[0] + 1) & 1]
+            step.load(cur)
+            step(next_points=nxt["points"])
+        secondary["ms_per_step_with_load"] = time_steps(step_with_load, args.steps)
+        # (b) the other BASELINE configurations on the same process / box: configs[3] per GPU (bf16
+        # compute mode) and BASELINE's "8 heads x 4 points" wording (P = 4; the reference config is 2)
+        import dataclasses
+
+        def other(dtype, points):
+            ops.set_compute_dtype(dtype)
+            try:
+                c2 = cfg if points == cfg.head.num_points else \
+                    dataclasses.replace(cfg, head=dataclasses.replace(cfg.head, num_points=points))
+                torch.manual_seed(0)
+                m2 = DeMFHotPath(c2).to(device).train()
+                t2 = engine.Trainer(m2)
+                r2 = t2.capture(batch, prefetch_geometry=not args.no_prefetch)
+                ms = time_steps(r2, args.steps)
+                ok = bool(torch.isfinite(t2.flat.flat).all())
+                return ms if ok else float("nan")
+            finally:
+                ops.set_compute_dtype(args.dtype)
+        if args.dtype != "bf16":
+            secondary["bf16_ms_per_step"] = other("bf16", args.msda_points)
+        if args.msda_points != 4:
+            secondary["p4_ms_per_step"] = other(args.dtype, 4)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,6 +394,9 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            # fp32 RESULTS; in the default mode the shared-MLP products are issued as 3-term bf16
+            # splits on the bf16 MFMA (emulated fp32, error vs fp64 = the fp32 MFMA's)
+            "emulated_fp32": args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"],
             "config": {"workload": "BASELINE configs[2]: full DeMF fusion hot path fwd+loss+bwd+"
                                    "allreduce+AdamW, %d scenes/GPU x (20000 pts, 800x1120 -> "
                                    "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=%d, %s"
@@ -347,7 +415,11 @@ def main():
         # runs underneath the step on a side stream).  Algorithmic bytes of that GEMM = read the
         # (R,64) input rows once, write the (R,128) raw output once, write the pooled extremum that
         # the sign of gamma selects + its row offset (2 x (R/64,128) words); weights < 1 %.
-        mfma_peak = MFMA_F32_PEAK_TFLOPS if args.dtype != "bf16" else MFMA_BF16_PEAK_TFLOPS
+        x3 = args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"]
+        # MFMA budget of the mode: native fp32 -> the fp32 MFMA peak; bf16 -> the bf16 peak; the
+        # three-term split issues 6 bf16 MFMAs per algorithmic product -> bf16 peak / 6
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else \
+            (MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS)
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 2 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
@@ -355,19 +427,30 @@ def main():
         traffic, src = pmc_per_launch(dom) if args.batch == 8 else (None, None)
         out["roofline"] = {
             "kernel": "%s (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (dom, sa1_rows),
-            "bound": "hbm", "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+            # priced against the HBM roof (its algorithmic bytes dominate its FLOPs at either MFMA
+            # rate); what actually limits it today is on-chip: VALU issue + latency at 2 waves/SIMD
+            # (PMC pipe counters)
+            "bound": "hbm", "limited_by": "valu-issue/latency (2 waves per SIMD), not HBM bytes",
+            "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,
             "avg_launch_ms": mlp_ms,
             "mfma_frac": mlp_flop / (mlp_ms * 1e-3) / 1e12 / mfma_peak,
-            "note": "also %.1f algorithmic GFLOP per launch (mfma_frac = of the %.1f TF/s dense %s MFMA "
-                    "peak; in the f32x3 mode each product is issued as 6 bf16 MFMAs = 3/8 of the fp32 "
-                    "MFMA's issue time)" % (mlp_flop / 1e9, mfma_peak, "bf16" if args.dtype == "bf16" else "fp32")}
+            "note": "also %.1f algorithmic GFLOP per launch; mfma_frac = of the %.1f TF/s the mode can "
+                    "issue (%s)" % (mlp_flop / 1e9, mfma_peak,
+                                    "dense bf16 MFMA peak" if args.dtype == "bf16" else
+                                    ("dense bf16 MFMA peak / 6: three-term split" if x3 else "dense fp32 MFMA peak"))}
         # ---- step level: what the metric asks for ("as achieved fraction of HBM roofline")
         step_bytes = ALGO_BYTES_PER_SCENE * args.batch
         step_flop = ALGO_FLOP_PER_SCENE * args.batch
+        traffic_step, src_step = pmc_per_step() if args.batch == 8 else (None, None)
         out["roofline_step"] = {
             "bound": "mfma" if args.dtype != "bf16" else "hbm", "algorithmic_bytes": step_bytes,
+            # HBM bytes the whole step actually moved (PMC, every kernel) and their ratio to the
+            # algorithmic bytes: > 1 = re-reads of materialised intermediates (Y_l read by the next
+            # layer, the dx and the dW pass)
+            "traffic_step": traffic_step, "traffic_source": src_step,
+            "traffic_over_algorithmic": (traffic_step / step_bytes) if traffic_step else None,
             "algorithmic_flop": step_flop,
             "hbm": {"achieved": step_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
@@ -389,6 +472,8 @@ def main():
                 "frac": FPS_FLOOR_CYCLES / cyc,
                 "note": "floor = one 16-wave barrier phase + the per-wave VALU work of 20000 points "
                         "(DESIGN.md section 3.1); HBM bytes are 2 MB per launch by construction"}
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))

@@ -84,6 +84,7 @@ SIGNATURES = {
     "demf_msda_prep_fwd": [_c_int] * 5 + [_ptr] * 10,
     "demf_msda_prep_bwd": [_c_int] * 5 + [_ptr] * 14,
     "demf_rng_advance": [_ptr, _ptr],
+    "demf_rng_next": [_ptr, _ptr, _ptr],
     "demf_dropout_mask": [ctypes.c_longlong, _c_float, _ptr, _c_int, _ptr, _ptr],
 }
 

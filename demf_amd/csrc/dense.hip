@@ -853,6 +853,14 @@ __global__ __launch_bounds__(256) void vote_combine_bwd_k(int R, const float* __
 }
 
 __global__ void rng_advance_k(unsigned long long* rng) { rng[1] += 1; }
+// advance + snapshot: the forward of a dropout-carrying node draws its own step and hands the backward
+// the (seed, step) pair it used, so two forwards before one backward re-derive the right masks
+__global__ void rng_next_k(unsigned long long* rng, unsigned long long* snap) {
+  const unsigned long long s = rng[1] + 1;
+  rng[1] = s;
+  snap[0] = rng[0];
+  snap[1] = s;
+}
 
 __global__ void dropout_mask_k(long long n, float p, const unsigned long long* __restrict__ rng,
                                unsigned op, float* __restrict__ out) {
@@ -1078,6 +1086,13 @@ extern "C" int demf_rng_advance(void* rng, demf_stream_t stream) {
   DEMF_REQUIRE(rng, "rng_advance: null state");
   hipLaunchKernelGGL(rng_advance_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)rng);
   return check_launch("rng_advance_k");
+}
+
+extern "C" int demf_rng_next(void* rng, void* snapshot, demf_stream_t stream) {
+  DEMF_REQUIRE(rng && snapshot, "rng_next: null state");
+  hipLaunchKernelGGL(rng_next_k, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)rng,
+                     (unsigned long long*)snapshot);
+  return check_launch("rng_next_k");
 }
 
 extern "C" int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* out,

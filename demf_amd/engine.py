@@ -239,22 +239,27 @@ class Trainer:
         return factor
 
     def state_dict(self):
-        """Model + optimizer state for resume (mmcv CheckpointHook, cfg:280)."""
-        return dict(model=self.model.state_dict(), optimizer=self.opt.state_dict())
+        """Model + optimizer state for resume (mmcv CheckpointHook, cfg:280), plus the dropout
+        counter [seed, step] of the fused decoder layer so that a resumed run continues the mask
+        sequence instead of replaying it from step 0."""
+        sd = dict(model=self.model.state_dict(), optimizer=self.opt.state_dict())
+        if self.fused:
+            from . import fused
+            sd["dropout_rng"] = fused.get_rng_state(self.flat.flat.device)
+        return sd
 
     def load_state_dict(self, sd):
         # copies INTO the existing (flat-buffer-resident) parameters: the views stay intact
         self.model.load_state_dict(sd["model"])
         self.opt.load_state_dict(sd["optimizer"])
+        if self.fused and sd.get("dropout_rng") is not None:
+            from . import fused
+            fused.set_rng_state(self.flat.flat.device, sd["dropout_rng"])
 
     def _fwd(self, batch, geometry=None):
         kw = {} if geometry is None else dict(geometry=geometry)
-        if self.fused:
-            # counter-based dropout of the fused decoder layer: one advance per step, inside the
-            # (captured) forward, so that every replay draws fresh masks; the backward re-derives
-            # the masks of the same step
-            from . import fused
-            fused.advance_rng(self.flat.flat.device)
+        # (the fused decoder layer advances its counter-based dropout state by itself, inside the
+        # forward and therefore inside the captured graph: demf_amd/fused.py)
         losses = self.model.forward_train(batch["points"], batch["img_features"],
                                           batch["img_metas"], batch["gt_bboxes_3d"],
                                           batch["gt_labels_3d"], **kw)
@@ -423,9 +428,20 @@ class Trainer:
             refresh = ops.MultiCopy([d for d, _ in pairs], [s for _, s in pairs])
 
         # Which cloud the static geometry buffers hold and which cloud's pre-pass sits in `fresh`
-        # (in flight or finished): tags = (data_ptr, _version, shape) of the tensors handed in.
-        tag = lambda t: (t.data_ptr(), t._version, tuple(t.shape))
-        state = dict(static="captured", fresh=None, pts="captured")   # static_pts holds the captured cloud
+        # (in flight or finished).  Identity is the tensor OBJECT handed in (held here, so the caching
+        # allocator cannot hand its address to the next batch) plus its version counter; an address /
+        # shape tag would match a recycled buffer and silently pair new points with old indices.
+        class _Cloud:
+            __slots__ = ("t", "v")
+
+            def __init__(self, t):
+                self.t, self.v = t, t._version
+
+            def holds(self, t):
+                return self.t is t and self.v == t._version
+
+        captured = _Cloud(batch["points"])     # the static copy made above: never seen by callers
+        state = dict(static=captured, fresh=None, pts=captured)   # static_pts holds the captured cloud
         one_deep = not os.environ.get("DEMF_GEO_TWO_DEEP")         # A/B: see replay()
 
         def take_fresh(main):
@@ -437,7 +453,7 @@ class Trainer:
         def launch_prepass(main, next_points):
             if next_points is not None:
                 static_pts.copy_(next_points)
-                state["pts"] = tag(next_points)
+                state["pts"] = _Cloud(next_points)
             side.wait_stream(main)                # the cloud is in place, `fresh` has been consumed
             with torch.cuda.stream(side):
                 geo_graph.replay()
@@ -453,8 +469,9 @@ class Trainer:
             the pre-pass is launched after the backward and runs underneath the optimizer update and
             the first layers of the next forward (measured: 7.80 vs 7.67 ms/step - the forward's
             statically striped pooled GEMMs lose more to the occupied CUs than the backward does;
-            the step alone is 7.03 ms).  Any other usage stays correct: ``load`` checks the tags and
-            waits for / recomputes the geometry it needs.  ``next_points=None`` recomputes the
+            the step alone is 7.03 ms).  Any other usage stays correct: ``load`` checks whether the
+            static / in-flight geometry belongs to the very tensor object it is given (same object,
+            same version) and otherwise recomputes it.  ``next_points=None`` recomputes the
             pre-pass of the cloud last given (every step still pays for one full pre-pass)."""
             main = torch.cuda.current_stream()
             if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
@@ -494,9 +511,9 @@ class Trainer:
             they do not hold THIS cloud's geometry, it is fetched from the finished / in-flight
             pre-pass (waiting for it) or recomputed here, so geometry and targets can never belong
             to different batches."""
-            if can_prefetch and state["static"] != tag(new["points"]):
+            if can_prefetch and not state["static"].holds(new["points"]):
                 main = torch.cuda.current_stream()
-                if state["fresh"] is not None and state["fresh"] == tag(new["points"]):
+                if state["fresh"] is not None and state["fresh"].holds(new["points"]):
                     take_fresh(main)
                 else:
                     # (an unrelated pre-pass in flight is left to finish; its result is dropped)

@@ -17,9 +17,13 @@ kernel of this package:
   x2 = LN(x1 + dropout((Wv_h z_h + bv_h ksum_h)_h Wop^T))   2 GEMMs + 1 row kernel
   x3 = LN(x2 + dropout(dropout(relu(x2 W0^T)) W1^T))         2 GEMMs + 1 row kernel
 
-Dropout masks are counter-based (seed, step, op, element) and recomputed in the backward; the step
-counter lives on the device and is advanced once per training step (``advance_rng``), so a captured
-hipGraph draws fresh masks at every replay.
+Dropout masks are counter-based (seed, step, op, element) and recomputed in the backward.  The step
+counter lives on the device; every TRAINING forward of the node advances it and takes a snapshot
+(``demf_rng_next``, one 1-thread launch inside the node, hence inside a captured hipGraph: every replay
+draws fresh masks) and the backward re-derives its masks from that snapshot, not from the live counter -
+so plain ``loss.backward()`` loops, gradient accumulation and a user's own optimizer all see fresh,
+correctly paired masks without any help from the step engine.  Streams of different decoder layers are
+salted with the layer index (``op = base + 8 * layer``).
 """
 import ctypes
 import math
@@ -56,14 +60,41 @@ def rng_state(device, seed=None):
 
 
 def advance_rng(device):
-    """One per training step (inside the captured step): the next step draws new masks."""
+    """Skip one step of the counter (the fused node advances it by itself on every training forward)."""
     _ffi.call("demf_rng_advance", rng_state(device).data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
-def dropout_mask(numel, p, op_id, device):
-    """keep / (1-p) per element, exactly as the fused kernels draw it for (rng state, op_id)."""
+def next_rng(device):
+    """Advance the device counter and return the (seed, step) snapshot the caller's masks are drawn
+    from (what a training forward of ``FusedDecoderLayer`` does first)."""
+    state = rng_state(device)
+    snap = torch.empty_like(state)
+    _ffi.call("demf_rng_next", state.data_ptr(), snap.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    return snap
+
+
+def peek_next_rng(device):
+    """The snapshot the NEXT training forward will draw from, without advancing (test hook)."""
+    snap = rng_state(device).clone()
+    snap[1] += 1
+    return snap
+
+
+def get_rng_state(device):
+    """[seed, step] as Python ints (checkpointing: Trainer.state_dict)."""
+    return [int(v) for v in rng_state(device).tolist()]
+
+
+def set_rng_state(device, seed_step):
+    rng_state(device).copy_(torch.tensor([int(seed_step[0]), int(seed_step[1])], dtype=torch.int64))
+
+
+def dropout_mask(numel, p, op_id, device, state=None):
+    """keep / (1-p) per element, exactly as the fused kernels draw it for (``state``, op_id);
+    ``state`` defaults to the live counter."""
     out = torch.empty(numel, dtype=torch.float32, device=device)
-    _ffi.call("demf_dropout_mask", numel, float(p), rng_state(device).data_ptr(), int(op_id),
+    st = rng_state(device) if state is None else state
+    _ffi.call("demf_dropout_mask", numel, float(p), st.data_ptr(), int(op_id),
               out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     return out
 
@@ -132,7 +163,8 @@ class FusedDecoderLayer(Function):
     def forward(ctx, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, dims, training,
                 in_w, in_b, out_w, out_b, g1, b1, off_w, off_b, aw_w, aw_b, vp_w, vp_b, op_w, op_b,
                 g2, b2, f0_w, f0_b, f1_w, f1_b, g3, b3):
-        B, Q, H, L, P, p_attn, p_ffn, eps = dims
+        B, Q, H, L, P, p_attn, p_ffn, eps = dims[:8]
+        salt = 8 * (int(dims[8]) if len(dims) > 8 else 0)     # decoder layer index: independent streams
         if not training:
             p_attn = p_ffn = 0.0
         dev = x.device
@@ -140,7 +172,10 @@ class FusedDecoderLayer(Function):
         Dh, F, Ct, S = E // H, f0_w.shape[0], tokens.shape[2], tokens.shape[1]
         HLP = H * L * P
         assert R == B * Q and x.is_contiguous() and pos.is_contiguous() and pts.is_contiguous()
-        rng = rng_state(dev).data_ptr()
+        # this forward's own (seed, step): drawn here, saved for the backward
+        snap = next_rng(dev) if (p_attn > 0.0 or p_ffn > 0.0) else rng_state(dev)
+        rng = snap.data_ptr()
+        OP_ATTN, OP_LN1, OP_LN2, OP_FFN, OP_LN3 = (salt + o for o in (1, 2, 3, 4, 5))
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         st = _st()
         # ---- self attention (nn.MultiheadAttention: q = k = x + pos, v = x) ----
@@ -193,8 +228,8 @@ class FusedDecoderLayer(Function):
         x3, st3 = new(R, E), new(R, 2)
         _ffi.call("demf_add_dropout_ln_fwd", R, E, _p(s3), _p(x2), _p(g3), _p(b3), eps, p_ffn, rng,
                   OP_LN3, _p(s3), _p(x3), _p(st3), st)
-        ctx.dims = (B, Q, H, L, P, p_attn, p_ffn, eps)
-        ctx.save_for_backward(x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att,
+        ctx.dims = (B, Q, H, L, P, p_attn, p_ffn, eps, salt)
+        ctx.save_for_backward(snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att,
                               s1, st1, x1, w, loc, uvw, z, ks4, mo, s2, st2, x2, hid, s3, st3,
                               in_w, out_w, g1, off_w, aw_w, vp_w, vp_b, op_w, g2, f0_w, f1_w, g3)
         return x3
@@ -202,15 +237,16 @@ class FusedDecoderLayer(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dx3):
-        (x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att, s1, st1, x1, w, loc,
+        (snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att, s1, st1, x1, w, loc,
          uvw, z, ks4, mo, s2, st2, x2, hid, s3, st3, in_w, out_w, g1, off_w, aw_w, vp_w, vp_b, op_w,
          g2, f0_w, f1_w, g3) = ctx.saved_tensors
-        B, Q, H, L, P, p_attn, p_ffn, eps = ctx.dims
+        B, Q, H, L, P, p_attn, p_ffn, eps, salt = ctx.dims
+        OP_ATTN, OP_LN1, OP_LN2, OP_FFN, OP_LN3 = (salt + o for o in (1, 2, 3, 4, 5))
         dev = x.device
         R, E = x.shape
         Dh, F, Ct, S = E // H, f0_w.shape[0], tokens.shape[2], tokens.shape[1]
         HLP = H * L * P
-        rng = rng_state(dev).data_ptr()
+        rng = snap.data_ptr()                        # the forward's own (seed, step)
         st = _st()
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         dx3 = dx3.contiguous()

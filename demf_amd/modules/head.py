@@ -168,7 +168,7 @@ class DeMFVoteHead(nn.Module):
                     .reshape(B * Q, -1)
                 rows = self.decoder[i].forward_rows(
                     rows, query_pos, pts, image_inputs["value_tokens"], spatial_shapes,
-                    level_start_index, (mt["M"], mt["ab"]), valid_ratios, B)
+                    level_start_index, (mt["M"], mt["ab"]), valid_ratios, B, layer_index=i)
                 cls_p, reg_p = self.conv_preds[i + 1](rows.view(B, Q, E).transpose(1, 2))
                 decode_res = self._split(cls_p, reg_p, aggregated_points)
                 decode_res_all.append(decode_res)

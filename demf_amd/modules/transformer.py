@@ -277,14 +277,15 @@ class DeMFTransformerDecoderLayer(nn.Module):
                 m.init_weights()
 
     def forward_rows(self, x, query_pos, points, value_tokens, spatial_shapes, level_start_index,
-                     proj, valid_ratios, batch):
+                     proj, valid_ratios, batch, layer_index=0):
         """The layer on batch-major rows through ONE autograd node (demf_amd/fused.py):
         x (B*Q, E) query rows, query_pos (B*Q, 6), points (B*Q, 3) the 3-D query points (projected
         into the image inside the sampling-location kernel: get_reference_points,
         class_agnostic_vote_head.py:524-547, with ``proj`` = (M (B,4,4), ab (B,4)) composed on the
         host), value_tokens = (tokens (B,S,C) padding-zeroed, keep4 (B,S,4)).  -> (B*Q, E).
         Same mathematics as ``forward`` (self-attn, norm, deformable cross-attn with the value
-        projection applied after sampling, norm, FFN, norm)."""
+        projection applied after sampling, norm, FFN, norm).  ``layer_index`` salts the dropout
+        streams so that stacked decoder layers draw independent masks (as nn.Dropout does)."""
         from ..fused import FusedDecoderLayer
         lyr = self.layer
         mha, msda, ffn = lyr.attentions[0], lyr.attentions[1], lyr.ffns[0]
@@ -300,7 +301,7 @@ class DeMFTransformerDecoderLayer(nn.Module):
         M, ab = proj
         Q = x.shape[0] // batch
         dims = (batch, Q, msda.num_heads, msda.num_levels, msda.num_points, p_attn, float(drop0.p),
-                float(n1.eps))
+                float(n1.eps), int(layer_index))
         return FusedDecoderLayer.apply(
             x.contiguous(), pos, points.contiguous(), tokens, keep4, spatial_shapes, level_start_index,
             M, ab, valid_ratios, dims, self.training,

@@ -57,14 +57,24 @@ class _ZeroArena:
 
     def __init__(self):
         self.buf, self.off, self.high, self.active = None, 0, 0, False
+        self._captured = []       # buffers whose address is baked into a captured hipGraph: kept alive
 
     def begin(self, device):
+        capturing = torch.cuda.is_current_stream_capturing() if torch.cuda.is_available() else False
         if self.buf is None or self.buf.device != device:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError("zero arena must be sized by an eager warm-up step before capture")
             self.buf = torch.zeros(1 << 22, dtype=torch.float32, device=device)
+        elif capturing:
+            # the recorded fill covers the WHOLE buffer: a piece first taken while capturing (beyond
+            # the warm-up steps' watermark) is re-zeroed on every replay too
+            self.buf.zero_()
         elif self.high:
             self.buf[:self.high].zero_()
+        if capturing and not any(b is self.buf for b in self._captured):
+            # the graph holds this buffer's address (its fill node, every weight-gradient workspace and
+            # loss accumulator): it must outlive any later growth of the arena
+            self._captured.append(self.buf)
         self.off, self.active = 0, True
 
     def end(self):
@@ -75,7 +85,9 @@ class _ZeroArena:
         if self.off + n > self.buf.numel():
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("zero arena overflow during capture")
-            # grow: pieces already handed out stay valid views of the old buffer (still zero-filled)
+            # grow: pieces already handed out stay valid views of the old buffer (still zero-filled);
+            # a buffer that a captured graph uses stays referenced in ``_captured`` and keeps serving
+            # that graph's replays, eager steps move on to the new one
             self.buf = torch.zeros(max(2 * self.buf.numel(), self.off + n), dtype=torch.float32,
                                    device=self.buf.device)
         out = self.buf[self.off:self.off + numel]

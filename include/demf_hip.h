@@ -576,6 +576,10 @@ int demf_msda_prep_bwd(int R, int Q, int H, int L, int P, const float* pts, cons
                        demf_stream_t stream);
 /* rng[1] += 1: one per training step (a captured graph then draws fresh masks at every replay). */
 int demf_rng_advance(void* rng, demf_stream_t stream);
+/* rng[1] += 1 and snapshot[0..1] = (seed, new step): the forward of a node that carries dropout
+ * (nn.Dropout inside mmcv's DetrTransformerDecoderLayer, configs/demf/demf_votenet.py:78,84,87) draws
+ * its own step and saves the pair for its backward, as torch saves the mask.                         */
+int demf_rng_next(void* rng, void* snapshot, demf_stream_t stream);
 /* out[i] = keep(i) / (1-p): the mask the fused kernels apply for (rng, op_id) - test hook.       */
 int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* out,
                       demf_stream_t stream);

@@ -199,9 +199,22 @@ def make_case(cfg, B, N, pyramid, in_shape, img_shape, seed):
     return batch, gtb, gtl
 
 
+_CASES = {}      # qualified cases of this pytest session: the B=8 oracle runs take minutes of CPU
+
+
 def qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=range(1, 12), log=print):
     """The first seed whose discrete events all keep their distance (module docstring).
-    -> dict(seed, batch, gtb, gtl, truth, cpu32) ; raises if none of ``seeds`` qualifies."""
+    -> dict(seed, batch, gtb, gtl, truth, cpu32) ; raises if none of ``seeds`` qualifies.
+    Cached per argument set for the session (the fp32 and the bf16 whole-path tests of the same
+    configuration share the oracle runs; the choice still depends on the oracle alone)."""
+    key = (repr(cfg), B, N, tuple(pyramid), tuple(in_shape), tuple(img_shape) if img_shape else None,
+           tuple(seeds))
+    if key not in _CASES:
+        _CASES[key] = _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log)
+    return _CASES[key]
+
+
+def _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log):
     why = []
     for seed in seeds:
         case = make_case(cfg, B, N, pyramid, in_shape, img_shape, seed)
@@ -242,7 +255,7 @@ def _group(name):
     return ".".join(parts)
 
 
-def compare_grads(truth, cpu32, gpu_grads, rtol=1e-3, mult=4.0, allowance=0.0):
+def compare_grads(truth, cpu32, gpu_grads, rtol=1e-3, mult=4.0, allowance=0.0, cap=None):
     """EVERY gradient tensor: rel-L2 error vs the fp64 oracle <= max(rtol, mult x the CPU fp32
     oracle's own error on that tensor) + ``allowance`` (the qualified seed's residual flip risk:
     the share of a layer's gradient that elements inside the fp32 noise window still carry).
@@ -252,7 +265,10 @@ def compare_grads(truth, cpu32, gpu_grads, rtol=1e-3, mult=4.0, allowance=0.0):
     (weight + bias + BN affine) instead of the cancelled sum's own norm; the no-flip part of the bound
     stays relative to the tensor itself.  Tensors that are mathematically zero (conv biases in front
     of a train-mode BN) must be at noise level relative to the largest gradient.
-    -> list of failure strings (empty = pass) and the table rows."""
+    ``cap``: hard ceiling on any tensor's error whatever the allowance says (2x the worst error
+    MEASURED on MI355X for the case, tests/test_gpu_model.py) - the bound a regression has to beat.
+    -> list of failure strings (empty = pass) and the table rows (name, |g|, gpu err, cpu32 err,
+    error in units of the flip scale)."""
     gt, gc = truth["grads"], cpu32["grads"]
     assert sorted(gt) == sorted(gpu_grads), set(gt) ^ set(gpu_grads)
     gmax = max(v.norm().item() for v in gt.values())
@@ -264,13 +280,17 @@ def compare_grads(truth, cpu32, gpu_grads, rtol=1e-3, mult=4.0, allowance=0.0):
         nt = gt[n].norm().item()
         if nt < 1e-6 * gmax:
             e = gpu_grads[n].double().cpu().norm().item()
-            rows.append((n, nt, e, float("nan")))
+            rows.append((n, nt, e, float("nan"), float("nan")))
             if e > 1e-4 * gmax:
                 bad.append(f"{n}: should be ~0, got norm {e:.2e} (largest gradient {gmax:.2e})")
             continue
         rg, rc = rel_l2(gpu_grads[n], gt[n]), rel_l2(gc[n], gt[n])
-        rows.append((n, nt, rg, rc))
         flip_scale = max(1.0, gnorm2[_group(n)] ** 0.5 / nt) if gt[n].dim() == 1 else 1.0
-        if rg > max(rtol, mult * rc) + allowance * flip_scale:
-            bad.append(f"{n}: gpu {rg:.2e} vs cpu32 {rc:.2e} (norm {nt:.2e}, flip scale {flip_scale:.1f})")
+        rows.append((n, nt, rg, rc, rg / flip_scale))
+        bound = max(rtol, mult * rc) + allowance * flip_scale
+        if cap is not None:
+            bound = min(bound, max(rtol, cap * flip_scale))
+        if rg > bound:
+            bad.append(f"{n}: gpu {rg:.2e} vs cpu32 {rc:.2e} (norm {nt:.2e}, flip scale {flip_scale:.1f}, "
+                       f"bound {bound:.2e})")
     return bad, rows

@@ -1,8 +1,8 @@
 """csrc/dense.hip on the GPU: the strided GEMM in every operand form the decoder layer uses, the row
-kernels, and the fused decoder layer (demf_amd/fused.py) against a plain torch restatement of
-mmcv's DetrTransformerDecoderLayer mathematics (demf/modeling/layers/transformer.py:55-80;
-configs/demf/demf_votenet.py:71-91) - with dropout OFF and with dropout ON (the test pulls the
-counter-based masks out of the library and feeds them to the torch restatement)."""
+kernels, and the fused decoder layer (demf_amd/fused.py) against the ORACLE's DetrTransformerDecoderLayer
+(oracle/deps.py, fp64; demf/modeling/layers/transformer.py:55-80; configs/demf/demf_votenet.py:71-91) -
+with dropout OFF and with dropout ON (the test pulls the counter-based masks out of the library and
+injects them into the oracle's dropout calls)."""
 import math
 
 import numpy as np
@@ -238,6 +238,91 @@ def _torch_layer(c, prm, dims, masks):
     return F.layer_norm(s3, (E,), prm["g3"], prm["b3"], eps)
 
 
+class _InjectedDropout:
+    """Context manager: while the ORACLE layer runs, every ``F.dropout`` call with p > 0 (nn.Dropout
+    modules and the attention-probability dropout inside nn.MultiheadAttention alike) multiplies by
+    the next mask of ``seq`` instead of drawing one - the oracle's mathematics stays its own, only
+    the random draw is replaced by the masks the HIP kernels use."""
+
+    def __init__(self, seq):
+        self.seq, self.i = list(seq), 0
+
+    def __enter__(self):
+        self.orig = F.dropout
+
+        def drop(input, p=0.5, training=True, inplace=False):
+            if p == 0.0 or not training:
+                return input
+            m = self.seq[self.i]
+            self.i += 1
+            assert m.numel() == input.numel(), (self.i, tuple(m.shape), tuple(input.shape))
+            return input * m.view_as(input)
+        torch.nn.functional.dropout = drop
+        return self
+
+    def __exit__(self, *a):
+        torch.nn.functional.dropout = self.orig
+
+
+def _oracle_layer(c, prm, dims, masks, training=True):
+    """oracle/deps.py's ``DetrTransformerDecoderLayer`` (the restatement of mmcv's BaseTransformerLayer
+    the whole-path oracle runs; configs/demf/demf_votenet.py:71-91) in fp64 on the CPU, project-then-
+    sample through the oracle's C MSDA operator, reference points as get_reference_points
+    (class_agnostic_vote_head.py:524-547) x valid ratios (transformer.py:62-68) composes them.
+    Inputs / parameters are fp64 CPU leaves; masks in the (seq, batch) order the oracle layer sees."""
+    from oracle import deps
+    B, Q, H, L, P, p_attn, p_ffn, eps = dims
+    x, pos, pts = c["x"], c["pos"], c["pts"]
+    R, E = x.shape
+    Fd = prm["f0_w"].shape[0]
+    layer = deps.DetrTransformerDecoderLayer(
+        attn_cfgs=[dict(type="MultiheadAttention", embed_dims=E, num_heads=H, dropout=p_attn),
+                   dict(type="MultiScaleDeformableAttention", embed_dims=E, num_heads=H, num_levels=L,
+                        num_points=P, dropout=p_attn)],
+        feedforward_channels=Fd, ffn_dropout=p_ffn,
+        operation_order=("self_attn", "norm", "cross_attn", "norm", "ffn", "norm")).double()
+    layer.train(training)
+    mha, msda, ffn = layer.attentions[0], layer.attentions[1], layer.ffns[0]
+    (fc0, _, _), fc1, _ = ffn.layers
+    slots = dict(in_w=(mha.attn, "in_proj_weight"), in_b=(mha.attn, "in_proj_bias"),
+                 out_w=(mha.attn.out_proj, "weight"), out_b=(mha.attn.out_proj, "bias"),
+                 g1=(layer.norms[0], "weight"), b1=(layer.norms[0], "bias"),
+                 off_w=(msda.sampling_offsets, "weight"), off_b=(msda.sampling_offsets, "bias"),
+                 aw_w=(msda.attention_weights, "weight"), aw_b=(msda.attention_weights, "bias"),
+                 vp_w=(msda.value_proj, "weight"), vp_b=(msda.value_proj, "bias"),
+                 op_w=(msda.output_proj, "weight"), op_b=(msda.output_proj, "bias"),
+                 g2=(layer.norms[1], "weight"), b2=(layer.norms[1], "bias"),
+                 f0_w=(fc0, "weight"), f0_b=(fc0, "bias"), f1_w=(fc1, "weight"), f1_b=(fc1, "bias"),
+                 g3=(layer.norms[2], "weight"), b3=(layer.norms[2], "bias"))
+    for k, (mod, attr) in slots.items():        # the test's leaves ARE the layer's parameters
+        del mod._parameters[attr]
+        setattr(mod, attr, prm[k])
+    for n in layer.norms:
+        n.eps = eps
+    margin = {}
+    fc0.register_forward_hook(lambda m, i, o: margin.__setitem__("z0", o.detach()))
+    cpu = lambda t_: t_.detach().double().cpu()
+    p4 = torch.cat([pts, torch.ones_like(pts[:, :1])], -1).view(B, Q, 4) @ cpu(c["M"]).transpose(1, 2)
+    uv = p4[..., :2] / p4[..., 2:3]
+    ab = cpu(c["ab"])
+    uv = torch.clamp(uv * ab[:, None, 0::2] + ab[:, None, 1::2], 0, 1)
+    ref = uv[:, :, None] * cpu(c["vr"])[:, None]                                   # (B,Q,L,2)
+    sb = lambda t_: t_.view(B, Q, -1).permute(1, 0, 2)                              # rows -> (Q,B,*)
+    tokens = cpu(c["tokens"]).permute(1, 0, 2)                                      # (S,B,E)
+    kpm = cpu(c["keep4"])[..., 0] == 0                                              # True = padding
+    seq = [masks["attn"].view(B * H, Q, Q), sb(masks["ln1"].view(R, E)), sb(masks["ln2"].view(R, E)),
+           sb(masks["ffn"].view(R, Fd)), sb(masks["ln3"].view(R, E))]
+    seq = [m for m, p in zip(seq, (p_attn, p_attn, p_attn, p_ffn, p_ffn)) if p > 0 and training]
+    with _InjectedDropout(seq) as inj:
+        out = layer(sb(x), None, tokens, query_pos=sb(pos), key_padding_mask=kpm, reference_points=ref,
+                    spatial_shapes=c["shapes"].cpu(), level_start_index=c["lsi"].cpu())
+    assert inj.i == len(seq)
+    z0 = margin["z0"].permute(1, 0, 2).reshape(R, Fd)
+    keep = masks["ffn"].view(R, Fd) != 0
+    masks["_relu_margin"] = z0.abs()[keep].min().item()
+    return out.permute(1, 0, 2).reshape(R, E)
+
+
 @pytest.mark.parametrize("B,Q,H,L,P,E,Fd,shapes,p_attn,p_ffn", [
     (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.0, 0.0),
     (2, 32, 4, 4, 2, 64, 128, ((16, 22), (8, 11), (4, 6), (2, 3)), 0.4, 0.0),
@@ -246,57 +331,100 @@ def _torch_layer(c, prm, dims, masks):
     (3, 256, 8, 4, 2, 256, 1024, ((50, 70), (25, 35), (13, 18), (7, 9)), 0.4, 0.1),
     (2, 128, 8, 4, 4, 256, 512, ((25, 35), (13, 18), (7, 9), (4, 5)), 0.0, 0.0),
 ])
-def test_fused_decoder_layer_vs_torch(B, Q, H, L, P, E, Fd, shapes, p_attn, p_ffn):
+def test_fused_decoder_layer_vs_oracle_fp64(B, Q, H, L, P, E, Fd, shapes, p_attn, p_ffn):
+    """The ONE-autograd-node decoder layer (19 + ~40 own launches) against the oracle's
+    DetrTransformerDecoderLayer in fp64, dropout off AND on: the counter-based masks of the forward
+    this test is about to run are pulled out of the library (``peek_next_rng`` + ``demf_dropout_mask``)
+    and injected into the oracle's dropout calls."""
     from demf_amd import fused
     dev = torch.device("cuda")
     fused.rng_state(dev, seed=99)
     c = _make_case(B, Q, H, L, P, E, Fd, shapes, seed=B * 100 + Q)
     dims = (B, Q, H, L, P, p_attn, p_ffn, 1e-5)
     R = B * Q
-    ones = lambda n: torch.ones(n, device="cuda")
+    ones = lambda n: torch.ones(n, dtype=torch.float64)
+    nxt = fused.peek_next_rng(dev)          # the (seed, step) the training forward below will draw
+    dm = lambda n, p, op: fused.dropout_mask(n, p, op, dev, state=nxt).double().cpu()
     masks = dict(
-        attn=fused.dropout_mask(B * H * Q * Q, p_attn, fused.OP_ATTN, dev) if p_attn else ones(B * H * Q * Q),
-        ln1=fused.dropout_mask(R * E, p_attn, fused.OP_LN1, dev) if p_attn else ones(R * E),
-        ln2=fused.dropout_mask(R * E, p_attn, fused.OP_LN2, dev) if p_attn else ones(R * E),
-        ffn=fused.dropout_mask(R * Fd, p_ffn, fused.OP_FFN, dev) if p_ffn else ones(R * Fd),
-        ln3=fused.dropout_mask(R * E, p_ffn, fused.OP_LN3, dev) if p_ffn else ones(R * E))
+        attn=dm(B * H * Q * Q, p_attn, fused.OP_ATTN) if p_attn else ones(B * H * Q * Q),
+        ln1=dm(R * E, p_attn, fused.OP_LN1) if p_attn else ones(R * E),
+        ln2=dm(R * E, p_attn, fused.OP_LN2) if p_attn else ones(R * E),
+        ffn=dm(R * Fd, p_ffn, fused.OP_FFN) if p_ffn else ones(R * Fd),
+        ln3=dm(R * E, p_ffn, fused.OP_LN3) if p_ffn else ones(R * E))
     leaves = [c["x"], c["pos"], c["pts"]] + [c["prm"][k] for k in PARAM_ORDER]
     gout = _r(R, E, seed=5)
 
-    def run(fn):
-        ins = [t.detach().clone().requires_grad_() for t in leaves]
+    def run(fn, f64):
+        conv = (lambda t_: t_.detach().double().cpu()) if f64 else (lambda t_: t_.detach().clone())
+        ins = [conv(t_).requires_grad_() for t_ in leaves]
         cc = dict(c, x=ins[0], pos=ins[1], pts=ins[2])
         prm = dict(zip(PARAM_ORDER, ins[3:]))
         out = fn(cc, prm)
-        out.backward(gout)
-        return out.detach(), [t.grad for t in ins]
+        out.backward(conv(gout))
+        return out.detach(), [t_.grad for t_ in ins]
 
-    want, gw = run(lambda cc, prm: _torch_layer(cc, prm, dims, masks))
+    want, gw = run(lambda cc, prm: _oracle_layer(cc, prm, dims, masks), True)
     got, gg = run(lambda cc, prm: fused.FusedDecoderLayer.apply(
         cc["x"], cc["pos"], cc["pts"], c["tokens"], c["keep4"], c["shapes"], c["lsi"], c["M"], c["ab"],
-        c["vr"], dims, True, *[prm[k] for k in PARAM_ORDER]))
+        c["vr"], dims, True, *[prm[k] for k in PARAM_ORDER]), False)
+    if p_attn or p_ffn:
+        assert fused.get_rng_state(dev) == [int(v) for v in nxt.tolist()], "the forward drew the peeked step"
     _close(got, want, 2e-4, "output")
     # The FFN's ReLU is the one discontinuity inside the layer: a pre-activation within the two
     # GEMMs' round-off of zero (~1e-6; there are R x F = up to 786 k of them) may resolve
     # differently, and that single element then shifts every upstream gradient by ~1e-3 relative
     # (traced with tools/debug_fused.py).  Element-wise agreement is therefore asserted when the
-    # reference's smallest |pre-activation| keeps its distance, and the relative L2 error always.
+    # oracle's smallest |pre-activation| keeps its distance, and the relative L2 error always.
     strict = masks["_relu_margin"] > 2e-5
-    bad = []
+    bad, worst = [], 0.0
     for name, a, b in zip(("x", "pos", "pts") + PARAM_ORDER, gg, gw):
         assert a is not None and b is not None, name
-        a, b = a.double(), b.double()
+        a, b = a.double().cpu(), b.double()
         err, rel = (a - b).abs().max().item(), ((a - b).norm() / b.norm()).item()
-        if rel > 5e-3 or (strict and err > 5e-4 * max(1.0, b.abs().max().item())):
+        worst = max(worst, rel)
+        if rel > 2e-3 or (strict and err > 5e-4 * max(1.0, b.abs().max().item())):
             bad.append(f"{name}: max {err:.2e} (scale {b.abs().max().item():.2f}) rel-l2 {rel:.2e}")
+    print(f"fused decoder layer vs fp64 oracle: worst gradient rel-L2 {worst:.2e}, relu margin "
+          f"{masks['_relu_margin']:.2e}")
     assert not bad, (masks["_relu_margin"], bad)
+    # a second training forward draws the NEXT step (fresh masks), and the first one's backward still
+    # re-derives ITS masks: (seed, step) travels with the node, not with the live counter
+    if p_attn or p_ffn:
+        ins = [t_.detach().clone().requires_grad_() for t_ in leaves]
+        call = lambda: fused.FusedDecoderLayer.apply(
+            ins[0], ins[1], ins[2], c["tokens"], c["keep4"], c["shapes"], c["lsi"], c["M"], c["ab"],
+            c["vr"], dims, True, *ins[3:])
+        fused.set_rng_state(dev, [99, int(nxt[1]) - 1])
+        o1 = call()
+        o2 = call()                                   # advances the counter past o1's step
+        assert not torch.equal(o1, o2), "two training forwards must draw different masks"
+        assert torch.equal(o1.detach(), got)
+        o1.backward(gout)
+        for name, a, b in zip(("x", "pos", "pts") + PARAM_ORDER, [t_.grad for t_ in ins], gg):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * max(1.0, float(b.abs().max()))), name
     # eval mode: no dropout whatever the rates
     with torch.no_grad():
         ev = fused.FusedDecoderLayer.apply(c["x"], c["pos"], c["pts"], c["tokens"], c["keep4"], c["shapes"],
                                            c["lsi"], c["M"], c["ab"], c["vr"], dims, False,
                                            *[c["prm"][k] for k in PARAM_ORDER])
-        nomask = {k: torch.ones_like(v) for k, v in masks.items() if torch.is_tensor(v)}
-        _close(ev, _torch_layer(c, c["prm"], dims, nomask), 2e-4, "eval output")
+        f64 = lambda t_: t_.detach().double().cpu()
+        cc = dict(c, x=f64(c["x"]), pos=f64(c["pos"]), pts=f64(c["pts"]))
+        _close(ev, _oracle_layer(cc, {k: f64(v) for k, v in c["prm"].items()}, dims,
+                                 {k: torch.ones_like(v) for k, v in masks.items() if torch.is_tensor(v)},
+                                 training=False), 2e-4, "eval output")
+
+
+def test_decoder_layers_draw_independent_dropout_streams():
+    """Stacked decoder layers (num_decoder_layers > 1) salt their dropout streams with the layer
+    index: same (seed, step), different masks - nn.Dropout draws them independently upstream."""
+    from demf_amd import fused
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=5)
+    st = fused.peek_next_rng(dev)
+    a = fused.dropout_mask(4096, 0.4, fused.OP_LN1, dev, state=st)
+    b = fused.dropout_mask(4096, 0.4, fused.OP_LN1 + 8, dev, state=st)
+    agree = float(((a != 0) == (b != 0)).float().mean())
+    assert 0.4 < agree < 0.65, agree           # independent Bernoulli(0.6) pairs agree 52 % of the time
 
 
 def test_vote_combine_matches_the_torch_specification():

@@ -115,3 +115,20 @@ def test_bench_two_ranks_prints_one_json_line():
     # whole-job aggregate: 2 ranks x 2 scenes x 3 steps over the max-over-ranks time
     assert abs(out["value"] - 2 * 2 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out            # rank 0 at N=1 only
+
+
+def test_plain_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun and without RANK in the environment: bench.py
+    re-executes itself under `python -m torch.distributed.run --nproc-per-node 2` (the reference's
+    launcher is the same one line: tools/dist_train.sh:8-9) and rank 0 prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(DEMF_SHARE_DEVICE="1", DEMF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=ROOT, MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "2"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"

@@ -14,12 +14,13 @@ c = T._make_case(B, Q, H, L, P, E, Fd, shapes, seed=B * 100 + Q)
 dims = (B, Q, H, L, P, p_attn, p_ffn, 1e-5)
 R = B * Q
 ones = lambda n: torch.ones(n, device="cuda")
+nxt = fused.peek_next_rng(dev)   # the (seed, step) the training forward below draws
 masks = dict(
-    attn=fused.dropout_mask(B * H * Q * Q, p_attn, fused.OP_ATTN, dev) if p_attn else ones(B * H * Q * Q),
-    ln1=fused.dropout_mask(R * E, p_attn, fused.OP_LN1, dev) if p_attn else ones(R * E),
-    ln2=fused.dropout_mask(R * E, p_attn, fused.OP_LN2, dev) if p_attn else ones(R * E),
-    ffn=fused.dropout_mask(R * Fd, p_ffn, fused.OP_FFN, dev) if p_ffn else ones(R * Fd),
-    ln3=fused.dropout_mask(R * E, p_ffn, fused.OP_LN3, dev) if p_ffn else ones(R * E))
+    attn=fused.dropout_mask(B * H * Q * Q, p_attn, fused.OP_ATTN, dev, state=nxt) if p_attn else ones(B * H * Q * Q),
+    ln1=fused.dropout_mask(R * E, p_attn, fused.OP_LN1, dev, state=nxt) if p_attn else ones(R * E),
+    ln2=fused.dropout_mask(R * E, p_attn, fused.OP_LN2, dev, state=nxt) if p_attn else ones(R * E),
+    ffn=fused.dropout_mask(R * Fd, p_ffn, fused.OP_FFN, dev, state=nxt) if p_ffn else ones(R * Fd),
+    ln3=fused.dropout_mask(R * E, p_ffn, fused.OP_LN3, dev, state=nxt) if p_ffn else ones(R * E))
 prm = {k: v.clone().requires_grad_() for k, v in c["prm"].items()}
 gout = T._r(R, E, seed=5)
 fused._DEBUG = {}

@@ -8,6 +8,12 @@ for r in csv.DictReader(open(path)):
     if r["Counter_Name"] == counter:
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
 print("kernel,calls,mean_%s_KiB,max_%s_KiB" % (counter, counter))
+# whole-step total (every kernel, library launches included): steps = launches of the once-per-step
+# 20000 -> 2048 FPS chain (warm-up, timed, repeat and eager-timing steps of bench.py alike)
+steps = max([len(v) for k, v in agg.items() if "fps_reg_kernel<1024, 20>" in k] or [0])
+if steps:
+    tot = sum(sum(v) for v in agg.values())
+    print('"__TOTAL_PER_STEP__",%d,%.1f,%.1f' % (steps, tot / steps, tot / steps))
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     if "demf::" in k or sum(v) > 1e5:
         print('"%s",%d,%.1f,%.1f' % (k[:110], len(v), sum(v) / len(v), max(v)))
