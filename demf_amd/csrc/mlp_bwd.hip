@@ -1,0 +1,526 @@
+// Fused backward of one shared-MLP layer for gfx950: input gradient, weight gradient and the
+// BatchNorm-backward sums of the layer below from ONE pass over the layer's saved output.
+//
+// Reference: the backward of Conv2d(1x1) -> BatchNorm2d(train) -> ReLU inside mmdet3d's PointSAModule
+// stacks (built by the reference at demf/modeling/heads/class_agnostic_vote_head.py:383 and by the
+// backbone config configs/demf/demf_votenet.py:48-62), which autograd runs as separate passes.
+//
+// Until round 2 a layer's backward was two launches here - demf_mlp_gemm_bwd_dx_red (dX = dY.W + the
+// sums of layer l-1) and demf_mlp_gemm_bwd_dw (dW = dY^T.act(Y_{l-1})) - each re-reading Y_l (and the
+// upstream gradient) and each re-doing the BN-backward transform dY = gi*dZ + a*y + b, and in the
+// fp32-grade mode (three bf16 terms per operand, csrc/mlp.hip) each splitting its operands per USE.
+// Here one workgroup of 4 or 8 waves walks 32-row slabs and
+//   * builds the dY tile ONCE: every wave owns one 32-channel slice of it (32 rows x 32 channels),
+//     loads it as 4-row x 4-channel register patches (full 128-byte lines), applies the BN-backward
+//     transform, splits it ONCE into bf16 planes h|m|l and leaves those planes in LDS in BOTH
+//     orientations - [row][channel] for the dX contraction (reduction over channels) and
+//     [channel][row] for the dW contraction (reduction over rows) - 16-byte chunks XOR-swizzled so
+//     that the MFMA fragment reads (ds_read_b128, 8 consecutive rows) are conflict-free without padding;
+//   * keeps the layer weight W as MFMA B fragments in REGISTERS for the whole launch (split once at
+//     kernel start), so dX = dY.W needs no weight staging at all; a wave contracts one K tile over a channel
+//     half and the two partial tiles of a K tile meet in an fp32 LDS tile in two ordered rounds of
+//     plain store / read-add-write on disjoint row chunks (LDS float atomics were measured at ~170
+//     cycles per wave instruction on gfx950: 1.15 ms of a 1.6 ms launch - not an option);
+//   * stages act(Y_{l-1}) - BN + ReLU of the layer below, split once - as [k][row] planes shared by
+//     the waves of a row group, the B operand of dW += dY^T.act(Y_{l-1}); dW tiles stay in
+//     accumulators for the whole row range of the workgroup and are flushed once;
+//   * finishes dX out of the LDS tile with coalesced float4 rows: either stores it and takes the BN-
+//     backward sums of layer l-1 on the way (RED), or - first layer of SA1, 4-float input rows, no input
+//     gradient - never stores it and takes the raw sums of layer 0's whole backward instead (FIRST, see
+//     mlp_first_finish_k in csrc/mlp.hip).
+// Algorithmic HBM bytes per row: 4*(N [Y_l] + N [G, dense only] + K [Y_{l-1}] + K [dX, RED only]).
+#include "common.h"
+
+namespace demf {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x4 = __bf16 __attribute__((ext_vector_type(4)));
+using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+
+struct FusedBwdArgs {
+  int R, N, K, ns;
+  const float* Yl;    // (R x N) pre-BN output of this layer
+  const float* G;     // dense upstream gradient (R x N), or null
+  const float* dP;    // sparse: pooled gradient (R/ns x N)
+  const int* arg;     //         arg-max slot   (R/ns x N)
+  const float* vec;   // 5 x N backward vectors of this layer (scale, shift, gi, a, b)
+  const float* Xp;    // (R x K) pre-BN output of layer l-1
+  const float* pss;   // [scale|shift] of layer l-1 (2K)
+  const float* pmi;   // [mean|invstd] of layer l-1 (2K)
+  const float* W;     // (N x K) weight of this layer
+  float* dX;          // (R x K) gradient of layer l-1's activation (RED), unused for FIRST
+  float* dW;          // (N x K) accumulated (arrives zeroed)
+  double* g12;        // RED: sum dZ | sum dZ*xhat of layer l-1 (2K), accumulated
+  const float* fX;    // FIRST: (R x 4) input rows of layer 0
+  double* fsum;       // FIRST: g1(K) | g2(K) | P(K x 4) | Q(K x 4) | cx(4), accumulated
+};
+
+// one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
+template <int P>
+__device__ __forceinline__ void split_planes(float x, __bf16 (&o)[P]) {
+  o[0] = (__bf16)x;
+  if constexpr (P == 3) {
+    const float r = x - (float)o[0];
+    o[1] = (__bf16)r;
+    o[2] = (__bf16)(r - (float)o[1]);
+  }
+}
+
+// Two fp32 values -> P packed bf16 pairs (low half = a, high half = b): one v_cvt_pk_bf16_f32 per plane,
+// the differences on both elements at once.  Pairs are formed along ROWS (same channel, rows j / j+1):
+// the [channel][row] planes take them as they are, the [row][channel] planes re-pair two channels with
+// one v_perm_b32.
+using f32x2 = float __attribute__((ext_vector_type(2)));
+template <int P>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[P]) {
+  const f32x2 x = {a, b};
+  const bf16x2 h = __builtin_convertvector(x, bf16x2);
+  o[0] = __builtin_bit_cast(unsigned, h);
+  if constexpr (P == 3) {
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r, bf16x2);
+    o[1] = __builtin_bit_cast(unsigned, m);
+    const f32x2 l = r - __builtin_convertvector(m, f32x2);
+    o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+  }
+}
+// (lo16(p0) | lo16(p1) << 16) and (hi16(p0) | hi16(p1) << 16)
+__device__ __forceinline__ unsigned pair_lo(unsigned p0, unsigned p1) { return __builtin_amdgcn_perm(p1, p0, 0x05040100u); }
+__device__ __forceinline__ unsigned pair_hi(unsigned p0, unsigned p1) { return __builtin_amdgcn_perm(p1, p0, 0x07060302u); }
+
+// byte offset of 16-byte chunk `chunk` (0..3) of 64-byte row `row`.  Chunks are XOR-swizzled by bits 2-3
+// of the row: a ds_read_b128 is served in lane groups {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32),
+// and within each group the four rows that share row & 3 (= the same 16-dword bank window) differ in
+// (row >> 2) & 3, so a fragment read (lane = row, same chunk index) touches all 64 banks exactly once.
+// (Measured with the earlier (row >> 1) & 3: SQ_LDS_BANK_CONFLICT = half of all LDS cycles.)
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int P>
+__device__ __forceinline__ void mfma_planes(f32x16& acc, const bf16x8 (&a)[P], const bf16x8 (&b)[P]) {
+  if constexpr (P == 3) {   // the six products of weight >= 2^-16, smallest first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  }
+}
+
+// NTN = N/32 channel slices, KT = K/32, KG = waves that share one channel slice (they split the K tiles,
+// KTW each, and the rows of the transform).  A workgroup = NTN*KG waves on one 32-row slab at a time;
+// 4-wave workgroups run two per CU.  Wave w -> nt = w % NTN, kg = w / NTN.
+template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI>   // CM 1 bf16 / 2 three-term ; EPI 0 RED / 1 FIRST
+__global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_fused_kernel(FusedBwdArgs p) {
+  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int N = NTN * 32, K = KT * 32;
+  constexpr int NW = NTN * KG;              // waves per workgroup
+  constexpr int NT = 64 * NW;               // threads
+  constexpr int RS = 32;                    // rows per slab
+  constexpr int KTW = KT / KG;              // K tiles per wave
+  constexpr int CW = 4 / KG;                // channels per lane patch of the dY transform (4 rows x CW)
+  constexpr int LPB = 32 / CW;              // lanes per 4-row block of the transform
+  constexpr int QK = K / 4;                 // float4 per dX row
+  constexpr int ER = NT / QK;               // rows per epilogue pass (2 passes per slab)
+  constexpr int NH = NW / KT;               // dX: waves per K tile = partial tiles to fold (channel halves)
+  constexpr int SL = NTN / NH;              // dX: channel slices a wave contracts
+  constexpr int CR = 16 / NH;               // accumulator registers per row chunk of the ordered rounds
+  static_assert(NW % KT == 0 && NH >= 1 && NTN % NH == 0 && SL >= 1, "dX wave map");
+  static_assert(KG >= 1 && KTW >= 1 && KT % KG == 0 && (NW == 4 || NW == 8), "unsupported shape");
+  static_assert(2 * ER == RS && 4 * (K / 64) == NW, "epilogue / staging maps");
+  static_assert(EPI == 0 || (!SPARSE), "FIRST is a dense layer");
+  constexpr int REGB = P * 2 * 2048;        // bytes per channel-slice region: P planes x 2 orientations
+  constexpr int XATB = P * K * 64;          // bytes of the act(Y_{l-1}) planes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_reg = smem;                                       // [NTN][2 orientations][P][32 x 64 B]
+  char* s_xat = s_reg + NTN * REGB;                         // [P][K x 64 B]
+  float* s_dx = reinterpret_cast<float*>(s_xat + XATB);     // [RS][K] fp32
+  float* s_vy = s_dx + RS * K;                              // 5N
+  float* s_px = s_vy + 5 * N;                               // pss (2K) | pmi (2K)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nt = wave % NTN, kg = wave / NTN;     // dW: channel slice nt, K tiles kg*KTW ..
+  const int dkt = wave % KT, dnh = wave / KT;     // dX: K tile dkt, channel slices dnh*SL ..
+  for (int i = tid; i < 5 * N; i += NT) s_vy[i] = p.vec[i];
+  for (int i = tid; i < 2 * K; i += NT) { s_px[i] = p.pss[i]; s_px[2 * K + i] = p.pmi[i]; }
+
+  // ---- the weight as B fragments of dX = dY.W, resident for the whole launch --------------------
+  // B^T[col j = k][red = n]: lane (k = 32*dkt + lr, n = 32*(dnh*SL + sl) + 16*s + 8*lh + e)
+  bf16x8 wf[SL][2][P];
+#pragma unroll
+  for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      __bf16 t[8][P];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        split_planes<P>(p.W[(size_t)(32 * (dnh * SL + sl) + 16 * s + 8 * lh + e) * K + 32 * dkt + lr], t[e]);
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[sl][s][q][e] = t[e][q];
+    }
+  f32x16 dwacc[KTW];
+#pragma unroll
+  for (int kk = 0; kk < KTW; ++kk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dwacc[kk][r] = 0.f;
+
+  // ---- per-lane slots ---------------------------------------------------------------------------
+  // dY transform: 4 rows x CW channels; the KG waves of a region split its 32 rows
+  const int cl = lane % LPB, rb = lane / LPB;
+  const int t_rl = (32 / KG) * kg + 4 * rb;          // first of the lane's 4 rows inside the 32-row group
+  const int t_c0 = CW * cl;                          // first of its CW channels inside the slice
+  const int t_col = 32 * nt + t_c0;                  // ... inside the layer
+  // act(Y_{l-1}) staging: a wave takes 8 rows x 64 channels of the 32 x K tile, a lane 4 rows x 2
+  // channels.  Lanes 0-7 / 8-15 of a 16-lane store group take the two 4-row blocks of the same 16
+  // channels, so that the [k][row] stores of a group spread over 8 of the 16 bank slots (2-way; with one
+  // row block per group they were 4-way conflicted).
+  constexpr int XU = K / 64;                         // 64-channel units per row block
+  const int x_c2 = 32 * (wave % XU) + ((lane & 7) | ((lane >> 4) << 3));
+  const int x_rl = 8 * (wave / XU) + 4 * ((lane >> 3) & 1);
+  // epilogue: fixed float4 column of the dX tile, rows e_r0 + i*ER
+  const int e_cq = tid % QK, e_r0 = tid / QK;
+  using vecT = float __attribute__((ext_vector_type(CW)));
+  vecT ry[4], rg[4];                                 // raw Y_l rows, raw upstream rows (dense)
+  using ivecT = int __attribute__((ext_vector_type(CW)));
+  vecT rdp;                                          // sparse: pooled gradient of the lane's group
+  ivecT rarg;                                        //         and its arg-max slots
+  float2 rx[4];                                      // raw Y_{l-1}
+  int r_slot = 0;
+  char* reg_base = s_reg + nt * REGB;
+  char* xat_base = s_xat;
+
+  // Rows beyond R are read from row R-1 (a valid address, no exec-mask branch per load) and zeroed by
+  // the transform.
+  auto fetch = [&](int slab) {
+    const int row0 = slab * RS;
+    const int last = p.R - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(row0 + t_rl + j, last);
+      ry[j] = *reinterpret_cast<const vecT*>(p.Yl + (size_t)row * N + t_col);
+      if constexpr (!SPARSE) rg[j] = *reinterpret_cast<const vecT*>(p.G + (size_t)row * N + t_col);
+      const int xrow = min(row0 + x_rl + j, last);
+      rx[j] = *reinterpret_cast<const float2*>(p.Xp + (size_t)xrow * K + 2 * x_c2);
+    }
+    if constexpr (SPARSE) {
+      // the lane's 4 rows start at a multiple of 4 and ns % 4 == 0: one pooled group for all of them
+      const int row = min(row0 + t_rl, last);
+      const int rp = row / p.ns;
+      r_slot = (row0 + t_rl) - rp * p.ns;
+      rdp = *reinterpret_cast<const vecT*>(p.dP + (size_t)rp * N + t_col);
+      rarg = *reinterpret_cast<const ivecT*>(p.arg + (size_t)rp * N + t_col);
+    }
+  };
+
+  const int nslab = (p.R + RS - 1) / RS;
+  int slab = blockIdx.x;
+  if (slab < nslab) fetch(slab);
+  // (measured: staggering the start of the second workgroup per CU by 0.5 ... 4 k cycles changes nothing)
+  // running column sums of the epilogue
+  float es1[4] = {0.f, 0.f, 0.f, 0.f}, es2[4] = {0.f, 0.f, 0.f, 0.f};
+  float fs[EPI == 1 ? 4 : 1][8];
+  float fcx[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fs[c][q] = 0.f;
+  }
+  __syncthreads();
+
+  for (; slab < nslab; slab += gridDim.x) {
+    const int row0 = slab * RS;
+    // ---- [A] dY = gi*dZ + a*y + b on the lane's patch, split once, both orientations into LDS -------
+    {
+      const bool tail = row0 + RS > p.R;                     // (uniform) rows beyond R become zeros
+      unsigned pr[CW][2][P];                                 // [channel][row pair][plane]
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        const int c = t_col + e;
+        const float sc = s_vy[c], sh = s_vy[N + c], gi = s_vy[2 * N + c], va = s_vy[3 * N + c], vb = s_vy[4 * N + c];
+        float dy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float y = ry[j][e];
+          const bool on = __builtin_fmaf(y, sc, sh) > 0.f;
+          float dz;
+          if constexpr (SPARSE) dz = (on && rarg[e] == r_slot + j) ? rdp[e] : 0.f;
+          else dz = on ? rg[j][e] : 0.f;
+          dy[j] = __builtin_fmaf(gi, dz, __builtin_fmaf(va, y, vb));
+          if (tail && row0 + t_rl + j >= p.R) dy[j] = 0.f;
+        }
+        split_pair<P>(dy[0], dy[1], pr[e][0]);
+        split_pair<P>(dy[2], dy[3], pr[e][1]);
+      }
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        // [channel][row]: the lane's 4 consecutive rows of channel t_c0 + e = its two row pairs
+#pragma unroll
+        for (int e = 0; e < CW; ++e)
+          *reinterpret_cast<uint2*>(reg_base + (P + q) * 2048 + swz(t_c0 + e, t_rl >> 3) + 2 * (t_rl & 7)) =
+              make_uint2(pr[e][0][q], pr[e][1][q]);
+        // [row][channel]: CW consecutive channels of row t_rl + j
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          char* d = reg_base + q * 2048 + swz(t_rl + j, t_c0 >> 3) + 2 * (t_c0 & 7);
+          const int jp = j >> 1;
+          if constexpr (CW == 4) {
+            *reinterpret_cast<uint2*>(d) =
+                (j & 1) ? make_uint2(pair_hi(pr[0][jp][q], pr[1][jp][q]), pair_hi(pr[2][jp][q], pr[3][jp][q]))
+                        : make_uint2(pair_lo(pr[0][jp][q], pr[1][jp][q]), pair_lo(pr[2][jp][q], pr[3][jp][q]));
+          } else {
+            *reinterpret_cast<unsigned*>(d) = (j & 1) ? pair_hi(pr[0][jp][q], pr[1][jp][q])
+                                                      : pair_lo(pr[0][jp][q], pr[1][jp][q]);
+          }
+        }
+      }
+      // act(Y_{l-1}) = relu(y*scale + shift) as [k][row] planes
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * x_c2 + e;
+        const float sc = s_px[k], sh = s_px[K + k];
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[j] = fmaxf(0.f, __builtin_fmaf(e == 0 ? rx[j].x : rx[j].y, sc, sh));
+          if (tail && row0 + x_rl + j >= p.R) a[j] = 0.f;
+        }
+        unsigned p0[P], p1[P];
+        split_pair<P>(a[0], a[1], p0);
+        split_pair<P>(a[2], a[3], p1);
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          *reinterpret_cast<uint2*>(xat_base + q * (K * 64) + swz(k, x_rl >> 3) + 2 * (x_rl & 7)) =
+              make_uint2(p0[q], p1[q]);
+      }
+    }
+    // ---- [B] next slab's rows in flight underneath the MFMA phase ----------------------------------
+    if (slab + (int)gridDim.x < nslab) fetch(slab + (int)gridDim.x);
+    lds_barrier();        // planes of every wave in place; the last epilogue is done with the dX tile
+    // ---- [C] dW += dY^T.act(Y_{l-1}); dX partial over this wave's channel slice ----------------------
+    f32x16 pa;
+    {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 at[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          at[q] = *reinterpret_cast<const bf16x8*>(reg_base + (P + q) * 2048 + swz(lr, 2 * t + lh));
+#pragma unroll
+        for (int kk = 0; kk < KTW; ++kk) {
+          bf16x8 bx[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q)
+            bx[q] = *reinterpret_cast<const bf16x8*>(xat_base + q * (K * 64) +
+                                                     swz(32 * (kg * KTW + kk) + lr, 2 * t + lh));
+          mfma_planes<P>(dwacc[kk], at, bx);
+        }
+      }
+      // dX tile (32 rows x K tile dkt) over this wave's SL channel slices: A fragments out of those
+      // slices' [row][channel] planes, B = the resident weight fragments
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 a[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q)
+            a[q] = *reinterpret_cast<const bf16x8*>(s_reg + (dnh * SL + sl) * REGB + q * 2048 + swz(lr, 2 * s + lh));
+          mfma_planes<P>(pa, a, wf[sl][s]);
+        }
+    }
+    // The NH partial tiles of a K tile meet in the fp32 LDS tile in NH ordered rounds: in round j wave
+    // (dkt, dnh) owns row chunk (dnh + j) % NH (32/NH rows = CR accumulator registers) - the first round
+    // stores, the others read-add-write; chunks are disjoint within a round, a barrier separates rounds.
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int c = (dnh + j) % NH;
+      float* d = s_dx + (size_t)(4 * lh) * K + 32 * dkt + lr;
+#pragma unroll
+      for (int cc = 0; cc < NH; ++cc) {
+        if (cc != c) continue;                 // (static register indices: select the chunk by unrolling)
+#pragma unroll
+        for (int i = 0; i < CR; ++i) {
+          const int r = cc * CR + i;
+          float* q = d + ((r & 3) + 8 * (r >> 2)) * K;
+          if (j == 0) *q = pa[r];
+          else *q += pa[r];
+        }
+      }
+      lds_barrier();
+    }
+    // ---- [D] dX rows out of the LDS tile: coalesced float4, + the sums of the layer below ------------
+    {
+      const int srow0 = slab * RS;
+      const float4 sc0 = *reinterpret_cast<const float4*>(s_px + 4 * e_cq);
+      const float4 sh0 = *reinterpret_cast<const float4*>(s_px + K + 4 * e_cq);
+      const float4 mu0 = *reinterpret_cast<const float4*>(s_px + 2 * K + 4 * e_cq);
+      const float4 is0 = *reinterpret_cast<const float4*>(s_px + 3 * K + 4 * e_cq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rl = e_r0 + i * ER, row = srow0 + rl;
+        const float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
+        if (row < p.R) {
+          const float4 y = *reinterpret_cast<const float4*>(p.Xp + (size_t)row * K + 4 * e_cq);
+          float dz[4];
+          dz[0] = __builtin_fmaf(y.x, sc0.x, sh0.x) > 0.f ? dx.x : 0.f;
+          dz[1] = __builtin_fmaf(y.y, sc0.y, sh0.y) > 0.f ? dx.y : 0.f;
+          dz[2] = __builtin_fmaf(y.z, sc0.z, sh0.z) > 0.f ? dx.z : 0.f;
+          dz[3] = __builtin_fmaf(y.w, sc0.w, sh0.w) > 0.f ? dx.w : 0.f;
+          const float xh[4] = {(y.x - mu0.x) * is0.x, (y.y - mu0.y) * is0.y, (y.z - mu0.z) * is0.z,
+                               (y.w - mu0.w) * is0.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            es1[c] += dz[c];
+            es2[c] = __builtin_fmaf(dz[c], xh[c], es2[c]);
+          }
+          if constexpr (EPI == 0) {
+            *reinterpret_cast<float4*>(p.dX + (size_t)row * K + 4 * e_cq) = dx;
+          } else {
+            const float4 x = *reinterpret_cast<const float4*>(p.fX + (size_t)row * 4);
+            const float yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              fs[c][0] = __builtin_fmaf(dz[c], x.x, fs[c][0]);
+              fs[c][1] = __builtin_fmaf(dz[c], x.y, fs[c][1]);
+              fs[c][2] = __builtin_fmaf(dz[c], x.z, fs[c][2]);
+              fs[c][3] = __builtin_fmaf(dz[c], x.w, fs[c][3]);
+              fs[c][4] = __builtin_fmaf(yv[c], x.x, fs[c][4]);
+              fs[c][5] = __builtin_fmaf(yv[c], x.y, fs[c][5]);
+              fs[c][6] = __builtin_fmaf(yv[c], x.z, fs[c][6]);
+              fs[c][7] = __builtin_fmaf(yv[c], x.w, fs[c][7]);
+            }
+            if (e_cq == 0) { fcx[0] += x.x; fcx[1] += x.y; fcx[2] += x.z; fcx[3] += x.w; }
+          }
+        }
+      }
+    }
+    // (no barrier here: the next [A] writes planes that nobody reads before the next barrier, and the dX
+    // tile is only written again after it)
+  }
+
+  // ---- flush: dW tiles (row groups folded through LDS first), column sums ---------------------------
+  __syncthreads();
+  float* s_red = reinterpret_cast<float*>(smem);             // the plane regions are free now
+  {
+#pragma unroll
+    for (int kk = 0; kk < KTW; ++kk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = 32 * (kg * KTW + kk) + lr;
+        atomicAdd(p.dW + (size_t)n * K + k, dwacc[kk][r]);
+      }
+  }
+  // column sums: lanes with the same float4 column inside a wave first, then the 8 waves through LDS
+  constexpr int NV = EPI == 1 ? 8 + 32 + 4 : 8;
+  float v[NV];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { v[c] = es1[c]; v[4 + c] = es2[c]; }
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[8 + c * 8 + q] = fs[c][q];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[40 + c] = fcx[c];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int m = QK; m < 64; m <<= 1) v[i] += __shfl_xor(v[i], m);
+  if (lane < QK) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s_red[(wave * QK + lane) * NV + i] = v[i];
+  }
+  __syncthreads();
+  // (a wave's lanes l, l + QK, ... hold the same float4 column at different rows: folded by the shuffles
+  // above; NW partials per column remain)
+  for (int i = tid; i < QK * NV; i += NT) {
+    const int cq = i / NV, q = i % NV;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[(w * QK + cq) * NV + q];
+    if (q < 8) {
+      const int col = 4 * cq + (q & 3);
+      if constexpr (EPI == 0) atomicAdd(p.g12 + (q >> 2) * K + col, (double)t);
+      else atomicAdd(p.fsum + (q >> 2) * K + col, (double)t);
+    } else if (q < 40) {
+      // FIRST: P (K x 4) at 2K, Q (K x 4) at 6K
+      const int c = (q - 8) >> 3, s = (q - 8) & 7, col = 4 * cq + c;
+      atomicAdd(p.fsum + (s < 4 ? 2 * K + col * 4 + s : 6 * K + col * 4 + (s - 4)), (double)t);
+    } else if (cq == 0) {
+      atomicAdd(p.fsum + 10 * K + (q - 40), (double)t);
+    }
+  }
+}
+
+template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI>
+static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
+  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int N = NTN * 32, K = KT * 32, NW = NTN * KG;
+  const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      set_error("mlp_bwd_fused: cannot reserve %zu bytes of LDS", bytes);
+      return DEMF_ELAUNCH;
+    }
+    configured = true;
+  }
+  const int nslab = (a.R + 31) / 32;
+  static const int cap_env = [] { const char* v = getenv("DEMF_BWD_FUSED_GRID"); return v ? atoi(v) : 0; }();
+  const int cap = cap_env ? cap_env : 256 * (8 / NW);  // persistent: 8 waves per CU
+  const int gx = nslab < cap ? nslab : cap;
+  hipLaunchKernelGGL((mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI>), dim3(gx), dim3(64 * NW), bytes, s, a);
+  return check_launch("mlp_bwd_fused");
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+static int fused_supported(int R, int N, int K, int ns, int sparse, int first) {
+  const int cm = compute_mode();
+  if (cm != 1 && cm != 2) return 0;
+  if (R < 1) return 0;
+  if (sparse && (ns < 4 || ns % 4 != 0 || R % ns != 0)) return 0;
+  if (first) return (N == 64 && K == 64 && !sparse) ? 1 : 0;
+  return ((N == 128 && K == 64) || (N == 128 && K == 128) || (N == 64 && K == 64)) ? 1 : 0;
+}
+
+extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, const int* arg,
+                                  int ns, const float* Y, const float* vec6, const float* W,
+                                  const float* Yprev, const float* scale_shift_prev,
+                                  const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
+                                  const float* X0, double* first_sums, demf_stream_t stream) {
+  const bool sparse = G == nullptr, first = first_sums != nullptr;
+  DEMF_REQUIRE(fused_supported(R, N, K, ns, sparse, first),
+               "mlp_bwd_fused: unsupported shape / mode R=%d N=%d K=%d ns=%d sparse=%d first=%d mode=%d",
+               R, N, K, ns, (int)sparse, (int)first, compute_mode());
+  DEMF_REQUIRE(Y && vec6 && W && Yprev && scale_shift_prev && mean_invstd_prev && dW &&
+                   (G || (dP && arg)) && (first ? (X0 != nullptr) : (dX && g12_prev)),
+               "mlp_bwd_fused: null pointer");
+  FusedBwdArgs a{};
+  a.R = R; a.N = N; a.K = K; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
+  a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.dX = dX; a.dW = dW;
+  a.g12 = g12_prev; a.fX = X0; a.fsum = first_sums;
+  hipStream_t s = (hipStream_t)stream;
+  const int cm = compute_mode();
+#define FGO(NTNv, KTv, KGv, SPv, EPv) \
+  return cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s)
+  if (first) { FGO(2, 2, 2, false, 1); }
+  if (N == 128 && K == 64) { if (sparse) { FGO(4, 2, 1, true, 0); } else { FGO(4, 2, 1, false, 0); } }
+  if (N == 128 && K == 128) { if (sparse) { FGO(4, 4, 2, true, 0); } else { FGO(4, 4, 2, false, 0); } }
+  if (sparse) { FGO(2, 2, 2, true, 0); } else { FGO(2, 2, 2, false, 0); }
+#undef FGO
+}

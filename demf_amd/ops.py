@@ -115,6 +115,8 @@ _COMPUTE_DTYPE = "f32"
 
 
 _COMPUTE_MODES = {"f32_native": 0, "bf16": 1, "f32x3": 2}
+# the library's mode (demf_set_compute_dtype); its initial value follows the same environment switch
+_COMPUTE_MODE = 0 if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else 2
 
 
 def set_compute_dtype(name):
@@ -137,7 +139,8 @@ def set_compute_dtype(name):
     else:
         raise ValueError("compute dtype must be 'f32' or one of %s" % sorted(_COMPUTE_MODES))
     _ffi.call("demf_set_compute_dtype", mode)
-    _COMPUTE_DTYPE = name
+    global _COMPUTE_MODE
+    _COMPUTE_DTYPE, _COMPUTE_MODE = name, mode
 
 
 def get_compute_dtype():
@@ -680,6 +683,19 @@ _OWN_GEMM_ROWS = int(__import__('os').environ.get('DEMF_OWN_GEMM_ROWS', '65536')
 _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0')))       # A/B switch
 _NO_RED_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_RED_FUSE', '0')))        # A/B switch
 _NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
+_NO_BWD_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_BWD_FUSE', '0')))        # A/B switch
+
+
+def _bwd_fused_ok(N, K, ns, sparse, first=False):
+    """Shapes / modes demf_mlp_bwd_fused covers (csrc/mlp_bwd.hip): one pass over a layer's saved
+    output for dX, dW and the sums of the layer below, instead of a dx and a dW launch."""
+    if _NO_BWD_FUSE or _COMPUTE_MODE not in (1, 2):
+        return False
+    if sparse and (ns < 4 or ns % 4):
+        return False
+    if first:
+        return N == 64 and K == 64 and not sparse
+    return (N, K) in ((128, 64), (128, 128), (64, 64))
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
@@ -907,6 +923,40 @@ class _SharedMLPPool(Function):
             dW = ws32[o32:o32 + N * K].view(N, K)
             o32 += N * K
             sparse = G is None
+            first_here = l == 1 and fuse_first
+            if l > 0 and ldx == K and _bwd_fused_ok(N, K, ns, sparse, first_here):
+                # ONE pass over Y_l: dX (or, for SA1's layer 1, the raw sums of layer 0's whole
+                # backward instead of dX), dW and layer l-1's BN-backward sums (csrc/mlp_bwd.hip)
+                grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
+                if ctx.bias_shapes[l] is not None:
+                    grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
+                    o32 += N
+                if first_here:
+                    N0 = K
+                    sums = ws64[o64:o64 + 10 * N0 + 4]
+                    o64 += 10 * N0 + 4
+                    _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), None, None, ns, _p(Ys[l]), _p(vec6),
+                              _p(W), _p(Ys[0]), _p(sss[0]), _p(mis[0]), None, _p(dW), None, _p(x),
+                              _p(sums), st)
+                    dW0 = ws32[o32:o32 + N0 * 4].view(N0, 4)
+                    o32 += N0 * 4
+                    dgamma0 = torch.empty(N0, dtype=torch.float32, device=dev)
+                    dbeta0 = torch.empty(N0, dtype=torch.float32, device=dev)
+                    _ffi.call("demf_mlp_first_finish", N0, R, _p(sums), _p(gammas[0]), _p(mis[0]),
+                              _p(dW0), _p(dgamma0), _p(dbeta0), st)
+                    grads[0], grads[1], grads[2] = dW0, dgamma0, dbeta0
+                    if ctx.bias_shapes[0] is not None:
+                        grads[5] = ws32[o32:o32 + N0].view(ctx.bias_shapes[0])
+                        o32 += N0
+                    break
+                dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+                g12_ready = ws64[o64:o64 + 2 * K]
+                o64 += 2 * K
+                _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), _p(dP if sparse else None),
+                          _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(Ys[l - 1]),
+                          _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12_ready), None, None, st)
+                G = dX
+                continue
             _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
                       _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(xprev),
                       _p(sss[l - 1] if l > 0 else None), _p(dW), st)

@@ -345,6 +345,22 @@ int demf_mlp_first_finish(int N0, long long count, double* sums, const float* ga
                           const float* mean_invstd0, float* dW0, float* dgamma0, float* dbeta0,
                           demf_stream_t stream);
 
+/* One pass over a layer's saved output for its whole backward (csrc/mlp_bwd.hip): what
+ * demf_mlp_gemm_bwd_dx_red + demf_mlp_gemm_bwd_dw do in two (or, with first_sums != NULL,
+ * demf_mlp_gemm_bwd_dx_first + demf_mlp_gemm_bwd_dw: dX is then not stored and X0 (R x 4) / first_sums
+ * take the place of dX / g12_prev).  The dY tile is rebuilt and split into bf16 planes once and feeds
+ * both contractions; W stays in registers.  Yprev (R x K) = pre-BN output of layer l-1, row stride K;
+ * dX row stride K; dW (N x K) accumulated (arrives zeroed).  Compute modes 1 (bf16) and 2 (fp32 as
+ * three bf16 terms) only; shapes (N,K) in {(128,64), (128,128), (64,64)}, ns % 4 == 0 when sparse
+ * (G == NULL); anything else returns DEMF_EINVAL and callers use the two-launch path.  Replaces the
+ * autograd backward of Conv2d -> BatchNorm2d -> ReLU in mmdet3d's PointSAModule stacks
+ * (configs/demf/demf_votenet.py:48-62; class_agnostic_vote_head.py:383). */
+int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, const int* arg, int ns,
+                       const float* Y, const float* vec6, const float* W, const float* Yprev,
+                       const float* scale_shift_prev, const float* mean_invstd_prev, float* dX,
+                       float* dW, double* g12_prev, const float* X0, double* first_sums,
+                       demf_stream_t stream);
+
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */
 int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G, const float* dP,

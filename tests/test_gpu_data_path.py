@@ -102,7 +102,7 @@ def test_data_path_output_through_the_hip_kernels_vs_oracle(tmp_path):
     inp = ref.pts_bbox_head.decoder_inputs(T["aggregated_points"], [torch.from_numpy(f).double() for f in feats],
                                            metas)
     vr = mt["valid_ratios"].contiguous()                                  # the product's own, from the metas
-    assert torch.allclose(vr.cpu().double(), inp["valid_ratios"], atol=1e-6), "valid ratios"
+    assert torch.allclose(vr.cpu().double(), inp["valid_ratios"].double(), atol=1e-6), "valid ratios"
     shapes = torch.tensor(spatial, dtype=torch.int64, device="cuda")
     R = B * Q
     raw = torch.zeros(R, 3 * H * L * P, device="cuda")                    # zero offsets / logits
@@ -112,7 +112,7 @@ def test_data_path_output_through_the_hip_kernels_vs_oracle(tmp_path):
     _ffi.call("demf_msda_prep_fwd", R, Q, H, L, P, agg.data_ptr(), mt["M"].data_ptr(), mt["ab"].data_ptr(),
               vr.data_ptr(), shapes.data_ptr(), raw.data_ptr(), loc.data_ptr(), w.data_ptr(), uvw.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
-    want = (inp["reference_points"][:, :, None] * inp["valid_ratios"][:, None]).reshape(R, 1, L, 1, 2)
+    want = (inp["reference_points"][:, :, None].double() * inp["valid_ratios"][:, None].double()).reshape(R, 1, L, 1, 2)
     got = loc.double().cpu()
     err = (got - want).abs().max().item()
     assert err <= 1e-4, f"reference points through msda_prep: {err:.2e}"

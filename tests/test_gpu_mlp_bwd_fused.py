@@ -1,0 +1,114 @@
+"""csrc/mlp_bwd.hip: the one-pass backward of a shared-MLP layer (dX + dW + the BN-backward sums of
+the layer below from one staged dY tile; W resident in registers; operands split into bf16 planes
+once) against (a) the two-launch path it replaces (demf_mlp_gemm_bwd_dx_red / _dx_first +
+demf_mlp_gemm_bwd_dw) on identical inputs and (b) an fp64 torch reference of the op chain
+(Conv1x1 -> train-mode BatchNorm -> ReLU, x L, max over ns: mmdet3d PointSAModule as the reference
+builds it, configs/demf/demf_votenet.py:48-62), in the fp32-grade and the bf16 compute mode."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # (groups, ns, ld, channels, x_grad)  - the layers the fused kernel takes are noted
+    (700, 64, 4, (64, 64, 128), False),       # SA1: L3 (128,64) sparse, L2 (64,64) FIRST
+    (333, 64, 4, (64, 64, 128), False),       # ... ragged last slab (R % 64 != 0 is impossible with ns=64; 333*64 rows)
+    (520, 32, 64, (128, 128, 128), True),     # L3 (128,128) sparse ns=32, L2 (128,128) dense
+    (45, 16, 64, (128, 128, 128), True),      # vote-aggregation-like, few rows (720: ragged 32-row slabs)
+    (1000, 4, 32, (64, 64, 64), True),        # (64,64) RED sparse ns=4 and dense
+    (2000, 1, 64, (128, 128, 64), True),      # ns = 1 (unpooled tail, two-launch path for the last layer); L2 (128,128) dense
+]
+
+
+def _make(Rp, ns, ld, chans, seed):
+    g = torch.Generator().manual_seed(seed)
+    R = Rp * ns
+    x = torch.randn(R, ld, generator=g, dtype=torch.float64) * 0.7 + 0.1
+    layers, k = [], ld
+    for n in chans:
+        layers.append((torch.randn(n, k, generator=g, dtype=torch.float64) / np.sqrt(k),
+                       1.0 + 0.2 * torch.randn(n, generator=g, dtype=torch.float64),
+                       0.1 * torch.randn(n, generator=g, dtype=torch.float64)))
+        k = n
+    layers[1][1][3] = -0.6                     # a negative BN scale below the fused layer
+    go = torch.randn(Rp, chans[-1], generator=g, dtype=torch.float64)
+    return x, layers, go
+
+
+def _run(x, layers, go, ns, xgrad):
+    from demf_amd import ops
+    xd = x.float().cuda().requires_grad_(xgrad)
+    ls = []
+    for W, gm, bt in layers:
+        n = W.shape[0]
+        ls.append((W.float().cuda().requires_grad_(), gm.float().cuda().requires_grad_(),
+                   bt.float().cuda().requires_grad_(), torch.zeros(n, device="cuda"),
+                   torch.ones(n, device="cuda")))
+    out = ops.shared_mlp_pool(xd, ns, ls, True)
+    out.backward(go.float().cuda())
+    grads = [t.grad for l in ls for t in l[:3]]
+    if xgrad:
+        grads.append(xd.grad)
+    return out.detach(), grads
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES)
+def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mode):
+    from demf_amd import ops
+    x, layers, go = _make(Rp, ns, ld, chans, seed=Rp + ns)
+    ops.set_compute_dtype(mode)
+    calls = []
+    from demf_amd import _ffi
+    orig = _ffi.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    try:
+        _ffi.call = spy
+        ops._NO_BWD_FUSE = False
+        out_f, g_f = _run(x, layers, go, ns, xgrad)
+        n_fused = calls.count("demf_mlp_bwd_fused")
+        calls.clear()
+        ops._NO_BWD_FUSE = True
+        out_u, g_u = _run(x, layers, go, ns, xgrad)
+        assert "demf_mlp_bwd_fused" not in calls
+    finally:
+        _ffi.call = orig
+        ops._NO_BWD_FUSE = False
+        ops.set_compute_dtype("f32")
+    assert n_fused >= 1, "the case must exercise the fused kernel"
+    assert torch.equal(out_f, out_u)
+    # same operands, same roundings (bf16 mode rounds dY, act(Y_{l-1}) and W at the same places in both
+    # paths); only the fp32 accumulation order differs
+    tol = 2e-5 if mode == "f32" else 3e-3   # (bf16: a re-rounded operand moves by one bf16 ulp)
+    for i, (a, b) in enumerate(zip(g_f, g_u)):
+        scale = max(1e-6, float(b.abs().max()))
+        err = float((a - b).abs().max())
+        assert err <= tol * scale, (i, err, scale)
+
+
+@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES[:4])
+def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
+    """fp32-grade mode against fp64 autograd of the same chain.  Gradients relative L2 (a single
+    ReLU / max-pool near-tie resolving differently in fp32 moves whole tensors by ~1e-3, see
+    tests/test_gpu_mlp.py, which does the on-branch comparison for every kernel variant)."""
+    from demf_amd import ops
+    x, layers, go = _make(Rp, ns, ld, chans, seed=Rp + ns)
+    xr = x.clone().requires_grad_(xgrad)
+    lr_ = [(W.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_())
+           for W, g, b in layers]
+    h = xr
+    for W, g, b in lr_:
+        h = F.relu(F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, 1e-5))
+    ref = h.view(Rp, ns, -1).max(1)[0]
+    ref.backward(go)
+    want = [t.grad for l in lr_ for t in l] + ([xr.grad] if xgrad else [])
+    ops._NO_BWD_FUSE = False
+    out, got = _run(x, layers, go, ns, xgrad)
+    assert float((out.double().cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    for i, (a, b) in enumerate(zip(got, want)):
+        rel = float((a.double().cpu() - b).norm() / b.norm())
+        assert rel <= 5e-3, (i, rel)

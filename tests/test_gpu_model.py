@@ -133,7 +133,9 @@ TARGET_NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_r
 # scale): 2x the worst value measured on MI355X for each case's qualified seed (printed by every run
 # as "[parity] worst ...").  The allowance term 2 x risk of the qualification stays; the cap is what
 # keeps a 10 % regression from hiding under it.
-GRAD_CAP = dict(mid=None, full2=None, full2p4=None, full8=None)
+# Worst observed: mid 7e-3 (r02) / 8.8e-3 (r03); full B=2 3e-2 / 7.8e-3; P=4 4e-2 / 3.7e-3; B=8 4e-2 / 4.8e-2
+# (which near-tie flips differs from run to run: atomics order), so each cap is 2x the larger one.
+GRAD_CAP = dict(mid=2e-2, full2=6e-2, full2p4=8e-2, full8=1e-1)
 
 
 def _parity(cfg, B, N, pyramid, in_shape, img_shape, seeds, cap=None):
@@ -252,6 +254,20 @@ def test_hot_path_bf16_full_config_batch_8(bf16_mode):
     worst = sorted(grads.items(), key=lambda kv: -kv[1])[:8]
     gn_g = np.sqrt(sum(v.double().pow(2).sum().item() for v in G["grads"].values()))
     gn_t = np.sqrt(sum(v.pow(2).sum().item() for v in T["grads"].values()))
+    dot = sum((G["grads"][n].double().cpu() * g.double()).sum().item() for n, g in T["grads"].items())
+    cosine = dot / (gn_g * gn_t)
+    # per stage: how far the gradient direction survives (cosine of the concatenated tensors)
+    def stage_cos(prefix):
+        names = [n for n in T["grads"] if n.startswith(prefix)]
+        a = torch.cat([G["grads"][n].double().cpu().reshape(-1) for n in names])
+        b = torch.cat([T["grads"][n].double().reshape(-1) for n in names])
+        return (a @ b / (a.norm() * b.norm())).item()
+    stages = {k: stage_cos(k) for k in ("pts_backbone.SA_modules.0", "pts_backbone.SA_modules.3",
+                                        "pts_backbone.FP_modules", "pts_bbox_head.vote_module",
+                                        "pts_bbox_head.vote_aggregation", "pts_bbox_head.decoder",
+                                        "pts_bbox_head.conv_pred")}
+    print("[bf16 full B=8] gradient cosine vs fp64: whole %.4f; per stage %s"
+          % (cosine, {k: "%.3f" % v for k, v in stages.items()}))
     print("[bf16 full B=8] seed %d; vote-stage rel-L2 %s; aggregated_indices identical: %s; total loss "
           "%.5f vs %.5f; per-loss rel %s; gradient norm %.4e vs %.4e; median gradient rel-L2 %.3e; worst %s"
           % (case["seed"], {k: "%.2e" % v for k, v in stage.items()}, same_agg, loss_g, loss_t,
