@@ -495,7 +495,7 @@ static int fused_supported(int R, int N, int K, int ns, int sparse, int first) {
   if (R < 1) return 0;
   if (sparse && (ns < 4 || ns % 4 != 0 || R % ns != 0)) return 0;
   if (first) return (N == 64 && K == 64 && !sparse) ? 1 : 0;
-  return ((N == 128 && K == 64) || (N == 128 && K == 128) || (N == 64 && K == 64)) ? 1 : 0;
+  return ((N == 128 && K == 64) || (N == 128 && K == 128) || (N == 64 && K == 64) || (N == 256 && K == 128)) ? 1 : 0;
 }
 
 extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, const int* arg,
@@ -521,6 +521,7 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
   if (first) { FGO(2, 2, 2, false, 1); }
   if (N == 128 && K == 64) { if (sparse) { FGO(4, 2, 1, true, 0); } else { FGO(4, 2, 1, false, 0); } }
   if (N == 128 && K == 128) { if (sparse) { FGO(4, 4, 2, true, 0); } else { FGO(4, 4, 2, false, 0); } }
+  if (N == 256 && K == 128) { if (sparse) { FGO(8, 4, 1, true, 0); } else { FGO(8, 4, 1, false, 0); } }
   if (sparse) { FGO(2, 2, 2, true, 0); } else { FGO(2, 2, 2, false, 0); }
 #undef FGO
 }

@@ -695,7 +695,7 @@ def _bwd_fused_ok(N, K, ns, sparse, first=False):
         return False
     if first:
         return N == 64 and K == 64 and not sparse
-    return (N, K) in ((128, 64), (128, 128), (64, 64))
+    return (N, K) in ((128, 64), (128, 128), (64, 64), (256, 128))
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 

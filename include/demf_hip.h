@@ -351,7 +351,7 @@ int demf_mlp_first_finish(int N0, long long count, double* sums, const float* ga
  * take the place of dX / g12_prev).  The dY tile is rebuilt and split into bf16 planes once and feeds
  * both contractions; W stays in registers.  Yprev (R x K) = pre-BN output of layer l-1, row stride K;
  * dX row stride K; dW (N x K) accumulated (arrives zeroed).  Compute modes 1 (bf16) and 2 (fp32 as
- * three bf16 terms) only; shapes (N,K) in {(128,64), (128,128), (64,64)}, ns % 4 == 0 when sparse
+ * three bf16 terms) only; shapes (N,K) in {(128,64), (128,128), (64,64), (256,128)}, ns % 4 == 0 when sparse
  * (G == NULL); anything else returns DEMF_EINVAL and callers use the two-launch path.  Replaces the
  * autograd backward of Conv2d -> BatchNorm2d -> ReLU in mmdet3d's PointSAModule stacks
  * (configs/demf/demf_votenet.py:48-62; class_agnostic_vote_head.py:383). */

@@ -15,6 +15,7 @@ CASES = [  # (groups, ns, ld, channels, x_grad)  - the layers the fused kernel t
     (700, 64, 4, (64, 64, 128), False),       # SA1: L3 (128,64) sparse, L2 (64,64) FIRST
     (333, 64, 4, (64, 64, 128), False),       # ... ragged last slab (R % 64 != 0 is impossible with ns=64; 333*64 rows)
     (520, 32, 64, (128, 128, 128), True),     # L3 (128,128) sparse ns=32, L2 (128,128) dense
+    (300, 16, 36, (128, 128, 256), True),     # SA3/SA4-like: L3 (256,128) sparse ns=16, L2 (128,128) dense
     (45, 16, 64, (128, 128, 128), True),      # vote-aggregation-like, few rows (720: ragged 32-row slabs)
     (1000, 4, 32, (64, 64, 64), True),        # (64,64) RED sparse ns=4 and dense
     (2000, 1, 64, (128, 128, 64), True),      # ns = 1 (unpooled tail, two-launch path for the last layer); L2 (128,128) dense
@@ -90,7 +91,7 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
         assert err <= tol * scale, (i, err, scale)
 
 
-@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES[:4])
+@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES[:5])
 def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
     """fp32-grade mode against fp64 autograd of the same chain.  Gradients relative L2 (a single
     ReLU / max-pool near-tie resolving differently in fp32 moves whole tensors by ~1e-3, see

@@ -7,7 +7,7 @@ import torch
 from demf_amd import _ffi, ops
 ops.set_compute_dtype(os.environ.get("MODE", "f32"))
 p = lambda t: None if t is None else t.data_ptr()
-SHAPES = [("SA1.L3", 1048576, 128, 64, 64), ("SA1.L2", 1048576, 64, 64, 0), ("SA2.L2", 262144, 128, 128, 0),
+SHAPES = [("SA2.L3", 262144, 256, 128, 32), ("SA1.L3", 1048576, 128, 64, 64), ("SA1.L2", 1048576, 64, 64, 0), ("SA2.L2", 262144, 128, 128, 0),
           ("AGG.L3", 32768, 128, 128, 16)]
 def timeit(fn, n=10):
     for _ in range(3): fn()
