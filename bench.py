@@ -35,8 +35,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
 # the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
 DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0, true>",
-                   "f32x3": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 2, true>",
-                   "bf16": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 1, true>"}
+                   "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2>",      # weight-resident forward (csrc/mlp.hip)
+                   "bf16": "mlp_fwd_res_kernel<4, 2, true, 1>"}
 DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
     "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
 MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",

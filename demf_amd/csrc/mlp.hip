@@ -977,219 +977,268 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   }
 }
 
-// ---- forward GEMM with the A rows streamed global -> LDS directly (global_load_lds_dwordx4) ---------
-// The register-staged kernel above keeps ONE K step of A per wave in flight (16 VGPRs; its 255 VGPRs
-// leave no room for a second) and a CU holds two such workgroups: ~32 KB in flight per CU, and
-// nothing is issued during a wave's 1.7 us MFMA burst - the memory system idles ~40 % of the time and
-// MFMA time adds serially to memory time (262 us = 178 + 84 at SA1's last layer).  Here the raw A rows
-// never pass through VGPRs: each wave owns a 3-stage LDS ring of its 32-row x 32-k slabs (4 KB each)
-// filled by LDS-direct loads issued two K steps ahead, so 2 x 4 KB per wave = 64 KB per CU are always
-// in flight (+ the weight slab), waves never wait for each other's A rows (the ring is wave-private:
-// no barrier for A), and the previous tile's output stores drain underneath the next tile's MFMAs:
-// every load a step needs is OLDER than those stores, so the step waits with s_waitcnt vmcnt(N>0)
-// instead of the vmcnt(0) the compiler emits for register prefetches in a loop.
-// The BN + ReLU prologue is applied on the LDS -> fragment read (8 VALU per float4).  16-byte chunks
-// of a row are XOR-swizzled by the row (chunk c of row r at position c ^ (r & 7)): LDS-direct places a
-// lane's 16 bytes at lane*16, so padding is impossible; the swizzle makes the fragment reads (same
-// chunk, 32 consecutive rows) 4-way instead of 32-way conflicted.
-// One 512-thread workgroup (8 waves x 32 rows = 256-row tiles) per CU; K % 32 == 0, N <= 128.
-constexpr int FL_NW = 8, FL_STG = 3;
-
-__device__ __forceinline__ void lds_dma16(const float* __restrict__ g, float* __restrict__ lds_base) {
-  // every lane's 16 bytes land at lds_base + lane * 16 (M0 = wave-uniform LDS byte address).  Inline
-  // asm on purpose: the compiler would otherwise guard every later ds_read with s_waitcnt vmcnt(0),
-  // i.e. wait for the stages that were just requested; the waits are placed by hand (wait_vm).
-  const unsigned m0 = __builtin_amdgcn_readfirstlane(
-      (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_base);
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(m0) : "memory", "m0");
+// ---- forward GEMM with the WEIGHT RESIDENT in LDS and free-running waves ---------------------------
+// mlp_gemm_kernel above restages the weight slab from L2 for every K step of every row tile and
+// separates the steps with workgroup barriers: at SA1's last layer (R = 1 M rows, 64 -> 128) every
+// 128-row tile costs 2 restagings + 4 barriers, the waves of a workgroup move in lockstep and the kernel
+// sits at 0.50 of the HBM roof with its VALU, MFMA and memory phases in series.
+// For layers whose whole weight fits LDS as split bf16 planes (N*K*2*P bytes: 48 KB for 128 x 64 in the
+// three-term mode) it is staged ONCE per workgroup; after that a wave needs nobody: it walks its own
+// 64-row units (two 32-row tiles), loads them as 4-channel register patches (full 256-byte rows), applies
+// the previous layer's BN + ReLU, splits the result once into bf16 planes in its PRIVATE LDS slab, and
+// runs the MFMAs against the resident weight planes - no workgroup barrier anywhere in the main loop, so
+// the eight waves of a CU drift apart and one's loads / transform / stores overlap another's MFMAs.
+// Epilogue as in mlp_gemm_kernel: raw output stored, column statistics (-> the in-kernel BN finalize by
+// the last workgroup), and the max-pool over ns = 16 / 32 / 64 rows on the extremum the sign of gamma
+// selects (a 64-row group = the wave's two tiles, folded in registers).
+// LDS rows are K bf16 = 128 B (K = 64); 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7): a
+// ds_read_b128 lane group {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} then touches every bank once.
+constexpr int FR_NW = 8;
+template <int KB>   // KB = bytes per row (K * 2)
+__device__ __forceinline__ int fr_swz(int row, int chunk) {
+  if constexpr (KB == 128) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  else return row * KB + ((chunk ^ (row & 15)) << 4);
+}
+using f32x2_t = float __attribute__((ext_vector_type(2)));
+using bf16x2_t = __bf16 __attribute__((ext_vector_type(2)));
+template <int P>
+__device__ __forceinline__ void fr_split_pair(float a, float b, unsigned (&o)[P]) {
+  const f32x2_t x = {a, b};
+  const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
+  o[0] = __builtin_bit_cast(unsigned, h);
+  if constexpr (P == 3) {
+    const f32x2_t r = x - __builtin_convertvector(h, f32x2_t);
+    const bf16x2_t m = __builtin_convertvector(r, bf16x2_t);
+    o[1] = __builtin_bit_cast(unsigned, m);
+    const f32x2_t l = r - __builtin_convertvector(m, f32x2_t);
+    o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2_t));
+  }
+}
+template <int P>
+__device__ __forceinline__ void fr_mfma(f32x16& acc, const bf16x8 (&a)[P], const bf16x8 (&b)[P]) {
+  if constexpr (P == 3) {   // six products of weight >= 2^-16, smallest first (as the CM = 2 path above)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  }
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int NT, bool PROBN, bool POOL>
-__global__ __launch_bounds__(512, 1) void mlp_fwd_lds_kernel(MlpArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float fl_smem[];
-  float* s_ring = fl_smem;                                   // [8 waves][3 stages][32 rows x 32 k]
-  float* s_w = s_ring + FL_NW * FL_STG * 1024;               // 2 x [NT*32 rows x 32 k], swizzled like A
-  float* s_vec = s_w + 2 * NT * 32 * 32;                     // [scale | shift] (2K)
-  float4* s_pool = reinterpret_cast<float4*>(s_vec + 2 * MLP_MAXK);     // [8*NT*32]
-  float* s_red = s_ring;                                     // [8][NT][64]: after the last step only
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+template <int NTN, int KT, bool POOL, int CM>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three-term
+__global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
+  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int N = NTN * 32, K = KT * 32, KB = K * 2;
+  constexpr int KS = K / 16;                       // MFMA K steps
+  constexpr int LPR = K / 4;                       // lanes per row of the patch load (float4 each)
+  constexpr int RPI = 64 / LPR;                    // rows per load instruction
+  constexpr int NLD = 32 / RPI;                    // loads per 32-row tile
+  static_assert(KT == 2, "rows of 64 channels");
+  extern __shared__ __attribute__((aligned(16))) char fr_smem[];
+  char* s_w = fr_smem;                                       // [P][N rows x KB]
+  char* s_a = s_w + P * N * KB;                              // [8 waves][P][32 rows x KB]
+  float* s_vec = reinterpret_cast<float*>(s_a + FR_NW * P * 32 * KB);   // scale | shift (2K)
+  float* s_red = s_vec + 2 * K;                              // [8][NTN][64]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  constexpr int BROWS = FL_NW * 32;
-  constexpr int W_INST = NT * 4;                             // wave-instructions per weight slab
-  constexpr int W_OPS = (W_INST + FL_NW - 1) / FL_NW;        // per wave (duplicates pad the last waves)
-  constexpr int NSTORE = 16 * NT;                            // unconditional output stores of a full tile
-  const int ntiles = (p.R + BROWS - 1) / BROWS;
-  const int ksteps = p.K / MLP_BK;
-  if constexpr (PROBN) {
-    for (int i = threadIdx.x; i < 2 * p.K; i += 512) s_vec[i] = p.vec[i];
-  }
-  float* ring = s_ring + wave * FL_STG * 1024;
-  auto issue_a = [&](int tile, int ks, int stage) {
-    const int row0 = tile * BROWS + wave * 32;
+  // ---- the weight (N x K) as split planes, once ------------------------------------------------------
+  for (int i = tid; i < N * (K / 4); i += 64 * FR_NW) {
+    const int n = i / (K / 4), k = 4 * (i % (K / 4));
+    const float4 w = *reinterpret_cast<const float4*>(p.Bt + (size_t)n * K + k);
+    unsigned p0[P], p1[P];
+    fr_split_pair<P>(w.x, w.y, p0);
+    fr_split_pair<P>(w.z, w.w, p1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int pos = i * 64 + lane;                         // 16-byte position inside the stage
-      const int r = pos >> 3, c = (pos & 7) ^ (r & 7);       // row, global chunk (swizzle)
-      int row = row0 + r;
-      row = row < p.R ? row : p.R - 1;                       // ragged tail: valid address, masked at use
-      lds_dma16(p.X + (size_t)row * p.ldx + ks * MLP_BK + 4 * c, ring + stage * 1024 + i * 256);
+    for (int q = 0; q < P; ++q)
+      *reinterpret_cast<uint2*>(s_w + q * N * KB + fr_swz<KB>(n, k >> 3) + 2 * (k & 7)) = make_uint2(p0[q], p1[q]);
+  }
+  for (int i = tid; i < 2 * K; i += 64 * FR_NW) s_vec[i] = p.vec[i];
+  __syncthreads();
+  // lane's patch: channels 4*c4 .. +3 of rows rq + RPI*j
+  const int c4 = lane % LPR, rq = lane / LPR;
+  const float4 sc = *reinterpret_cast<const float4*>(s_vec + 4 * c4);
+  const float4 sh = *reinterpret_cast<const float4*>(s_vec + K + 4 * c4);
+  char* my_a = s_a + wave * P * 32 * KB;
+  unsigned selbits = 0;
+  if constexpr (POOL) {
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt)
+      if (p.fin.gamma[nt * 32 + lr] < 0.f) selbits |= 1u << nt;
+  }
+  float cs1[NTN], cs2[NTN];
+#pragma unroll
+  for (int nt = 0; nt < NTN; ++nt) cs1[nt] = cs2[nt] = 0.f;
+  const int ntile = (p.R + 31) / 32;
+  const int nunit = (ntile + 1) / 2;
+  float4 raw[NLD];
+  auto fetch = [&](int tile) {
+    const int row0 = tile * 32;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      int row = row0 + rq + RPI * j;
+      row = row < p.R ? row : p.R - 1;                     // valid address; zeroed by the transform
+      raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + 4 * c4);
     }
   };
-  auto issue_w = [&](int ks, int buf) {
+  int unit = blockIdx.x * FR_NW + wave;
+  const int ustride = gridDim.x * FR_NW;
+  if (unit < nunit) fetch(2 * unit);
+  for (; unit < nunit; unit += ustride) {
+    float pmx[NTN];
+    int pax[NTN];
 #pragma unroll
-    for (int i = 0; i < W_OPS; ++i) {
-      const int inst = (wave * W_OPS + i) % W_INST;          // identical rewrites pad the tail waves
-      const int pos = inst * 64 + lane;
-      const int r = pos >> 3, c = (pos & 7) ^ (r & 7);
-      const int n = r < p.N ? r : p.N - 1;
-      lds_dma16(p.Bt + (size_t)n * p.K + ks * MLP_BK + 4 * c, s_w + buf * NT * 1024 + inst * 256);
-    }
-  };
-  float cs1[NT], cs2[NT];
+    for (int half = 0; half < 2; ++half) {
+      const int tile = 2 * unit + half;
+      if (tile >= ntile) break;
+      const int row0 = tile * 32;
+      // ---- BN + ReLU of the previous layer, split once, into the wave's private planes ---------------
+      const bool tail = row0 + 32 > p.R;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) cs1[nt] = cs2[nt] = 0.f;
-  f32x16 acc[1][NT];
-  int tile = blockIdx.x;
-  // Issue order per wave:  A(0) W(0) A(1) | step 0: W(1) A(2) | step 1: W(2) A(3) | ...
-  // Step s waits for W(s) (and thereby A(s)); younger than W(s) are A(s+1) [4 ops, if it exists] and
-  // the output stores of step s-1's epilogue [NSTORE, if it was the full-tile path].
-  int t1 = tile, k1 = 0;                                     // (tile, ks) of step s+1
-  bool a1 = false;                                           // A(s+1) was issued
-  if (tile < ntiles) {
-    issue_a(tile, 0, 0);
-    issue_w(0, 0);
-    k1 = ksteps > 1 ? 1 : 0;
-    t1 = ksteps > 1 ? tile : tile + (int)gridDim.x;
-    a1 = t1 < ntiles;
-    if (a1) issue_a(t1, k1, 1);
-  }
-  int seq = 0, ks = 0;
-  bool stores_behind = false;
-  while (tile < ntiles) {
-    const int row0 = tile * BROWS + wave * 32;
-    const bool last_ks = ks == ksteps - 1;
-    if (a1) { if (stores_behind) wait_vm<(4 + NSTORE > 63 ? 63 : 4 + NSTORE)>(); else wait_vm<4>(); }
-    else { if (stores_behind) wait_vm<(NSTORE > 63 ? 63 : NSTORE)>(); else wait_vm<0>(); }
-    lds_barrier();        // W(s) landed for every wave; everyone is past step s-1's MFMAs (s_vec visible)
-    int t2 = t1, k2 = k1 + 1;                                // (tile, ks) of step s+2
-    if (k2 == ksteps) { k2 = 0; t2 = t1 + (int)gridDim.x; }
-    if (a1) issue_w(k1, (seq + 1) & 1);                      // W(s+1): the buffer step s-1 read
-    const bool a2 = a1 && t2 < ntiles;
-    if (a2) issue_a(t2, k2, (seq + 2) % FL_STG);
-    if (ks == 0) {
+      for (int j = 0; j < NLD; ++j) {
+        const int rl = rq + RPI * j;
+        float4 x = raw[j];
+        x.x = fmaxf(0.f, __builtin_fmaf(x.x, sc.x, sh.x));
+        x.y = fmaxf(0.f, __builtin_fmaf(x.y, sc.y, sh.y));
+        x.z = fmaxf(0.f, __builtin_fmaf(x.z, sc.z, sh.z));
+        x.w = fmaxf(0.f, __builtin_fmaf(x.w, sc.w, sh.w));
+        if (tail && row0 + rl >= p.R) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned p0[P], p1[P];
+        fr_split_pair<P>(x.x, x.y, p0);
+        fr_split_pair<P>(x.z, x.w, p1);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int q = 0; q < P; ++q)
+          *reinterpret_cast<uint2*>(my_a + q * 32 * KB + fr_swz<KB>(rl, c4 >> 1) + 8 * (c4 & 1)) =
+              make_uint2(p0[q], p1[q]);
+      }
+      // next tile's rows in flight underneath this tile's MFMAs and epilogue
+      {
+        const int nxt = half == 0 ? tile + 1 : 2 * (unit + ustride);
+        if (nxt < ntile && (half == 0 || unit + ustride < nunit)) fetch(nxt);
+      }
+      f32x16 acc[1][NTN];
+#pragma unroll
+      for (int nt = 0; nt < NTN; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][nt][r] = 0.f;
-    }
-    const float* sa = ring + (seq % FL_STG) * 1024;
-    const float* sw = s_w + (seq & 1) * NT * 1024;
-    const bool row_ok = row0 + lr < p.R;
 #pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-      const int c = c8 * 2 + lh;                             // 16-byte chunk of the K step
-      float4 a4 = *reinterpret_cast<const float4*>(sa + lr * 32 + 4 * (c ^ (lr & 7)));
-      if constexpr (PROBN) {
-        const float4 sc = *reinterpret_cast<const float4*>(s_vec + ks * MLP_BK + 4 * c);
-        const float4 sh = *reinterpret_cast<const float4*>(s_vec + p.K + ks * MLP_BK + 4 * c);
-        a4.x = fmaxf(0.f, __builtin_fmaf(a4.x, sc.x, sh.x));
-        a4.y = fmaxf(0.f, __builtin_fmaf(a4.y, sc.y, sh.y));
-        a4.z = fmaxf(0.f, __builtin_fmaf(a4.z, sc.z, sh.z));
-        a4.w = fmaxf(0.f, __builtin_fmaf(a4.w, sc.w, sh.w));
+      for (int s = 0; s < KS; ++s) {
+        bf16x8 a[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          a[q] = *reinterpret_cast<const bf16x8*>(my_a + q * 32 * KB + fr_swz<KB>(lr, 2 * s + lh));
+#pragma unroll
+        for (int nt = 0; nt < NTN; ++nt) {
+          bf16x8 b[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q)
+            b[q] = *reinterpret_cast<const bf16x8*>(s_w + q * N * KB + fr_swz<KB>(nt * 32 + lr, 2 * s + lh));
+          fr_mfma<P>(acc[0][nt], a, b);
+        }
       }
-      if (!row_ok) a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // ---- epilogue: raw output, column statistics, pooled extremum ---------------------------------
+      const bool full = row0 + 32 <= p.R;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = nt * 32 + lr;
-        float4 b4 = *reinterpret_cast<const float4*>(sw + n * 32 + 4 * (c ^ (n & 7)));
-        if (n >= p.N) b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[0][nt], 0, 0, 0);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[0][nt], 0, 0, 0);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[0][nt], 0, 0, 0);
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[0][nt], 0, 0, 0);
-      }
-    }
-    stores_behind = false;
-    if (last_ks) {
-      const bool full = tile * BROWS + BROWS <= p.R && NT * 32 <= p.N;
-      stores_behind = full;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float s1 = 0.f, s2 = 0.f;
+      for (int nt = 0; nt < NTN; ++nt) {
         const int col = nt * 32 + lr;
+        float* yp = p.Y + (size_t)(row0 + 4 * lh) * N + col;
         if (full) {
 #pragma unroll
+          for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = acc[0][nt][r];
+        } else {
+#pragma unroll
           for (int r = 0; r < 16; ++r)
-            p.Y[(size_t)(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * p.ldy + col] = acc[0][nt][r];
+            if (row0 + 4 * lh + (r & 3) + 8 * (r >> 2) < p.R) yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = acc[0][nt][r];
         }
+        f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const float v = acc[0][nt][r];
-          if (!full && row < p.R && col < p.N) p.Y[(size_t)row * p.ldy + col] = v;
-          s1 += v;                                           // rows >= R are exact zeros
-          s2 = __builtin_fmaf(v, v, s2);
+        for (int r = 0; r < 16; r += 2) {                    // rows >= R are exact zeros
+          const f32x2_t v = {acc[0][nt][r], acc[0][nt][r + 1]};
+          a1 += v;
+          a2 = __builtin_elementwise_fma(v, v, a2);
         }
-        cs1[nt] += s1;
-        cs2[nt] += s2;
+        cs1[nt] += a1.x + a1.y;
+        cs2[nt] += a2.x + a2.y;
         if constexpr (POOL) {
-          if (p.ns == 16) pool_epilogue<1, NT, 16>(p, acc, nt, row0, col, lh);
-          else if (p.ns == 32) pool_epilogue<1, NT, 32>(p, acc, nt, row0, col, lh);
-          else pool_half_reduce<NT>(acc, nt, wave, lr, lh, s_pool);
-        }
-      }
-      if constexpr (POOL) {
-        if (p.ns == 64) {                                    // merge the two half groups of each wave pair
-          lds_barrier();
-          if ((wave & 1) == 0 && lh == 0) {
+          const unsigned flip = ((selbits >> nt) & 1u) << 31;
+          if (p.ns == 16) pool_epilogue_sel<1, NTN, 16>(p, acc, nt, row0, col, lh, flip);
+          else if (p.ns == 32) pool_epilogue_sel<1, NTN, 32>(p, acc, nt, row0, col, lh, flip);
+          else {
+            // ns = 64: this tile's extremum (first maximum wins: rows ascend), folded with the other half
+            float mx = -__builtin_inff();
+            int ax = 0;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const int col = nt * 32 + lr;
-              const float4 a = s_pool[(wave * NT + nt) * 32 + lr];
-              const float4 b = s_pool[((wave + 1) * NT + nt) * 32 + lr];
-              float mx = a.x, mn = a.y;
-              int ax = __builtin_bit_cast(int, a.z), an = __builtin_bit_cast(int, a.w);
-              if (b.x > mx) { mx = b.x; ax = __builtin_bit_cast(int, b.z); }
-              if (b.y < mn) { mn = b.y; an = __builtin_bit_cast(int, b.w); }
-              if (row0 < p.R && col < p.N) {
-                const size_t o = (size_t)(row0 / 64) * p.N + col;
-                p.pmax[o] = mx; p.pmin[o] = mn; p.amax[o] = ax; p.amin[o] = an;
+            for (int r = 0; r < 16; ++r) {
+              const int rho = 32 * half + 4 * lh + (r & 3) + 8 * (r >> 2);
+              const float v = flip_sign(acc[0][nt][r], flip);
+              const bool up = v > mx;
+              mx = up ? v : mx; ax = up ? rho : ax;
+            }
+            const float omx = __shfl_xor(mx, 32);
+            const int oax = __shfl_xor(ax, 32);
+            if (omx > mx || (omx == mx && oax < ax)) { mx = omx; ax = oax; }
+            if (half == 0) { pmx[nt] = mx; pax[nt] = ax; }
+            else {
+              if (!(mx > pmx[nt])) { mx = pmx[nt]; ax = pax[nt]; }     // the earlier half wins ties
+              if (lh == 0) {
+                const size_t o = (size_t)unit * N + col;
+                p.pmax[o] = flip_sign(mx, flip);
+                p.amax[o] = ax;
               }
             }
           }
         }
       }
     }
-    // advance the sequence
-    ++seq;
-    if (last_ks) { ks = 0; tile += (int)gridDim.x; } else { ++ks; }
-    t1 = t2; k1 = k2; a1 = a2;
   }
-  // column statistics: lanes l and l+32 hold the same column; fold, the 8 waves, one fp64 atomic
-  if (p.stats != nullptr) {
-    wait_vm<0>();
-    lds_barrier();                                           // the ring is free: s_red aliases it
+  // ---- column statistics: lanes l / l+32 share a column, then the 8 waves, one fp64 atomic each -------
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      cs1[nt] += __shfl_xor(cs1[nt], 32);
-      cs2[nt] += __shfl_xor(cs2[nt], 32);
-      if (lh == 0) {
-        s_red[(wave * NT + nt) * 64 + lr] = cs1[nt];
-        s_red[(wave * NT + nt) * 64 + 32 + lr] = cs2[nt];
-      }
+  for (int nt = 0; nt < NTN; ++nt) {
+    cs1[nt] += __shfl_xor(cs1[nt], 32);
+    cs2[nt] += __shfl_xor(cs2[nt], 32);
+    if (lh == 0) {
+      s_red[(wave * NTN + nt) * 64 + lr] = cs1[nt];
+      s_red[(wave * NTN + nt) * 64 + 32 + lr] = cs2[nt];
     }
-    lds_barrier();
-    for (int i = threadIdx.x; i < NT * 64; i += 512) {
-      float v = 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < NTN * 64; i += 64 * FR_NW) {
+    float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < FL_NW; ++w) v += s_red[w * NT * 64 + i];
-      const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
-      if (nt * 32 + c < p.N) atomicAdd(p.stats + which * p.N + nt * 32 + c, (double)v);
+    for (int w = 0; w < FR_NW; ++w) v += s_red[w * NTN * 64 + i];
+    const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
+    atomicAdd(p.stats + which * N + nt * 32 + c, (double)v);
+  }
+  if (p.fin.ss != nullptr) {
+    // train-mode BN bookkeeping by the last workgroup (as mlp_gemm_kernel: only atomics touch the sums)
+    __syncthreads();
+    if (tid == 0) {
+      const int total = (int)gridDim.x;
+      const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
+      const int g = (int)blockIdx.x % SCHED_GROUPS;
+      const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
+      int* t = p.fin.ticket + FIN_OFF;
+      int last = 0;
+      if (atomicAdd(t + 1 + g, 1) == members - 1) {
+        atomicExch(t + 1 + g, 0);
+        if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+      const BnFin& f = p.fin;
+      if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
+      for (int c = tid; c < N; c += 64 * FR_NW) {
+        const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+        const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        bn_finalize_channel(c, N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss,
+                            f.mi, f.conv_bias);
+      }
     }
   }
 }
@@ -1667,39 +1716,37 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   }
 }
 
-// forward launches that qualify for the LDS-direct kernel (mlp_fwd_lds_kernel)
-template <int NT, bool PROBN, bool POOL>
-static int launch_fwd_lds(const MlpArgs& a, hipStream_t s) {
-  const size_t bytes = sizeof(float) * (FL_NW * FL_STG * 1024 + 2 * NT * 1024 + 2 * MLP_MAXK) +
-                       (POOL ? sizeof(float4) * FL_NW * NT * 32 : 0);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_lds_kernel<NT, PROBN, POOL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-      set_error("mlp_fwd_lds: cannot reserve %zu bytes of LDS", bytes);
-      return DEMF_ELAUNCH;
-    }
-    configured = true;
-  }
-  const int tiles = (a.R + FL_NW * 32 - 1) / (FL_NW * 32);
-  const int gx = tiles < 256 ? tiles : 256;                 // one 512-thread workgroup per CU
-  hipLaunchKernelGGL((mlp_fwd_lds_kernel<NT, PROBN, POOL>), dim3(gx), dim3(512), bytes, s, a);
-  return check_launch("mlp_fwd_lds");
-}
-
 template <int PRO, bool STATS, bool POOL, bool RED, int BF16>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
-  if constexpr (BF16 == 0 && !RED && STATS && (PRO == PRO_NONE || PRO == PRO_BNRELU)) {
-    const int ntl = (a.N + 31) / 32;
-    if (env_int("DEMF_FWD_LDS", 0) && a.K % MLP_BK == 0 && a.K >= MLP_BK && ntl <= 4 && a.ldb == 0 &&
-        a.ldy == a.N && a.R >= 256 * 128 && (!POOL || a.R % (FL_NW * 32) == 0)) {
-      constexpr bool PB = PRO == PRO_BNRELU;
-      switch (ntl) {
-        case 1: return launch_fwd_lds<1, PB, POOL>(a, s);
-        case 2: return launch_fwd_lds<2, PB, POOL>(a, s);
-        case 3: return launch_fwd_lds<3, PB, POOL>(a, s);
-        default: return launch_fwd_lds<4, PB, POOL>(a, s);
-      }
+  if constexpr ((BF16 == 1 || BF16 == 2) && !RED && STATS && PRO == PRO_BNRELU) {
+    // weight-resident, barrier-free forward (mlp_fwd_res_kernel): 64-channel inputs, N = 64 / 128
+    static const int fr_on = env_int("DEMF_FWD_RES", 1);
+    const bool sel = !POOL || (a.pmin == nullptr && a.fin.gamma != nullptr);
+    if (fr_on && a.K == 64 && (a.N == 64 || a.N == 128) && a.ldx == 64 && a.ldy == a.N && a.ldb == 0 && sel &&
+        a.R >= 64 * 256 && (!POOL || ((a.ns == 16 || a.ns == 32 || a.ns == 64) && a.R % 64 == 0)) &&
+        (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
+      constexpr int P = BF16 == 2 ? 3 : 1;
+      const int ntn = a.N / 32;
+      const size_t bytes = (size_t)P * a.N * 128 + (size_t)FR_NW * P * 32 * 128 + sizeof(float) * (2 * 64 + FR_NW * ntn * 64);
+      const int nunit = (a.R + 63) / 64;
+      int gx = (nunit + FR_NW - 1) / FR_NW;
+      if (gx > 256) gx = 256;
+#define FRGO(NTNv)                                                                                          \
+      do {                                                                                                  \
+        static bool configured = false;                                                                     \
+        if (!configured) {                                                                                  \
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_res_kernel<NTNv, 2, POOL, BF16>),   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {   \
+            set_error("mlp_fwd_res: cannot reserve %zu bytes of LDS", bytes);                                \
+            return DEMF_ELAUNCH;                                                                             \
+          }                                                                                                 \
+          configured = true;                                                                                \
+        }                                                                                                   \
+        hipLaunchKernelGGL((mlp_fwd_res_kernel<NTNv, 2, POOL, BF16>), dim3(gx), dim3(64 * FR_NW), bytes, s, a); \
+      } while (0)
+      if (ntn == 2) FRGO(2); else FRGO(4);
+#undef FRGO
+      return check_launch("mlp_fwd_res");
     }
   }
   const dim3 block(256);
@@ -1857,10 +1904,10 @@ extern "C" int demf_mlp_gemm_fwd_pool(int R, int K, int N, int ldx, const float*
 }
 
 // forward launch + train-mode BN bookkeeping: in the kernel's last workgroup when a counter set is
-// available, as a separate launch otherwise (DEMF_STATIC_TILES=1, DEMF_FWD_LDS=1, DEMF_NO_FIN=1)
+// available, as a separate launch otherwise (DEMF_STATIC_TILES=1, DEMF_NO_FIN=1)
 template <typename Launch>
 static int launch_with_finalize(MlpArgs& a, BnFin fin, Launch launch, hipStream_t s) {
-  static const int off = env_int("DEMF_NO_FIN", 0) || env_int("DEMF_FWD_LDS", 0);
+  static const int off = env_int("DEMF_NO_FIN", 0);
   fin.ticket = off ? nullptr : sched_slot();
   a.fin = fin;
   if (fin.ticket != nullptr) return launch(a);

@@ -265,9 +265,11 @@ class DeMFVoteHead(nn.Module):
             ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
             hw=torch.as_tensor(hw, device=dev),
             mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
+            # (converted to float in numpy: torch's bool -> float32 copy of this 0.6 M-element array costs
+            # 60-75 ms on the host, numpy's 0.5 ms - it is on the per-batch path of replay.load)
             keep4=None if empty else torch.as_tensor(np.stack(
-                [~np.concatenate(masks, 1)] + [np.zeros_like(np.concatenate(masks, 1))] * 3, -1),
-                dtype=dt, device=dev),
+                [(~np.concatenate(masks, 1)).astype(np.float32)] +
+                [np.zeros(np.concatenate(masks, 1).shape, np.float32)] * 3, -1)).to(device=dev, dtype=dt),
             valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
             spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
             level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),

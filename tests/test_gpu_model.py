@@ -278,14 +278,25 @@ def test_hot_path_bf16_full_config_batch_8(bf16_mode):
     assert stage["vote_points"] <= BF16_BOUNDS["vote_points"], stage
     assert stage["vote_features"] <= BF16_BOUNDS["vote_features"], stage
     assert abs(loss_g - loss_t) <= BF16_BOUNDS["loss"] * abs(loss_t), (loss_g, loss_t)
+    assert max(per_loss.values()) <= BF16_BOUNDS["per_loss"], per_loss
     assert abs(gn_g - gn_t) <= BF16_BOUNDS["grad_norm"] * gn_t, (gn_g, gn_t)
     assert float(np.median(list(grads.values()))) <= BF16_BOUNDS["grad_median"], worst
     assert worst[0][1] <= BF16_BOUNDS["grad_worst"], worst
+    assert stages["pts_bbox_head.conv_pred"] >= BF16_BOUNDS["conv_pred_cosine"], stages
 
 
-# 2x the deviations measured on MI355X (see the print above)
-BF16_BOUNDS = dict(vote_points=5e-2, vote_features=1e-1, loss=0.3, grad_norm=1.0, grad_median=1.0,
-                   grad_worst=2.0)
+# 2x the deviations measured on MI355X in round 3 (two runs; the print above):
+# vote_points 4.1e-2, vote_features 1.18e-1, total loss -2.5 / -2.6 %, worst single loss 6.6 / 6.8 %,
+# gradient norm -7 / -18 %.  PER-TENSOR GRADIENTS: median rel-L2 1.31-1.33, worst 1.63-1.65, cosine of
+# the whole gradient vs fp64 = -0.03 (conv_pred heads 0.69, decoder 0.08, everything upstream ~0): with
+# seeded RANDOM weights this 30-BN-layer network amplifies forward noise into the gradient by ~1e6 (fp32
+# itself: 6e-8 -> up to 5e-2, test above), so bf16's 4e-3 operand rounding decorrelates every gradient
+# upstream of the prediction heads - a property of the untrained network, the bf16 kernels themselves
+# are pinned against bf16-emulating references in tests/test_gpu_bf16.py.  rel-L2 of two unrelated
+# vectors of equal norm is sqrt(2): the per-tensor bounds below only exclude blow-ups; the direction
+# is asserted where it exists (the heads).
+BF16_BOUNDS = dict(vote_points=8.2e-2, vote_features=0.24, loss=0.06, per_loss=0.14, grad_norm=0.4,
+                   grad_median=1.6, grad_worst=2.0, conv_pred_cosine=0.35)
 
 
 # Seeds to try, in order.  The first entries were found by running the (oracle-only) qualification

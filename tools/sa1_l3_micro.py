@@ -1,5 +1,5 @@
 """The dominant kernel alone: demf_mlp_gemm_fwd_pool at SA1's last layer (R = 8*2048*64 rows, 64 -> 128,
-ns = 64), N launches back to back; DEMF_FWD_LDS=0/1 selects the register-staged / LDS-direct kernel,
+ns = 64), N launches back to back; DEMF_FWD_RES=0/1 selects the register-staged / weight-resident kernel,
 DEMF_MODE=f32|f32_native|f32x3|bf16 the compute mode.
 Used under rocprofv3 --pmc for pipe-utilisation counters."""
 import sys, os, torch
@@ -33,4 +33,4 @@ s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True
 s.record()
 for _ in range(n): run()
 e.record(); torch.cuda.synchronize()
-print("DEMF_MODE=%s DEMF_VARIANT=%s DEMF_FWD_LDS=%s  avg %.1f us" % (os.environ.get("DEMF_MODE", "f32"), VARIANT, os.environ.get("DEMF_FWD_LDS", "0"), s.elapsed_time(e) * 1e3 / n))
+print("DEMF_MODE=%s DEMF_VARIANT=%s DEMF_FWD_RES=%s  avg %.1f us" % (os.environ.get("DEMF_MODE", "f32"), VARIANT, os.environ.get("DEMF_FWD_RES", "1"), s.elapsed_time(e) * 1e3 / n))
