@@ -76,6 +76,7 @@ SIGNATURES = {
     "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
     "demf_gemm_f32": [_ptr, _ptr],
+    "demf_gemm_group_f32": [_ptr, _c_int, _ptr],
     "demf_set_compute_dtype": [_c_int],
     "demf_multi_copy": [_c_int, _ptr, _c_int, _ptr],
     "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
@@ -111,6 +112,7 @@ class GemmDesc(ctypes.Structure):
         ("drop_p", _c_float),
         ("rng", _ptr),
         ("op_id", _c_int),
+        ("asum", _ptr),
     ]
 
 _lib = None

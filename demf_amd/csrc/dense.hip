@@ -395,14 +395,16 @@ __device__ __forceinline__ void gemm_commit_s(float* __restrict__ s, const GemmR
 }
 
 template <int MA, int MB, bool ADD, bool BF16>
-__global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
-  __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
-  __shared__ float s_red[4][16][64];
+__device__ __forceinline__ void gemm_ks_body(const GemmArgs& p, int bx, int by, int bz, float* __restrict__ s_a,
+                                             float* __restrict__ s_b, float (*s_red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-  const int z = blockIdx.z / p.splitk, sp = blockIdx.z - z * p.splitk;
+  const int m0 = by * 32, n0 = bx * 32;
+  const int z = bz / p.splitk, sp = bz - z * p.splitk;
+  // asum (weight-gradient launches, A reduction-strided): row sums of the A operand = the bias gradient
+  // of the linear layer, taken by the first column of workgroups from the rows they stage anyway
+  const bool do_asum = MA == 2 && p.asum != nullptr && bx == 0;
+  float4 rs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int kchunk = ((p.K + p.splitk - 1) / p.splitk + G_BK - 1) / G_BK * G_BK;
   const int kbeg = sp * kchunk, kend = min(p.K, kbeg + kchunk);
   const int zo = z / p.zdiv, zi = z - zo * p.zdiv;
@@ -428,6 +430,11 @@ __global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
     constexpr int S = decltype(stage)::value;
     lds_barrier();
     if (ADD && A2 != nullptr) gemm_commit_s<MA, ADD, BF16>(s_a, ga[S], sa8[S]); else gemm_commit_s<MA, false, BF16>(s_a, ga[S], sa8[S]);
+    if constexpr (MA == 2) {
+      if (do_asum) {           // this thread's two float4 = 4 consecutive rows m at two reduction steps
+        rs4 = add4(rs4, add4(ga[S].v[0], ga[S].v[1]));
+      }
+    }
     if (ADD && B2 != nullptr) gemm_commit_s<MB, ADD, BF16>(s_b, gb[S], sb8[S]); else gemm_commit_s<MB, false, BF16>(s_b, gb[S], sb8[S]);
     lds_barrier();
     if (k0 + NS * G_BK < kend) fetch(stage, k0 + NS * G_BK);
@@ -466,17 +473,66 @@ __global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
   for (int r = 0; r < 16; ++r) s_red[wave][r][lane] = acc[r];
   lds_barrier();
   const int n = n0 + lr;
-  if (n >= p.N) return;
-  float bias = 0.f;
-  if (p.bias != nullptr && sp == 0) bias = p.bias[(size_t)z * p.sbias_b + n];
-  const size_t oc = (size_t)zo * p.scb + (size_t)zi * p.scb2;
+  if (n < p.N) {
+    float bias = 0.f;
+    if (p.bias != nullptr && sp == 0) bias = p.bias[(size_t)z * p.sbias_b + n];
+    const size_t oc = (size_t)zo * p.scb + (size_t)zi * p.scb2;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = 4 * wave + q;
-    const int m = m0 + q + 8 * wave + 4 * lh;
-    const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
-    if (m < p.M) gemm_store(p, z, oc, sp, m, n, bias, v);
+    for (int q = 0; q < 4; ++q) {
+      const int r = 4 * wave + q;
+      const int m = m0 + q + 8 * wave + 4 * lh;
+      const float v = (s_red[0][r][lane] + s_red[1][r][lane]) + (s_red[2][r][lane] + s_red[3][r][lane]);
+      if (m < p.M) gemm_store(p, z, oc, sp, m, n, bias, v);
+    }
   }
+  if constexpr (MA == 2) {
+    if (do_asum) {
+      // thread t staged rows 4*(t & 7) .. +3 at reduction steps (t >> 3) + 32 i: 32 threads per row quad
+      lds_barrier();
+      float4* q4 = reinterpret_cast<float4*>(&s_red[0][0][0]);
+      q4[threadIdx.x] = rs4;
+      lds_barrier();
+      if (threadIdx.x < 32 && m0 + (int)threadIdx.x < p.M) {
+        const int rq = threadIdx.x >> 2, c = threadIdx.x & 3;
+        const float* f = &s_red[0][0][0];
+        float t = 0.f;
+        for (int j = 0; j < 32; ++j) t += f[(8 * j + rq) * 4 + c];
+        atomicAdd(p.asum + (size_t)z * p.M + m0 + threadIdx.x, t);
+      }
+    }
+  }
+}
+
+template <int MA, int MB, bool ADD, bool BF16>
+__global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
+  __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
+  __shared__ float s_red[4][16][64];
+  gemm_ks_body<MA, MB, ADD, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, s_a, s_b, s_red);
+}
+
+// Several small GEMMs of the SAME operand form in ONE launch (the weight gradients of a decoder layer:
+// ten reduction-strided products that depend on nothing but saved tensors): the descriptors travel by
+// value in the kernel arguments, a workgroup finds its problem from the tile prefix table.
+constexpr int GEMM_GROUP_MAX = 12;
+struct GemmGroup {
+  GemmArgs p[GEMM_GROUP_MAX];
+  int start[GEMM_GROUP_MAX + 1];
+  int n;
+};
+template <int MA, int MB, bool ADD, bool BF16>
+__global__ __launch_bounds__(256, 4) void gemm_ks_group_kernel(GemmGroup g) {
+  __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
+  __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
+  __shared__ float s_red[4][16][64];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.start[i + 1]) ++i;
+  const GemmArgs& p = g.p[i];
+  const int local = b - g.start[i];
+  const int gx = (p.N + 31) / 32, gy = (p.M + 31) / 32;
+  const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+  gemm_ks_body<MA, MB, ADD, BF16>(p, bx, by, bz, s_a, s_b, s_red);
 }
 
 // staging mode of an operand with rows R, reduction K, strides (sr, sk).  Global dwordx4 loads only
@@ -872,9 +928,7 @@ __global__ void dropout_mask_k(long long n, float p, const unsigned long long* _
 
 using namespace demf;
 
-extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
-  DEMF_REQUIRE(d != nullptr, "gemm: null descriptor");
-  GemmArgs p = *d;
+static int gemm_validate(const GemmArgs& p) {
   DEMF_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0 && p.splitk > 0 && p.zdiv > 0,
                "gemm: bad sizes %d %d %d %d %d %d", p.M, p.N, p.K, p.batch, p.splitk, p.zdiv);
   DEMF_REQUIRE(p.A && p.B && p.C, "gemm: null operand");
@@ -884,13 +938,27 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
   DEMF_REQUIRE(p.splitk == 1 || !(p.flags & (GEMM_RELU | GEMM_DROPOUT | GEMM_GATE)),
                "gemm: split-K cannot carry a non-linear epilogue");
   DEMF_REQUIRE((long long)p.batch * p.splitk <= 65535, "gemm: batch*splitk too large");
+  return DEMF_OK;
+}
+
+static bool gemm_is_small(const GemmArgs& p) {
+  const long long tiles = (long long)cdiv(p.N, G_BN) * cdiv(p.M, G_BM) * p.batch * p.splitk;
+  return tiles <= env_tiles() || p.N <= 32;
+}
+
+extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
+  DEMF_REQUIRE(d != nullptr, "gemm: null descriptor");
+  GemmArgs p = *d;
+  if (int e = gemm_validate(p)) return e;
   const int modeA = stage_mode(p.sam, p.sak, p.M, p.K);
   const int modeB = stage_mode(p.sbn, p.sbk, p.N, p.K);
   dim3 grid(cdiv(p.N, G_BN), cdiv(p.M, G_BM), p.batch * p.splitk);
   const bool add = p.A2 != nullptr || p.B2 != nullptr;
   const bool bf = compute_bf16() && !(p.flags & GEMM_FP32);
   // few 64 x 64 tiles (or a narrow output): 32 x 32 tiles with the K step split over the waves
-  const bool small = (long long)grid.x * grid.y * grid.z <= env_tiles() || p.N <= 32;
+  const bool small = gemm_is_small(p);
+  DEMF_REQUIRE(p.asum == nullptr || (small && modeA == 2 && p.A2 == nullptr),
+               "gemm: asum needs the reduction-strided A form (no A2) on the small-tile path");
   if (small) {
     grid = dim3(cdiv(p.N, 32), cdiv(p.M, 32), p.batch * p.splitk);
 #define GEMM_LAUNCH_S(MA_, MB_)                                                                        \
@@ -940,6 +1008,41 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
   }
 #undef GEMM_LAUNCH
   return check_launch("gemm_kernel");
+}
+
+extern "C" int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stream_t stream) {
+  DEMF_REQUIRE(descs != nullptr && n >= 1, "gemm_group: no descriptors");
+  const bool bf = compute_bf16();
+  int i0 = 0;
+  while (i0 < n) {
+    // longest run of consecutive problems that can share one launch: small-tile path, both operands
+    // reduction-strided (the weight-gradient form), no non-linear epilogue flags that need other staging
+    GemmGroup g{};
+    int cnt = 0, tiles = 0;
+    while (i0 + cnt < n && cnt < GEMM_GROUP_MAX) {
+      const GemmArgs& p = descs[i0 + cnt];
+      if (int e = gemm_validate(p)) return e;
+      const bool ok = gemm_is_small(p) && stage_mode(p.sam, p.sak, p.M, p.K) == 2 &&
+                      stage_mode(p.sbn, p.sbk, p.N, p.K) == 2 && !(p.flags & GEMM_FP32) && p.A2 == nullptr;
+      if (!ok) break;
+      g.p[cnt] = p;
+      g.start[cnt] = tiles;
+      tiles += cdiv(p.N, 32) * cdiv(p.M, 32) * p.batch * p.splitk;
+      ++cnt;
+    }
+    if (cnt == 0) {                       // not groupable: its own launch
+      if (int e = demf_gemm_f32(descs + i0, stream)) return e;
+      ++i0;
+      continue;
+    }
+    g.start[cnt] = tiles;
+    g.n = cnt;
+    if (bf) hipLaunchKernelGGL((gemm_ks_group_kernel<2, 2, true, true>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL((gemm_ks_group_kernel<2, 2, true, false>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+    if (int e = check_launch("gemm_ks_group_kernel")) return e;
+    i0 += cnt;
+  }
+  return DEMF_OK;
 }
 
 #define LN_DISPATCH(C, CALL)                       \

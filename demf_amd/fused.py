@@ -110,9 +110,10 @@ def _p(t, off=0):
 def gemm(M, N, K, A, sa, B, sb, C, scm, *, batch=1, zdiv=1, sab=(0, 0), sbb=(0, 0), scb=(0, 0),
          A2=None, a2_cols=0, B2=None, b2_rows=0, C2=None, bias=None, sbias_b=0, rowscale=None,
          srs=(0, 0), alpha=1.0, flags=0, gate=None, sg=(0, 0), gate_scale=1.0, drop_p=0.0, rng=None,
-         op_id=0, splitk=1):
+         op_id=0, splitk=1, asum=None, group=None):
     """demf_gemm_f32 (include/demf_hip.h).  A, B, C, ... are device ADDRESSES (``_p(tensor, offset)``);
-    sa = (sam, sak), sb = (sbn, sbk) element strides."""
+    sa = (sam, sak), sb = (sbn, sbk) element strides.  ``group``: a list that collects the descriptor
+    instead of launching it (``gemm_group`` then issues the whole list, demf_gemm_group_f32)."""
     d = _ffi.GemmDesc()
     d.M, d.N, d.K, d.batch, d.zdiv, d.splitk = M, N, K, batch, zdiv, splitk
     d.A, d.sam, d.sak, d.sab, d.sab2 = A, sa[0], sa[1], sab[0], sab[1]
@@ -126,7 +127,19 @@ def gemm(M, N, K, A, sa, B, sb, C, scm, *, batch=1, zdiv=1, sab=(0, 0), sbb=(0, 
     d.alpha, d.flags = alpha, flags
     d.gate, d.sgm, d.sgb, d.gate_scale = gate, sg[0], sg[1], gate_scale
     d.drop_p, d.rng, d.op_id = drop_p, rng, op_id
+    d.asum = asum
+    if group is not None:
+        group.append(d)
+        return
     _ffi.call("demf_gemm_f32", ctypes.addressof(d), _st())
+
+
+def gemm_group(descs):
+    """Issue the collected descriptors: consecutive weight-gradient-shaped ones share one launch."""
+    if not descs:
+        return
+    arr = (_ffi.GemmDesc * len(descs))(*descs)
+    _ffi.call("demf_gemm_group_f32", ctypes.addressof(arr), len(descs), _st())
 
 
 def _splitk(K):
@@ -144,15 +157,18 @@ def linear_fwd(x, w, b, out=None, **kw):
     return out
 
 
-def weight_grad(dy, x, dw, db=None, x2=None, dy_cols=None, dy_off=0, x2_rows=0):
-    """dw (N,K) += dy[:, off:off+N]^T . (x + x2) ;  db (N) += column sums.  dw / db arrive ZEROED
-    (split-K accumulates with atomics)."""
+def weight_grad(dy, x, dw, db=None, x2=None, dy_cols=None, dy_off=0, x2_rows=0, group=None):
+    """dw (N,K) += dy[:, off:off+N]^T . (x + x2) ;  db (N) += column sums of dy (taken by the same
+    launch from the rows it stages: ``asum``).  dw / db arrive ZEROED (split-K accumulates with atomics).
+    ``group``: collect the descriptor for one grouped launch (``gemm_group``)."""
     R = dy.shape[0]
     N, K = dw.shape
     ldy = dy.shape[1]
+    fused_bias = db is not None and N % 4 == 0
     gemm(N, K, R, _p(dy, dy_off), (1, ldy), _p(x), (1, x.shape[1]), _p(dw), K,
-         B2=_p(x2), b2_rows=x2_rows if x2 is not None else 0, splitk=_splitk(R))
-    if db is not None:
+         B2=_p(x2), b2_rows=x2_rows if x2 is not None else 0, splitk=_splitk(R),
+         asum=_p(db) if fused_bias else None, group=group)
+    if db is not None and not fused_bias:
         _ffi.call("demf_colsum_f32", R, N, ldy, _p(dy, dy_off), _p(db), _st())
 
 
@@ -250,6 +266,7 @@ class FusedDecoderLayer(Function):
         st = _st()
         new = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         dx3 = dx3.contiguous()
+        wg = []     # the weight / bias gradients depend on saved tensors only: ONE grouped launch at the end
         # every parameter gradient lives in ONE zero-filled workspace (split-K GEMMs, column sums and
         # the LayerNorm reductions accumulate into it)
         shp = [(3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (2 * HLP, E), (2 * HLP,), (HLP, E), (HLP,),
@@ -267,17 +284,17 @@ class FusedDecoderLayer(Function):
         dx2, df = new(R, E), new(R, E)               # gradient of x2 (accumulated), of fc1's output
         _ffi.call("demf_add_dropout_ln_bwd", R, E, _p(dx3), None, _p(s3), _p(st3), _p(g3), p_ffn, rng,
                   OP_LN3, _p(dx2), 0, _p(df), _p(d_g3), _p(d_b3), st)
-        weight_grad(df, hid, d_f1_w, d_f1_b)
+        weight_grad(df, hid, d_f1_w, d_f1_b, group=wg)
         dh = new(R, F)                               # through dropout + ReLU: gate on hid != 0
         gemm(R, F, E, _p(df), (E, 1), _p(f1_w), (1, F), _p(dh), F, flags=GATE, gate=_p(hid), sg=(F, 0),
              gate_scale=1.0 / (1.0 - p_ffn))
-        weight_grad(dh, x2, d_f0_w, d_f0_b)
+        weight_grad(dh, x2, d_f0_w, d_f0_b, group=wg)
         gemm(R, E, F, _p(dh), (F, 1), _p(f0_w), (1, E), _p(dx2), E, flags=ACCUM)
         # ---- cross attention ----
         dx1, dco = new(R, E), new(R, E)
         _ffi.call("demf_add_dropout_ln_bwd", R, E, _p(dx2), None, _p(s2), _p(st2), _p(g2), p_attn, rng,
                   OP_LN2, _p(dx1), 0, _p(dco), _p(d_g2), _p(d_b2), st)
-        weight_grad(dco, mo, d_op_w, d_op_b)
+        weight_grad(dco, mo, d_op_w, d_op_b, group=wg)
         dmo = new(R, E)
         gemm(R, E, E, _p(dco), (E, 1), _p(op_w), (1, E), _p(dmo), E)
         # per-head value projection applied after sampling: mo[:, h] = z_h Wv_h^T + bv_h * ksum_h
@@ -285,7 +302,7 @@ class FusedDecoderLayer(Function):
         gemm(R, Ct, Dh, _p(dmo), (E, 1), _p(vp_w), (1, Ct), _p(dz), H * Ct, batch=H, sab=(Dh, 0),
              sbb=(Dh * Ct, 0), scb=(Ct, 0))
         gemm(Dh, Ct, R, _p(dmo), (1, E), _p(z), (1, H * Ct), _p(d_vp_w), Ct, batch=H, sab=(Dh, 0),
-             sbb=(Ct, 0), scb=(Dh * Ct, 0), splitk=_splitk(R))
+             sbb=(Ct, 0), scb=(Dh * Ct, 0), splitk=_splitk(R), group=wg)
         gemm(Dh, 1, R, _p(dmo), (1, E), _p(ks4), (0, 4 * H), _p(d_vp_b), 1, batch=H, sab=(Dh, 0),
              sbb=(4, 0), scb=(Dh, 0), splitk=_splitk(R))
         gemm(R, 1, Dh, _p(dmo), (E, 1), _p(vp_b), (0, 1), _p(dks4), 4 * H, batch=H, sab=(Dh, 0),
@@ -299,8 +316,8 @@ class FusedDecoderLayer(Function):
         draw, dpts = new(R, 3 * HLP), new(R, 3)
         _ffi.call("demf_msda_prep_bwd", R, Q, H, L, P, _p(pts), _p(M), _p(ab), _p(vr), shapes.data_ptr(),
                   _p(w), _p(uvw), _p(dloc), _p(dloc2), _p(dw), _p(dw2), _p(draw), _p(dpts), st)
-        weight_grad(draw, x1, d_off_w, d_off_b, x2=pos, x2_rows=2 * HLP)
-        weight_grad(draw, x1, d_aw_w, d_aw_b, x2=pos, x2_rows=HLP, dy_off=2 * HLP)
+        weight_grad(draw, x1, d_off_w, d_off_b, x2=pos, x2_rows=2 * HLP, group=wg)
+        weight_grad(draw, x1, d_aw_w, d_aw_b, x2=pos, x2_rows=HLP, dy_off=2 * HLP, group=wg)
         dpos = new(R, E)
         gemm(R, E, 2 * HLP, _p(draw), (3 * HLP, 1), _p(off_w), (1, E), _p(dx1), E, C2=_p(dpos), flags=ACCUM)
         gemm(R, E, HLP, _p(draw, 2 * HLP), (3 * HLP, 1), _p(aw_w), (1, E), _p(dx1), E, C2=_p(dpos),
@@ -309,7 +326,7 @@ class FusedDecoderLayer(Function):
         dx, dao = new(R, E), new(R, E)
         _ffi.call("demf_add_dropout_ln_bwd", R, E, _p(dx1), None, _p(s1), _p(st1), _p(g1), p_attn, rng,
                   OP_LN1, _p(dx), 0, _p(dao), _p(d_g1), _p(d_b1), st)
-        weight_grad(dao, att, d_out_w, d_out_b)
+        weight_grad(dao, att, d_out_w, d_out_b, group=wg)
         datt = new(R, E)
         gemm(R, E, E, _p(dao), (E, 1), _p(out_w), (1, E), _p(datt), E)
         dqkv, ds = new(R, 3 * E), new(B * H, Q, Q)
@@ -325,10 +342,11 @@ class FusedDecoderLayer(Function):
              sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dq = a dS k
         gemm(Q, Dh, Q, _p(ds), (1, Q), _p(qkv), (1, 3 * E), _p(dqkv, E), 3 * E, batch=B * H, zdiv=H,
              sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dk = a dS^T q
-        weight_grad(dqkv, x, d_in_w, d_in_b, x2=pos, x2_rows=2 * E)
+        weight_grad(dqkv, x, d_in_w, d_in_b, x2=pos, x2_rows=2 * E, group=wg)
         gemm(R, E, 2 * E, _p(dqkv), (3 * E, 1), _p(in_w), (1, E), _p(dx), E, C2=_p(dpos),
              flags=ACCUM | ACCUM2)                                               # q, k see x + pos
         gemm(R, E, E, _p(dqkv, 2 * E), (3 * E, 1), _p(in_w, 2 * E * E), (1, E), _p(dx), E, flags=ACCUM)
+        gemm_group(wg)
         if _DEBUG is not None:
             _DEBUG.update(df=df, dh=dh, dx2=dx2, dco=dco, dmo=dmo, dz=dz, dks4=dks4, dloc=dloc, dw=dw,
                           dloc2=dloc2, dw2=dw2, draw=draw, dx1=dx1, dao=dao, datt=datt, ds=ds, dqkv=dqkv,

@@ -635,10 +635,12 @@ class _LinearRows(Function):
                 # one zero-filled workspace for dW | db (split-K atomics, column sums)
                 ws = zeros(N * K + N, g.device)
                 gw = ws[:N * K].view(N, K)
+                # (+ the bias gradient = row sums of the A operand, taken by the same launch)
+                gb = ws[N * K:] if ctx.has_bias else None
+                in_gemm = gb is not None and N % 4 == 0 and N >= 4
                 fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, x.stride(0)), _p(gw), K,
-                           splitk=fused._splitk(R))
-                if ctx.has_bias:
-                    gb = ws[N * K:]
+                           splitk=fused._splitk(R), asum=_p(gb) if in_gemm else None)
+                if gb is not None and not in_gemm:
                     _ffi.call("demf_colsum_f32", R, N, N, _p(g), _p(gb), _stream())
             return gx, gw, gb, None
         if len(ctx.saved_tensors) == 3:

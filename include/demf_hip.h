@@ -543,9 +543,17 @@ typedef struct demf_gemm_desc {
   float drop_p;
   const void* rng;                                /* 2 x uint64: seed, step counter       */
   int op_id;
+  float* asum;   /* optional, accumulated: asum[z*M + m] += sum_k A[m,k] - the bias gradient when this
+                  * launch is a weight gradient dW = dY^T.X (A = dY, reduction-strided, small-tile path) */
 } demf_gemm_desc;
 
 int demf_gemm_f32(const demf_gemm_desc* desc, demf_stream_t stream);
+/* n GEMMs in as few launches as possible: consecutive descriptors of the weight-gradient form (both
+ * operands reduction-strided, few tiles) share ONE launch (their descriptors travel by value in the
+ * kernel arguments); anything else runs as its own demf_gemm_f32.  The weight / bias gradients of the
+ * linear layers of mmcv's DetrTransformerDecoderLayer (configs/demf/demf_votenet.py:71-91) depend on
+ * nothing but saved tensors, so a decoder layer issues them as one group at the end of its backward. */
+int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stream_t stream);
 
 /* Compute dtype of the dense MFMA kernels (demf_mlp_gemm_*, demf_gemm_f32): 0 = fp32 MFMA (the
  * reference's precision, class_agnostic_vote_head.py:384 fp16_enabled=False), 1 = bf16 MFMA with
