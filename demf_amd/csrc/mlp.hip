@@ -1730,7 +1730,10 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
       const size_t bytes = (size_t)P * a.N * 128 + (size_t)FR_NW * P * 32 * 128 + sizeof(float) * (2 * 64 + FR_NW * ntn * 64);
       const int nunit = (a.R + 63) / 64;
       int gx = (nunit + FR_NW - 1) / FR_NW;
-      if (gx > 256) gx = 256;
+      // one 8-wave workgroup per CU, on 240 of the 256: the rest is left to the resident FPS chain of
+      // the next batch (csrc/mlp_bwd.hip launch_fused has the measurements)
+      static const int cus = env_int("DEMF_PERSIST_CUS", 240);
+      if (gx > cus) gx = cus;
 #define FRGO(NTNv)                                                                                          \
       do {                                                                                                  \
         static bool configured = false;                                                                     \

@@ -478,8 +478,12 @@ static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
     configured = true;
   }
   const int nslab = (a.R + 31) / 32;
-  static const int cap_env = [] { const char* v = getenv("DEMF_BWD_FUSED_GRID"); return v ? atoi(v) : 0; }();
-  const int cap = cap_env ? cap_env : 256 * (8 / NW);  // persistent: 8 waves per CU
+  // persistent: 8 waves per CU on DEMF_PERSIST_CUS compute units.  Default 240 of 256: the coordinate
+  // pre-pass of the next batch (8 FPS workgroups that each own a CU) is resident underneath the step;
+  // a grid sized for all 256 CUs leaves 8 workgroups waiting for a CU and the launch ends with them
+  // (measured on the step: 256 -> 6.41 ms, 248 -> 6.35, 240 -> 6.32, 232 -> 6.31, 224 -> 6.33; alone 5.86 either way)
+  static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
+  const int cap = cus * (8 / NW);
   const int gx = nslab < cap ? nslab : cap;
   hipLaunchKernelGGL((mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI>), dim3(gx), dim3(64 * NW), bytes, s, a);
   return check_launch("mlp_bwd_fused");

@@ -340,9 +340,9 @@ class Trainer:
 
         ``prefetch_geometry``: the coordinate-only pre-pass of the NEXT batch (every FPS level,
         the backbone ball queries, 3-NN - ``DeMFHotPath.index_geometry``) is issued on a side
-        HIP stream between the forward and the backward graph of the current batch, so the
-        latency-bound FPS chain (B workgroups on 256 CUs) runs underneath the current step's
-        backward instead of in front of the next step.  Every step still computes one full
+        HIP stream in front of the current batch's fwd+bwd graph, so the latency-bound FPS chain
+        (B workgroups on 256 CUs) runs underneath the current step's forward instead of in front
+        of the next step (``DEMF_GEO_AT_BWD=1``: between a forward and a backward graph).  Every step still computes one full
         pre-pass; the graph reads it from static buffers that are refreshed by ONE ~6 MB multi-copy
         launch at the step boundary."""
         dev = batch["points"].device
@@ -375,11 +375,13 @@ class Trainer:
         self.flat.reserve_table()
         graph = torch.cuda.CUDAGraph()
         graph_bwd = None
-        if can_prefetch and not os.environ.get("DEMF_GEO_AT_FWD"):
-            # forward and backward are two graphs (one memory pool) so that the pre-pass can be
-            # started in between: it then runs underneath the backward, whose long persistent
-            # kernels take their tiles dynamically and lose less to the resident FPS chain than the
-            # forward does (measured 9.26 -> 9.11 ms/step; DEMF_GEO_AT_FWD=1 restores the old order)
+        if can_prefetch and os.environ.get("DEMF_GEO_AT_BWD"):
+            # DEMF_GEO_AT_BWD=1: forward and backward as two graphs (one memory pool) with the pre-pass
+            # started in between, underneath the backward (round 2's default: 9.26 -> 9.11 ms/step then).
+            # With the one-pass backward kernels of round 3 the backward is ~230 mostly small launches and
+            # every launch pays ~2 us more while a second hardware queue is active, so the pre-pass now
+            # goes underneath the FORWARD (~110 launches) in front of a single fwd+bwd graph:
+            # 6.49 -> 6.39 ms/step.
             self.flat.captured_pack = True
             try:
                 with torch.cuda.graph(graph):
@@ -461,10 +463,9 @@ class Trainer:
 
         def replay(next_points=None):
             """One training step.  Default (one-deep): ``next_points`` is the cloud of the NEXT batch;
-            its coordinate pre-pass is launched on the side stream between the forward and the
-            backward graph and runs underneath the backward, whose long persistent kernels claim
-            their tiles dynamically and lose least to the 8 CUs the FPS chain occupies; the result
-            is moved into the static buffers at the end of the call.
+            its coordinate pre-pass is launched on the side stream in front of the step's graph and
+            runs underneath the forward (with ``DEMF_GEO_AT_BWD=1``: between the forward and the
+            backward graph); the result is moved into the static buffers at the end of the call.
             ``DEMF_GEO_TWO_DEEP=1``: ``next_points`` is the cloud of the batch AFTER the next one;
             the pre-pass is launched after the backward and runs underneath the optimizer update and
             the first layers of the next forward (measured: 7.80 vs 7.67 ms/step - the forward's
@@ -496,7 +497,7 @@ class Trainer:
                 self._update()
                 return loss
             if can_prefetch:
-                # single-graph step (DEMF_GEO_AT_FWD): the pre-pass goes first - enqueueing the
+                # single-graph step (the default): the pre-pass goes first - enqueueing the
                 # ~900-node step graph takes the host about a millisecond
                 launch_prepass(main, next_points)
             graph.replay()
