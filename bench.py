@@ -45,8 +45,10 @@ MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
                       "tests/test_gpu_split.py)",
              "bf16": "operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
 MFMA_PATH["f32"] = MFMA_PATH["f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
-# FPS: per round one barrier phase (~450 cycles with 16 waves) + 20 points/lane x 8 VALU ops
-FPS_FLOOR_CYCLES = 900.0
+# FPS floor per dependent round = the SIMD's VALU issue for the bit-exact distance update: 4 waves per
+# SIMD x ~105 packed instructions x 4 cycles (round 2's 900 assumed a one-barrier
+# round that was measured not to pay)
+FPS_FLOOR_CYCLES = 1700.0
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
 ALGO_BYTES_PER_SCENE = 190e6
 ALGO_FLOP_PER_SCENE = 46e9
@@ -470,8 +472,9 @@ def main():
                 "bound": "latency", "avg_launch_ms": fps_ms, "dependent_rounds": rounds,
                 "cycles_per_round": cyc, "floor_cycles_per_round": FPS_FLOOR_CYCLES,
                 "frac": FPS_FLOOR_CYCLES / cyc,
-                "note": "floor = one 16-wave barrier phase + the per-wave VALU work of 20000 points "
-                        "(DESIGN.md section 3.1); HBM bytes are 2 MB per launch by construction"}
+                "note": "floor = VALU issue of the distance update of 20000 points on one CU (4 waves per "
+                        "SIMD x ~105 packed instructions x 4 cycles, DESIGN.md section 7); HBM bytes are "
+                        "2 MB per launch by construction"}
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

@@ -2039,7 +2039,7 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
   // (measured on the training step, sparse form: caps of 256 / 128 / 64 / 32 blocks cost +0.04 / +0.21 /
   // +0.45 / +1.0 ms per step - the launch is bound by its dependent loads per block, not by the
   // 2N same-address fp64 atomics each block ends with)
-  int grid = cdiv(rows, rows_par * 8);
+  int grid = cdiv(rows, rows_par * (G ? 8 : env_int("DEMF_BNRED_SPARSE_RPT", 8)));
   const int scap = G ? 1024 : env_int("DEMF_BNRED_SPARSE_GRID", 1024);
   if (grid > scap) grid = scap;
   if (grid < 1) grid = 1;
