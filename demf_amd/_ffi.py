@@ -67,7 +67,9 @@ SIGNATURES = {
     "demf_mlp_first_finish": [_c_int, ctypes.c_longlong] + [_ptr] * 7,
     "demf_mlp_gemm_bwd_dx_red": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 9,
     "demf_mlp_gemm_bwd_dx_w": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
-    "demf_mlp_bwd_fused": [_c_int] * 3 + [_ptr] * 3 + [_c_int] + [_ptr] * 12,
+    "demf_mlp_bwd_fused": [_c_int] * 3 + [_ptr] * 3 + [_c_int] + [_ptr] * 16,
+    "demf_mlp_gemm_bwd_dx_red_v": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 13,
+    "demf_bn_bwd_reduce_vectors": [_c_int] * 3 + [_ptr] * 12,
     "demf_mlp_gemm_bwd_dw": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 6,
     "demf_mlp_gemm_bwd_dw_ld": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5 + [_c_int, _ptr],
     "demf_head_loss_fwd": [_c_int] * 3 + [_ptr] * 14,

@@ -23,6 +23,7 @@
 // k = k0 + 4*(lane>>5) .. +3, and feeds component m to MFMA m: MFMA m then contracts over
 // k in {k0+m, k0+4+m} on both operands consistently - four MFMAs consume the two float4.
 #include "common.h"
+#include "bn_fin.h"
 #include <atomic>
 #include <type_traits>
 
@@ -175,6 +176,7 @@ struct MlpArgs {
   int fld, fc0;
   int* sched;                  // persistent launches: SCHED_GROUPS tile counters, 1 + SCHED_GROUPS exit counters, or null
   BnFin fin;                   // STATS launches: in-kernel finalize when fin.ss != null
+  BnVecFin vfin;               // RED launches: layer l-1's backward vectors by the last workgroup (ticket != null)
 };
 
 // Raw operands of one float4 of A: fetched early (kept in flight across the MFMA phase of the
@@ -939,6 +941,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         atomicAdd(p.stats + which * (RED ? p.fld : p.N) + (RED ? p.fc0 : 0) + cofs + nt * 32 + c, (double)v);
     }
   }
+  if constexpr (RED) {
+    if (p.vfin.ticket != nullptr) {
+      // layer l-1's backward vectors for this launch's columns, by its last workgroup (csrc/bn_fin.h)
+      __syncthreads();
+      if (threadIdx.x == 0)
+        s_next = last_workgroup(p.vfin.ticket, (int)(gridDim.x * gridDim.y), (int)(blockIdx.y * gridDim.x + blockIdx.x));
+      __syncthreads();
+      if (s_next) bn_vec_finalize(p.vfin, p.fld, p.fc0, p.N, p.stats, threadIdx.x, 256);
+    }
+  }
   if constexpr (STATS) {
     if (p.fin.ss != nullptr) {
       // Only atomics touch the sums and the counters, and __syncthreads() waits for this block's own
@@ -1326,9 +1338,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
                                                        const float* __restrict__ ss,
                                                        const float* __restrict__ mi,
                                                        double* __restrict__ g12,
-                                                       const float* __restrict__ yraw) {
+                                                       const float* __restrict__ yraw, BnVecFin fin) {
   // thread -> one column, strided rows; columns are the fast index so reads coalesce
   __shared__ float red[2][256];
+  __shared__ int s_last;
   const int cols_per_pass = N < 256 ? N : 256;
   const int rows_par = 256 / cols_per_pass;           // row lanes per block pass
   const int c_in = threadIdx.x % cols_per_pass, r_in = threadIdx.x / cols_per_pass;
@@ -1369,6 +1382,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
       atomicAdd(g12 + N + cb + threadIdx.x, (double)t2);
     }
     __syncthreads();
+  }
+  if (fin.ticket != nullptr) {     // this layer's backward vectors by the last workgroup (csrc/bn_fin.h)
+    if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
+    __syncthreads();
+    if (s_last) bn_vec_finalize(fin, N, 0, N, g12, threadIdx.x, 256);
   }
 }
 
@@ -1681,7 +1699,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
 // 1024 launches apart on the calling thread's stream order (the MLP path is single-stream).
 constexpr int SCHED_SLOTS = 1024;
 __device__ int g_tile_sched[SCHED_INTS * SCHED_SLOTS];
-static int* sched_slot() {
+int* sched_slot() {
   static int* base = nullptr;
   static std::atomic<unsigned> next{0};
   if (base == nullptr) {
@@ -2015,10 +2033,13 @@ extern "C" int demf_bnrelu_maxpool_fwd(int R, int ns, int C, const float* Y,
   return check_launch("bnrelu_maxpool_fwd");
 }
 
-extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP,
-                                  const int* arg, const float* Y, const float* yraw,
-                                  const float* scale_shift, const float* mean_invstd, double* g12,
-                                  demf_stream_t stream) {
+extern "C" int demf_bn_bwd_vectors(int, long long, double*, const float*, const float*, const float*, float*,
+                                   float*, float*, demf_stream_t);
+
+static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float* dP,
+                              const int* arg, const float* Y, const float* yraw,
+                              const float* scale_shift, const float* mean_invstd, double* g12,
+                              const BnVecFin& vf, demf_stream_t stream) {
   DEMF_REQUIRE(R >= 0 && N >= 1, "bn_bwd_reduce: bad sizes R=%d N=%d", R, N);
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
@@ -2045,11 +2066,33 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
   if (grid < 1) grid = 1;
   if (G)
     hipLaunchKernelGGL((bn_bwd_reduce_k<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, nullptr);
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, nullptr, BnVecFin{});
   else
     hipLaunchKernelGGL((bn_bwd_reduce_k<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, yraw);
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, yraw, vf);
   return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const float* dP,
+                                  const int* arg, const float* Y, const float* yraw,
+                                  const float* scale_shift, const float* mean_invstd, double* g12,
+                                  demf_stream_t stream) {
+  return bn_bwd_reduce_impl(R, N, ns, G, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, BnVecFin{}, stream);
+}
+
+// Sparse (pooled last layer) reduce + the layer's backward vectors in ONE launch: what
+// demf_bn_bwd_reduce(G = NULL) followed by demf_bn_bwd_vectors does in two.
+extern "C" int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP, const int* arg,
+                                          const float* Y, const float* yraw, const float* scale_shift,
+                                          const float* mean_invstd, double* g12, const float* gamma,
+                                          float* vec6, float* dgamma, float* dbeta, demf_stream_t stream) {
+  DEMF_REQUIRE(gamma && vec6 && dgamma && dbeta && dP && arg, "bn_bwd_reduce_vectors: null pointer");
+  BnVecFin vf{(double)R, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, sched_slot()};
+  if (vf.ticket == nullptr) {              // DEMF_STATIC_TILES=1: no counter sets - two launches
+    if (int e = bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, BnVecFin{}, stream)) return e;
+    return demf_bn_bwd_vectors(N, R, g12, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, stream);
+  }
+  return bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, vf, stream);
 }
 
 extern "C" int demf_bn_bwd_vectors(int N, long long count, double* g12, const float* gamma,
@@ -2070,6 +2113,10 @@ struct DxReduce {            // optional: layer l-1 operands for the RED epilogu
   const float* ss;           // [scale|shift] (2K)
   const float* mi;           // [mean|invstd] (2K)
   double* g12;               // (2K) accumulated
+  const float* gamma = nullptr;   // + layer l-1's backward vectors by the last workgroup when given
+  float* vec6 = nullptr;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
 };
 
 static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const float* G, const float* dP,
@@ -2091,6 +2138,8 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
     int e;
     if (red) {
       a.fY = red->Yprev; a.fss = red->ss; a.fmi = red->mi; a.stats = red->g12; a.fld = K; a.fc0 = c0;
+      if (red->gamma != nullptr)
+        a.vfin = BnVecFin{(double)R, red->gamma, red->ss, red->mi, red->vec6, red->dgamma, red->dbeta, sched_slot()};
       e = G ? launch_gemm<PRO_DY_DENSE, false, false, true>(a, s)
             : launch_gemm<PRO_DY_SPARSE, false, false, true>(a, s);
     } else {
@@ -2124,6 +2173,22 @@ extern "C" int demf_mlp_gemm_bwd_dx_red(int R, int N, int K, int ldo, const floa
   DEMF_REQUIRE(K % 4 == 0 && Yprev && scale_shift_prev && mean_invstd_prev && g12_prev,
                "mlp_gemm_bwd_dx_red: bad arguments (K %% 4 == 0)");
   const DxReduce red{Yprev, scale_shift_prev, mean_invstd_prev, g12_prev};
+  return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, &red, stream);
+}
+
+// Same + layer l-1's backward vectors (demf_bn_bwd_vectors on g12_prev) formed by the launch's last
+// workgroup: vec6_prev (5K), dgamma_prev, dbeta_prev are complete and g12_prev is zeroed on return.
+extern "C" int demf_mlp_gemm_bwd_dx_red_v(int R, int N, int K, int ldo, const float* G, const float* dP,
+                                          const int* arg, int ns, const float* Y, const float* vec6,
+                                          const float* W, float* dX, const float* Yprev,
+                                          const float* scale_shift_prev, const float* mean_invstd_prev,
+                                          double* g12_prev, const float* gamma_prev, float* vec6_prev,
+                                          float* dgamma_prev, float* dbeta_prev, demf_stream_t stream) {
+  DEMF_REQUIRE(K % 4 == 0 && Yprev && scale_shift_prev && mean_invstd_prev && g12_prev && gamma_prev &&
+                   vec6_prev && dgamma_prev && dbeta_prev,
+               "mlp_gemm_bwd_dx_red_v: bad arguments (K %% 4 == 0)");
+  DxReduce red{Yprev, scale_shift_prev, mean_invstd_prev, g12_prev};
+  red.gamma = gamma_prev; red.vec6 = vec6_prev; red.dgamma = dgamma_prev; red.dbeta = dbeta_prev;
   return mlp_bwd_dx_impl(true, R, N, K, ldo, G, dP, arg, ns, Y, vec6, W, dX, &red, stream);
 }
 

@@ -30,6 +30,7 @@
 //     mlp_first_finish_k in csrc/mlp.hip).
 // Algorithmic HBM bytes per row: 4*(N [Y_l] + N [G, dense only] + K [Y_{l-1}] + K [dX, RED only]).
 #include "common.h"
+#include "bn_fin.h"
 
 namespace demf {
 
@@ -54,6 +55,7 @@ struct FusedBwdArgs {
   double* g12;        // RED: sum dZ | sum dZ*xhat of layer l-1 (2K), accumulated
   const float* fX;    // FIRST: (R x 4) input rows of layer 0
   double* fsum;       // FIRST: g1(K) | g2(K) | P(K x 4) | Q(K x 4) | cx(4), accumulated
+  BnVecFin vfin;      // RED: layer l-1's backward vectors by the last workgroup (ticket != null)
 };
 
 // one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
@@ -461,6 +463,15 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       atomicAdd(p.fsum + 10 * K + (q - 40), (double)t);
     }
   }
+  if constexpr (EPI == 0) {
+    if (p.vfin.ticket != nullptr) {        // layer l-1's backward vectors by the last workgroup (csrc/bn_fin.h)
+      __shared__ int s_last;
+      __syncthreads();
+      if (tid == 0) s_last = last_workgroup(p.vfin.ticket, (int)gridDim.x, (int)blockIdx.x);
+      __syncthreads();
+      if (s_last) bn_vec_finalize(p.vfin, K, 0, K, p.g12, tid, NT);
+    }
+  }
 }
 
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI>
@@ -506,7 +517,9 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
                                   int ns, const float* Y, const float* vec6, const float* W,
                                   const float* Yprev, const float* scale_shift_prev,
                                   const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
-                                  const float* X0, double* first_sums, demf_stream_t stream) {
+                                  const float* X0, double* first_sums, const float* gamma_prev,
+                                  float* vec6_prev, float* dgamma_prev, float* dbeta_prev,
+                                  demf_stream_t stream) {
   const bool sparse = G == nullptr, first = first_sums != nullptr;
   DEMF_REQUIRE(fused_supported(R, N, K, ns, sparse, first),
                "mlp_bwd_fused: unsupported shape / mode R=%d N=%d K=%d ns=%d sparse=%d first=%d mode=%d",
@@ -518,6 +531,11 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
   a.R = R; a.N = N; a.K = K; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
   a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.dX = dX; a.dW = dW;
   a.g12 = g12_prev; a.fX = X0; a.fsum = first_sums;
+  if (!first && gamma_prev != nullptr) {
+    DEMF_REQUIRE(vec6_prev && dgamma_prev && dbeta_prev, "mlp_bwd_fused: vectors of layer l-1 need all three outputs");
+    a.vfin = BnVecFin{(double)R, gamma_prev, scale_shift_prev, mean_invstd_prev, vec6_prev, dgamma_prev,
+                      dbeta_prev, sched_slot()};
+  }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
 #define FGO(NTNv, KTv, KGv, SPv, EPv) \

@@ -686,6 +686,7 @@ _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0'))
 _NO_RED_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_RED_FUSE', '0')))        # A/B switch
 _NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
 _NO_BWD_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_BWD_FUSE', '0')))        # A/B switch
+_VEC_FIN = int(__import__('os').environ.get('DEMF_VEC_FIN', '7'))   # A/B: bit 0 sparse reduce, 1 fused, 2 dx_red
 
 
 def _bwd_fused_ok(N, K, ns, sparse, first=False):
@@ -867,23 +868,37 @@ class _SharedMLPPool(Function):
         nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
         ws32 = zeros(sum(W.numel() for W in Ws) + nbias, dev)
         o64 = o32 = 0
-        g12_ready = None      # layer l's sums already taken by the dx GEMM of layer l+1 (RED epilogue)
+        g12_pending = None
+        vec_ready = None      # layer l's sums taken by the dx launch of layer l+1 (RED epilogue), whose last
+        #                       workgroup also formed the backward vectors (vec6, dgamma, dbeta)
         for l in range(L - 1, -1, -1):
             W = Ws[l]
             N, K = W.shape
-            if g12_ready is not None:
-                g12, g12_ready = g12_ready, None
+            if vec_ready is not None:
+                # formed by the last workgroup of the launch that produced this layer's sums
+                vec6, dgamma, dbeta = vec_ready
+                vec_ready = None
+                if g12_pending is not None:          # (A/B: the producer left the sums, vectors as a launch)
+                    _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12_pending), _p(gammas[l]), _p(sss[l]),
+                              _p(mis[l]), _p(vec6), _p(dgamma), _p(dbeta), st)
+                    g12_pending = None
             else:
+                vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
+                dgamma = torch.empty(N, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(N, dtype=torch.float32, device=dev)
                 g12 = ws64[o64:o64 + 2 * N]
                 o64 += 2 * N
-                _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
-                          _p(arg if G is None else None), _p(Ys[l]),
-                          _p(yraw if G is None else None), _p(sss[l]), _p(mis[l]), _p(g12), st)
-            vec6 = torch.empty(5 * N, dtype=torch.float32, device=dev)
-            dgamma = torch.empty(N, dtype=torch.float32, device=dev)
-            dbeta = torch.empty(N, dtype=torch.float32, device=dev)
-            _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12), _p(gammas[l]), _p(sss[l]), _p(mis[l]),
-                      _p(vec6), _p(dgamma), _p(dbeta), st)
+                if G is None and (_VEC_FIN & 1):
+                    # pooled last layer: sums + vectors in one launch
+                    _ffi.call("demf_bn_bwd_reduce_vectors", R, N, ns, _p(dP), _p(arg), _p(Ys[l]), _p(yraw),
+                              _p(sss[l]), _p(mis[l]), _p(g12), _p(gammas[l]), _p(vec6), _p(dgamma),
+                              _p(dbeta), st)
+                else:
+                    _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
+                              _p(arg if G is None else None), _p(Ys[l]), _p(yraw if G is None else None),
+                              _p(sss[l]), _p(mis[l]), _p(g12), st)
+                    _ffi.call("demf_bn_bwd_vectors", N, R, _p(g12), _p(gammas[l]), _p(sss[l]), _p(mis[l]),
+                              _p(vec6), _p(dgamma), _p(dbeta), st)
             if l == 0 and ctx.geo is not None:
                 # factored first layer: dU per source point through the inverse lists, then the
                 # feature half of dW and the input gradient are GEMMs over the source points
@@ -939,7 +954,7 @@ class _SharedMLPPool(Function):
                     o64 += 10 * N0 + 4
                     _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), None, None, ns, _p(Ys[l]), _p(vec6),
                               _p(W), _p(Ys[0]), _p(sss[0]), _p(mis[0]), None, _p(dW), None, _p(x),
-                              _p(sums), st)
+                              _p(sums), None, None, None, None, st)
                     dW0 = ws32[o32:o32 + N0 * 4].view(N0, 4)
                     o32 += N0 * 4
                     dgamma0 = torch.empty(N0, dtype=torch.float32, device=dev)
@@ -952,11 +967,18 @@ class _SharedMLPPool(Function):
                         o32 += N0
                     break
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
-                g12_ready = ws64[o64:o64 + 2 * K]
+                g12p = ws64[o64:o64 + 2 * K]
                 o64 += 2 * K
+                vec_ready = (torch.empty(5 * K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev))
                 _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), _p(dP if sparse else None),
                           _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(Ys[l - 1]),
-                          _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12_ready), None, None, st)
+                          _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p), None, None,
+                          _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]), _p(vec_ready[1]),
+                          _p(vec_ready[2]), st)
+                if not (_VEC_FIN & 2):
+                    g12_pending = g12p
                 G = dX
                 continue
             _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
@@ -987,11 +1009,21 @@ class _SharedMLPPool(Function):
                 dX = torch.empty((R, K), dtype=torch.float32, device=dev)
                 if K % 4 == 0 and l > 0 and not _NO_RED_FUSE:
                     # + layer l-1's BN-backward sums from the output tiles (no separate reduce pass)
-                    g12_ready = ws64[o64:o64 + 2 * K]
+                    g12p = ws64[o64:o64 + 2 * K]
                     o64 += 2 * K
-                    _ffi.call("demf_mlp_gemm_bwd_dx_red", R, N, K, K, _p(G), _p(dP if sparse else None),
-                              _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX),
-                              _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(g12_ready), st)
+                    vec_ready = (torch.empty(5 * K, dtype=torch.float32, device=dev),
+                                 torch.empty(K, dtype=torch.float32, device=dev),
+                                 torch.empty(K, dtype=torch.float32, device=dev))
+                    if _VEC_FIN & 4:
+                        _ffi.call("demf_mlp_gemm_bwd_dx_red_v", R, N, K, K, _p(G), _p(dP if sparse else None),
+                                  _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX),
+                                  _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(g12p), _p(gammas[l - 1]),
+                                  _p(vec_ready[0]), _p(vec_ready[1]), _p(vec_ready[2]), st)
+                    else:
+                        _ffi.call("demf_mlp_gemm_bwd_dx_red", R, N, K, K, _p(G), _p(dP if sparse else None),
+                                  _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(dX),
+                                  _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(g12p), st)
+                        g12_pending = g12p
                 elif K % 4 == 0:
                     # W read as it is: the kernel transposes the slab on its way into LDS
                     _ffi.call("demf_mlp_gemm_bwd_dx_w", R, N, K, K, _p(G), _p(dP if sparse else None),

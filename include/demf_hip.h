@@ -345,6 +345,20 @@ int demf_mlp_first_finish(int N0, long long count, double* sums, const float* ga
                           const float* mean_invstd0, float* dW0, float* dgamma0, float* dbeta0,
                           demf_stream_t stream);
 
+/* demf_mlp_gemm_bwd_dx_red + layer l-1's backward vectors (demf_bn_bwd_vectors on g12_prev) formed by
+ * the launch's last workgroup: the ~5 us vectors launch behind every layer's backward disappears. */
+int demf_mlp_gemm_bwd_dx_red_v(int R, int N, int K, int ldo, const float* G, const float* dP,
+                               const int* arg, int ns, const float* Y, const float* vec6,
+                               const float* W, float* dX, const float* Yprev,
+                               const float* scale_shift_prev, const float* mean_invstd_prev,
+                               double* g12_prev, const float* gamma_prev, float* vec6_prev,
+                               float* dgamma_prev, float* dbeta_prev, demf_stream_t stream);
+/* demf_bn_bwd_reduce (sparse form: the pooled last layer of a stack) + demf_bn_bwd_vectors in ONE launch. */
+int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP, const int* arg, const float* Y,
+                               const float* yraw, const float* scale_shift, const float* mean_invstd,
+                               double* g12, const float* gamma, float* vec6, float* dgamma, float* dbeta,
+                               demf_stream_t stream);
+
 /* One pass over a layer's saved output for its whole backward (csrc/mlp_bwd.hip): what
  * demf_mlp_gemm_bwd_dx_red + demf_mlp_gemm_bwd_dw do in two (or, with first_sums != NULL,
  * demf_mlp_gemm_bwd_dx_first + demf_mlp_gemm_bwd_dw: dX is then not stored and X0 (R x 4) / first_sums
@@ -352,13 +366,17 @@ int demf_mlp_first_finish(int N0, long long count, double* sums, const float* ga
  * both contractions; W stays in registers.  Yprev (R x K) = pre-BN output of layer l-1, row stride K;
  * dX row stride K; dW (N x K) accumulated (arrives zeroed).  Compute modes 1 (bf16) and 2 (fp32 as
  * three bf16 terms) only; shapes (N,K) in {(128,64), (128,128), (64,64), (256,128)}, ns % 4 == 0 when sparse
- * (G == NULL); anything else returns DEMF_EINVAL and callers use the two-launch path.  Replaces the
+ * (G == NULL); anything else returns DEMF_EINVAL and callers use the two-launch path.  With gamma_prev !=
+ * NULL (and not first_sums) the launch's last workgroup also forms layer l-1's backward vectors - what
+ * demf_bn_bwd_vectors(K, R, g12_prev, gamma_prev, ...) would: vec6_prev (5K), dgamma_prev, dbeta_prev,
+ * g12_prev left zeroed.  Replaces the
  * autograd backward of Conv2d -> BatchNorm2d -> ReLU in mmdet3d's PointSAModule stacks
  * (configs/demf/demf_votenet.py:48-62; class_agnostic_vote_head.py:383). */
 int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, const int* arg, int ns,
                        const float* Y, const float* vec6, const float* W, const float* Yprev,
                        const float* scale_shift_prev, const float* mean_invstd_prev, float* dX,
                        float* dW, double* g12_prev, const float* X0, double* first_sums,
+                       const float* gamma_prev, float* vec6_prev, float* dgamma_prev, float* dbeta_prev,
                        demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
