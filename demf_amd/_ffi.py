@@ -53,6 +53,8 @@ SIGNATURES = {
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,
     "demf_mlp_gemm_fwd_bn": [_c_int] * 4 + [_ptr] * 7 + [_c_float, _c_float] + [_ptr] * 7,
     "demf_mlp_gemm_fwd_pool_bn": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 6 + [_c_float, _c_float] + [_ptr] * 7,
+    "demf_mlp_gemm_fwd_bn_st": [_c_int] * 4 + [_ptr] * 7 + [_c_float, _c_float] + [_ptr] * 6 + [_c_int, _ptr],
+    "demf_mlp_gemm_fwd_pool_bn_st": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 4 + [_c_float, _c_float] + [_ptr] * 6 + [_c_int, _ptr],
     "demf_pool_select": [_c_int] * 2 + [_ptr] * 9,
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 7,
     "demf_l2norm_rows_fwd": [_c_int] * 2 + [_ptr] * 4,
@@ -67,9 +69,9 @@ SIGNATURES = {
     "demf_mlp_first_finish": [_c_int, ctypes.c_longlong] + [_ptr] * 7,
     "demf_mlp_gemm_bwd_dx_red": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 9,
     "demf_mlp_gemm_bwd_dx_w": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
-    "demf_mlp_bwd_fused": [_c_int] * 3 + [_ptr] * 3 + [_c_int] + [_ptr] * 16,
+    "demf_mlp_bwd_fused": [_c_int] * 3 + [_ptr] * 3 + [_c_int] + [_ptr] * 15 + [_c_int, _ptr],
     "demf_mlp_gemm_bwd_dx_red_v": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 13,
-    "demf_bn_bwd_reduce_vectors": [_c_int] * 3 + [_ptr] * 12,
+    "demf_bn_bwd_reduce_vectors": [_c_int] * 3 + [_ptr] * 11 + [_c_int, _ptr],
     "demf_mlp_gemm_bwd_dw": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 6,
     "demf_mlp_gemm_bwd_dw_ld": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5 + [_c_int, _ptr],
     "demf_head_loss_fwd": [_c_int] * 3 + [_ptr] * 14,

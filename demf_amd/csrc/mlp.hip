@@ -162,6 +162,7 @@ struct MlpArgs {
   int* amax;
   int* amin;
   int halves;                  // pooled launches: 2 = two column halves interleaved in a 1-D grid
+  int st;                      // bf16 STORAGE of the rows (weight-resident forward only): bit 0 X, bit 1 Y
   // FIRST epilogue (backward of a stack whose first layer has a 4-float input and no input
   // gradient): the output tile IS the gradient of layer 0's activation; instead of storing it, the
   // raw sums of layer 0's whole backward are taken from it (see mlp_first_finish_k)
@@ -1040,8 +1041,13 @@ __device__ __forceinline__ void fr_mfma(f32x16& acc, const bf16x8 (&a)[P], const
   }
 }
 
-template <int NTN, int KT, bool POOL, int CM>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three-term
+// ST (bf16 compute mode only, BASELINE configs[3]): the rows themselves live in HBM as bf16 - bit 0: the
+// input rows X, bit 1: the raw output Y (statistics and pooling still see the fp32 accumulators).  A
+// lane pair (columns 2c, 2c+1) swaps one register per row pair through DPP so that every lane stores one
+// packed dword: half the bytes AND half the store instructions of the fp32 form.
+template <int NTN, int KT, bool POOL, int CM, int ST = 0>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three-term
 __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
+  constexpr bool XB = (ST & 1) != 0, YB = (ST & 2) != 0;
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32, KB = K * 2;
   constexpr int KS = K / 16;                       // MFMA K steps
@@ -1094,7 +1100,13 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
     for (int j = 0; j < NLD; ++j) {
       int row = row0 + rq + RPI * j;
       row = row < p.R ? row : p.R - 1;                     // valid address; zeroed by the transform
-      raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + 4 * c4);
+      if constexpr (XB) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.X) + (size_t)row * p.ldx + 4 * c4);
+        raw[j] = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                             __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+      } else {
+        raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)row * p.ldx + 4 * c4);
+      }
     }
   };
   int unit = blockIdx.x * FR_NW + wave;
@@ -1157,6 +1169,22 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
         const int col = nt * 32 + lr;
+        if constexpr (YB) {
+          // lanes (2c, 2c+1): the even lane stores row r, the odd lane row r+1 of the register pair
+          const bool odd = lane & 1;
+          unsigned* yp = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(p.Y) +
+                                                      (size_t)(row0 + 4 * lh) * N + (col & ~1));
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float send = odd ? acc[0][nt][r] : acc[0][nt][r + 1];
+            const float recv = dpp_f32<0xB1>(send, send);              // quad_perm [1,0,3,2]
+            const f32x2_t v = {odd ? recv : acc[0][nt][r], odd ? acc[0][nt][r + 1] : recv};
+            const int rr = r + (odd ? 1 : 0);
+            const int rl = (rr & 3) + 8 * (rr >> 2);
+            if (full || row0 + 4 * lh + rl < p.R)
+              yp[(size_t)rl * (N / 2)] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+          }
+        } else {
         float* yp = p.Y + (size_t)(row0 + 4 * lh) * N + col;
         if (full) {
 #pragma unroll
@@ -1165,6 +1193,7 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (row0 + 4 * lh + (r & 3) + 8 * (r >> 2) < p.R) yp[(size_t)((r & 3) + 8 * (r >> 2)) * N] = acc[0][nt][r];
+        }
         }
         f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
 #pragma unroll
@@ -1338,7 +1367,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
                                                        const float* __restrict__ ss,
                                                        const float* __restrict__ mi,
                                                        double* __restrict__ g12,
-                                                       const float* __restrict__ yraw, BnVecFin fin) {
+                                                       const float* __restrict__ yraw, BnVecFin fin,
+                                                       int y_bf16) {
   // thread -> one column, strided rows; columns are the fast index so reads coalesce
   __shared__ float red[2][256];
   __shared__ int s_last;
@@ -1355,7 +1385,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
         for (int rp = blockIdx.x * rows_par + r_in; rp < Rp; rp += gridDim.x * rows_par) {
           // y at the arg-max row: handed over by demf_pool_select, else gathered from Y
           float y = yraw ? yraw[(size_t)rp * N + c] : __builtin_nanf("");
-          if (y != y) y = Y[((size_t)rp * ns + arg[(size_t)rp * N + c]) * N + c];
+          if (y != y) {
+            const size_t o = ((size_t)rp * ns + arg[(size_t)rp * N + c]) * N + c;
+            y = y_bf16 ? (float)reinterpret_cast<const __bf16*>(Y)[o] : Y[o];
+          }
           const float dz = __builtin_fmaf(y, sc, sh) > 0.f ? dP[(size_t)rp * N + c] : 0.f;
           a1 += dz;
           a2 = __builtin_fmaf(dz, (y - mu) * is, a2);
@@ -1740,7 +1773,7 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     // weight-resident, barrier-free forward (mlp_fwd_res_kernel): 64-channel inputs, N = 64 / 128
     static const int fr_on = env_int("DEMF_FWD_RES", 1);
     const bool sel = !POOL || (a.pmin == nullptr && a.fin.gamma != nullptr);
-    if (fr_on && a.K == 64 && (a.N == 64 || a.N == 128) && a.ldx == 64 && a.ldy == a.N && a.ldb == 0 && sel &&
+    if ((fr_on || a.st) && a.K == 64 && (a.N == 64 || a.N == 128) && a.ldx == 64 && a.ldy == a.N && a.ldb == 0 && sel &&
         a.R >= 64 * 256 && (!POOL || ((a.ns == 16 || a.ns == 32 || a.ns == 64) && a.R % 64 == 0)) &&
         (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
       constexpr int P = BF16 == 2 ? 3 : 1;
@@ -1752,23 +1785,43 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
       // the next batch (csrc/mlp_bwd.hip launch_fused has the measurements)
       static const int cus = env_int("DEMF_PERSIST_CUS", 240);
       if (gx > cus) gx = cus;
-#define FRGO(NTNv)                                                                                          \
+#define FRGO(NTNv, STv)                                                                                     \
       do {                                                                                                  \
         static bool configured = false;                                                                     \
         if (!configured) {                                                                                  \
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_res_kernel<NTNv, 2, POOL, BF16>),   \
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_res_kernel<NTNv, 2, POOL, BF16, STv>),   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {   \
             set_error("mlp_fwd_res: cannot reserve %zu bytes of LDS", bytes);                                \
             return DEMF_ELAUNCH;                                                                             \
           }                                                                                                 \
           configured = true;                                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((mlp_fwd_res_kernel<NTNv, 2, POOL, BF16>), dim3(gx), dim3(64 * FR_NW), bytes, s, a); \
+        hipLaunchKernelGGL((mlp_fwd_res_kernel<NTNv, 2, POOL, BF16, STv>), dim3(gx), dim3(64 * FR_NW), bytes, s, a); \
       } while (0)
-      if (ntn == 2) FRGO(2); else FRGO(4);
+      if (a.st == 0) {
+        if (ntn == 2) FRGO(2, 0); else FRGO(4, 0);
+      } else {
+        // bf16 storage: the two forms SA1 uses (fp32 rows in -> bf16 rows out; bf16 in -> bf16 out, pooled)
+        bool done = false;
+        if constexpr (BF16 == 1 && !POOL) {
+          if (a.st == 2 && ntn == 2) { FRGO(2, 2); done = true; }
+        }
+        if constexpr (BF16 == 1 && POOL) {
+          if (a.st == 3 && ntn == 4) { FRGO(4, 3); done = true; }
+        }
+        if (!done) {
+          set_error("mlp_fwd_res: bf16 storage form st=%d N=%d pool=%d mode=%d not built", a.st, a.N, (int)POOL, BF16);
+          return DEMF_EUNSUPPORTED;
+        }
+      }
 #undef FRGO
       return check_launch("mlp_fwd_res");
     }
+  }
+  if (a.st != 0) {
+    set_error("mlp_gemm: bf16 row storage (st=%d) is only built into the weight-resident forward (K = 64, "
+              "N = 64 / 128, R >= 16384, bf16 compute mode)", a.st);
+    return DEMF_EUNSUPPORTED;
   }
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
@@ -1946,18 +1999,18 @@ static int fin_check(long long count, const float* gamma, const float* beta, con
   return DEMF_OK;
 }
 
-extern "C" int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X,
-                                    const float* pro_scale_shift, const float* Wt, float* Y,
-                                    double* stats, const float* gamma, const float* beta, float eps,
-                                    float momentum, float* running_mean, float* running_var,
-                                    long long* num_batches_tracked, float* scale_shift,
-                                    float* mean_invstd, const float* conv_bias, demf_stream_t stream) {
+static int mlp_gemm_fwd_bn_impl(int R, int K, int N, int ldx, const float* X,
+                                const float* pro_scale_shift, const float* Wt, float* Y,
+                                double* stats, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float* scale_shift,
+                                float* mean_invstd, const float* conv_bias, int st, demf_stream_t stream) {
   if (int e = mlp_check(R, K, N, ldx)) return e;
   DEMF_REQUIRE(R >= 1 && X && Wt && Y, "mlp_gemm_fwd_bn: null pointer / no rows");
   if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
   MlpArgs a{};
   a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
-  a.Y = Y; a.stats = stats;
+  a.Y = Y; a.stats = stats; a.st = st;
   hipStream_t s = (hipStream_t)stream;
   BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
             num_batches_tracked, scale_shift, mean_invstd, nullptr};
@@ -1966,14 +2019,41 @@ extern "C" int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X
   return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_NONE, true>(b, s); }, s);
 }
 
-extern "C" int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const float* X,
-                                         const float* pro_scale_shift, const float* Wt, float* Y,
-                                         double* stats, int ns, float* pmax, float* pmin, int* amax,
-                                         int* amin, const float* gamma, const float* beta, float eps,
-                                         float momentum, float* running_mean, float* running_var,
-                                         long long* num_batches_tracked, float* scale_shift,
-                                         float* mean_invstd, const float* conv_bias,
-                                         demf_stream_t stream) {
+extern "C" int demf_mlp_gemm_fwd_bn(int R, int K, int N, int ldx, const float* X,
+                                    const float* pro_scale_shift, const float* Wt, float* Y,
+                                    double* stats, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* scale_shift,
+                                    float* mean_invstd, const float* conv_bias, demf_stream_t stream) {
+  return mlp_gemm_fwd_bn_impl(R, K, N, ldx, X, pro_scale_shift, Wt, Y, stats, gamma, beta, eps, momentum,
+                              running_mean, running_var, num_batches_tracked, scale_shift, mean_invstd,
+                              conv_bias, 0, stream);
+}
+
+// Same with the rows stored as bf16 in HBM (store_flags bit 0: X is bf16, bit 1: Y is bf16; X / Y then
+// point to 2-byte elements, ldx still counts elements).  bf16 compute mode, weight-resident forward only
+// (K = 64, N = 64 / 128, R >= 16384): DEMF_EUNSUPPORTED otherwise.  BASELINE configs[3].
+extern "C" int demf_mlp_gemm_fwd_bn_st(int R, int K, int N, int ldx, const void* X,
+                                       const float* pro_scale_shift, const float* Wt, void* Y,
+                                       double* stats, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var,
+                                       long long* num_batches_tracked, float* scale_shift,
+                                       float* mean_invstd, const float* conv_bias, int store_flags,
+                                       demf_stream_t stream) {
+  DEMF_REQUIRE(store_flags >= 1 && store_flags <= 3 && pro_scale_shift, "mlp_gemm_fwd_bn_st: store_flags in 1..3, BN prologue");
+  return mlp_gemm_fwd_bn_impl(R, K, N, ldx, (const float*)X, pro_scale_shift, Wt, (float*)Y, stats, gamma, beta,
+                              eps, momentum, running_mean, running_var, num_batches_tracked, scale_shift,
+                              mean_invstd, conv_bias, store_flags, stream);
+}
+
+static int mlp_gemm_fwd_pool_bn_impl(int R, int K, int N, int ldx, const float* X,
+                                     const float* pro_scale_shift, const float* Wt, float* Y,
+                                     double* stats, int ns, float* pmax, float* pmin, int* amax,
+                                     int* amin, const float* gamma, const float* beta, float eps,
+                                     float momentum, float* running_mean, float* running_var,
+                                     long long* num_batches_tracked, float* scale_shift,
+                                     float* mean_invstd, const float* conv_bias, int st,
+                                     demf_stream_t stream) {
   if (int e = mlp_check(R, K, N, ldx)) return e;
   const bool ok = (ns == 16 || ns == 32 || ns == 64) && R % ns == 0 && R >= 1;
   if (!ok) {
@@ -1986,10 +2066,40 @@ extern "C" int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const flo
   MlpArgs a{};
   a.R = R; a.K = K; a.N = N; a.ldx = ldx; a.ldy = N; a.X = X; a.vec = pro_scale_shift; a.Bt = Wt;
   a.Y = Y; a.stats = stats; a.ns = ns; a.pmax = pmax; a.pmin = pmin; a.amax = amax; a.amin = amin;
+  a.st = st;
   hipStream_t s = (hipStream_t)stream;
   BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
             num_batches_tracked, scale_shift, mean_invstd, nullptr};
   return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_BNRELU, true, true>(b, s); }, s);
+}
+
+extern "C" int demf_mlp_gemm_fwd_pool_bn(int R, int K, int N, int ldx, const float* X,
+                                         const float* pro_scale_shift, const float* Wt, float* Y,
+                                         double* stats, int ns, float* pmax, float* pmin, int* amax,
+                                         int* amin, const float* gamma, const float* beta, float eps,
+                                         float momentum, float* running_mean, float* running_var,
+                                         long long* num_batches_tracked, float* scale_shift,
+                                         float* mean_invstd, const float* conv_bias,
+                                         demf_stream_t stream) {
+  return mlp_gemm_fwd_pool_bn_impl(R, K, N, ldx, X, pro_scale_shift, Wt, Y, stats, ns, pmax, pmin, amax, amin,
+                                   gamma, beta, eps, momentum, running_mean, running_var,
+                                   num_batches_tracked, scale_shift, mean_invstd, conv_bias, 0, stream);
+}
+
+// Pooled form with bf16 row storage (see demf_mlp_gemm_fwd_bn_st); pmin / amin must be NULL.
+extern "C" int demf_mlp_gemm_fwd_pool_bn_st(int R, int K, int N, int ldx, const void* X,
+                                            const float* pro_scale_shift, const float* Wt, void* Y,
+                                            double* stats, int ns, float* pmax, int* amax,
+                                            const float* gamma, const float* beta, float eps,
+                                            float momentum, float* running_mean, float* running_var,
+                                            long long* num_batches_tracked, float* scale_shift,
+                                            float* mean_invstd, const float* conv_bias, int store_flags,
+                                            demf_stream_t stream) {
+  DEMF_REQUIRE(store_flags >= 1 && store_flags <= 3, "mlp_gemm_fwd_pool_bn_st: store_flags in 1..3");
+  return mlp_gemm_fwd_pool_bn_impl(R, K, N, ldx, (const float*)X, pro_scale_shift, Wt, (float*)Y, stats, ns,
+                                   pmax, nullptr, amax, nullptr, gamma, beta, eps, momentum, running_mean,
+                                   running_var, num_batches_tracked, scale_shift, mean_invstd, conv_bias,
+                                   store_flags, stream);
 }
 
 extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,
@@ -2039,7 +2149,7 @@ extern "C" int demf_bn_bwd_vectors(int, long long, double*, const float*, const 
 static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float* dP,
                               const int* arg, const float* Y, const float* yraw,
                               const float* scale_shift, const float* mean_invstd, double* g12,
-                              const BnVecFin& vf, demf_stream_t stream) {
+                              const BnVecFin& vf, demf_stream_t stream, int y_bf16 = 0) {
   DEMF_REQUIRE(R >= 0 && N >= 1, "bn_bwd_reduce: bad sizes R=%d N=%d", R, N);
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
@@ -2066,10 +2176,10 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
   if (grid < 1) grid = 1;
   if (G)
     hipLaunchKernelGGL((bn_bwd_reduce_k<false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, nullptr, BnVecFin{});
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, nullptr, BnVecFin{}, 0);
   else
     hipLaunchKernelGGL((bn_bwd_reduce_k<true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N,
-                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, yraw, vf);
+                       ns, G, dP, arg, Y, scale_shift, mean_invstd, g12, yraw, vf, y_bf16);
   return check_launch("bn_bwd_reduce");
 }
 
@@ -2085,14 +2195,15 @@ extern "C" int demf_bn_bwd_reduce(int R, int N, int ns, const float* G, const fl
 extern "C" int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP, const int* arg,
                                           const float* Y, const float* yraw, const float* scale_shift,
                                           const float* mean_invstd, double* g12, const float* gamma,
-                                          float* vec6, float* dgamma, float* dbeta, demf_stream_t stream) {
+                                          float* vec6, float* dgamma, float* dbeta, int y_bf16,
+                                          demf_stream_t stream) {
   DEMF_REQUIRE(gamma && vec6 && dgamma && dbeta && dP && arg, "bn_bwd_reduce_vectors: null pointer");
   BnVecFin vf{(double)R, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, sched_slot()};
   if (vf.ticket == nullptr) {              // DEMF_STATIC_TILES=1: no counter sets - two launches
-    if (int e = bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, BnVecFin{}, stream)) return e;
+    if (int e = bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, BnVecFin{}, stream, y_bf16)) return e;
     return demf_bn_bwd_vectors(N, R, g12, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, stream);
   }
-  return bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, vf, stream);
+  return bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, vf, stream, y_bf16);
 }
 
 extern "C" int demf_bn_bwd_vectors(int N, long long count, double* g12, const float* gamma,

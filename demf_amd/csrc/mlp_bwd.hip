@@ -112,11 +112,35 @@ __device__ __forceinline__ void mfma_planes(f32x16& acc, const bf16x8 (&a)[P], c
   }
 }
 
+// CW (2 or 4) consecutive elements of a row stored as fp32 or bf16 -> fp32 vector
+template <int CW, bool B16>
+__device__ __forceinline__ auto load_row(const float* __restrict__ base, size_t elem) {
+  using vecT = float __attribute__((ext_vector_type(CW)));
+  if constexpr (!B16) {
+    return *reinterpret_cast<const vecT*>(base + elem);
+  } else {
+    const __bf16* b = reinterpret_cast<const __bf16*>(base) + elem;
+    vecT v;
+    if constexpr (CW == 4) {
+      const uint2 u = *reinterpret_cast<const uint2*>(b);
+      v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xffff0000u);
+      v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xffff0000u);
+    } else {
+      const unsigned u = *reinterpret_cast<const unsigned*>(b);
+      v[0] = __builtin_bit_cast(float, u << 16); v[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    }
+    return v;
+  }
+}
+
 // NTN = N/32 channel slices, KT = K/32, KG = waves that share one channel slice (they split the K tiles,
 // KTW each, and the rows of the transform).  A workgroup = NTN*KG waves on one 32-row slab at a time;
 // 4-wave workgroups run two per CU.  Wave w -> nt = w % NTN, kg = w / NTN.
-template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI>   // CM 1 bf16 / 2 three-term ; EPI 0 RED / 1 FIRST
+// ST (bf16 compute mode, BASELINE configs[3]): rows stored as bf16 in HBM - bit 0: Y_{l-1} (Xp), bit 1:
+// Y_l, the dense upstream gradient G and the input gradient dX this launch writes.
+template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>   // CM 1 bf16 / 2 three-term ; EPI 0 RED / 1 FIRST
 __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_fused_kernel(FusedBwdArgs p) {
+  constexpr bool XB = (ST & 1) != 0, YB = (ST & 2) != 0;
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32;
   constexpr int NW = NTN * KG;              // waves per workgroup
@@ -205,10 +229,13 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = min(row0 + t_rl + j, last);
-      ry[j] = *reinterpret_cast<const vecT*>(p.Yl + (size_t)row * N + t_col);
-      if constexpr (!SPARSE) rg[j] = *reinterpret_cast<const vecT*>(p.G + (size_t)row * N + t_col);
+      ry[j] = load_row<CW, YB>(p.Yl, (size_t)row * N + t_col);
+      if constexpr (!SPARSE) rg[j] = load_row<CW, YB>(p.G, (size_t)row * N + t_col);
       const int xrow = min(row0 + x_rl + j, last);
-      rx[j] = *reinterpret_cast<const float2*>(p.Xp + (size_t)xrow * K + 2 * x_c2);
+      {
+        const auto xv = load_row<2, XB>(p.Xp, (size_t)xrow * K + 2 * x_c2);
+        rx[j] = make_float2(xv[0], xv[1]);
+      }
     }
     if constexpr (SPARSE) {
       // the lane's 4 rows start at a multiple of 4 and ns % 4 == 0: one pooled group for all of them
@@ -371,7 +398,8 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         const int rl = e_r0 + i * ER, row = srow0 + rl;
         const float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
         if (row < p.R) {
-          const float4 y = *reinterpret_cast<const float4*>(p.Xp + (size_t)row * K + 4 * e_cq);
+          const auto yv = load_row<4, XB>(p.Xp, (size_t)row * K + 4 * e_cq);
+          const float4 y = make_float4(yv[0], yv[1], yv[2], yv[3]);
           float dz[4];
           dz[0] = __builtin_fmaf(y.x, sc0.x, sh0.x) > 0.f ? dx.x : 0.f;
           dz[1] = __builtin_fmaf(y.y, sc0.y, sh0.y) > 0.f ? dx.y : 0.f;
@@ -385,7 +413,14 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
             es2[c] = __builtin_fmaf(dz[c], xh[c], es2[c]);
           }
           if constexpr (EPI == 0) {
-            *reinterpret_cast<float4*>(p.dX + (size_t)row * K + 4 * e_cq) = dx;
+            if constexpr (YB) {
+              unsigned o0[1], o1[1];
+              split_pair<1>(dx.x, dx.y, o0);
+              split_pair<1>(dx.z, dx.w, o1);
+              *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.dX) + (size_t)row * K + 4 * e_cq) = make_uint2(o0[0], o1[0]);
+            } else {
+              *reinterpret_cast<float4*>(p.dX + (size_t)row * K + 4 * e_cq) = dx;
+            }
           } else {
             const float4 x = *reinterpret_cast<const float4*>(p.fX + (size_t)row * 4);
             const float yv[4] = {y.x, y.y, y.z, y.w};
@@ -474,14 +509,14 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   }
 }
 
-template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI>
+template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
 static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32, NW = NTN * KG;
   const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K);
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI, ST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
       set_error("mlp_bwd_fused: cannot reserve %zu bytes of LDS", bytes);
       return DEMF_ELAUNCH;
@@ -496,7 +531,7 @@ static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
   const int cap = cus * (8 / NW);
   const int gx = nslab < cap ? nslab : cap;
-  hipLaunchKernelGGL((mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI>), dim3(gx), dim3(64 * NW), bytes, s, a);
+  hipLaunchKernelGGL((mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI, ST>), dim3(gx), dim3(64 * NW), bytes, s, a);
   return check_launch("mlp_bwd_fused");
 }
 
@@ -519,7 +554,7 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
                                   const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
                                   const float* X0, double* first_sums, const float* gamma_prev,
                                   float* vec6_prev, float* dgamma_prev, float* dbeta_prev,
-                                  demf_stream_t stream) {
+                                  int store_flags, demf_stream_t stream) {
   const bool sparse = G == nullptr, first = first_sums != nullptr;
   DEMF_REQUIRE(fused_supported(R, N, K, ns, sparse, first),
                "mlp_bwd_fused: unsupported shape / mode R=%d N=%d K=%d ns=%d sparse=%d first=%d mode=%d",
@@ -538,6 +573,15 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
   }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
+  if (store_flags != 0) {
+    // bf16 row storage (bf16 compute mode): the two forms SA1's stack uses
+    DEMF_REQUIRE(cm == 1, "mlp_bwd_fused: bf16 row storage needs the bf16 compute mode");
+    if (first && store_flags == 2 && N == 64 && K == 64) return launch_fused<2, 2, 2, false, 1, 1, 2>(a, s);
+    if (!first && sparse && store_flags == 3 && N == 128 && K == 64) return launch_fused<4, 2, 1, true, 1, 0, 3>(a, s);
+    set_error("mlp_bwd_fused: bf16 storage form store_flags=%d N=%d K=%d sparse=%d first=%d not built",
+              store_flags, N, K, (int)sparse, (int)first);
+    return DEMF_EUNSUPPORTED;
+  }
 #define FGO(NTNv, KTv, KGv, SPv, EPv) \
   return cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s)
   if (first) { FGO(2, 2, 2, false, 1); }

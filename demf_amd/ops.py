@@ -686,6 +686,9 @@ _NO_FPS_CHECK = bool(int(__import__('os').environ.get('DEMF_NO_FPS_CHECK', '0'))
 _NO_RED_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_RED_FUSE', '0')))        # A/B switch
 _NO_FIRST_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_FIRST_FUSE', '0')))    # A/B switch
 _NO_BWD_FUSE = bool(int(__import__('os').environ.get('DEMF_NO_BWD_FUSE', '0')))        # A/B switch
+# bf16 ROW storage of SA1's stack in the bf16 compute mode: built and parity-tested, measured neutral on
+# the step (5.26 vs 5.23 ms: these kernels are not HBM-bound), so opt-in (DEMF_BF16_STORE=1)
+_NO_BF16_STORE = not bool(int(__import__('os').environ.get('DEMF_BF16_STORE', '0')))
 _VEC_FIN = int(__import__('os').environ.get('DEMF_VEC_FIN', '7'))   # A/B: bit 0 sparse reduce, 1 fused, 2 dx_red
 
 
@@ -747,6 +750,15 @@ class _SharedMLPPool(Function):
         Ys, sss, mis = [], [], []
         cur, cur_ld, pro = x, ld, None
         fuse_pool = False
+        # bf16 compute mode (BASELINE configs[3]): SA1-shaped stacks (4-float rows -> 64 -> 64 -> 128, the
+        # 1 M-row layers that carry most of the step's HBM traffic) keep the raw outputs of layers 1 and 2
+        # - and the gradient that flows between their backwards - as bf16 rows; every kernel on that path
+        # is a round-3 kernel that loads / stores them directly (csrc/mlp.hip mlp_fwd_res_kernel,
+        # csrc/mlp_bwd.hip).  Statistics, pooled extrema, vectors and weight gradients stay fp32.
+        store16 = (_COMPUTE_MODE == 1 and not _NO_BF16_STORE and training and geo is None and L == 3
+                   and ld == 4 and not x.requires_grad and R >= 16384 and R % 64 == 0
+                   and ns in (16, 32, 64) and not _NO_FUSED_POOL and not _NO_BWD_FUSE and not _NO_FIRST_FUSE
+                   and [tuple(tensors[7 * l].shape) for l in range(3)] == [(64, 4), (64, 64), (128, 64)])
         # the self-cleaning fp64 accumulator holds every layer's statistics (no fill launches)
         ws = _accum64(2 * sum(tensors[7 * l].shape[0] for l in range(L)), dev) if training else None
         woff = 0
@@ -758,7 +770,7 @@ class _SharedMLPPool(Function):
             first_geo = geo is not None and l == 0
             assert first_geo or K == cur_ld, \
                 f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
-            Y = torch.empty((R, N), dtype=torch.float32, device=dev)
+            Y = torch.empty((R, N), dtype=torch.bfloat16 if (store16 and l >= 1) else torch.float32, device=dev)
             ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
             mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
             fuse_pool = training and l == L - 1 and l > 0 and not _NO_FUSED_POOL and \
@@ -793,16 +805,27 @@ class _SharedMLPPool(Function):
                 pm = torch.empty((R // ns, N), dtype=torch.float32, device=dev)
                 am = torch.empty((R // ns, N), dtype=torch.int32, device=dev)
                 # (+ the BN bookkeeping, in the GEMM's last workgroup)
-                _ffi.call("demf_mlp_gemm_fwd_pool_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
-                          _p(stats), ns, _p(pm), None, _p(am), None, _p(gamma),
-                          _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss),
-                          _p(mi), _p(tensors[7 * l + 5]), st)
+                if store16:
+                    _ffi.call("demf_mlp_gemm_fwd_pool_bn_st", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                              _p(stats), ns, _p(pm), _p(am), _p(gamma), _p(beta), float(eps),
+                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi),
+                              _p(tensors[7 * l + 5]), 3, st)
+                else:
+                    _ffi.call("demf_mlp_gemm_fwd_pool_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                              _p(stats), ns, _p(pm), None, _p(am), None, _p(gamma),
+                              _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss),
+                              _p(mi), _p(tensors[7 * l + 5]), st)
             elif training:
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
-                _ffi.call("demf_mlp_gemm_fwd_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
-                          _p(stats), _p(gamma), _p(beta), float(eps), float(momentum), _p(rmean),
-                          _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
+                if store16 and l == 1:
+                    _ffi.call("demf_mlp_gemm_fwd_bn_st", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                              _p(stats), _p(gamma), _p(beta), float(eps), float(momentum), _p(rmean),
+                              _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), 2, st)
+                else:
+                    _ffi.call("demf_mlp_gemm_fwd_bn", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
+                              _p(stats), _p(gamma), _p(beta), float(eps), float(momentum), _p(rmean),
+                              _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
             else:
                 _ffi.call("demf_mlp_gemm_fwd", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                           None, st)
@@ -834,6 +857,7 @@ class _SharedMLPPool(Function):
         ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
+        ctx.store16 = store16
         ctx.geo = None
         if geo is not None:
             ctx.geo = (g_xyz, g_center, g_off, g_rows, float(g_radius), int(bool(g_norm)))
@@ -892,7 +916,7 @@ class _SharedMLPPool(Function):
                     # pooled last layer: sums + vectors in one launch
                     _ffi.call("demf_bn_bwd_reduce_vectors", R, N, ns, _p(dP), _p(arg), _p(Ys[l]), _p(yraw),
                               _p(sss[l]), _p(mis[l]), _p(g12), _p(gammas[l]), _p(vec6), _p(dgamma),
-                              _p(dbeta), st)
+                              _p(dbeta), int(Ys[l].dtype == torch.bfloat16), st)
                 else:
                     _ffi.call("demf_bn_bwd_reduce", R, N, ns, _p(G), _p(dP if G is None else None),
                               _p(arg if G is None else None), _p(Ys[l]), _p(yraw if G is None else None),
@@ -941,6 +965,7 @@ class _SharedMLPPool(Function):
             o32 += N * K
             sparse = G is None
             first_here = l == 1 and fuse_first
+            s16 = getattr(ctx, "store16", False)
             if l > 0 and ldx == K and _bwd_fused_ok(N, K, ns, sparse, first_here):
                 # ONE pass over Y_l: dX (or, for SA1's layer 1, the raw sums of layer 0's whole
                 # backward instead of dX), dW and layer l-1's BN-backward sums (csrc/mlp_bwd.hip)
@@ -954,7 +979,7 @@ class _SharedMLPPool(Function):
                     o64 += 10 * N0 + 4
                     _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), None, None, ns, _p(Ys[l]), _p(vec6),
                               _p(W), _p(Ys[0]), _p(sss[0]), _p(mis[0]), None, _p(dW), None, _p(x),
-                              _p(sums), None, None, None, None, st)
+                              _p(sums), None, None, None, None, 2 if s16 else 0, st)
                     dW0 = ws32[o32:o32 + N0 * 4].view(N0, 4)
                     o32 += N0 * 4
                     dgamma0 = torch.empty(N0, dtype=torch.float32, device=dev)
@@ -966,7 +991,7 @@ class _SharedMLPPool(Function):
                         grads[5] = ws32[o32:o32 + N0].view(ctx.bias_shapes[0])
                         o32 += N0
                     break
-                dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+                dX = torch.empty((R, K), dtype=torch.bfloat16 if s16 else torch.float32, device=dev)
                 g12p = ws64[o64:o64 + 2 * K]
                 o64 += 2 * K
                 vec_ready = (torch.empty(5 * K, dtype=torch.float32, device=dev),
@@ -976,7 +1001,7 @@ class _SharedMLPPool(Function):
                           _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(Ys[l - 1]),
                           _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p), None, None,
                           _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]), _p(vec_ready[1]),
-                          _p(vec_ready[2]), st)
+                          _p(vec_ready[2]), 3 if s16 else 0, st)
                 if not (_VEC_FIN & 2):
                     g12_pending = g12p
                 G = dX

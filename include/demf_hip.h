@@ -353,11 +353,30 @@ int demf_mlp_gemm_bwd_dx_red_v(int R, int N, int K, int ldo, const float* G, con
                                const float* scale_shift_prev, const float* mean_invstd_prev,
                                double* g12_prev, const float* gamma_prev, float* vec6_prev,
                                float* dgamma_prev, float* dbeta_prev, demf_stream_t stream);
-/* demf_bn_bwd_reduce (sparse form: the pooled last layer of a stack) + demf_bn_bwd_vectors in ONE launch. */
+/* demf_bn_bwd_reduce (sparse form: the pooled last layer of a stack) + demf_bn_bwd_vectors in ONE launch.
+ * y_bf16: Y holds bf16 rows (demf_mlp_gemm_fwd_pool_bn_st).                                              */
 int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP, const int* arg, const float* Y,
                                const float* yraw, const float* scale_shift, const float* mean_invstd,
                                double* g12, const float* gamma, float* vec6, float* dgamma, float* dbeta,
-                               demf_stream_t stream);
+                               int y_bf16, demf_stream_t stream);
+
+/* demf_mlp_gemm_fwd_bn / demf_mlp_gemm_fwd_pool_bn with the rows stored as bf16 in HBM (bf16 compute
+ * mode, BASELINE configs[3]: "bf16 training step"): store_flags bit 0 = X holds bf16, bit 1 = Y is
+ * written as bf16; ldx counts elements.  Statistics and the pooled extremum are taken from the fp32
+ * accumulators.  Weight-resident forward only (K = 64, N = 64 / 128, R >= 16384; the forms built:
+ * flags 2 for N = 64, flags 3 pooled for N = 128): DEMF_EUNSUPPORTED otherwise, callers keep fp32 rows. */
+int demf_mlp_gemm_fwd_bn_st(int R, int K, int N, int ldx, const void* X, const float* pro_scale_shift,
+                            const float* Wt, void* Y, double* stats, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, float* scale_shift,
+                            float* mean_invstd, const float* conv_bias, int store_flags,
+                            demf_stream_t stream);
+int demf_mlp_gemm_fwd_pool_bn_st(int R, int K, int N, int ldx, const void* X,
+                                 const float* pro_scale_shift, const float* Wt, void* Y, double* stats,
+                                 int ns, float* pmax, int* amax, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var,
+                                 long long* num_batches_tracked, float* scale_shift, float* mean_invstd,
+                                 const float* conv_bias, int store_flags, demf_stream_t stream);
 
 /* One pass over a layer's saved output for its whole backward (csrc/mlp_bwd.hip): what
  * demf_mlp_gemm_bwd_dx_red + demf_mlp_gemm_bwd_dw do in two (or, with first_sums != NULL,
@@ -369,7 +388,9 @@ int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP, const int*
  * (G == NULL); anything else returns DEMF_EINVAL and callers use the two-launch path.  With gamma_prev !=
  * NULL (and not first_sums) the launch's last workgroup also forms layer l-1's backward vectors - what
  * demf_bn_bwd_vectors(K, R, g12_prev, gamma_prev, ...) would: vec6_prev (5K), dgamma_prev, dbeta_prev,
- * g12_prev left zeroed.  Replaces the
+ * g12_prev left zeroed.  store_flags != 0 (bf16 compute mode, BASELINE configs[3]): rows stored as bf16 -
+ * bit 0: Yprev, bit 1: Y, G and dX (the pointers then address 2-byte elements); built for the two forms
+ * of SA1's stack ((128,64) sparse with 3, (64,64) first_sums with 2), DEMF_EUNSUPPORTED otherwise.  Replaces the
  * autograd backward of Conv2d -> BatchNorm2d -> ReLU in mmdet3d's PointSAModule stacks
  * (configs/demf/demf_votenet.py:48-62; class_agnostic_vote_head.py:383). */
 int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, const int* arg, int ns,
@@ -377,7 +398,7 @@ int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, con
                        const float* scale_shift_prev, const float* mean_invstd_prev, float* dX,
                        float* dW, double* g12_prev, const float* X0, double* first_sums,
                        const float* gamma_prev, float* vec6_prev, float* dgamma_prev, float* dbeta_prev,
-                       demf_stream_t stream);
+                       int store_flags, demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */

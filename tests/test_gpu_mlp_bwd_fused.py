@@ -113,3 +113,43 @@ def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
     for i, (a, b) in enumerate(zip(got, want)):
         rel = float((a.double().cpu() - b).norm() / b.norm())
         assert rel <= 5e-3, (i, rel)
+
+
+def test_bf16_row_storage_of_the_sa1_stack():
+    """bf16 compute mode (BASELINE configs[3]): an SA1-shaped stack keeps the raw outputs of layers 1 / 2
+    and the gradient between their backwards as bf16 ROWS in HBM (demf_mlp_gemm_fwd_bn_st /
+    _pool_bn_st, demf_mlp_bwd_fused store_flags) - against the same stack with fp32 rows: the only
+    difference is one extra bf16 rounding of those rows (4e-3 relative per element)."""
+    from demf_amd import _ffi, ops
+    Rp, ns, ld, chans = 512, 64, 4, (64, 64, 128)
+    x, layers, go = _make(Rp, ns, ld, chans, seed=77)
+    layers[2][1][5] = -0.8          # pooled layer: a negative scale (min selected) ...
+    layers[2][1][9] = 0.0           # ... and a zero scale (the sparse reduce gathers the row from bf16 Y)
+    ops.set_compute_dtype("bf16")
+    calls = []
+    orig = _ffi.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    try:
+        _ffi.call = spy
+        ops._NO_BF16_STORE = False
+        out_s, g_s = _run(x, layers, go, ns, False)
+        st_calls = [c for c in calls if c.endswith("_st")]
+        calls.clear()
+        ops._NO_BF16_STORE = True
+        out_f, g_f = _run(x, layers, go, ns, False)
+        assert not [c for c in calls if c.endswith("_st")]
+    finally:
+        _ffi.call = orig
+        ops._NO_BF16_STORE = False
+        ops.set_compute_dtype("f32")
+    assert sorted(st_calls) == ["demf_mlp_gemm_fwd_bn_st", "demf_mlp_gemm_fwd_pool_bn_st"], st_calls
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert rel(out_s, out_f) <= 2e-2, rel(out_s, out_f)
+    worst = max(rel(a, b) for a, b in zip(g_s, g_f))
+    print("bf16 row storage vs fp32 rows (bf16 compute): output rel-L2 %.2e, worst gradient rel-L2 %.2e"
+          % (rel(out_s, out_f), worst))
+    assert worst <= 0.15, worst
+    assert all(torch.isfinite(g).all() for g in g_s)

@@ -33,7 +33,7 @@ for name, R, N, K, ns in SHAPES:
     fs = torch.zeros(10 * K + 4, dtype=torch.float64, device="cuda") if first else None
     def fused():
         _ffi.call("demf_mlp_bwd_fused", R, N, K, p(G), p(dP), p(arg), max(ns, 1), p(Y), p(vec), p(W), p(Yp), p(pss), p(pmi),
-                  None if first else p(dX), p(dW), None if first else p(g12), p(X0), p(fs), None, None, None, None, st)
+                  None if first else p(dX), p(dW), None if first else p(g12), p(X0), p(fs), None, None, None, None, 0, st)
     def two():
         _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, K, p(G), p(dP), p(arg), max(ns, 1), p(Y), p(vec), p(Yp), p(pss), p(dW), st)
         if first:
