@@ -113,7 +113,8 @@ def gemm(M, N, K, A, sa, B, sb, C, scm, *, batch=1, zdiv=1, sab=(0, 0), sbb=(0, 
          op_id=0, splitk=1, asum=None, group=None):
     """demf_gemm_f32 (include/demf_hip.h).  A, B, C, ... are device ADDRESSES (``_p(tensor, offset)``);
     sa = (sam, sak), sb = (sbn, sbk) element strides.  ``group``: a list that collects the descriptor
-    instead of launching it (``gemm_group`` then issues the whole list, demf_gemm_group_f32)."""
+    instead of launching it (``gemm_group`` then issues the whole list, demf_gemm_group_f32); descriptors
+    hold raw addresses, so the caller keeps every operand tensor alive until ``gemm_group`` has run."""
     d = _ffi.GemmDesc()
     d.M, d.N, d.K, d.batch, d.zdiv, d.splitk = M, N, K, batch, zdiv, splitk
     d.A, d.sam, d.sak, d.sab, d.sab2 = A, sa[0], sa[1], sab[0], sab[1]

@@ -459,3 +459,34 @@ def test_vote_combine_matches_the_torch_specification():
     vx.sum().backward()
     assert float(rows.grad.abs().max()) == 0.0 and float(votes.grad[:, 3:].abs().max()) == 0.0
     assert torch.equal(votes.grad[:, :3], torch.ones(64, 3, device="cuda"))
+
+
+def test_gemm_group_and_bias_row_sums():
+    """demf_gemm_group_f32: several weight-gradient-shaped products (dW = dY^T.(X [+ X2]), split-K
+    atomics into zeroed outputs) in ONE launch, each with its bias gradient taken as the row sums of
+    the A operand (``asum``), + a descriptor that is not groupable (runs as its own launch) - against
+    fp64 products."""
+    from demf_amd import fused
+    from demf_amd.fused import _p
+    R = 2048
+    specs = [(256, 256, False), (768, 256, True), (64, 256, False), (1024, 256, False), (256, 1024, False)]
+    descs, outs, keep = [], [], []          # (descriptors hold raw addresses: operands must stay alive)
+    for i, (N, K, with_x2) in enumerate(specs):
+        dy, x, x2 = _r(R, N, seed=20 + i), _r(R, K, seed=40 + i), _r(R, K, seed=60 + i)
+        dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+        keep += [dy, x, x2]
+        fused.weight_grad(dy, x, dw, db, x2=x2 if with_x2 else None, x2_rows=N // 2 if with_x2 else 0, group=descs)
+        want = dy.double().t() @ x.double()
+        if with_x2:
+            want[:N // 2] += dy.double()[:, :N // 2].t() @ x2.double()
+        outs.append((dw, db, want, dy.double().sum(0)))
+    # one more that cannot join a group (A K-contiguous): Y = X W^T
+    xa, wa = _r(300, 64, seed=90), _r(96, 64, seed=91)
+    ya = torch.empty(300, 96, device="cuda")
+    fused.gemm(300, 96, 64, _p(xa), (64, 1), _p(wa), (64, 1), _p(ya), 96, group=descs)
+    assert len(descs) == 6
+    fused.gemm_group(descs)
+    for dw, db, want, wb in outs:
+        _close(dw, want, 1e-4, "grouped dW")
+        _close(db, wb, 1e-4, "bias gradient = row sums of the A operand")
+    _close(ya, xa.double() @ wa.double().t(), 1e-4, "ungroupable member")
