@@ -131,6 +131,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). demf_amd has no CPU fallback.")
+    # torch first: PyTorch-ROCm bundles its own HIP / HSA runtime; if this library were loaded before
+    # it, the process would hold two runtimes and the second one finds no device ("no ROCm-capable
+    # device is detected" at the first launch - seen with build() and smoke() in one process)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.demf_version.restype = _c_int
     lib.demf_version.argtypes = []
