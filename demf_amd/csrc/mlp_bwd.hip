@@ -249,7 +249,8 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 
   const int nslab = (p.R + RS - 1) / RS;
   int slab = blockIdx.x;
-  if (slab < nslab) fetch(slab);
+  constexpr bool PREF = !(NTN == 8 && P == 3);   // (256,128) three-term: no registers to hold a slab ahead
+  if (PREF && slab < nslab) fetch(slab);
   // (measured: staggering the start of the second workgroup per CU by 0.5 ... 4 k cycles changes nothing)
   // running column sums of the epilogue
   float es1[4] = {0.f, 0.f, 0.f, 0.f}, es2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 
   for (; slab < nslab; slab += gridDim.x) {
     const int row0 = slab * RS;
+    if constexpr (!PREF) fetch(slab);
     // ---- [A] dY = gi*dZ + a*y + b on the lane's patch, split once, both orientations into LDS -------
     {
       const bool tail = row0 + RS > p.R;                     // (uniform) rows beyond R become zeros
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       }
     }
     // ---- [B] next slab's rows in flight underneath the MFMA phase ----------------------------------
-    if (slab + (int)gridDim.x < nslab) fetch(slab + (int)gridDim.x);
+    if (PREF && slab + (int)gridDim.x < nslab) fetch(slab + (int)gridDim.x);
     lds_barrier();        // planes of every wave in place; the last epilogue is done with the dX tile
     // ---- [C] dW += dY^T.act(Y_{l-1}); dX partial over this wave's channel slice ----------------------
     f32x16 pa;
