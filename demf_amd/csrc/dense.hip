@@ -504,7 +504,7 @@ __device__ __forceinline__ void gemm_ks_body(const GemmArgs& p, int bx, int by, 
 }
 
 template <int MA, int MB, bool ADD, bool BF16>
-__global__ __launch_bounds__(256, 4) void gemm_ks_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, ADD ? 2 : 4) void gemm_ks_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
   __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
   __shared__ float s_red[4][16][64];
@@ -521,7 +521,7 @@ struct GemmGroup {
   int n;
 };
 template <int MA, int MB, bool ADD, bool BF16>
-__global__ __launch_bounds__(256, 4) void gemm_ks_group_kernel(GemmGroup g) {
+__global__ __launch_bounds__(256, ADD ? 2 : 4) void gemm_ks_group_kernel(GemmGroup g) {
   __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
   __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
   __shared__ float s_red[4][16][64];
@@ -791,18 +791,35 @@ __global__ void msda_prep_bwd_k(int R, int Q, int H, int L, int P, const float* 
       dlg[i] = w[base + i] * (DW(base + i) - dot);
     }
   }
-  if (h != 0 || dpts == nullptr) return;
-  // d(u,v): sum over heads / levels / points of dloc * valid ratio, gated by the clamp
+  if (dpts == nullptr) return;
+  // d(u,v): sum over heads / levels / points of dloc * valid ratio, gated by the clamp.  The H threads
+  // of a row are neighbours in a wave (H a power of two <= 64, 256 % H == 0): each sums its own head,
+  // a butterfly over the H lanes adds them; any other H: the thread of head 0 loops the heads.
   float du = 0.f, dv = 0.f;
-  for (int hh = 0; hh < H; ++hh)
+  const bool pow2 = (H & (H - 1)) == 0 && H <= 64;
+  if (pow2) {
     for (int l = 0; l < L; ++l) {
       const float vx = vr[(b * L + l) * 2], vy = vr[(b * L + l) * 2 + 1];
       for (int q = 0; q < P; ++q) {
-        const size_t o = ((size_t)row * H + hh) * LP + l * P + q;
+        const size_t o = base + l * P + q;
         du = __builtin_fmaf(DL(2 * o), vx, du);
         dv = __builtin_fmaf(DL(2 * o + 1), vy, dv);
       }
     }
+    for (int m = 1; m < H; m <<= 1) { du += __shfl_xor(du, m, 64); dv += __shfl_xor(dv, m, 64); }
+    if (h != 0) return;
+  } else {
+    if (h != 0) return;
+    for (int hh = 0; hh < H; ++hh)
+      for (int l = 0; l < L; ++l) {
+        const float vx = vr[(b * L + l) * 2], vy = vr[(b * L + l) * 2 + 1];
+        for (int q = 0; q < P; ++q) {
+          const size_t o = ((size_t)row * H + hh) * LP + l * P + q;
+          du = __builtin_fmaf(DL(2 * o), vx, du);
+          dv = __builtin_fmaf(DL(2 * o + 1), vy, dv);
+        }
+      }
+  }
   const float u0 = uvw[4 * row], v0 = uvw[4 * row + 1], xw = uvw[4 * row + 2], yw = uvw[4 * row + 3];
   if (!(u0 >= 0.f && u0 <= 1.f)) du = 0.f;          // torch.clamp passes the gradient on [min, max]
   if (!(v0 >= 0.f && v0 <= 1.f)) dv = 0.f;
@@ -1088,8 +1105,10 @@ extern "C" int demf_add_dropout_ln_bwd(int R, int C, const float* dy, const floa
                                        float* dgamma, float* dbeta, demf_stream_t stream) {
   DEMF_REQUIRE(R > 0 && dy && s && stats && gamma && dgamma && dbeta, "add_dropout_ln_bwd: bad arguments");
   DEMF_REQUIRE(p == 0.f || rng, "add_dropout_ln_bwd: dropout needs the rng state");
-  // ~64 blocks: each wave walks rows_per_wave rows, so a column sees <= 64 atomics
-  const int rpw = max(1, cdiv(R, 64 * 4));
+  // ~256 blocks (one per CU): each wave walks rows_per_wave rows one after the other (two wave
+  // reductions per row, ~2 us each), so a column sees <= 256 atomics
+  static const int ln_blocks = getenv("DEMF_LN_BWD_BLOCKS") ? max(1, atoi(getenv("DEMF_LN_BWD_BLOCKS"))) : 256;
+  const int rpw = max(1, cdiv(R, ln_blocks * 4));
   const int blocks = cdiv(R, 4 * rpw);
 #define CALL(V) hipLaunchKernelGGL(add_dropout_ln_bwd_k<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream,  \
                                    R, rpw, dy, dy2, s, stats, gamma, p, (const unsigned long long*)rng,       \

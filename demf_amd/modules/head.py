@@ -500,11 +500,13 @@ class DeMFVoteHead(nn.Module):
     _PAD_CACHE = {}
 
     @staticmethod
-    def pad_gt(gt_bboxes_3d, gt_labels_3d, device):
+    def pad_gt(gt_bboxes_3d, gt_labels_3d, device, with_slot_labels=False):
         """list[DepthBoxes|(n,7) tensor], list[(n,) long] -> padded (B,G,7), (B,G), valid (B,G).
         An empty scene gets the reference's single all-zero fake box (:766-773).
-        One concatenation + one indexed write per tensor; the slot indices and the valid mask
-        depend only on the per-scene counts and are cached per count signature."""
+        One concatenation + one row gather per tensor: the rows are [0-row | all boxes] and
+        [-1, 0 | all labels]; the slot -> row table and the valid mask depend only on the per-scene
+        counts and are cached per count signature.  ``with_slot_labels``: the labels keep -1 in the
+        padding slots (the form ``ops.gt_prep`` reads ``valid`` from) instead of 0."""
         boxes = [b.tensor if isinstance(b, DepthBoxes) else b for b in gt_bboxes_3d]
         counts = tuple(int(b.shape[0]) for b in boxes)
         G = max(1, max(counts))
@@ -514,19 +516,29 @@ class DeMFVoteHead(nn.Module):
         if key not in cache:
             if len(cache) > 64:
                 cache.clear()
-            pos = [i * G + j for i, n in enumerate(counts) for j in range(n)]
             valid = np.zeros((B, G), dtype=bool)
+            box_row = np.zeros((B, G), dtype=np.int64)          # row 0 of the box rows: zeros
+            lab_row = np.zeros((B, G), dtype=np.int64)          # row 0 of the label rows: -1 (padding)
+            at = 0
             for i, n in enumerate(counts):
                 valid[i, :max(n, 1)] = True
-            cache[key] = (torch.as_tensor(pos, dtype=torch.long, device=device),
-                          torch.as_tensor(valid, device=device))
-        pos, valid = cache[key]
-        gt = torch.zeros((B * G, 7), dtype=torch.float32, device=device)
-        lab = torch.zeros((B * G,), dtype=torch.long, device=device)
-        if pos.numel():
-            gt.index_copy_(0, pos, torch.cat([b.to(device) for b in boxes if b.shape[0]]).float())
-            lab.index_copy_(0, pos, torch.cat([l.to(device) for l, n in zip(gt_labels_3d, counts) if n]))
-        return gt.view(B, G, 7), lab.view(B, G), valid
+                box_row[i, :n] = 1 + at + np.arange(n)
+                lab_row[i, :n] = 2 + at + np.arange(n)
+                if n == 0:
+                    lab_row[i, 0] = 1                           # row 1: label 0 of the fake box
+                at += n
+            cache[key] = (torch.as_tensor(box_row.reshape(-1), device=device),
+                          torch.as_tensor(lab_row.reshape(-1), device=device),
+                          torch.as_tensor(valid, device=device),
+                          torch.zeros((1, 7), dtype=torch.float32, device=device),
+                          torch.tensor([-1, 0], dtype=torch.long, device=device))
+        box_row, lab_row, valid, zero_row, lab_head = cache[key]
+        gt = torch.cat([zero_row] + [b.to(device).float() for b in boxes if b.shape[0]]).index_select(0, box_row)
+        slot = torch.cat([lab_head] + [l.to(device) for l, n in zip(gt_labels_3d, counts) if n]) \
+            .index_select(0, lab_row).view(B, G)
+        if with_slot_labels:
+            return gt.view(B, G, 7), slot, valid
+        return gt.view(B, G, 7), slot.clamp_(min=0), valid
 
     @torch.no_grad()
     def vote_targets(self, points, gt_bboxes_3d, gt_labels_3d):
@@ -535,6 +547,11 @@ class DeMFVoteHead(nn.Module):
         detector computes it on a side stream.  -> dict incl. the padded GT."""
         if isinstance(points, (list, tuple)):
             points = torch.stack(points)
+        if isinstance(gt_bboxes_3d, (list, tuple)) and points.is_cuda:
+            # per-scene lists on the device: pad to (B,G,7) / (B,G) with -1 in the padding slots and
+            # take the padded path below (2 x (cat + row gather), then gt_prep + vote_targets_k)
+            gt_bboxes_3d, gt_labels_3d, _ = self.pad_gt(gt_bboxes_3d, gt_labels_3d, points.device,
+                                                        with_slot_labels=True)
         if isinstance(gt_bboxes_3d, (list, tuple)):
             gt, lab, valid = self.pad_gt(gt_bboxes_3d, gt_labels_3d, points.device)
         else:

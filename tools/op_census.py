@@ -27,10 +27,13 @@ class Census(TorchDispatchMode):
         name = str(func)
         if not name.startswith(SKIP):
             site = "backward/autograd"
-            for f in reversed(traceback.extract_stack()):
-                if "/demf_amd/" in f.filename and "op_census" not in f.filename:
-                    site = f"{f.filename.split('/demf_amd/')[-1]}:{f.lineno} {f.name}"
+            f = sys._getframe(0)
+            while f is not None:                      # no source-line lookups: frames only
+                fn = f.f_code.co_filename
+                if "/demf_amd/" in fn:
+                    site = f"{fn.split('/demf_amd/')[-1]}:{f.f_lineno} {f.f_code.co_name}"
                     break
+                f = f.f_back
             shp = [tuple(a.shape) for a in args if torch.is_tensor(a)][:2]
             cnt[(name, site, str(shp))] += 1
         return func(*args, **(kwargs or {}))
