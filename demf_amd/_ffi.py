@@ -26,6 +26,7 @@ SIGNATURES = {
     "demf_gather_points_fwd": [_c_int] * 4 + [_ptr] * 4,
     "demf_gather_points_bwd": [_c_int] * 4 + [_ptr] * 4,
     "demf_three_nn_f32": [_c_int] * 3 + [_ptr] * 5,
+    "demf_three_nn_weights_f32": [_c_int] * 3 + [_ptr] * 6,
     "demf_three_interpolate_fwd": [_c_int] * 4 + [_ptr] * 5,
     "demf_three_interpolate_bwd": [_c_int] * 4 + [_ptr] * 5,
     "demf_group_concat_cl_fwd": [_c_int] * 8 + [_c_float, _c_int] + [_ptr] * 6,
@@ -34,6 +35,7 @@ SIGNATURES = {
     "demf_gather_rows_cl_bwd": [_c_int] * 4 + [_ptr] * 4,
     "demf_three_interpolate_cl_fwd": [_c_int] * 6 + [_ptr] * 5,
     "demf_three_interpolate_cl_bwd": [_c_int] * 6 + [_ptr] * 5,
+    "demf_three_interpolate_cat_cl_fwd": [_c_int] * 5 + [_ptr] * 6,
     "demf_maxpool_ns_fwd": [_c_int] * 3 + [_ptr] * 4,
     "demf_maxpool_ns_bwd": [_c_int] * 3 + [_ptr] * 4,
     "demf_colsum_f32": [_c_int] * 3 + [_ptr] * 3,
@@ -77,6 +79,7 @@ SIGNATURES = {
     "demf_head_loss_fwd": [_c_int] * 3 + [_ptr] * 14,
     "demf_head_loss_bwd": [_c_int] * 3 + [_ptr] * 17,
     "demf_vote_loss": [_c_int] * 4 + [_c_float] + [_ptr] * 10,
+    "demf_vote_loss_fwd": [_c_int] * 4 + [_c_float] + [_ptr] * 8,
     "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
     "demf_gemm_f32": [_ptr, _ptr],

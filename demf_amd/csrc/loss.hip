@@ -196,19 +196,40 @@ __global__ __launch_bounds__(256) void head_loss_bwd_k(
 }
 
 // ---- vote loss: sum over seeds of min_j L1(vote - (gt_vote_j + seed)) * mask/(sum mask) * w --
+// COUNT (forward only): the number of seeds on a positive point - the denominator, torch.gather(mask, 1,
+// seed_indices).sum() in the reference's VoteModule.get_loss - is counted here by every workgroup
+// (B*S int64 loads from L2, an exact integer) instead of by three library launches; workgroup 0
+// stores it to mask_sum_out for the backward.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void vote_loss_k(
     int B, int S, int N, int G3 /*3*gt_per_seed*/, float wdst, const float* __restrict__ seed,
     const float* __restrict__ vote, const long long* __restrict__ seed_idx,
     const long long* __restrict__ tmask, const float* __restrict__ vtgt,
     const float* __restrict__ mask_sum, const float* __restrict__ gout /*null: forward*/,
-    float* __restrict__ out, float* __restrict__ gvote) {
+    float* __restrict__ out, float* __restrict__ gvote, float* __restrict__ mask_sum_out) {
   __shared__ float red[256];
+  __shared__ long long cnt[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float msum;
+  if constexpr (COUNT) {
+    long long c = 0;
+    for (int j = threadIdx.x; j < B * S; j += 256) c += tmask[(size_t)(j / S) * N + seed_idx[j]];
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) cnt[threadIdx.x] += cnt[threadIdx.x + s];
+      __syncthreads();
+    }
+    msum = (float)cnt[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) mask_sum_out[0] = msum;
+  } else {
+    msum = mask_sum[0];
+  }
   float l = 0.f;
   if (i < B * S) {
     const int b = i / S;
     const long long k = seed_idx[i];
-    const float w = (float)tmask[(size_t)b * N + k] / (mask_sum[0] + 1e-6f) * wdst;
+    const float w = (float)tmask[(size_t)b * N + k] / (msum + 1e-6f) * wdst;
     const float* t = vtgt + ((size_t)b * N + k) * G3;
     float best = 3.0e38f;
     int bj = 0;
@@ -488,11 +509,29 @@ extern "C" int demf_vote_loss(int B, int S, int N, int gt_per_seed, float dst_we
   DEMF_REQUIRE(seed_points && vote_points && seed_indices && vote_target_masks && vote_targets &&
                    mask_sum && (grad_out ? grad_vote != nullptr : out != nullptr),
                "vote_loss: null pointer");
-  hipLaunchKernelGGL(vote_loss_k, dim3(cdiv(B * S, 256)), dim3(256), 0, (hipStream_t)stream, B, S, N,
+  hipLaunchKernelGGL(vote_loss_k<false>, dim3(cdiv(B * S, 256)), dim3(256), 0, (hipStream_t)stream, B, S, N,
                      3 * gt_per_seed, dst_weight, seed_points, vote_points,
                      (const long long*)seed_indices, (const long long*)vote_target_masks,
-                     vote_targets, mask_sum, grad_out, out, grad_vote);
+                     vote_targets, mask_sum, grad_out, out, grad_vote, (float*)nullptr);
   return check_launch("vote_loss");
+}
+
+extern "C" int demf_vote_loss_fwd(int B, int S, int N, int gt_per_seed, float dst_weight,
+                                  const float* seed_points, const float* vote_points,
+                                  const int64_t* seed_indices, const int64_t* vote_target_masks,
+                                  const float* vote_targets, float* mask_sum_out, float* out,
+                                  demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && S >= 0 && N >= 1 && gt_per_seed >= 1, "vote_loss_fwd: bad sizes");
+  DEMF_REQUIRE(mask_sum_out && out, "vote_loss_fwd: null pointer");
+  if (B * S == 0) return DEMF_OK;
+  DEMF_REQUIRE(seed_points && vote_points && seed_indices && vote_target_masks && vote_targets,
+               "vote_loss_fwd: null pointer");
+  hipLaunchKernelGGL(vote_loss_k<true>, dim3(cdiv(B * S, 256)), dim3(256), 0, (hipStream_t)stream, B, S, N,
+                     3 * gt_per_seed, dst_weight, seed_points, vote_points,
+                     (const long long*)seed_indices, (const long long*)vote_target_masks,
+                     vote_targets, (const float*)nullptr, (const float*)nullptr, out, (float*)nullptr,
+                     mask_sum_out);
+  return check_launch("vote_loss_fwd");
 }
 
 extern "C" int demf_vote_targets(int B, int N, int point_stride, int G, const float* points,

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float* __restrict__ target,
                                                        const float* __restrict__ source,
                                                        float* __restrict__ dist2_out,
-                                                       int* __restrict__ idx_out) {
+                                                       int* __restrict__ idx_out,
+                                                       float* __restrict__ weight_out) {
   __shared__ float sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
   const int b = blockIdx.y;
   target += (size_t)b * n * 3;
@@ -58,8 +59,19 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
   if (ok) {
     float* dd = dist2_out + ((size_t)b * n + t) * 3;
     int* ii = idx_out + ((size_t)b * n + t) * 3;
-    dd[0] = b1; dd[1] = b2; dd[2] = b3;
     ii[0] = i1; ii[1] = i2; ii[2] = i3;
+    if (weight_out == nullptr) {
+      dd[0] = b1; dd[1] = b2; dd[2] = b3;
+    } else {
+      // PointFPModule.forward: dist = sqrt(dist2); r = 1 / (dist + 1e-8); weight = r / sum(r) -
+      // the five element-wise launches of the reference's expression, in its operation order
+      const float d1 = sqrtf(b1), d2 = sqrtf(b2), d3 = sqrtf(b3);
+      const float r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f), r3 = 1.0f / (d3 + 1e-8f);
+      const float sum = (r1 + r2) + r3;
+      float* ww = weight_out + ((size_t)b * n + t) * 3;
+      dd[0] = d1; dd[1] = d2; dd[2] = d3;
+      ww[0] = r1 / sum; ww[1] = r2 / sum; ww[2] = r3 / sum;
+    }
   }
 }
 
@@ -126,7 +138,10 @@ __global__ __launch_bounds__(256) void interp_cl_fwd(int m, int n, int C, int ld
                                                      const int* __restrict__ idx,
                                                      const float* __restrict__ w,
                                                      float* __restrict__ out,
-                                                     long long rows) {
+                                                     long long rows,
+                                                     const float* __restrict__ skip, int Cs) {
+  // skip (rows, Cs), optional: the target level's own features, copied behind the interpolated
+  // columns - the torch.cat of PointFPModule.forward written by the same launch
   const int lane = threadIdx.x & 63;
   long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
@@ -140,6 +155,10 @@ __global__ __launch_bounds__(256) void interp_cl_fwd(int m, int n, int C, int ld
     const float w0 = ww[0], w1 = ww[1], w2 = ww[2];
     float* o = out + row * ldo + col0;
     for (int c = lane; c < C; c += 64) o[c] = interp3(w0, f0[c], w1, f1[c], w2, f2[c]);
+    if (skip != nullptr) {
+      const float* sk = skip + row * Cs;
+      for (int c = lane; c < Cs; c += 64) o[C + c] = sk[c];
+    }
   }
 }
 
@@ -187,8 +206,18 @@ extern "C" int demf_three_nn_f32(int B, int n, int m, const float* target,
   if (B == 0 || n == 0) return DEMF_OK;
   DEMF_REQUIRE(target && source && dist2 && idx, "three_nn: null pointer");
   hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
-                     (hipStream_t)stream, n, m, target, source, dist2, idx);
+                     (hipStream_t)stream, n, m, target, source, dist2, idx, (float*)nullptr);
   return check_launch("three_nn");
+}
+
+extern "C" int demf_three_nn_weights_f32(int B, int n, int m, const float* target, const float* source,
+                                         float* dist, int* idx, float* weight, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && n >= 0 && m >= 1, "three_nn_weights: bad sizes B=%d n=%d m=%d", B, n, m);
+  if (B == 0 || n == 0) return DEMF_OK;
+  DEMF_REQUIRE(target && source && dist && idx && weight, "three_nn_weights: null pointer");
+  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
+                     (hipStream_t)stream, n, m, target, source, dist, idx, weight);
+  return check_launch("three_nn_weights");
 }
 
 extern "C" int demf_three_interpolate_fwd(int B, int C, int m, int n, const float* features,
@@ -223,8 +252,20 @@ extern "C" int demf_three_interpolate_cl_fwd(int B, int m, int n, int C, int ldo
   DEMF_REQUIRE(feat && idx && weight && out, "three_interpolate_cl: null pointer");
   const long long rows = (long long)B * n;
   hipLaunchKernelGGL(interp_cl_fwd, dim3(grid_rows(rows)), dim3(256), 0, (hipStream_t)stream,
-                     m, n, C, ldo, col0, feat, idx, weight, out, rows);
+                     m, n, C, ldo, col0, feat, idx, weight, out, rows, (const float*)nullptr, 0);
   return check_launch("three_interpolate_cl_fwd");
+}
+
+extern "C" int demf_three_interpolate_cat_cl_fwd(int B, int m, int n, int C, int Cs, const float* feat,
+                                                 const int* idx, const float* weight, const float* skip,
+                                                 float* out, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && m >= 1 && n >= 0 && C >= 1 && Cs >= 1, "three_interpolate_cat_cl: bad sizes");
+  if (B == 0 || n == 0) return DEMF_OK;
+  DEMF_REQUIRE(feat && idx && weight && skip && out, "three_interpolate_cat_cl: null pointer");
+  const long long rows = (long long)B * n;
+  hipLaunchKernelGGL(interp_cl_fwd, dim3(grid_rows(rows)), dim3(256), 0, (hipStream_t)stream,
+                     m, n, C, C + Cs, 0, feat, idx, weight, out, rows, skip, Cs);
+  return check_launch("three_interpolate_cat_cl_fwd");
 }
 
 extern "C" int demf_three_interpolate_cl_bwd(int B, int m, int n, int C, int ldo, int col0,

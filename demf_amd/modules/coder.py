@@ -5,6 +5,20 @@ import numpy as np
 import torch
 
 
+class _Preds(dict):
+    """split_pred's result dict.  The reference also stores ``dir_res`` (coder.py:233); nothing on the
+    training path reads it (the losses take ``dir_res_norm``), so it is computed when first asked for
+    (decode, tests) instead of costing a launch + an autograd node per prediction head and step."""
+    dir_res_scale = None
+
+    def __missing__(self, key):
+        if key == "dir_res" and self.dir_res_scale is not None:
+            v = self["dir_res_norm"] * self.dir_res_scale
+            self[key] = v
+            return v
+        raise KeyError(key)
+
+
 class DeMFClassAgnosticBBoxCoder:
     def __init__(self, num_dir_bins, with_rot=True, **unused):
         self.num_dir_bins = num_dir_bins
@@ -60,7 +74,7 @@ class DeMFClassAgnosticBBoxCoder:
 
     # ---- coder.py:196-240 ----
     def split_pred(self, cls_preds, reg_preds, base_xyz):
-        results = {}
+        results = _Preds()
         cls_t = cls_preds.transpose(2, 1)
         reg_t = reg_preds.transpose(2, 1)
         with_sem = cls_t.shape[-1] > 2
@@ -72,7 +86,8 @@ class DeMFClassAgnosticBBoxCoder:
         results["dir_class"] = reg_t[..., 6:6 + nb]
         dir_res_norm = reg_t[..., 6 + nb:6 + 2 * nb]
         results["dir_res_norm"] = dir_res_norm
-        results["dir_res"] = dir_res_norm * (np.pi / nb)
+        # "dir_res" = dir_res_norm * (pi / nb) is only read by decode(): materialised on first access
+        results.dir_res_scale = np.pi / nb
         results["obj_scores"] = cls_t[..., 0:2]
         if with_sem:
             results["sem_scores"] = cls_t[..., 2:]

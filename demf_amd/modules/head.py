@@ -164,7 +164,10 @@ class DeMFVoteHead(nn.Module):
             rows = features.transpose(1, 2).reshape(B * Q, E)
             pts = aggregated_points.reshape(B * Q, 3)
             for i in range(self.num_decoder_layers):
-                query_pos = torch.cat([decode_res["center"], decode_res["size"]], dim=-1).detach() \
+                # (center | size | zero columns up to a multiple of 4: the row width the position
+                # embedding's first GEMM stages, written by this one concatenation)
+                zpad = self._zero_cols(B, Q, (-6) % 4, features)
+                query_pos = torch.cat([decode_res["center"], decode_res["size"], zpad], dim=-1).detach() \
                     .reshape(B * Q, -1)
                 rows = self.decoder[i].forward_rows(
                     rows, query_pos, pts, image_inputs["value_tokens"], spatial_shapes,
@@ -191,6 +194,13 @@ class DeMFVoteHead(nn.Module):
             decode_res = self._split(cls_p, reg_p, aggregated_points)
             decode_res_all.append(decode_res)
         return decode_res_all
+
+    def _zero_cols(self, B, Q, n, like):
+        key = (B, Q, n, like.device, like.dtype)
+        cache = self.__dict__.setdefault("_zero_cols_cache", {})
+        if key not in cache:
+            cache[key] = torch.zeros((B, Q, n), dtype=like.dtype, device=like.device)
+        return cache[key]
 
     def _split(self, cls_p, reg_p, base_xyz):
         """split_pred + private handles on the raw conv-head rows ((B*Q, 12) / (B*Q, 30) - the

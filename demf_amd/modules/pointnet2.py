@@ -144,6 +144,8 @@ class PointFPModule(nn.Module):
     @staticmethod
     def index_geometry(target, source):
         """3-NN indices and inverse-distance weights (coordinates only)."""
+        if target.is_cuda and not (target.requires_grad or source.requires_grad):
+            return ops.three_nn_weights(target.contiguous(), source.contiguous())
         dist, idx = ops.three_nn(target, source)
         dist_recip = 1.0 / (dist + 1e-8)
         return idx, (dist_recip / dist_recip.sum(dim=2, keepdim=True)).contiguous()
@@ -151,8 +153,12 @@ class PointFPModule(nn.Module):
     def forward(self, target, source, target_feats, source_feats, nn=None):
         B, n, _ = target.shape
         idx, weight = nn if nn is not None else self.index_geometry(target, source)
-        interp = ops.three_interpolate_cl(_rows(source_feats), idx, weight.contiguous())
-        x = torch.cat([interp, _rows(target_feats)], dim=2) if target_feats is not None else interp
+        if target_feats is not None and source_feats.is_cuda:
+            x = ops.three_interpolate_cat_cl(_rows(source_feats), idx, weight.contiguous(),
+                                             _rows(target_feats).contiguous())
+        else:
+            interp = ops.three_interpolate_cl(_rows(source_feats), idx, weight.contiguous())
+            x = torch.cat([interp, _rows(target_feats)], dim=2) if target_feats is not None else interp
         x = self.mlps.forward_rows(x.view(B * n, -1))
         return x.view(B, n, -1).transpose(1, 2)
 

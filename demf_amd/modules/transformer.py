@@ -48,9 +48,11 @@ class PositionEmbeddingLearned(nn.Module):
         shared-MLP GEMM (input rows zero-padded to a multiple of 4 columns), the second Conv1d through
         the strided GEMM of csrc/dense.hip."""
         c0, bn, _, c1 = self.position_embedding_head
-        R, cin = rows.shape
+        cin = c0.in_channels
         pad = (-cin) % 4
-        x = F.pad(rows, (0, pad)) if pad else rows.contiguous()
+        # (rows that already carry the zero columns - the head concatenates them in - skip the pad launch)
+        x = rows.contiguous() if rows.shape[1] == cin + pad else F.pad(rows, (0, pad))
+        R = x.shape[0]
         w0 = F.pad(c0.weight.view(c0.out_channels, cin), (0, pad)) if pad else c0.weight.view(c0.out_channels, cin)
         h = ops.shared_mlp_pool(x, 1, [(w0.contiguous(), bn.weight, bn.bias, bn.running_mean,
                                         bn.running_var, c0.bias, bn.num_batches_tracked)],

@@ -16,7 +16,7 @@ from . import _ffi
 
 __all__ = [
     "set_compute_dtype", "get_compute_dtype", "gt_prep", "target_weights", "vote_combine", "furthest_point_sample", "ball_query", "grouping_operation", "gather_points",
-    "three_nn", "three_interpolate", "MultiScaleDeformableAttnFunction",
+    "three_nn", "three_nn_weights", "three_interpolate", "three_interpolate_cat_cl", "MultiScaleDeformableAttnFunction",
     "group_concat_cl", "gather_rows_cl", "three_interpolate_cl", "maxpool_ns", "shared_mlp_pool",
 ]
 
@@ -310,6 +310,23 @@ def three_nn(target, source):
     return _ThreeNN.apply(target, source)
 
 
+@torch.no_grad()
+def three_nn_weights(target, source):
+    """-> (idx (B,n,3) i32, weight (B,n,3)): the 3-NN search and the inverse-distance weights
+    PointFPModule.forward derives from it (1/(dist+1e-8), normalised over the three), one launch.
+    Coordinates only: no gradient (the reference's three_nn is not differentiable either)."""
+    _chk(target, "target")
+    _chk(source, "source")
+    B, n, _ = target.shape
+    m = source.shape[1]
+    dist = torch.empty((B, n, 3), dtype=torch.float32, device=target.device)
+    weight = torch.empty((B, n, 3), dtype=torch.float32, device=target.device)
+    idx = torch.empty((B, n, 3), dtype=torch.int32, device=target.device)
+    _ffi.call("demf_three_nn_weights_f32", B, n, m, _p(target), _p(source), _p(dist), _p(idx),
+              _p(weight), _stream())
+    return idx, weight
+
+
 class _ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features, indices, weight):
@@ -537,6 +554,41 @@ class _ThreeInterpolateCL(Function):
         _ffi.call("demf_three_interpolate_cl_bwd", B, ctx.m, n, C, C, 0, _p(grad_out), _p(idx),
                   _p(weight), _p(g), _stream())
         return g, None, None
+
+
+class _ThreeInterpolateCatCL(Function):
+    @staticmethod
+    def forward(ctx, feat, idx, weight, skip):
+        _chk(feat, "feat")
+        _chk(idx, "idx", torch.int32)
+        _chk(weight, "weight")
+        _chk(skip, "skip")
+        B, m, C = feat.shape
+        n, Cs = idx.shape[1], skip.shape[2]
+        out = torch.empty((B, n, C + Cs), dtype=feat.dtype, device=feat.device)
+        _ffi.call("demf_three_interpolate_cat_cl_fwd", B, m, n, C, Cs, _p(feat), _p(idx), _p(weight),
+                  _p(skip), _p(out), _stream())
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (m, C, Cs)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        m, C, Cs = ctx.dims
+        grad_out = grad_out.contiguous()
+        B, n, _ = grad_out.shape
+        g = zeros((B, m, C), grad_out.device)
+        _ffi.call("demf_three_interpolate_cl_bwd", B, m, n, C, C + Cs, 0, _p(grad_out), _p(idx),
+                  _p(weight), _p(g), _stream())
+        return g, None, None, grad_out[..., C:]
+
+
+def three_interpolate_cat_cl(feat, idx, weight, skip):
+    """[three_interpolate_cl(feat, idx, weight) | skip (B,n,Cs)] -> (B,n,C+Cs) in one launch (the
+    interpolation + concatenation of PointFPModule.forward); differentiable wrt feat and skip."""
+    return _ThreeInterpolateCatCL.apply(feat, idx, weight, skip)
 
 
 def three_interpolate_cl(feat, idx, weight):
@@ -1218,11 +1270,12 @@ class _VoteLoss(Function):
         _chk(vote_targets, "vote_targets")
         B, S, _ = seed_points.shape
         N = masks.shape[1]
-        msum = torch.gather(masks, 1, seed_indices).sum().to(torch.float32).reshape(1)
+        # (the denominator gather(masks, 1, seed_indices).sum() is counted inside the kernel)
+        msum = torch.empty(1, dtype=torch.float32, device=vote_points.device)
         out = zeros(1, vote_points.device)
-        _ffi.call("demf_vote_loss", B, S, N, int(gt_per_seed), float(dst_weight), _p(seed_points),
-                  _p(vote_points), _p(seed_indices), _p(masks), _p(vote_targets), _p(msum), None,
-                  _p(out), None, _stream())
+        _ffi.call("demf_vote_loss_fwd", B, S, N, int(gt_per_seed), float(dst_weight), _p(seed_points),
+                  _p(vote_points), _p(seed_indices), _p(masks), _p(vote_targets), _p(msum),
+                  _p(out), _stream())
         ctx.save_for_backward(vote_points, seed_points, seed_indices, masks, vote_targets, msum)
         ctx.meta = (B, S, N, int(gt_per_seed), float(dst_weight))
         return out[0]

@@ -96,6 +96,11 @@ int demf_gather_points_bwd(int B, int C, int N, int M, const float* grad_out,
  * Reference: PointFPModule of the backbone (demf_votenet.py:56).             */
 int demf_three_nn_f32(int B, int n, int m, const float* target, const float* source,
                       float* dist2, int* idx, demf_stream_t stream);
+/* the same search + what PointFPModule.forward derives from it (mmdet3d PointFPModule: dist_recip =
+ * 1 / (dist + 1e-8), weight = dist_recip / sum(dist_recip)): dist (B,n,3) = sqrt of the squared
+ * distances, idx (B,n,3), weight (B,n,3) - one launch instead of the search + 6 element-wise ones. */
+int demf_three_nn_weights_f32(int B, int n, int m, const float* target, const float* source,
+                              float* dist, int* idx, float* weight, demf_stream_t stream);
 
 /* three_interpolate: features (B,C,m), idx (B,n,3), weight (B,n,3) -> (B,C,n).
  * bwd: grad_out (B,C,n) -> grad_features (B,C,m), accumulated.               */
@@ -149,6 +154,13 @@ int demf_three_interpolate_cl_bwd(int B, int m, int n, int C, int ldo, int col0,
                                   const float* grad_out, const int* idx,
                                   const float* weight, float* grad_feat,
                                   demf_stream_t stream);
+/* PointFPModule.forward's interpolate + torch.cat([interpolated, target_feats]) in one launch:
+ * out (B,n,C+Cs) = [ three_interpolate(feat (B,m,C)) | skip (B,n,Cs) ].  Backward: the interpolated
+ * columns through demf_three_interpolate_cl_bwd(ldo = C+Cs, col0 = 0); the skip gradient is the
+ * column range [C, C+Cs) of the incoming gradient itself.                                        */
+int demf_three_interpolate_cat_cl_fwd(int B, int m, int n, int C, int Cs, const float* feat,
+                                      const int* idx, const float* weight, const float* skip,
+                                      float* out, demf_stream_t stream);
 
 /* max over the ns neighbours: x (R, ns, C) -> out (R, C), arg (R, C) i32
  * (first maximum wins, as torch max_pool2d does).  bwd scatters to x grad.   */
@@ -447,6 +459,14 @@ int demf_vote_loss(int B, int S, int N, int gt_per_seed, float dst_weight,
                    const int64_t* seed_indices, const int64_t* vote_target_masks,
                    const float* vote_targets, const float* mask_sum, const float* grad_out,
                    float* out, float* grad_vote, demf_stream_t stream);
+/* forward of the same with the denominator counted in the kernel: mask_sum = sum over the seeds of
+ * vote_target_masks[b, seed_indices[b, s]] (torch.gather(...).sum() of VoteModule.get_loss), stored to
+ * mask_sum_out[0] for the backward call above; out[0] accumulated.                              */
+int demf_vote_loss_fwd(int B, int S, int N, int gt_per_seed, float dst_weight,
+                       const float* seed_points, const float* vote_points,
+                       const int64_t* seed_indices, const int64_t* vote_target_masks,
+                       const float* vote_targets, float* mask_sum_out, float* out,
+                       demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * DeMF fusion: multi-scale deformable attention core

@@ -104,6 +104,14 @@ def test_three_nn_bit_exact(ops, n, m):
     dist, gi = ops.three_nn(dev(tgt), dev(src))
     np.testing.assert_array_equal(gi.cpu().numpy(), idx)
     np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    # search + inverse-distance weights in one launch == PointFPModule.forward's expression on the
+    # oracle's distances, in float32 numpy (IEEE sqrt / divide, the same operation order): bit-exact
+    wi, w = ops.three_nn_weights(dev(tgt), dev(src))
+    np.testing.assert_array_equal(wi.cpu().numpy(), idx)
+    r = np.float32(1.0) / (np.sqrt(d2) + np.float32(1e-8))
+    want = r / ((r[..., 0] + r[..., 1]) + r[..., 2])[..., None]
+    np.testing.assert_array_equal(w.cpu().numpy(), want.astype(np.float32))
+    assert np.isfinite(want).all() or m < 3
 
 
 def test_three_interpolate(ops):
@@ -181,6 +189,18 @@ def test_gather_rows_interp_maxpool_cl(ops):
     out.backward(dev(g))
     want = ok.three_interpolate_bwd(np.ascontiguousarray(g.transpose(0, 2, 1)), idx3, w, N)
     np.testing.assert_allclose(f.grad.cpu().numpy(), want.transpose(0, 2, 1), rtol=1e-4, atol=1e-4)
+
+    # interpolate + concatenate with the target level's own features in one launch (PointFPModule.forward)
+    skip = rng.standard_normal((B, M, 24)).astype(np.float32)
+    f2, sk = dev(feat).requires_grad_(), dev(skip).requires_grad_()
+    cat = ops.three_interpolate_cat_cl(f2, dev(idx3), dev(w), sk)
+    assert torch.equal(cat.detach(), torch.cat([out.detach(), dev(skip)], dim=2))
+    gc = rng.standard_normal(cat.shape).astype(np.float32)
+    cat.backward(dev(gc))
+    f3 = dev(feat).requires_grad_()
+    ops.three_interpolate_cl(f3, dev(idx3), dev(w)).backward(dev(np.ascontiguousarray(gc[..., :feat.shape[2]])))
+    torch.testing.assert_close(f2.grad, f3.grad, rtol=1e-5, atol=1e-5)      # (atomic order differs)
+    assert torch.equal(sk.grad, dev(np.ascontiguousarray(gc[..., feat.shape[2]:])))
 
     x = rng.standard_normal((300, 16, 70)).astype(np.float32)
     x[5, 3:9, 4] = 7.0  # tie: first maximum must win
