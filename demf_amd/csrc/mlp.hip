@@ -1432,8 +1432,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
                                                               const float* __restrict__ Y,
                                                               const float* __restrict__ ss,
                                                               const float* __restrict__ mi,
-                                                              double* __restrict__ g12, int rev) {
+                                                              double* __restrict__ g12, int rev,
+                                                              BnVecFin fin) {
   __shared__ float4 red[2][256];
+  __shared__ int s_last;
   const int cg = N >> 2;
   const int rows_par = 256 / cg;
   const int c4 = threadIdx.x % cg, r_in = threadIdx.x / cg;
@@ -1489,6 +1491,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
     atomicAdd(o1 + 2, (double)t1.z); atomicAdd(o1 + 3, (double)t1.w);
     atomicAdd(o2, (double)t2.x); atomicAdd(o2 + 1, (double)t2.y);
     atomicAdd(o2 + 2, (double)t2.z); atomicAdd(o2 + 3, (double)t2.w);
+  }
+  if (fin.ticket != nullptr) {     // this layer's backward vectors by the last workgroup (csrc/bn_fin.h)
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
+    __syncthreads();
+    if (s_last) bn_vec_finalize(fin, N, 0, N, g12, threadIdx.x, 256);
   }
 }
 
@@ -1832,9 +1840,10 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
   constexpr int RT2_MAX = PRO >= PRO_DY_DENSE ? 2 : 4;
   constexpr int NT_MAX = PRO >= PRO_DY_DENSE ? 4 : 8;
   const int nt = (a.N + 31) / 32;
-  if (nt < 1 || nt > NT_MAX) {
+  // (non-pooled launches wider than NT_MAX column tiles split their columns over blockIdx.y below)
+  if (nt < 1 || nt > (POOL ? NT_MAX : 16)) {
     set_error("mlp_gemm: N=%d unsupported for this prologue (max %d columns per launch)", a.N,
-              NT_MAX * 32);
+              (POOL ? NT_MAX : 16) * 32);
     return DEMF_EUNSUPPORTED;
   }
   if constexpr (POOL) {
@@ -1880,8 +1889,9 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     return check_launch("mlp_gemm_pool");
   } else {
   const int tiles1 = (a.R + 127) / 128;
-  if (tiles1 < 192 && nt > 1) {
+  if ((tiles1 < 192 && nt > 1) || nt > NT_MAX) {
     int ysplit = (256 + tiles1 - 1) / tiles1;
+    if (ysplit < (nt + 3) / 4) ysplit = (nt + 3) / 4;     // at most 4 column tiles per block
     if (ysplit > nt) ysplit = nt;
     const int ntl = (nt + ysplit - 1) / ysplit;          // column tiles per block
     const dim3 grid(tiles1, (nt + ntl - 1) / ntl);
@@ -2154,6 +2164,9 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
                "bn_bwd_reduce: null pointer");
+  // (a "pooled" layer with one sample per group - the row MLPs of the FP / vote / head modules - is the
+  // dense case: dP is the upstream gradient of every row and the selected row is the row itself)
+  if (!G && ns == 1 && !y_bf16 && N % 4 == 0 && N <= 1024 && env_int("DEMF_BNRED_NS1_DENSE", 1)) G = dP;
   if (G && N % 4 == 0 && N <= 1024) {
     const int rp = 256 / (N / 4);
     // few blocks: every block ends with 2N same-address fp64 atomics, which serialise in L2
@@ -2162,7 +2175,7 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
     const int cap = env_int("DEMF_BNRED_GRID", 256);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(bn_bwd_reduce_dense4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
-                       Y, scale_shift, mean_invstd, g12, env_int("DEMF_BNRED_REV", 1));
+                       Y, scale_shift, mean_invstd, g12, env_int("DEMF_BNRED_REV", 1), vf);
     return check_launch("bn_bwd_reduce");
   }
   const int rows_par = N < 256 ? 256 / N : 1;
@@ -2238,10 +2251,15 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && vec6 && Wtt && dX && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dx: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  for (int c0 = 0; c0 < K; c0 += 128) {
+  // Outputs wider than 128 columns: ONE launch whose column tiles are split over blockIdx.y (every
+  // block rebuilds its dY row tile, as the per-chunk launches did, but the chunks now run side by side
+  // instead of as 2-4 dependent launches of one block per CU each); DEMF_DX_CHUNKS=1: chunk launches.
+  static const int chunked = env_int("DEMF_DX_CHUNKS", 0);
+  const int cstep = (!chunked && K <= 512) ? K : 128;
+  for (int c0 = 0; c0 < K; c0 += cstep) {
     // here the reduction runs over this layer's N channels and the output has K columns
     MlpArgs a{};
-    a.R = R; a.K = N; a.N = (K - c0) < 128 ? (K - c0) : 128; a.ldx = N; a.ldy = ldo; a.X = Y;
+    a.R = R; a.K = N; a.N = (K - c0) < cstep ? (K - c0) : cstep; a.ldx = N; a.ldy = ldo; a.X = Y;
     a.G = G; a.dP = dP; a.arg = arg; a.ns = ns; a.vec = vec6;
     if (w_direct) { a.Bt = Wtt + c0; a.ldb = K; }      // Wtt is W (N x K) itself: columns c0.. of it
     else a.Bt = Wtt + (size_t)c0 * N;
