@@ -448,10 +448,85 @@ __global__ __launch_bounds__(256) void nchw_to_tokens_k(int C, int HW, int S, in
   }
 }
 
+// All levels of the pyramid in one launch, 64 pixels x 64 channels per workgroup: 256-byte segments on
+// the channel-major side, whole 256-byte row pieces on the token side, float4 both ways.
+struct TokLevels {
+  const float* src[8];
+  int hw[8], row0[8], tile0[9];
+  int n;
+};
+__global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLevels lv,
+                                                           const unsigned char* __restrict__ mask,
+                                                           float* __restrict__ dst) {
+  __shared__ float tile[64][65];
+  const int bx = blockIdx.x, b = blockIdx.z, t = threadIdx.x;
+  int l = 0;
+  while (l + 1 < lv.n && bx >= lv.tile0[l + 1]) ++l;
+  const int HW = lv.hw[l], p0 = (bx - lv.tile0[l]) * 64, c0 = blockIdx.y * 64;
+  const float* __restrict__ src = lv.src[l] + (size_t)b * C * HW;
+  float* __restrict__ d = dst + ((size_t)b * S + lv.row0[l]) * C;
+  const unsigned char* m = mask != nullptr ? mask + (size_t)b * S + lv.row0[l] : nullptr;
+  const int q = t & 15, r = t >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = r + 16 * i, c = c0 + cl, p = p0 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      const float* g = src + (size_t)c * HW + p;
+      if (p + 3 < HW) {
+        v = *reinterpret_cast<const float4*>(g);
+      } else {
+        if (p < HW) v.x = g[0];
+        if (p + 1 < HW) v.y = g[1];
+        if (p + 2 < HW) v.z = g[2];
+      }
+    }
+    tile[cl][4 * q] = v.x; tile[cl][4 * q + 1] = v.y; tile[cl][4 * q + 2] = v.z; tile[cl][4 * q + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pl = r + 16 * i, pp = p0 + pl, c = c0 + 4 * q;
+    if (pp >= HW || c >= C) continue;
+    const bool z = m != nullptr && m[pp];                       // padding token
+    float4 v = make_float4(tile[4 * q][pl], tile[4 * q + 1][pl], tile[4 * q + 2][pl], tile[4 * q + 3][pl]);
+    if (z) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* o = d + (size_t)pp * C + c;
+    if (c + 3 < C) {
+      *reinterpret_cast<float4*>(o) = v;
+    } else {
+      o[0] = v.x;
+      if (c + 1 < C) o[1] = v.y;
+      if (c + 2 < C) o[2] = v.z;
+    }
+  }
+}
+
 }  // namespace demf
 
 
 using namespace demf;
+
+extern "C" int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                                      const unsigned char* mask, float* dst, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && C >= 1 && nlev >= 1 && nlev <= 8 && srcs && hws, "pyramid_to_tokens: bad arguments");
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(dst, "pyramid_to_tokens: null pointer");
+  TokLevels lv{};
+  int row = 0, tiles = 0;
+  for (int l = 0; l < nlev; ++l) {
+    DEMF_REQUIRE(srcs[l] && hws[l] >= 1, "pyramid_to_tokens: level %d", l);
+    lv.src[l] = srcs[l]; lv.hw[l] = hws[l]; lv.row0[l] = row; lv.tile0[l] = tiles;
+    row += hws[l];
+    tiles += (hws[l] + 63) / 64;
+  }
+  lv.tile0[nlev] = tiles;
+  lv.n = nlev;
+  DEMF_REQUIRE(row == S, "pyramid_to_tokens: the levels hold %d tokens, S = %d", row, S);
+  hipLaunchKernelGGL(pyramid_to_tokens_k, dim3(tiles, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
+                     C, S, lv, mask, dst);
+  return check_launch("pyramid_to_tokens");
+}
 
 extern "C" int demf_group_points_fwd(int B, int C, int N, int M, int ns,
                                      const float* features, const int* idx, float* out,

@@ -213,7 +213,16 @@ __global__ __launch_bounds__(256) void vote_loss_k(
   float msum;
   if constexpr (COUNT) {
     long long c = 0;
-    for (int j = threadIdx.x; j < B * S; j += 256) c += tmask[(size_t)(j / S) * N + seed_idx[j]];
+    const int total = B * S;
+    int j = threadIdx.x;
+    for (; j + 7 * 256 < total; j += 8 * 256) {          // 8 independent index -> mask chains in flight
+      long long k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = seed_idx[j + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) c += tmask[(size_t)((j + 256 * u) / S) * N + k[u]];
+    }
+    for (; j < total; j += 256) c += tmask[(size_t)(j / S) * N + seed_idx[j]];
     cnt[threadIdx.x] = c;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {

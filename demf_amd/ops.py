@@ -6,6 +6,7 @@ reference calls (cited per function); tensors stay PyTorch-ROCm tensors and only
 raw device pointers + the current HIP stream cross the C ABI.  There is no CPU or
 eager fallback: a CPU tensor or a missing library raises.
 """
+import ctypes
 import os
 
 import torch
@@ -1421,9 +1422,16 @@ def pyramid_to_tokens(mlvl_feats, zero_mask=None):
     S = sum(sizes)
     out = torch.empty((B, S, C), dtype=torch.float32, device=mlvl_feats[0].device)
     m = None if zero_mask is None else zero_mask.to(torch.uint8).contiguous()
+    for f in mlvl_feats:
+        _chk(f, "feature map")
+    if len(sizes) <= 8:                  # every level in one launch
+        srcs = (ctypes.c_void_p * len(sizes))(*[f.data_ptr() for f in mlvl_feats])
+        hws = (ctypes.c_int * len(sizes))(*sizes)
+        _ffi.call("demf_pyramid_to_tokens", B, C, S, len(sizes), ctypes.addressof(srcs), ctypes.addressof(hws),
+                  _p(m), _p(out), _stream())
+        return out
     row0 = 0
     for f, hw in zip(mlvl_feats, sizes):
-        _chk(f, "feature map")
         _ffi.call("demf_nchw_to_tokens", B, C, hw, S, row0, _p(f), _p(m), _p(out), _stream())
         row0 += hw
     return out

@@ -217,6 +217,10 @@ int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius, int 
  * with a non-zero mask byte (image padding) are written as zeros.                               */
 int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const float* src,
                         const unsigned char* mask, float* dst, demf_stream_t stream);
+/* Every level of the pyramid in one launch: srcs[l] (B,C,hws[l]) channel-major -> consecutive row
+ * ranges of dst (B,S,C), S = sum hws (nlev <= 8; srcs / hws are HOST arrays of device pointers / sizes). */
+int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                           const unsigned char* mask, float* dst, demf_stream_t stream);
 
 /* out (N) += column sums of x (R,N; row stride ld).  out arrives zeroed.  The bias gradient of the
  * path's linear layers (mmcv FFN / MultiheadAttention / MultiScaleDeformableAttention projections,

@@ -281,7 +281,8 @@ def test_invert_index(ops, B, N, M, ns):
 
 
 @pytest.mark.parametrize("B,C,shapes", [(2, 256, [(100, 140), (50, 70), (25, 35), (13, 18)]),
-                                        (3, 37, [(5, 7), (1, 1), (33, 2)])])
+                                        (3, 37, [(5, 7), (1, 1), (33, 2)]), (1, 130, [(9, 15), (64, 1), (3, 43)]),
+                                        (2, 8, [(2, 3)] * 9)])
 def test_pyramid_to_tokens(B, C, shapes):
     """demf_nchw_to_tokens == flatten(2).transpose(1,2) + cat (bit-exact: a pure re-layout)."""
     from demf_amd import ops
