@@ -2420,7 +2420,12 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
   const int TNt = cdiv(N, 32), TKt = cdiv(K, 32);
   // one launch: grid.x strides the 32-row slabs, grid.y enumerates the (<= 4x4-tile) sub-blocks
   // of the N x K output, so even a 4 k-row layer spreads over the whole chip
-  const int tn = TNt > 2 ? 2 : 1, tk = TKt > 2 ? 2 : 1;
+  int tn = TNt > 2 ? 2 : 1, tk = TKt > 2 ? 2 : 1;
+  // few rows: 64 x 64 sub-blocks (4x as many blockIdx.y columns) and correspondingly fewer row chunks -
+  // every block ends by adding its whole sub-block to dW with atomics, and with 128 x 128 sub-blocks x
+  // R/128 chunks that flush (R/128 x N x K atomics) is most of a small launch
+  static const int small_r = env_int("DEMF_DW_SMALL_R", 16384);
+  if (R <= small_r) tn = tk = 1;
   DwArgs a{};
   a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
   a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW; a.lddw = lddw;
