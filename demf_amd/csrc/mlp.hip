@@ -1889,7 +1889,10 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     return check_launch("mlp_gemm_pool");
   } else {
   const int tiles1 = (a.R + 127) / 128;
-  if ((tiles1 < 192 && nt > 1) || nt > NT_MAX) {
+  // (three-term mode: more than 4 column tiles per block would not leave LDS for two blocks per CU -
+  // the columns go to blockIdx.y instead of the launch falling back to the fp32 MFMA)
+  static const int wide_split = env_int("DEMF_X3_WIDE_SPLIT", 1);
+  if ((tiles1 < 192 && nt > 1) || nt > NT_MAX || (BF16 == 2 && nt > 4 && wide_split)) {
     int ysplit = (256 + tiles1 - 1) / tiles1;
     if (ysplit < (nt + 3) / 4) ysplit = (nt + 3) / 4;     // at most 4 column tiles per block
     if (ysplit > nt) ysplit = nt;
