@@ -21,6 +21,8 @@ SIGNATURES = {
     "demf_fps_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
     "demf_ball_query_f32": [_c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _ptr, _ptr,
                             _ptr, _ptr],
+    "demf_ball_query_grid_ws": [_c_int, _c_int, _ptr, _ptr],
+    "demf_ball_query_grid_f32": [_c_int, _c_int, _c_int, _c_float, _c_int] + [_ptr] * 6,
     "demf_group_points_fwd": [_c_int] * 5 + [_ptr] * 4,
     "demf_group_points_bwd": [_c_int] * 5 + [_ptr] * 4,
     "demf_gather_points_fwd": [_c_int] * 4 + [_ptr] * 4,

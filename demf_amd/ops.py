@@ -200,6 +200,9 @@ def furthest_point_sample(points_xyz, num_points):
     return _FurthestPointSampling.apply(points_xyz, num_points)
 
 
+_BQ_GRID_MIN_N = int(os.environ.get("DEMF_BQ_GRID_MIN_N", "8192"))     # smaller clouds: the all-pairs scan
+
+
 class _BallQuery(Function):
     @staticmethod
     def forward(ctx, min_radius, max_radius, sample_num, xyz, center_xyz):
@@ -209,6 +212,16 @@ class _BallQuery(Function):
         B, N, _ = xyz.shape
         M = center_xyz.shape[1]
         idx = torch.empty((B, M, sample_num), dtype=torch.int32, device=xyz.device)
+        if min_radius == 0 and _BQ_GRID_MIN_N <= N <= 32768 and M > 0 and B > 0:
+            # large cloud (SA1): hashed-grid search, same hits in the same order (csrc/ball_query.hip)
+            n_start, n_cells = ctypes.c_longlong(), ctypes.c_longlong()
+            _ffi.call("demf_ball_query_grid_ws", B, N, ctypes.addressof(n_start), ctypes.addressof(n_cells))
+            ws_start = torch.empty(n_start.value, dtype=torch.int32, device=xyz.device)
+            ws_cells = torch.empty(n_cells.value, dtype=torch.float32, device=xyz.device)
+            _ffi.call("demf_ball_query_grid_f32", B, N, M, float(max_radius), int(sample_num),
+                      _p(center_xyz), _p(xyz), _p(idx), _p(ws_start), _p(ws_cells), _stream())
+            ctx.mark_non_differentiable(idx)
+            return idx
         _ffi.call("demf_ball_query_f32", B, N, M, float(min_radius), float(max_radius),
                   int(sample_num), _p(center_xyz), _p(xyz), _p(idx), _stream())
         ctx.mark_non_differentiable(idx)

@@ -76,6 +76,15 @@ int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, int* idx,
 int demf_ball_query_f32(int B, int N, int M, float min_radius, float max_radius,
                         int nsample, const float* center_xyz, const float* xyz,
                         int* idx, demf_stream_t stream);
+/* The same result (min_radius = 0) for large clouds, N <= 32768, through a hashed uniform grid built on
+ * the fly (two launches): every centre only meets the points of the 2x2x2 cells of edge 2r its ball can
+ * reach instead of all N; the hit set and the index order are the scan's (csrc/ball_query.hip).
+ * Workspace (device): ws_start = *start_ints ints, ws_cells = *cell_floats floats (16-byte aligned), the
+ * sizes from demf_ball_query_grid_ws.                                                              */
+int demf_ball_query_grid_ws(int B, int N, long long* start_ints, long long* cell_floats);
+int demf_ball_query_grid_f32(int B, int N, int M, float max_radius, int nsample,
+                             const float* center_xyz, const float* xyz, int* idx,
+                             int* ws_start, float* ws_cells, demf_stream_t stream);
 
 /* grouping_operation: features (B,C,N), idx (B,M,ns) -> out (B,C,M,ns).
  * bwd: grad_out (B,C,M,ns) -> grad_features (B,C,N), accumulated.            */

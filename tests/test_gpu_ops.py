@@ -49,7 +49,11 @@ def test_fps_clustered_and_duplicates(ops):
 
 
 BQ_CASES = [(20000, 2048, 0.2, 64), (2048, 1024, 0.4, 32), (1024, 512, 0.8, 16),
-            (512, 256, 1.2, 16), (1024, 256, 0.3, 16), (70, 5, 0.5, 3), (1, 1, 0.1, 4)]
+            (512, 256, 1.2, 16), (1024, 256, 0.3, 16), (70, 5, 0.5, 3), (1, 1, 0.1, 4),
+            # the hashed-grid path (N >= 8192): its bounds, a ball that swallows most of the cloud,
+            # a tiny radius (mostly empty balls), more samples than a wave
+            (8192, 100, 0.2, 64), (32768, 300, 0.15, 16), (20000, 64, 3.0, 64), (10000, 500, 0.02, 8),
+            (20000, 33, 0.4, 200)]
 
 
 @pytest.mark.parametrize("n,m,r,ns", BQ_CASES)
@@ -62,6 +66,11 @@ def test_ball_query_bit_exact(ops, n, m, r, ns, kind):
     want = ok.ball_query(0.0, r, ns, xyz, center)
     got = ops.ball_query(0.0, r, ns, dev(xyz), dev(center)).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+    if n >= 8192:                      # and far from the origin / negative coordinates (cell hashing)
+        shift = np.array([-37.3, 55.1, -4.9], dtype=np.float32)
+        want = ok.ball_query(0.0, r, ns, xyz + shift, center + shift)
+        got = ops.ball_query(0.0, r, ns, dev(xyz + shift), dev(center + shift)).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
 
 
 def test_ball_query_min_radius(ops):
