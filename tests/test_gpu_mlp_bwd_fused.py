@@ -109,7 +109,7 @@ def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
     want = [t.grad for l in lr_ for t in l] + ([xr.grad] if xgrad else [])
     ops._NO_BWD_FUSE = False
     out, got = _run(x, layers, go, ns, xgrad)
-    assert float((out.double().cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.detach().abs().max()))
     for i, (a, b) in enumerate(zip(got, want)):
         rel = float((a.double().cpu() - b).norm() / b.norm())
         assert rel <= 5e-3, (i, rel)
