@@ -75,6 +75,7 @@ SIGNATURES = {
     "demf_mlp_gemm_bwd_dx_red": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 9,
     "demf_mlp_gemm_bwd_dx_w": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 5,
     "demf_mlp_bwd_fused": [_c_int] * 3 + [_ptr] * 3 + [_c_int] + [_ptr] * 15 + [_c_int, _ptr],
+    "demf_mlp_bwd_fused_cols": [_c_int] * 5 + [_ptr] * 3 + [_c_int] + [_ptr] * 14,
     "demf_mlp_gemm_bwd_dx_red_v": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 13,
     "demf_bn_bwd_reduce_vectors": [_c_int] * 3 + [_ptr] * 11 + [_c_int, _ptr],
     "demf_mlp_gemm_bwd_dw": [_c_int] * 4 + [_ptr] * 3 + [_c_int] + [_ptr] * 6,

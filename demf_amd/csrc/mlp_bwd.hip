@@ -56,6 +56,9 @@ struct FusedBwdArgs {
   const float* fX;    // FIRST: (R x 4) input rows of layer 0
   double* fsum;       // FIRST: g1(K) | g2(K) | P(K x 4) | Q(K x 4) | cx(4), accumulated
   BnVecFin vfin;      // RED: layer l-1's backward vectors by the last workgroup (ticket != null)
+  // A launch may cover K of the fld >= K channels of layer l-1 (columns fc0 .. fc0 + K): Xp, dX, W, dW
+  // then arrive offset by fc0 with row strides ldk / ldw; pss, pmi, g12 and vfin are the WHOLE layer's.
+  int ldk, ldw, fld, fc0;
 };
 
 // one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
@@ -172,7 +175,11 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   const int nt = wave % NTN, kg = wave / NTN;     // dW: channel slice nt, K tiles kg*KTW ..
   const int dkt = wave % KT, dnh = wave / KT;     // dX: K tile dkt, channel slices dnh*SL ..
   for (int i = tid; i < 5 * N; i += NT) s_vy[i] = p.vec[i];
-  for (int i = tid; i < 2 * K; i += NT) { s_px[i] = p.pss[i]; s_px[2 * K + i] = p.pmi[i]; }
+  for (int i = tid; i < 2 * K; i += NT) {
+    const int g = (i < K ? i : p.fld + i - K) + p.fc0;           // [scale | shift], [mean | invstd] of the chunk
+    s_px[i] = p.pss[g];
+    s_px[2 * K + i] = p.pmi[g];
+  }
 
   // ---- the weight as B fragments of dX = dY.W, resident for the whole launch --------------------
   // B^T[col j = k][red = n]: lane (k = 32*dkt + lr, n = 32*(dnh*SL + sl) + 16*s + 8*lh + e)
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       __bf16 t[8][P];
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        split_planes<P>(p.W[(size_t)(32 * (dnh * SL + sl) + 16 * s + 8 * lh + e) * K + 32 * dkt + lr], t[e]);
+        split_planes<P>(p.W[(size_t)(32 * (dnh * SL + sl) + 16 * s + 8 * lh + e) * p.ldw + 32 * dkt + lr], t[e]);
 #pragma unroll
       for (int q = 0; q < P; ++q)
 #pragma unroll
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       if constexpr (!SPARSE) rg[j] = load_row<CW, YB>(p.G, (size_t)row * N + t_col);
       const int xrow = min(row0 + x_rl + j, last);
       {
-        const auto xv = load_row<2, XB>(p.Xp, (size_t)xrow * K + 2 * x_c2);
+        const auto xv = load_row<2, XB>(p.Xp, (size_t)xrow * p.ldk + 2 * x_c2);
         rx[j] = make_float2(xv[0], xv[1]);
       }
     }
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         const int rl = e_r0 + i * ER, row = srow0 + rl;
         const float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
         if (row < p.R) {
-          const auto yv = load_row<4, XB>(p.Xp, (size_t)row * K + 4 * e_cq);
+          const auto yv = load_row<4, XB>(p.Xp, (size_t)row * p.ldk + 4 * e_cq);
           const float4 y = make_float4(yv[0], yv[1], yv[2], yv[3]);
           float dz[4];
           dz[0] = __builtin_fmaf(y.x, sc0.x, sh0.x) > 0.f ? dx.x : 0.f;
@@ -419,9 +426,9 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
               unsigned o0[1], o1[1];
               split_pair<1>(dx.x, dx.y, o0);
               split_pair<1>(dx.z, dx.w, o1);
-              *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.dX) + (size_t)row * K + 4 * e_cq) = make_uint2(o0[0], o1[0]);
+              *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(p.dX) + (size_t)row * p.ldk + 4 * e_cq) = make_uint2(o0[0], o1[0]);
             } else {
-              *reinterpret_cast<float4*>(p.dX + (size_t)row * K + 4 * e_cq) = dx;
+              *reinterpret_cast<float4*>(p.dX + (size_t)row * p.ldk + 4 * e_cq) = dx;
             }
           } else {
             const float4 x = *reinterpret_cast<const float4*>(p.fX + (size_t)row * 4);
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       for (int r = 0; r < 16; ++r) {
         const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int k = 32 * (kg * KTW + kk) + lr;
-        atomicAdd(p.dW + (size_t)n * K + k, dwacc[kk][r]);
+        atomicAdd(p.dW + (size_t)n * p.ldw + k, dwacc[kk][r]);
       }
   }
   // column sums: lanes with the same float4 column inside a wave first, then the 8 waves through LDS
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
     for (int w = 0; w < NW; ++w) t += s_red[(w * QK + cq) * NV + q];
     if (q < 8) {
       const int col = 4 * cq + (q & 3);
-      if constexpr (EPI == 0) atomicAdd(p.g12 + (q >> 2) * K + col, (double)t);
+      if constexpr (EPI == 0) atomicAdd(p.g12 + (q >> 2) * p.fld + p.fc0 + col, (double)t);
       else atomicAdd(p.fsum + (q >> 2) * K + col, (double)t);
     } else if (q < 40) {
       // FIRST: P (K x 4) at 2K, Q (K x 4) at 6K
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       __syncthreads();
       if (tid == 0) s_last = last_workgroup(p.vfin.ticket, (int)gridDim.x, (int)blockIdx.x);
       __syncthreads();
-      if (s_last) bn_vec_finalize(p.vfin, K, 0, K, p.g12, tid, NT);
+      if (s_last) bn_vec_finalize(p.vfin, p.fld, p.fc0, K, p.g12, tid, NT);
     }
   }
 }
@@ -568,6 +575,7 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
   a.R = R; a.N = N; a.K = K; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
   a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.dX = dX; a.dW = dW;
   a.g12 = g12_prev; a.fX = X0; a.fsum = first_sums;
+  a.ldk = K; a.ldw = K; a.fld = K; a.fc0 = 0;
   if (!first && gamma_prev != nullptr) {
     DEMF_REQUIRE(vec6_prev && dgamma_prev && dbeta_prev, "mlp_bwd_fused: vectors of layer l-1 need all three outputs");
     a.vfin = BnVecFin{(double)R, gamma_prev, scale_shift_prev, mean_invstd_prev, vec6_prev, dgamma_prev,
@@ -591,5 +599,42 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
   if (N == 128 && K == 128) { if (sparse) { FGO(4, 4, 2, true, 0); } else { FGO(4, 4, 2, false, 0); } }
   if (N == 256 && K == 128) { if (sparse) { FGO(8, 4, 1, true, 0); } else { FGO(8, 4, 1, false, 0); } }
   if (sparse) { FGO(2, 2, 2, true, 0); } else { FGO(2, 2, 2, false, 0); }
+#undef FGO
+}
+
+// The same pass for a layer whose input is wider than the kernel's K tile: columns c0 .. c0 + Kc of the
+// Ktot channels of layer l-1 (Kc a supported K: 64 / 128).  One call per column chunk: each rebuilds the
+// dY row tiles (as the dx + dW launches it replaces did) and produces its chunk of dX, dW, the BN-backward
+// sums and - by its last workgroup - the vectors of those channels.  Pointers are the WHOLE layer's.
+extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, const float* G, const float* dP,
+                                       const int* arg, int ns, const float* Y, const float* vec6,
+                                       const float* W, const float* Yprev, const float* scale_shift_prev,
+                                       const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
+                                       const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
+                                       float* dbeta_prev, demf_stream_t stream) {
+  const bool sparse = G == nullptr;
+  DEMF_REQUIRE(fused_supported(R, N, Kc, ns, sparse, 0) && c0 >= 0 && c0 + Kc <= Ktot && c0 % 4 == 0 && Ktot % 4 == 0,
+               "mlp_bwd_fused_cols: unsupported shape / mode R=%d N=%d Ktot=%d c0=%d Kc=%d ns=%d sparse=%d mode=%d",
+               R, N, Ktot, c0, Kc, ns, (int)sparse, compute_mode());
+  DEMF_REQUIRE(Y && vec6 && W && Yprev && scale_shift_prev && mean_invstd_prev && dW && (G || (dP && arg)) && dX &&
+                   g12_prev, "mlp_bwd_fused_cols: null pointer");
+  FusedBwdArgs a{};
+  a.R = R; a.N = N; a.K = Kc; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
+  a.Xp = Yprev + c0; a.dX = dX + c0; a.W = W + c0; a.dW = dW + c0;
+  a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.g12 = g12_prev;
+  a.ldk = Ktot; a.ldw = Ktot; a.fld = Ktot; a.fc0 = c0;
+  if (gamma_prev != nullptr) {
+    DEMF_REQUIRE(vec6_prev && dgamma_prev && dbeta_prev, "mlp_bwd_fused_cols: vectors of layer l-1 need all three outputs");
+    a.vfin = BnVecFin{(double)R, gamma_prev, scale_shift_prev, mean_invstd_prev, vec6_prev, dgamma_prev,
+                      dbeta_prev, sched_slot()};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int cm = compute_mode();
+#define FGO(NTNv, KTv, KGv, SPv) \
+  return cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, 0>(a, s)
+  if (N == 128 && Kc == 64) { if (sparse) { FGO(4, 2, 1, true); } else { FGO(4, 2, 1, false); } }
+  if (N == 128 && Kc == 128) { if (sparse) { FGO(4, 4, 2, true); } else { FGO(4, 4, 2, false); } }
+  if (N == 256 && Kc == 128) { if (sparse) { FGO(8, 4, 1, true); } else { FGO(8, 4, 1, false); } }
+  if (sparse) { FGO(2, 2, 2, true); } else { FGO(2, 2, 2, false); }
 #undef FGO
 }

@@ -768,6 +768,23 @@ def _bwd_fused_ok(N, K, ns, sparse, first=False):
     if first:
         return N == 64 and K == 64 and not sparse
     return (N, K) in ((128, 64), (128, 128), (64, 64), (256, 128))
+# rows from which a 256-output layer with a 256 / 384 / 512-channel input takes the one-pass backward per
+# 128-column chunk; 0 = never (default: measured neutral on the step - 5.67 vs 5.67 ms - because the
+# (256,128) kernel walks a 32-row slab in ~8 us and the vote aggregation's 32 768 rows are 4 slabs per block)
+_FUSED_COLS_MIN_R = int(os.environ.get("DEMF_FUSED_COLS_MIN_R", "0"))
+
+
+def _bwd_fused_cols_ok(R, N, K, ns, sparse):
+    """demf_mlp_bwd_fused_cols: the one-pass backward on 128-column chunks of a 256-output layer whose
+    input has K = 256 / 384 / 512 channels (the vote aggregation stack), on enough rows to fill the
+    persistent grid."""
+    if _NO_BWD_FUSE or _COMPUTE_MODE not in (1, 2) or _FUSED_COLS_MIN_R <= 0 or R < _FUSED_COLS_MIN_R:
+        return False
+    if sparse and (ns < 4 or ns % 4):
+        return False
+    return N == 256 and K > 128 and K % 128 == 0 and K <= 512
+
+
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
@@ -1068,6 +1085,30 @@ class _SharedMLPPool(Function):
                           _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p), None, None,
                           _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]), _p(vec_ready[1]),
                           _p(vec_ready[2]), 3 if s16 else 0, st)
+                if not (_VEC_FIN & 2):
+                    g12_pending = g12p
+                G = dX
+                continue
+            if l > 0 and ldx == K and not first_here and not s16 and _bwd_fused_cols_ok(R, N, K, ns, sparse):
+                # the one-pass backward per 128-column chunk of a wider layer l-1 (vote aggregation:
+                # 256 -> 256 on 32 768 rows): each launch yields its columns of dX and dW, the sums and
+                # (last workgroup) the vectors of those channels
+                grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
+                if ctx.bias_shapes[l] is not None:
+                    grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
+                    o32 += N
+                dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+                g12p = ws64[o64:o64 + 2 * K]
+                o64 += 2 * K
+                vec_ready = (torch.empty(5 * K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev))
+                for c0 in range(0, K, 128):
+                    _ffi.call("demf_mlp_bwd_fused_cols", R, N, K, c0, 128, _p(G), _p(dP if sparse else None),
+                              _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(W), _p(Ys[l - 1]),
+                              _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p),
+                              _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]),
+                              _p(vec_ready[1]), _p(vec_ready[2]), st)
                 if not (_VEC_FIN & 2):
                     g12_pending = g12p
                 G = dX

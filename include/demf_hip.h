@@ -424,6 +424,15 @@ int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const float* dP, con
                        float* dW, double* g12_prev, const float* X0, double* first_sums,
                        const float* gamma_prev, float* vec6_prev, float* dgamma_prev, float* dbeta_prev,
                        int store_flags, demf_stream_t stream);
+/* The same pass over columns c0 .. c0 + Kc of a Ktot-channel layer l-1 (Kc = 64 / 128, (N, Kc) one of the
+ * shapes above; dense row storage): Yprev, dX (R x Ktot), W, dW (N x Ktot), scale_shift_prev / mean_invstd_prev
+ * (2 Ktot), g12_prev (2 Ktot) and the vector outputs are the WHOLE layer's; one call per column chunk. */
+int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, const float* G, const float* dP,
+                            const int* arg, int ns, const float* Y, const float* vec6, const float* W,
+                            const float* Yprev, const float* scale_shift_prev,
+                            const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
+                            const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
+                            float* dbeta_prev, demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */

@@ -16,6 +16,8 @@ CASES = [  # (groups, ns, ld, channels, x_grad)  - the layers the fused kernel t
     (333, 64, 4, (64, 64, 128), False),       # ... ragged last slab (R % 64 != 0 is impossible with ns=64; 333*64 rows)
     (520, 32, 64, (128, 128, 128), True),     # L3 (128,128) sparse ns=32, L2 (128,128) dense
     (300, 16, 36, (128, 128, 256), True),     # SA3/SA4-like: L3 (256,128) sparse ns=16, L2 (128,128) dense
+    (1030, 16, 128, (256, 256, 256), True),   # vote aggregation (256 -> 256 on >= 16384 rows): L3 sparse and L2 dense
+                                              # per 128-column chunk (demf_mlp_bwd_fused_cols), L1 (256,128) dense
     (45, 16, 64, (128, 128, 128), True),      # vote-aggregation-like, few rows (720: ragged 32-row slabs)
     (1000, 4, 32, (64, 64, 64), True),        # (64,64) RED sparse ns=4 and dense
     (2000, 1, 64, (128, 128, 64), True),      # ns = 1 (unpooled tail, two-launch path for the last layer); L2 (128,128) dense
@@ -67,20 +69,25 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
     def spy(name, *a):
         calls.append(name)
         return orig(name, *a)
+    cols_min = ops._FUSED_COLS_MIN_R
     try:
         _ffi.call = spy
         ops._NO_BWD_FUSE = False
+        ops._FUSED_COLS_MIN_R = 16384          # (opt-in: DEMF_FUSED_COLS_MIN_R, measured neutral on the step)
         out_f, g_f = _run(x, layers, go, ns, xgrad)
         n_fused = calls.count("demf_mlp_bwd_fused")
+        n_cols = calls.count("demf_mlp_bwd_fused_cols")
         calls.clear()
         ops._NO_BWD_FUSE = True
         out_u, g_u = _run(x, layers, go, ns, xgrad)
-        assert "demf_mlp_bwd_fused" not in calls
+        assert "demf_mlp_bwd_fused" not in calls and "demf_mlp_bwd_fused_cols" not in calls
     finally:
         _ffi.call = orig
         ops._NO_BWD_FUSE = False
+        ops._FUSED_COLS_MIN_R = cols_min
         ops.set_compute_dtype("f32")
-    assert n_fused >= 1, "the case must exercise the fused kernel"
+    assert n_fused + n_cols >= 1, "the case must exercise the fused kernel"
+    assert n_cols == (4 if chans == (256, 256, 256) else 0)       # two layers x two column chunks
     assert torch.equal(out_f, out_u)
     # same operands, same roundings (bf16 mode rounds dY, act(Y_{l-1}) and W at the same places in both
     # paths); only the fp32 accumulation order differs
@@ -91,7 +98,7 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
         assert err <= tol * scale, (i, err, scale)
 
 
-@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES[:5])
+@pytest.mark.parametrize("Rp,ns,ld,chans,xgrad", CASES[:6])
 def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
     """fp32-grade mode against fp64 autograd of the same chain.  Gradients relative L2 (a single
     ReLU / max-pool near-tie resolving differently in fp32 moves whole tensors by ~1e-3, see
@@ -108,7 +115,11 @@ def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
     ref.backward(go)
     want = [t.grad for l in lr_ for t in l] + ([xr.grad] if xgrad else [])
     ops._NO_BWD_FUSE = False
-    out, got = _run(x, layers, go, ns, xgrad)
+    cols_min, ops._FUSED_COLS_MIN_R = ops._FUSED_COLS_MIN_R, 16384      # also the per-column-chunk form
+    try:
+        out, got = _run(x, layers, go, ns, xgrad)
+    finally:
+        ops._FUSED_COLS_MIN_R = cols_min
     assert float((out.detach().double().cpu() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.detach().abs().max()))
     for i, (a, b) in enumerate(zip(got, want)):
         rel = float((a.double().cpu() - b).norm() / b.norm())
