@@ -1427,13 +1427,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
 // row lanes fill the rest of the block; 4 rows in flight per thread.  `rev`: rows are visited last to
 // first - G has just been written front to back by the dx GEMM, so its tail is what the 256 MB
 // memory-side cache still holds (measured -0.03 ms/step).
+// GATHER: the pooled (sparse) form on its R/ns pooled rows - G = dP, Y = yraw (the raw output at the
+// selected row, handed over by demf_pool_select); a NaN there (zero BN scale: no extremum was selected)
+// sends that one value to the arg-max row of the full output Yfull, as bn_bwd_reduce_k<true> does.
+template <bool GATHER>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
                                                               const float* __restrict__ G,
                                                               const float* __restrict__ Y,
                                                               const float* __restrict__ ss,
                                                               const float* __restrict__ mi,
                                                               double* __restrict__ g12, int rev,
-                                                              BnVecFin fin) {
+                                                              BnVecFin fin, const float* __restrict__ Yfull,
+                                                              const int* __restrict__ arg, int ns, int y_bf16) {
   __shared__ float4 red[2][256];
   __shared__ int s_last;
   const int cg = N >> 2;
@@ -1457,6 +1462,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
       a2.z = __builtin_fmaf(d2, (y.z - mu.z) * is.z, a2.z);
       a2.w = __builtin_fmaf(d3, (y.w - mu.w) * is.w, a2.w);
     };
+    auto fix = [&](float4& y, int rr) {          // GATHER: NaN -> the value at the arg-max row
+      if constexpr (GATHER) {
+        auto one = [&](float& v, int c) {
+          if (v != v) {
+            const size_t o = ((size_t)rr * ns + arg[(size_t)rr * N + c]) * N + c;
+            v = y_bf16 ? (float)reinterpret_cast<const __bf16*>(Yfull)[o] : Yfull[o];
+          }
+        };
+        one(y.x, 4 * c4); one(y.y, 4 * c4 + 1); one(y.z, 4 * c4 + 2); one(y.w, 4 * c4 + 3);
+      }
+    };
     int r = blockIdx.x * rows_par + r_in;
     for (; r + 3 * step < R; r += 4 * step) {
       float4 g[4], y[4];
@@ -1468,11 +1484,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
         y[u] = *reinterpret_cast<const float4*>(Y + o);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc(g[u], y[u]);
+      for (int u = 0; u < 4; ++u) {
+        fix(y[u], rev ? R - 1 - (r + u * step) : r + u * step);
+        acc(g[u], y[u]);
+      }
     }
     for (; r < R; r += step) {
-      const size_t o = (size_t)(rev ? R - 1 - r : r) * N + 4 * c4;
-      acc(*reinterpret_cast<const float4*>(G + o), *reinterpret_cast<const float4*>(Y + o));
+      const int rr = rev ? R - 1 - r : r;
+      const size_t o = (size_t)rr * N + 4 * c4;
+      float4 y = *reinterpret_cast<const float4*>(Y + o);
+      fix(y, rr);
+      acc(*reinterpret_cast<const float4*>(G + o), y);
     }
   }
   red[0][threadIdx.x] = a1;
@@ -2177,8 +2199,22 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
     int grid = cdiv(R, rp * 16);
     const int cap = env_int("DEMF_BNRED_GRID", 256);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(bn_bwd_reduce_dense4_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
-                       Y, scale_shift, mean_invstd, g12, env_int("DEMF_BNRED_REV", 1), vf);
+    hipLaunchKernelGGL(bn_bwd_reduce_dense4_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
+                       Y, scale_shift, mean_invstd, g12, env_int("DEMF_BNRED_REV", 1), vf,
+                       (const float*)nullptr, (const int*)nullptr, 1, 0);
+    return check_launch("bn_bwd_reduce");
+  }
+  // pooled form with the selected rows' raw outputs at hand: the same float4 kernel over the R/ns pooled
+  // rows (<= 256 blocks -> <= 256 same-address fp64 atomics per channel instead of 1 024: at SA1 the
+  // sparse kernel's 31 us were mostly that tail)
+  if (!G && yraw && N % 4 == 0 && N <= 1024 && R % ns == 0 && env_int("DEMF_BNRED_POOLED_DENSE", 1)) {
+    const int Rp = R / ns, rp = 256 / (N / 4);
+    int grid = cdiv(Rp, rp * 16);
+    const int cap = env_int("DEMF_BNRED_GRID", 256);
+    if (grid > cap) grid = cap;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_dense4_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, Rp, N, dP,
+                       yraw, scale_shift, mean_invstd, g12, 0, vf, Y, arg, ns, y_bf16);
     return check_launch("bn_bwd_reduce");
   }
   const int rows_par = N < 256 ? 256 / N : 1;
