@@ -293,7 +293,8 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   hipStream_t s = (hipStream_t)stream;
   const int lpr = C1 / 4, gpb = 256 / lpr;
   long long blocks = (points + gpb - 1) / gpb;
-  if (blocks > 1024) blocks = 1024;  // 3*C1 fp32 atomics per block
+  static const int bcap = getenv("DEMF_GF_BWD_BLOCKS") ? atoi(getenv("DEMF_GF_BWD_BLOCKS")) : 1024;
+  if (blocks > bcap) blocks = bcap;  // 3*C1 fp32 atomics per block
   const dim3 grid((unsigned)blocks);
   DEMF_REQUIRE((dxyz == nullptr) == (dcenter == nullptr) && (dxyz == nullptr || Wx != nullptr),
                "group_first_bwd: dxyz, dcenter (and Wx) must be given together");

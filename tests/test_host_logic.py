@@ -103,6 +103,36 @@ def test_targets_empty_scene_and_padding():
     assert torch.equal(vt[0, i, 0:3], vt[0, i, 3:6]) and torch.equal(vt[0, i, 0:3], vt[0, i, 6:9])
 
 
+def test_pad_gt_slots_and_lazy_dir_res():
+    """pad_gt: per-scene GT lists -> (B,G,7) / (B,G) by one concatenation + one row gather each; an empty
+    scene gets the reference's all-zero fake box with label 0 (class_agnostic_vote_head.py:766-773), padding
+    slots are zero boxes with label 0 (or -1 in the slot form the device target kernels read).  split_pred:
+    `dir_res` (coder.py:233) is computed on first access only."""
+    from demf_amd.modules.head import DeMFVoteHead
+    from demf_amd.modules.coder import DeMFClassAgnosticBBoxCoder
+    g = torch.Generator().manual_seed(0)
+    boxes = [torch.randn(3, 7, generator=g), torch.zeros(0, 7), torch.randn(1, 7, generator=g)]
+    labels = [torch.tensor([4, 0, 9]), torch.zeros(0, dtype=torch.long), torch.tensor([2])]
+    gt, lab, valid = DeMFVoteHead.pad_gt(boxes, labels, torch.device("cpu"))
+    assert gt.shape == (3, 3, 7) and lab.shape == (3, 3)
+    assert torch.equal(gt[0], boxes[0]) and torch.equal(gt[2, 0], boxes[2][0])
+    assert (gt[1] == 0).all() and (gt[2, 1:] == 0).all()
+    assert lab.tolist() == [[4, 0, 9], [0, 0, 0], [2, 0, 0]]
+    assert valid.tolist() == [[True, True, True], [True, False, False], [True, False, False]]
+    _, slot, _ = DeMFVoteHead.pad_gt(boxes, labels, torch.device("cpu"), with_slot_labels=True)
+    assert slot.tolist() == [[4, 0, 9], [0, -1, -1], [2, -1, -1]]
+    assert torch.equal(slot >= 0, valid)
+
+    coder = DeMFClassAgnosticBBoxCoder(num_dir_bins=12)
+    cls, reg = torch.randn(2, 12, 5, generator=g), torch.randn(2, 30, 5, generator=g)
+    res = coder.split_pred(cls, reg, torch.zeros(2, 5, 3))
+    assert "dir_res" not in res and "dir_res" not in dict(res)
+    want = res["dir_res_norm"] * (np.pi / 12)
+    assert torch.equal(res["dir_res"], want) and "dir_res" in res
+    with pytest.raises(KeyError):
+        res["no_such_key"]
+
+
 def test_compute_dtype_names_and_native_override(monkeypatch):
     """ops.set_compute_dtype: 'f32' is the three-term split (mode 2) unless DEMF_F32_NATIVE=1 asks for
     the fp32 MFMA (mode 0); unknown names are rejected; the C entry refuses modes outside 0..2.
