@@ -89,6 +89,14 @@ __device__ __forceinline__ void split3(const float4& v0, const float4& v1, bf16x
   l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+#ifdef DEMF_MLP_PROFILE   // tools/mlp_phase_prof.py: per-phase shader cycles of block (0,0), thread 0
+__device__ long long g_mlp_prof[16];
+#define MP_T(k) const long long mp##k = __builtin_readcyclecounter();
+#define MP_ACC(i, a, b) if (mp_on) mp_acc[i] += (b) - (a);
+#else
+#define MP_T(k)
+#define MP_ACC(i, a, b)
+#endif
 constexpr int MLP_BK = 32;        // K step staged per iteration
 constexpr int SCHED_GROUPS = 16;  // counters per dynamically scheduled persistent launch
 constexpr int DW_CHUNK = 16;      // 32-row slabs per claim of the weight-gradient kernel
@@ -508,11 +516,16 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       }
     }
   };
+#ifdef DEMF_MLP_PROFILE
+  long long mp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool mp_on = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+#endif
   int tile = bx;
   if (tile < ntiles) prefetch(tile, 0);
 
   int ks = 0;
   while (tile < ntiles) {
+    MP_T(0)
     const int k0 = ks * MLP_BK;
     const int row0 = tile * BROWS + wave * WROWS;
     const bool last_ks = ks == ksteps - 1;
@@ -531,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     }
     lds_barrier();                                    // everyone is done reading the old Bt slab (LDS-only
                                                       // wait: the previous tile's output stores stay in flight)
+    MP_T(1) MP_ACC(0, mp0, mp1)
     if constexpr (BF16) {
       // bf16 element (row, k) lives at byte row * 4*MLP_LD + 2*k of the slab
       char* sab = reinterpret_cast<char*>(sa);
@@ -590,7 +604,9 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         *reinterpret_cast<float4*>(sb + (br + 32 * i) * MLP_LD + pc) = preb[i];
       }
     }
+    MP_T(2) MP_ACC(1, mp1, mp2)
     lds_barrier();
+    MP_T(3) MP_ACC(2, mp2, mp3)
     // the pooling epilogue needs registers: on the last k-step of a tile the next tile's
     // operands are fetched after it instead of being held in flight across it
     constexpr bool DEFER = (POOL && RT == 2) || FIRST;   // epilogues that need the prefetch registers
@@ -598,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
     const int next_tile = last_ks ? (dyn ? s_next : tile + gx) : tile;
     const int next_ks = last_ks ? 0 : ks + 1;
     if (next_tile < ntiles && !defer_prefetch) prefetch(next_tile, next_ks);
+    MP_T(4) MP_ACC(3, mp3, mp4)
     // FIRST: the wave's 64 x 32 half tile of layer 0's output (coalesced float4 rows) and its input
     // rows are fetched before the MFMAs of the last k-step and staged through the wave's A slab
     float4 yq[(FIRST || RED) ? 2 * RT * 2 : 1];
@@ -695,6 +712,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       }
     }
     }
+    MP_T(5) MP_ACC(4, mp4, mp5)
     if (last_ks) {
       // epilogue: C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
@@ -871,9 +889,13 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         if (next_tile < ntiles) prefetch(next_tile, next_ks);
       }
     }
+    MP_T(6) MP_ACC(5, mp5, mp6)
     tile = next_tile;
     ks = next_ks;
   }
+#ifdef DEMF_MLP_PROFILE
+  if (mp_on) { for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&g_mlp_prof[i], (unsigned long long)mp_acc[i]); atomicAdd((unsigned long long*)&g_mlp_prof[15], 1ull); }
+#endif
   if (dyn) {
     // the last block out re-arms the counter pair for the next launch that uses this slot
     if (threadIdx.x == 0) {
@@ -2522,3 +2544,16 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
 #undef DW
   return check_launch("mlp_gemm_bwd_dw");
 }
+
+#ifdef DEMF_MLP_PROFILE
+// phases of mlp_gemm_kernel's K loop: 0 wait at the first barrier, 1 transform + LDS writes, 2 second barrier,
+// 3 prefetch issue, 4 MFMA section (LDS reads + split + MFMAs), 5 epilogue + bookkeeping; [15] = launches
+extern "C" int demf_mlp_prof_read(long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(demf::g_mlp_prof), 16 * sizeof(long long)) != hipSuccess) return -1;
+  if (reset) {
+    long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(demf::g_mlp_prof), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
