@@ -1937,7 +1937,8 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
   // the columns go to blockIdx.y instead of the launch falling back to the fp32 MFMA)
   static const int wide_split = env_int("DEMF_X3_WIDE_SPLIT", 1);
   if ((tiles1 < 192 && nt > 1) || nt > NT_MAX || (BF16 == 2 && nt > 4 && wide_split)) {
-    int ysplit = (256 + tiles1 - 1) / tiles1;
+    static const int split_target = env_int("DEMF_SPLIT_TARGET", 256);   // blocks the column split aims at
+    int ysplit = (split_target + tiles1 - 1) / tiles1;
     if (ysplit < (nt + 3) / 4) ysplit = (nt + 3) / 4;     // at most 4 column tiles per block
     if (ysplit > nt) ysplit = nt;
     const int ntl = (nt + ysplit - 1) / ysplit;          // column tiles per block
