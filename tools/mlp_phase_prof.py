@@ -20,7 +20,7 @@ def layer(R, K, N):
               torch.zeros(N, device="cuda", requires_grad=True), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")),
              ((torch.randn(N, N, generator=g) / N ** 0.5).cuda().requires_grad_(), torch.ones(N, device="cuda", requires_grad=True),
               torch.zeros(N, device="cuda", requires_grad=True), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"))])
-for R, K, N in [(8192, 512, 256), (8192, 256, 256), (262144, 128, 128)]:
+for R, K, N in [(128, 256, 256), (8192, 256, 256), (8192, 512, 256), (262144, 128, 128)]:
     x, ls = layer(R, K, N)
     x.requires_grad_()
     for _ in range(2):
