@@ -307,6 +307,14 @@ class Trainer:
         padding slots; an empty scene gets the reference's single all-zero fake box with label 0
         (class_agnostic_vote_head.py:766-773)."""
         B = len(gt_boxes)
+        first = gt_boxes[0].tensor if hasattr(gt_boxes[0], "tensor") else gt_boxes[0]
+        if first.is_cuda:
+            # device-resident lists: padded on the device (one concatenation + one row gather per tensor,
+            # DeMFVoteHead.pad_gt) - a `.cpu()` here would make the host wait for the step in flight and
+            # serialise the input path with the GPU (measured: 6.66 instead of 5.6 ms per step)
+            from .modules.head import DeMFVoteHead
+            gt, lab, _ = DeMFVoteHead.pad_gt(gt_boxes, gt_labels, device, with_slot_labels=True, G=G)
+            return gt, lab
         gt = torch.zeros((B, G, 7), dtype=torch.float32)
         lab = torch.full((B, G), -1, dtype=torch.int64)
         for i, (b, l) in enumerate(zip(gt_boxes, gt_labels)):

@@ -226,10 +226,29 @@ class DeMFVoteHead(nn.Module):
             if mid != id(static_metas):
                 continue
             found = True
-            fresh = self._build_meta_tensors(new_metas, shapes, torch.device(dev), entry["M"].dtype)
-            for k, v in fresh.items():
-                if torch.is_tensor(v) and torch.is_tensor(entry.get(k)):
-                    entry[k].copy_(v)
+            fresh = self._build_meta_arrays(new_metas, shapes, entry["M"].dtype)
+            if not entry["M"].is_cuda:
+                for k, v in fresh.items():
+                    if v is not None and torch.is_tensor(entry.get(k)):
+                        entry[k].copy_(torch.as_tensor(v))
+                continue
+            # Device entries: uploaded on a SIDE stream into fresh device tensors, then copied device to
+            # device on the current stream.  A pageable host -> device copy makes the host wait for everything
+            # queued on ITS stream; on the stream of the training step that is the step in flight, and the
+            # per-batch input path would run behind the GPU instead of underneath it (measured: the host
+            # spent 5.3 ms per load in these copies; pinned staging + non-blocking copies on the step's own
+            # stream were worse still - the DMA copies between graph launches cost milliseconds).
+            cur = torch.cuda.current_stream()
+            up = self.__dict__.get("_meta_upload_stream")
+            if up is None:
+                up = self.__dict__.setdefault("_meta_upload_stream", torch.cuda.Stream())
+            with torch.cuda.stream(up):
+                dev_fresh = {k: torch.as_tensor(v, device=entry["M"].device)
+                             for k, v in fresh.items() if v is not None and torch.is_tensor(entry.get(k))}
+            cur.wait_stream(up)
+            for k, v in dev_fresh.items():
+                v.record_stream(cur)
+                entry[k].copy_(v.view(entry[k].shape) if v.numel() == entry[k].numel() else v)
         if not found:
             raise RuntimeError("refresh_metas: no cached device constants for this metas object "
                                "(it was never used in a forward, or its entry was evicted)")
@@ -256,7 +275,10 @@ class DeMFVoteHead(nn.Module):
             cache[key] = cache.pop(key)      # most recently used goes last
         return cache[key]
 
-    def _build_meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
+    @staticmethod
+    def _build_meta_arrays(img_metas, mlvl_shapes, dt):
+        """The per-batch constants as host arrays in their final dtypes (name -> ndarray or None)."""
+        fdt = {torch.float32: np.float32, torch.float64: np.float64, torch.float16: np.float16}.get(dt, np.float32)
         comp = [compose_projection(m) for m in img_metas]
         sizes = [h * w for h, w in mlvl_shapes]
         # padding masks (:559-568): nearest-neighbour resize of the (B,Hpad,Wpad) mask is an
@@ -270,20 +292,22 @@ class DeMFVoteHead(nn.Module):
             valid_w = (~m[:, 0, :]).sum(1).astype(np.float32)
             ratios.append(np.stack([valid_w / np.float32(w), valid_h / np.float32(h)], -1))
         empty = len(mlvl_shapes) == 0
+        flat = None if empty else np.concatenate(masks, 1)
         return dict(
-            M=torch.as_tensor(np.stack([c[0] for c in comp]), dtype=dt, device=dev),
-            ab=torch.as_tensor(np.asarray([c[1:] for c in comp]), dtype=dt, device=dev),
-            hw=torch.as_tensor(hw, device=dev),
-            mask_flatten=None if empty else torch.as_tensor(np.concatenate(masks, 1), device=dev),
+            M=np.stack([c[0] for c in comp]).astype(fdt),
+            ab=np.asarray([c[1:] for c in comp]).astype(fdt),
+            hw=hw,
+            mask_flatten=None if empty else np.ascontiguousarray(flat),
             # (converted to float in numpy: torch's bool -> float32 copy of this 0.6 M-element array costs
             # 60-75 ms on the host, numpy's 0.5 ms - it is on the per-batch path of replay.load)
-            keep4=None if empty else torch.as_tensor(np.stack(
-                [(~np.concatenate(masks, 1)).astype(np.float32)] +
-                [np.zeros(np.concatenate(masks, 1).shape, np.float32)] * 3, -1)).to(device=dev, dtype=dt),
-            valid_ratios=None if empty else torch.as_tensor(np.stack(ratios, 1), dtype=dt, device=dev),
-            spatial_shapes=torch.as_tensor(list(mlvl_shapes), dtype=torch.long, device=dev),
-            level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
-                                              dtype=torch.long, device=dev))
+            keep4=None if empty else np.stack([(~flat).astype(fdt)] + [np.zeros(flat.shape, fdt)] * 3, -1),
+            valid_ratios=None if empty else np.stack(ratios, 1).astype(fdt),
+            spatial_shapes=np.asarray(list(mlvl_shapes), dtype=np.int64).reshape(-1, 2),
+            level_start_index=np.asarray([0] + list(np.cumsum(sizes)[:-1]), dtype=np.int64))
+
+    def _build_meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
+        return {k: None if v is None else torch.as_tensor(v, device=dev)
+                for k, v in self._build_meta_arrays(img_metas, mlvl_shapes, dt).items()}
 
     # ---- :524-547 ------------------------------------------------------------
     def get_reference_points(self, seeds_3d_batch, img_metas, mlvl_shapes=()):
@@ -510,7 +534,7 @@ class DeMFVoteHead(nn.Module):
     _PAD_CACHE = {}
 
     @staticmethod
-    def pad_gt(gt_bboxes_3d, gt_labels_3d, device, with_slot_labels=False):
+    def pad_gt(gt_bboxes_3d, gt_labels_3d, device, with_slot_labels=False, G=None):
         """list[DepthBoxes|(n,7) tensor], list[(n,) long] -> padded (B,G,7), (B,G), valid (B,G).
         An empty scene gets the reference's single all-zero fake box (:766-773).
         One concatenation + one row gather per tensor: the rows are [0-row | all boxes] and
@@ -519,9 +543,12 @@ class DeMFVoteHead(nn.Module):
         padding slots (the form ``ops.gt_prep`` reads ``valid`` from) instead of 0."""
         boxes = [b.tensor if isinstance(b, DepthBoxes) else b for b in gt_bboxes_3d]
         counts = tuple(int(b.shape[0]) for b in boxes)
-        G = max(1, max(counts))
+        if G is None:
+            G = max(1, max(counts))                      # (a captured step passes its static slot count)
+        elif max(counts) > G:
+            raise ValueError(f"a scene has {max(counts)} ground-truth boxes, the padded form holds {G}")
         B = len(boxes)
-        key = (counts, str(device))
+        key = (counts, G, str(device))
         cache = DeMFVoteHead._PAD_CACHE
         if key not in cache:
             if len(cache) > 64:
