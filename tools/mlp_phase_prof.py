@@ -20,17 +20,19 @@ def layer(R, K, N):
               torch.zeros(N, device="cuda", requires_grad=True), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")),
              ((torch.randn(N, N, generator=g) / N ** 0.5).cuda().requires_grad_(), torch.ones(N, device="cuda", requires_grad=True),
               torch.zeros(N, device="cuda", requires_grad=True), torch.zeros(N, device="cuda"), torch.ones(N, device="cuda"))])
-for R, K, N in [(128, 256, 256), (8192, 256, 256), (8192, 512, 256), (262144, 128, 128)]:
+CASES = [(128, 256, 256, 1), (8192, 256, 256, 1), (8192, 512, 256, 1), (262144, 128, 128, 1),
+         (262144, 128, 256, 32)]          # last: SA2-like pooled stack (the second launch is the pooled GEMM)
+for R, K, N, ns in CASES:
     x, ls = layer(R, K, N)
     x.requires_grad_()
     for _ in range(2):
-        out = ops.shared_mlp_pool(x, 1, ls, True)
+        out = ops.shared_mlp_pool(x, ns, ls, True)
     torch.cuda.synchronize(); read()
-    out = ops.shared_mlp_pool(x, 1, ls, True)
+    out = ops.shared_mlp_pool(x, ns, ls, True)
     torch.cuda.synchronize(); f = read()
     out.backward(torch.randn_like(out))
     torch.cuda.synchronize(); b = read()
     for tag, v in (("forward (2 launches)", f), ("backward dx launches", b)):
         tot = sum(v[:6]) or 1
-        print(f"R={R} K={K} N={N} {tag}: launches {v[15]}, cycles of block 0: {tot}  " +
+        print(f"R={R} K={K} N={N} ns={ns} {tag}: launches {v[15]}, cycles of block 0: {tot}  " +
               "  ".join(f"{n} {100 * c / tot:.0f}%" for n, c in zip(NAMES, v[:6])), flush=True)
