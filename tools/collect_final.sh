@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the artefacts of tools/_run_final.sh (gpurun_out/r03_final_*) into profiles/ under the round's names
+# copies the artefacts of tools/final_run.sh (gpurun_out/r03_final_*) into profiles/ under the round's names
 tag=${1:-r03_final}
 for m in f32 bf16; do
   cp gpurun_out/${tag}_$m/kernel_stats.csv profiles/${tag}_${m}_kernel_stats.csv
