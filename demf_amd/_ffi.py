@@ -48,6 +48,7 @@ SIGNATURES = {
     "demf_aligned_nms": [_c_int, _c_int, _c_float] + [_ptr] * 6,
     "demf_proposal_targets": [_c_int] * 4 + [_c_float] * 3 + [_ptr] * 18,
     "demf_gt_prep": [_c_int] * 3 + [_ptr] * 10,
+    "demf_pad_gt": [_c_int] * 2 + [_ptr] * 8,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,

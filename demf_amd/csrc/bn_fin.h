@@ -44,8 +44,17 @@ __device__ __forceinline__ void bn_bwd_vectors_channel(int c, int N, double coun
 
 // Call from ONE thread of every workgroup, after the workgroup's own atomics have been issued and a
 // __syncthreads(): returns 1 in exactly one workgroup, the last to arrive, and leaves the counters zeroed
-// for the next launch that is handed this set.  (No fence: only atomics touch the sums and the counters.)
+// for the next launch that is handed this set.
+// Ordering: the sums and the counters are touched by device-scope atomics ONLY (performed at the
+// coherence point, read back with atomicExch), so no cache write-back is needed - a release fence at
+// agent scope writes the XCD's L2 back once per workgroup and was measured at +14 us per launch.  What IS
+// needed is that every sum atomic of this workgroup has been ACKNOWLEDGED before the ticket is taken:
+// the other waves drained their vector-memory counters in front of the __syncthreads() the caller runs
+// first (HIP's barrier waits for vmcnt(0)), and this thread drains its own here explicitly instead of
+// relying on that code generation.
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ int last_workgroup(int* __restrict__ set, int total, int lin) {
+  drain_vmem();
   const int ngroups = total < BV_GROUPS ? total : BV_GROUPS;
   const int g = lin % BV_GROUPS;
   const int members = total / BV_GROUPS + (g < total % BV_GROUPS ? 1 : 0);

@@ -974,8 +974,23 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
   const bool bf = compute_bf16() && !(p.flags & GEMM_FP32);
   // few 64 x 64 tiles (or a narrow output): 32 x 32 tiles with the K step split over the waves
   const bool small = gemm_is_small(p);
-  DEMF_REQUIRE(p.asum == nullptr || (small && modeA == 2 && p.A2 == nullptr),
-               "gemm: asum needs the reduction-strided A form (no A2) on the small-tile path");
+  if (p.asum != nullptr && !(small && modeA == 2 && p.A2 == nullptr)) {
+    // The in-kernel row sums ride on the small-tile, reduction-strided staging only.  Any other launch
+    // shape (more than DEMF_GEMM_SMALL_TILES tiles: a wider FFN, a long ops.linear; a lowered A/B knob)
+    // runs the product without them and takes the sums - the column sums of the (K x M) row-major
+    // matrix behind A - as demf_colsum_f32 launches, so a caller never has to mirror this predicate.
+    DEMF_REQUIRE(p.sam == 1 && p.A2 == nullptr,
+                 "gemm: asum needs A contiguous along M (sam == 1) and no A2");
+    float* asum = p.asum;
+    p.asum = nullptr;
+    if (int e = demf_gemm_f32(&p, stream)) return e;
+    for (int z = 0; z < p.batch; ++z) {
+      const int zo = z / p.zdiv, zi = z - zo * p.zdiv;
+      const float* a = p.A + (size_t)zo * p.sab + (size_t)zi * p.sab2;
+      if (int e = demf_colsum_f32(p.K, p.M, (int)p.sak, a, asum + (size_t)z * p.M, stream)) return e;
+    }
+    return DEMF_OK;
+  }
   if (small) {
     grid = dim3(cdiv(p.N, 32), cdiv(p.M, 32), p.batch * p.splitk);
 #define GEMM_LAUNCH_S(MA_, MB_)                                                                        \

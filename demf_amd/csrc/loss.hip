@@ -434,6 +434,39 @@ __global__ void gt_prep_k(int n, int nbins, const float* __restrict__ gt,
   center[(size_t)i * 3 + 2] = t[2] + t[5] * 0.5f;
 }
 
+// Per-scene ground-truth lists -> static-shape (B, G, 7) boxes + (B, G) labels (-1 on padding slots; an
+// empty scene gets the reference's single all-zero fake box with label 0,
+// class_agnostic_vote_head.py:766-773).  The per-scene device pointers and box counts travel BY VALUE in
+// the kernel arguments (B <= 32), so padding a new batch costs one launch and no host -> device copy: a
+// pageable upload on the step's stream makes the host wait for the step in flight.
+constexpr int PAD_GT_MAX_B = 32;
+struct PadGtArgs {
+  const float* boxes[PAD_GT_MAX_B];          // (count_b, box_dim) rows, box_dim >= 7
+  const long long* labels[PAD_GT_MAX_B];     // (count_b)
+  int count[PAD_GT_MAX_B];
+  int box_dim[PAD_GT_MAX_B];
+  int B, G;
+};
+__global__ void pad_gt_k(PadGtArgs a, float* __restrict__ gt, long long* __restrict__ lab,
+                         unsigned char* __restrict__ valid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.B * a.G) return;
+  const int b = i / a.G, g = i - b * a.G;
+  const int n = a.count[b];
+  float* o = gt + (size_t)i * 7;
+  if (g < n) {
+    const float* t = a.boxes[b] + (size_t)g * a.box_dim[b];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o[c] = t[c];
+    lab[i] = a.labels[b][g];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o[c] = 0.f;
+    lab[i] = (n == 0 && g == 0) ? 0 : -1;
+  }
+  if (valid != nullptr) valid[i] = g < (n > 1 ? n : 1) ? 1 : 0;
+}
+
 // objectness_weights = masks / (sum(masks) + 1e-6); box_loss_weights = obj / (sum(obj) + 1e-6)
 // (class_agnostic_vote_head.py:797-816), R <= a few thousand proposals: one workgroup.
 __global__ __launch_bounds__(1024) void target_weights_k(int R, const float* __restrict__ obj_mask,
@@ -604,6 +637,28 @@ extern "C" int demf_gt_prep(int B, int G, int num_dir_bins, const float* gt_boxe
                      (long long*)gt_dir_class, gt_dir_res, valid, (long long*)labels_clamped,
                      gravity_center);
   return check_launch("gt_prep");
+}
+
+extern "C" int demf_pad_gt(int B, int G, const int* counts, const int* box_dims, const void* const* boxes,
+                           const void* const* labels, float* gt_padded, int64_t* labels_padded,
+                           unsigned char* valid, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && B <= PAD_GT_MAX_B && G >= 1, "pad_gt: bad sizes B=%d (max %d) G=%d", B, PAD_GT_MAX_B, G);
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(counts && box_dims && boxes && labels && gt_padded && labels_padded, "pad_gt: null pointer");
+  PadGtArgs a{};
+  a.B = B; a.G = G;
+  for (int b = 0; b < B; ++b) {
+    DEMF_REQUIRE(counts[b] >= 0 && counts[b] <= G, "pad_gt: scene %d has %d boxes, the padded form holds %d", b, counts[b], G);
+    DEMF_REQUIRE(counts[b] == 0 || (boxes[b] && labels[b] && box_dims[b] >= 7), "pad_gt: scene %d: null list / box_dim < 7", b);
+    a.boxes[b] = (const float*)boxes[b];
+    a.labels[b] = (const long long*)labels[b];
+    a.count[b] = counts[b];
+    a.box_dim[b] = box_dims[b];
+  }
+  const int n = B * G;
+  hipLaunchKernelGGL(pad_gt_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, gt_padded,
+                     (long long*)labels_padded, valid);
+  return check_launch("pad_gt");
 }
 
 extern "C" int demf_target_weights(int R, const float* objectness_masks,

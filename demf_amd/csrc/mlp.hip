@@ -987,6 +987,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
         int* t = p.fin.ticket + FIN_OFF;
         int last = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own sum atomics acknowledged first (csrc/bn_fin.h)
         if (atomicAdd(t + 1 + g, 1) == members - 1) {
           atomicExch(t + 1 + g, 0);
           if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }
@@ -1286,6 +1287,7 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
       const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
       int* t = p.fin.ticket + FIN_OFF;
       int last = 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own sum atomics acknowledged first (csrc/bn_fin.h)
       if (atomicAdd(t + 1 + g, 1) == members - 1) {
         atomicExch(t + 1 + g, 0);
         if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }

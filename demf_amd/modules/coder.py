@@ -8,15 +8,57 @@ import torch
 class _Preds(dict):
     """split_pred's result dict.  The reference also stores ``dir_res`` (coder.py:233); nothing on the
     training path reads it (the losses take ``dir_res_norm``), so it is computed when first asked for
-    (decode, tests) instead of costing a launch + an autograd node per prediction head and step."""
+    (decode, tests) instead of costing a launch + an autograd node per prediction head and step.
+    Every read access of the dict contract sees the key - ``d["dir_res"]``, ``.get``, ``in``, iteration,
+    ``keys / items / values``, ``dict(d)`` / ``{**d}`` and ``.copy()`` (which also keeps the scale)."""
     dir_res_scale = None
 
+    def _lazy(self):
+        if self.dir_res_scale is not None and not dict.__contains__(self, "dir_res") \
+                and dict.__contains__(self, "dir_res_norm"):
+            dict.__setitem__(self, "dir_res", dict.__getitem__(self, "dir_res_norm") * self.dir_res_scale)
+
     def __missing__(self, key):
-        if key == "dir_res" and self.dir_res_scale is not None:
-            v = self["dir_res_norm"] * self.dir_res_scale
-            self[key] = v
-            return v
+        if key == "dir_res":
+            self._lazy()
+            if dict.__contains__(self, key):
+                return dict.__getitem__(self, key)
         raise KeyError(key)
+
+    def get(self, key, default=None):
+        if key == "dir_res":
+            self._lazy()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        if key == "dir_res":
+            self._lazy()
+        return dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._lazy()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._lazy()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._lazy()
+        return dict.keys(self)
+
+    def items(self):
+        self._lazy()
+        return dict.items(self)
+
+    def values(self):
+        self._lazy()
+        return dict.values(self)
+
+    def copy(self):
+        out = _Preds(dict.items(self))
+        out.dir_res_scale = self.dir_res_scale
+        return out
 
 
 class DeMFClassAgnosticBBoxCoder:

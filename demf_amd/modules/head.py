@@ -384,7 +384,9 @@ class DeMFVoteHead(nn.Module):
             # not depend on the decode layer, so it is evaluated once ((v+v)/2 == v exactly).
             # "_total" (sum of all eight) is what a training loop should differentiate: it avoids
             # the per-entry select/stack nodes of the dict.
-            vecs, vote = zip(*[self._loss_fused({**bbox_preds, **d}, targets, d["_rows"],
+            # (the fused kernels read the raw rows + the vote / seed tensors of the outer dict only: no
+            # merged dict, which would materialise the lazy "dir_res" of every decode result)
+            vecs, vote = zip(*[self._loss_fused(bbox_preds, targets, d["_rows"],
                                                  with_vote=(i == 0))
                                for i, d in enumerate(decode_res_all)])
             mean7 = vecs[0]
@@ -548,6 +550,14 @@ class DeMFVoteHead(nn.Module):
         elif max(counts) > G:
             raise ValueError(f"a scene has {max(counts)} ground-truth boxes, the padded form holds {G}")
         B = len(boxes)
+        if B <= 32 and torch.device(device).type == "cuda" and all(b.is_cuda for b in boxes) \
+                and all(l.is_cuda for l in gt_labels_3d):
+            # device lists: ONE launch, pointers + counts by value in the kernel arguments - no index
+            # tables, no host -> device copy whatever the per-scene counts are (ops.pad_gt_lists)
+            gt, slot, valid = ops.pad_gt_lists(boxes, gt_labels_3d, G)
+            if with_slot_labels:
+                return gt, slot, valid
+            return gt, slot.clamp_(min=0), valid
         key = (counts, G, str(device))
         cache = DeMFVoteHead._PAD_CACHE
         if key not in cache:

@@ -1376,6 +1376,33 @@ def gt_prep(gt, labels_padded, num_dir_bins):
     return out
 
 
+def pad_gt_lists(boxes, labels, G):
+    """list of (n_b, >=7) fp32 device box rows, list of (n_b,) int64 device labels -> (gt (B,G,7),
+    labels (B,G) int64 with -1 on padding slots, valid (B,G) bool): demf_pad_gt - one launch, the per-
+    scene pointers and counts travel by value, nothing is uploaded.  An empty scene gets the reference's
+    all-zero fake box with label 0 (class_agnostic_vote_head.py:766-773).  B <= 32."""
+    B = len(boxes)
+    dev = boxes[0].device
+    keep = []
+    for i in range(B):
+        b, l = boxes[i], labels[i]
+        if b.dtype != torch.float32 or not b.is_contiguous():
+            b = b.float().contiguous()
+        if l.dtype != torch.int64 or not l.is_contiguous():
+            l = l.long().contiguous()
+        keep.append((b, l))
+    counts = (ctypes.c_int * B)(*[int(b.shape[0]) for b, _ in keep])
+    dims = (ctypes.c_int * B)(*[int(b.shape[1]) if b.dim() == 2 else 7 for b, _ in keep])
+    bp = (ctypes.c_void_p * B)(*[b.data_ptr() if b.numel() else None for b, _ in keep])
+    lp = (ctypes.c_void_p * B)(*[l.data_ptr() if l.numel() else None for _, l in keep])
+    gt = torch.empty((B, G, 7), dtype=torch.float32, device=dev)
+    lab = torch.empty((B, G), dtype=torch.int64, device=dev)
+    valid = torch.empty((B, G), dtype=torch.uint8, device=dev)
+    _ffi.call("demf_pad_gt", B, int(G), ctypes.addressof(counts), ctypes.addressof(dims), ctypes.addressof(bp),
+              ctypes.addressof(lp), _p(gt), _p(lab), _p(valid), _stream())
+    return gt, lab, valid.view(torch.bool)
+
+
 def target_weights(objectness_masks, objectness_targets):
     """-> (objectness_weights, box_loss_weights): each tensor divided by (its sum + 1e-6)
     (class_agnostic_vote_head.py:797-816), one launch."""

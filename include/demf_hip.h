@@ -540,6 +540,17 @@ int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, floa
                           float* distance_targets, int64_t* objectness_targets,
                           float* objectness_masks, demf_stream_t stream);
 
+/* Per-scene ground-truth lists -> the static-shape padded form the target kernels read: gt_padded
+ * (B,G,7) fp32, labels_padded (B,G) int64 with -1 on padding slots, valid (B,G) u8 or NULL.  An empty
+ * scene gets the reference's single all-zero fake box with label 0
+ * (demf/modeling/heads/class_agnostic_vote_head.py:766-773).  counts / box_dims / boxes / labels are
+ * HOST arrays of length B (<= 32): scene b's device pointers to its (counts[b], box_dims[b] >= 7) fp32
+ * box rows and (counts[b]) int64 labels; they travel by value in the kernel arguments, so the call
+ * issues one launch and no host -> device copy.                                                      */
+int demf_pad_gt(int B, int G, const int* counts, const int* box_dims, const void* const* boxes,
+                const void* const* labels, float* gt_padded, int64_t* labels_padded,
+                unsigned char* valid, demf_stream_t stream);
+
 /* Everything the two target kernels need that depends on the padded ground truth alone (label -1 =
  * padding slot), one launch: cos/sin(-yaw), PartialBinBasedBBoxCoder.angle2class(yaw) in torch's
  * fp32 remainder / floor-divide semantics (class_agnostic_vote_head.py:877-883 via

@@ -107,7 +107,7 @@ def test_pad_gt_slots_and_lazy_dir_res():
     """pad_gt: per-scene GT lists -> (B,G,7) / (B,G) by one concatenation + one row gather each; an empty
     scene gets the reference's all-zero fake box with label 0 (class_agnostic_vote_head.py:766-773), padding
     slots are zero boxes with label 0 (or -1 in the slot form the device target kernels read).  split_pred:
-    `dir_res` (coder.py:233) is computed on first access only."""
+    `dir_res` (coder.py:233) is computed on first access only, whichever dict access that is."""
     from demf_amd.modules.head import DeMFVoteHead
     from demf_amd.modules.coder import DeMFClassAgnosticBBoxCoder
     g = torch.Generator().manual_seed(0)
@@ -126,8 +126,17 @@ def test_pad_gt_slots_and_lazy_dir_res():
     coder = DeMFClassAgnosticBBoxCoder(num_dir_bins=12)
     cls, reg = torch.randn(2, 12, 5, generator=g), torch.randn(2, 30, 5, generator=g)
     res = coder.split_pred(cls, reg, torch.zeros(2, 5, 3))
-    assert "dir_res" not in res and "dir_res" not in dict(res)
+    # not materialised by split_pred itself (no launch on the training path) ...
+    assert not dict.__contains__(res, "dir_res")
     want = res["dir_res_norm"] * (np.pi / 12)
+    # ... but every read of the dict contract sees it, as the reference's split_pred result (coder.py:233)
+    res2 = coder.split_pred(cls, reg, torch.zeros(2, 5, 3))
+    assert "dir_res" in res2 and torch.equal(res2.get("dir_res"), want)
+    for view in (dict(coder.split_pred(cls, reg, torch.zeros(2, 5, 3))),
+                 {**coder.split_pred(cls, reg, torch.zeros(2, 5, 3))},
+                 coder.split_pred(cls, reg, torch.zeros(2, 5, 3)).copy()):
+        assert torch.equal(view["dir_res"], want)
+    assert "dir_res" in list(coder.split_pred(cls, reg, torch.zeros(2, 5, 3)))
     assert torch.equal(res["dir_res"], want) and "dir_res" in res
     with pytest.raises(KeyError):
         res["no_such_key"]
