@@ -33,10 +33,13 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
-# the kernel instantiation behind demf_mlp_gemm_fwd_pool at SA1 (name as rocprofv3 prints it)
+# The kernel the headline `roofline` object prices: SA1's last shared-MLP layer (R = B*2048*64 grouped
+# rows, 64 -> 128 channels, BN statistics + max-pool in the epilogue).  `prefix`: how rocprofv3 prints the
+# instantiation - matched BY PREFIX against the committed PMC / stats files (trailing template
+# arguments come and go with the kernel's options).
 DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0, true>",
-                   "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2>",      # weight-resident forward (csrc/mlp.hip)
-                   "bf16": "mlp_fwd_res_kernel<4, 2, true, 1>"}
+                   "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2",       # weight-resident forward (csrc/mlp.hip)
+                   "bf16": "mlp_fwd_res_kernel<4, 2, true, 1"}
 DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
     "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
 MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
@@ -45,43 +48,56 @@ MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
                       "tests/test_gpu_split.py)",
              "bf16": "operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
 MFMA_PATH["f32"] = MFMA_PATH["f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
-# FPS floor per dependent round = the SIMD's VALU issue for the bit-exact distance update: 4 waves per
-# SIMD x ~105 packed instructions x 4 cycles (round 2's 900 assumed a one-barrier
-# round that was measured not to pay)
-FPS_FLOOR_CYCLES = 1700.0
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
 ALGO_BYTES_PER_SCENE = 190e6
 ALGO_FLOP_PER_SCENE = 46e9
 
 
-def pmc_per_launch(kernel_substr, which="max"):
-    """HBM bytes per launch of the kernel whose name contains ``kernel_substr``, from the newest
-    committed PMC summaries profiles/r*_pmc_{FETCH,WRITE}_SIZE.csv (separate --pmc passes of this
-    same command, summarised by tools/pmc_summary.py: columns kernel, calls, mean KiB, max KiB).
+def newest_profile(pattern):
+    """Newest committed profiles/<pattern> (round tags sort lexicographically: r04_b > r04_a > r03_final)."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return hits[-1] if hits else None
+
+
+def pmc_per_launch(kernel_prefix, which="max", required=False):
+    """HBM bytes per launch of the kernel whose name STARTS WITH ``kernel_prefix`` (after the
+    ``void demf::`` decoration), from the NEWEST committed PMC summaries
+    profiles/r*_pmc_{FETCH,WRITE}_SIZE.csv (separate --pmc passes of this same command, summarised by
+    tools/pmc_summary.py: columns kernel, calls, mean KiB, max KiB).
     FETCH_SIZE is doubled: gfx950 counts 64 B per 128-B request for wide coalesced reads
     (MI355X_MICROARCH.md, HBM section; calibrated on the SA1 dx GEMM).
     ``which``: 'max' = the largest launch of that instantiation (the SA1-sized one), 'mean'.
+    Only the newest pair of files counts: an older round's row for a kernel that has since changed is
+    not evidence.  ``required``: raise instead of returning (None, source) when that pair has no row.
     -> (bytes | None, source file | None)"""
     import csv
-    import glob
-    pdir = os.path.join(ROOT, "profiles")
-    fetch = sorted(glob.glob(os.path.join(pdir, "r*_pmc_FETCH_SIZE.csv")))
-    for f in reversed(fetch):
-        w = f.replace("FETCH_SIZE", "WRITE_SIZE")
-        if not os.path.exists(w):
-            continue
-        vals = []
-        for path in (f, w):
-            hit = None
-            with open(path) as fh:
-                for row in csv.reader(fh):
-                    if len(row) >= 4 and kernel_substr in row[0]:
-                        hit = float(row[3] if which == "max" else row[2])
-                        break
-            vals.append(hit)
-        if None not in vals:
-            return (2.0 * vals[0] + vals[1]) * 1024.0, os.path.relpath(f, ROOT)
-    return None, None
+    f = newest_profile("r*_pmc_FETCH_SIZE.csv")
+    if f is None or not os.path.exists(f.replace("FETCH_SIZE", "WRITE_SIZE")):
+        if required:
+            raise RuntimeError("no committed PMC passes under profiles/")
+        return None, None
+    vals = []
+    for path in (f, f.replace("FETCH_SIZE", "WRITE_SIZE")):
+        hit = None
+        with open(path) as fh:
+            for row in csv.reader(fh):
+                if len(row) < 4:
+                    continue
+                name = row[0]
+                for deco in ("void ", "demf::"):
+                    if name.startswith(deco):
+                        name = name[len(deco):]
+                if name.startswith(kernel_prefix):
+                    hit = float(row[3] if which == "max" else row[2])
+                    break
+        vals.append(hit)
+    src = os.path.relpath(f, ROOT)
+    if None in vals:
+        if required:
+            raise RuntimeError("%s has no row for kernel prefix %r" % (src, kernel_prefix))
+        return None, src
+    return (2.0 * vals[0] + vals[1]) * 1024.0, src
 
 
 def pmc_per_step():
@@ -91,14 +107,25 @@ def pmc_per_step():
     return pmc_per_launch("__TOTAL_PER_STEP__", which="mean")
 
 
-def make_batch(B, seed, device):
+def make_batch(B, seed, device, cloud="uniform", gt_counts=None):
     raw = synthetic.make_scene_batch(B, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, 256, seed=seed,
-                                     n_gt=8, img_shape=IMG_SHAPE[:2], scale_factor=1.5094)
+                                     n_gt=8, img_shape=IMG_SHAPE[:2], scale_factor=1.5094, cloud=cloud,
+                                     gt_counts=gt_counts)
     return dict(points=torch.from_numpy(raw["points"]).to(device),
                 img_features=[torch.from_numpy(f).to(device) for f in raw["img_features"]],
                 img_metas=raw["img_metas"],
                 gt_bboxes_3d=[torch.from_numpy(b).to(device) for b in raw["gt_boxes"]],
                 gt_labels_3d=[torch.from_numpy(l).to(device) for l in raw["gt_labels"]]), raw
+
+
+def top_kernels():
+    """The newest committed per-kernel digest (tools/top_kernels.py, written by tools/prof.sh from a
+    rocprofv3 kernel trace + the PMC passes of this same command) -> (dict | None, source | None)."""
+    f = newest_profile("r*_top_kernels.json")
+    if f is None:
+        return None, None
+    with open(f) as fh:
+        return json.load(fh), os.path.relpath(f, ROOT)
 
 
 class KernelTimer:
@@ -217,12 +244,46 @@ def cpu_baseline(seconds_budget=20.0):
                                              min_ms=1e3 * min(tc), median_ms=1e3 * float(np.median(tc)))})
 
 
+def sa_path_ms(model, device, B, seed=0):
+    """BASELINE configs[1]: the PointNet++ SA path alone (FPS / ball query / grouping + the shared MLPs
+    of the 4 SA + 2 FP levels), fp32, pre-pass NOT pipelined (every pass pays its own FPS chain):
+    -> (forward ms, forward+backward ms, coordinate pre-pass alone ms)."""
+    pts, _ = make_batch(B, seed, device)
+    pts = pts["points"]
+    bb = model.pts_backbone
+
+    def fwd():
+        with torch.no_grad():
+            return bb(pts)
+
+    def fwdbwd():
+        out = bb(pts)
+        torch.autograd.grad(out["fp_features"][-1].sum(), [p for p in bb.parameters() if p.requires_grad])
+
+    def geo():
+        return bb.index_geometry(pts)
+
+    def timed(f, n=10):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3
+    return timed(fwd), timed(fwdbwd), timed(geo)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU (BASELINE configs[2])")
+    ap.add_argument("--cloud", choices=("uniform", "clustered"), default="uniform",
+                    help="synthetic cloud of the headline loop (BASELINE.md section 3: uniform volume / 20 "
+                         "Gaussian blobs); the other one is reported under `secondary`")
     ap.add_argument("--msda-points", type=int, default=2,
                     help="sampling points per level of the fusion attention: 2 = reference config "
                          "(demf_votenet.py:83), 4 = BASELINE.json's wording; secondary figure only")
@@ -236,6 +297,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--resident", action="store_true",
+                    help="time the replay of ONE resident batch (rounds 1-3's headline) instead of the "
+                         "training loop that loads a different batch every step")
     ap.add_argument("--stream-priority", action="store_true",
                     help="run the step graph on a high-priority HIP stream (experiment)")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -244,7 +308,7 @@ def main():
                     help="pin the FPS pre-pass to its own CUs (hipExtStreamCreateWithCUMask); measured: "
                          "no effect under hipGraph replay, off by default")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary legs (bf16 / P=4 step times, the replay.load() input-path leg)")
+                    help="skip the secondary legs (resident / bf16 / P=4 / clustered / B=16 step times, SA path)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -278,10 +342,20 @@ def main():
         cfg = dataclasses.replace(cfg, head=dataclasses.replace(cfg.head, num_points=args.msda_points))
     model = DeMFHotPath(cfg).to(device).train()
     trainer = engine.Trainer(model)
-    batch, _ = make_batch(args.batch, seed=1000 + rank, device=device)   # weak scaling: B per GPU
+    # The training loop's data: NB distinct batches per rank (weak scaling: B scenes per GPU, distinct
+    # seeds per rank), every one with its own per-scene GT counts - a real loader never repeats a
+    # count signature, and the per-batch input path (target padding, meta refresh, static-buffer
+    # copies, the next cloud's pre-pass) is part of the step a training loop pays.  All of it is resident
+    # in HBM before the timed region.
+    NB, MAX_GT = 4, 8
+    cnt_rng = np.random.default_rng(4242 + rank)
+    batches = [make_batch(args.batch, seed=1000 + rank + 7919 * i, device=device, cloud=args.cloud,
+                          gt_counts=None if i == 0 else cnt_rng.integers(0, MAX_GT + 1, size=args.batch))[0]
+               for i in range(NB)]
+    batch = batches[0]
 
     fps_timer = KernelTimer(ops, "furthest_point_sample")
-    # the largest kernel ON the critical path (the FPS chain runs underneath the step on a side
+    # the largest FORWARD kernel on the critical path (the FPS chain runs underneath the step on a side
     # stream): SA1's last shared-MLP layer, 64 -> 128 channels over B*2048*64 grouped rows, with
     # BN statistics and the max-pool fused into its epilogue
     from demf_amd import _ffi
@@ -303,8 +377,25 @@ def main():
         trainer.side_stream = torch.cuda.Stream(priority=0)
         main_s.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main_s)
-    step = (lambda: trainer.step(batch)) if args.no_graph else \
-        trainer.capture(batch, prefetch_geometry=not args.no_prefetch)
+    replay = None if args.no_graph else \
+        trainer.capture(batch, prefetch_geometry=not args.no_prefetch, max_gt=MAX_GT)
+    k = [0]
+
+    def step_resident():
+        return trainer.step(batch) if replay is None else replay()
+
+    def step_loop():
+        """One step of the training loop: batch k is loaded into the captured step's static buffers
+        (its pre-pass was launched underneath step k-1), the step runs, batch k+1's cloud is handed to
+        the pipelined pre-pass."""
+        k[0] += 1
+        cur, nxt = batches[k[0] % NB], batches[(k[0] + 1) % NB]
+        if replay is None:
+            return trainer.step(cur)
+        replay.load(cur)
+        return replay(next_points=nxt["points"])
+
+    step = step_resident if args.resident else step_loop
     for _ in range(args.warmup):
         step()
     sync()
@@ -325,6 +416,17 @@ def main():
     if not bool(torch.isfinite(trainer.flat.flat).all()) or \
             not all(bool(torch.isfinite(p).all()) for p in model.parameters()):
         raise RuntimeError("non-finite gradients/parameters after the timed steps")
+    # the collective's own time (HIP events around the all-reduce of the flat 8.76 MB buffer)
+    allreduce_us = None
+    if world > 1:
+        trainer.allreduce_events = []
+        for _ in range(min(args.steps, 10)):
+            step()
+        torch.cuda.synchronize()
+        ev = trainer.allreduce_events
+        trainer.allreduce_events = None
+        if ev:
+            allreduce_us = 1e3 * float(np.mean([a.elapsed_time(b) for a, b in ev]))
     # dominant-kernel duration: HIP events around the same launches, same inputs, same stream,
     # in an eager pass right after the timed region (a graph replay cannot host per-kernel
     # events); profiles/ holds the rocprofv3 figure for the same kernel inside the replays
@@ -346,24 +448,19 @@ def main():
 
     secondary = {}
     if world == 1 and not args.no_secondary and not args.no_graph:
-        # (a) the per-step input path: two DISTINCT batches cycled through replay.load() (target
-        # padding's host round trip, meta refresh, the H2D of the static buffers) with the next
-        # cloud handed to the pipelined pre-pass - what a real training loop pays per step
-        batch_b, _ = make_batch(args.batch, seed=2000 + rank, device=device)
-        pair = [batch, batch_b]
-        k = [0]
-
-        def step_with_load():
-            k[0] += 1
-            cur, nxt = pair[k[0] & 1], pair[(k[0] + 1) & 1]
-            step.load(cur)
-            step(next_points=nxt["points"])
-        secondary["ms_per_step_with_load"] = time_steps(step_with_load, args.steps)
-        # (b) the other BASELINE configurations on the same process / box: configs[3] per GPU (bf16
-        # compute mode) and BASELINE's "8 heads x 4 points" wording (P = 4; the reference config is 2)
+        # (a) the other way of running the same captured step: ONE resident batch replayed (the headline
+        # of rounds 1-3) if `value` is the loading loop, and vice versa
+        if args.resident:
+            secondary["ms_per_step_with_load"] = time_steps(step_loop, args.steps)
+        else:
+            secondary["ms_per_step_resident"] = time_steps(step_resident, args.steps)
+        # (b) the other BASELINE configurations on the same process / box, resident replay each: configs[3]
+        # per GPU (bf16 compute mode), BASELINE's "8 heads x 4 points" wording (P = 4; the reference config
+        # is 2), the other cloud distribution and the reference's own per-GPU batch
+        # (samples_per_gpu=16, configs/_base_/datasets/sunrgbd-3d-10class.py:75)
         import dataclasses
 
-        def other(dtype, points):
+        def other(dtype, points, cloud=args.cloud, B=args.batch):
             ops.set_compute_dtype(dtype)
             try:
                 c2 = cfg if points == cfg.head.num_points else \
@@ -371,7 +468,9 @@ def main():
                 torch.manual_seed(0)
                 m2 = DeMFHotPath(c2).to(device).train()
                 t2 = engine.Trainer(m2)
-                r2 = t2.capture(batch, prefetch_geometry=not args.no_prefetch)
+                b2 = batch if (cloud == args.cloud and B == args.batch) else \
+                    make_batch(B, seed=3000 + rank, device=device, cloud=cloud)[0]
+                r2 = t2.capture(b2, prefetch_geometry=not args.no_prefetch)
                 ms = time_steps(r2, args.steps)
                 ok = bool(torch.isfinite(t2.flat.flat).all())
                 return ms if ok else float("nan")
@@ -381,14 +480,37 @@ def main():
             secondary["bf16_ms_per_step"] = other("bf16", args.msda_points)
         if args.msda_points != 4:
             secondary["p4_ms_per_step"] = other(args.dtype, 4)
+        oc = "clustered" if args.cloud == "uniform" else "uniform"
+        secondary[oc + "_ms_per_step"] = other(args.dtype, args.msda_points, cloud=oc)
+        if args.batch != 16:
+            secondary["b16_ms_per_step"] = other(args.dtype, args.msda_points, B=16)
+        # (c) BASELINE configs[1]: the SA path alone (forward / forward+backward / the index pre-pass)
+        for B1 in (1, 8):
+            f, fb, g = sa_path_ms(model, device, B1)
+            secondary["sa_path_b%d_fwd_ms" % B1] = f
+            secondary["sa_path_b%d_fwdbwd_ms" % B1] = fb
+            secondary["sa_path_b%d_prepass_ms" % B1] = g
+    rank_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # what makes the ranks different replicas of one job: their data seeds and dropout streams
+        from demf_amd import fused
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, dict(rank=rank, batch_seeds=[1000 + rank + 7919 * i for i in range(NB)],
+                                               dropout_seed=fused.get_rng_state(device)[0]))
 
     if rank == 0:
         scenes = args.batch * world * args.steps
         ms_step = 1000.0 * elapsed / args.steps
+        two_graphs = bool(os.environ.get("DEMF_GEO_AT_BWD"))
+        if args.no_graph:
+            launch = "eager"
+        else:
+            launch = ("hipGraphs(fwd+loss | bwd), pre-pass of the next batch launched in between" if two_graphs
+                      else "one hipGraph(fwd+loss+bwd), pre-pass of the next batch launched in front of it") + \
+                " on a side stream; eager allreduce / clip / AdamW"
         out = {
             "metric": "DeMF fusion fwd+bwd scenes/sec at 20k pts + 530x730 RGB",
             "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world,
@@ -407,16 +529,26 @@ def main():
                                       "bf16 MFMA / fp32 accumulate+storage (BASELINE configs[3] per GPU)"),
                        "compute_mode": args.dtype, "mfma_path": MFMA_PATH[args.dtype],
                        "scenes_per_gpu": args.batch, "parallelism": f"dp{world}",
-                       "launch": "eager" if args.no_graph else "hipGraphs(fwd+loss | bwd) + eager allreduce/AdamW; "
-                                 "next batch's FPS/ball-query pre-pass pipelined on a side stream"},
+                       "cloud": args.cloud,
+                       "timed_loop": ("one resident batch replayed" if args.resident else
+                                      "%d distinct HBM-resident batches cycled through replay.load(): target "
+                                      "padding, meta refresh, static-buffer copies and the next cloud's "
+                                      "pre-pass are inside the timed step" % NB),
+                       "launch": launch},
             # two more passes of the same K steps right after the timed region (stability check;
             # `value` is the first, contract-shaped region only)
             "repeat_ms_per_step": repeats,
         }
-        # ---- headline roofline: the dominant kernel ON the step's critical path (the FPS chain
-        # runs underneath the step on a side stream).  Algorithmic bytes of that GEMM = read the
-        # (R,64) input rows once, write the (R,128) raw output once, write the pooled extremum that
-        # the sign of gamma selects + its row offset (2 x (R/64,128) words); weights < 1 %.
+        if allreduce_us is not None:
+            # HIP events around the one all-reduce of the flat 8.76 MB gradient buffer (rank 0's view)
+            out["allreduce_us"] = allreduce_us
+        if rank_info is not None:
+            out["ranks"] = [dict(rank=r["rank"], batch_seeds=r["batch_seeds"], dropout_seed=r["dropout_seed"])
+                            for r in rank_info]
+        # ---- headline roofline: the largest forward kernel ON the step's critical path.  Algorithmic
+        # bytes of that GEMM = read the (R,64) input rows once, write the (R,128) raw output once, write
+        # the pooled extremum that the sign of gamma selects + its row offset (2 x (R/64,128) words);
+        # weights < 1 %.
         x3 = args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"]
         # MFMA budget of the mode: native fp32 -> the fp32 MFMA peak; bf16 -> the bf16 peak; the
         # three-term split issues 6 bf16 MFMAs per algorithmic product -> bf16 peak / 6
@@ -426,9 +558,14 @@ def main():
         mlp_bytes = sa1_rows * (64 + 128) * 4 + 2 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2.0 * sa1_rows * 64 * 128
         dom = DOMINANT_KERNEL[args.dtype]
-        traffic, src = pmc_per_launch(dom) if args.batch == 8 else (None, None)
+        # (the committed PMC passes are B = 8 runs of the default mode; no row for this kernel in the
+        # newest pair is an error there, not a silent fall-back to an older round's file)
+        traffic, src = pmc_per_launch(dom, required=(args.batch == 8 and args.dtype == "f32"
+                                                      and not os.environ.get("DEMF_F32_NATIVE"))) \
+            if args.batch == 8 else (None, None)
+        tk, tk_src = top_kernels()
         out["roofline"] = {
-            "kernel": "%s (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (dom, sa1_rows),
+            "kernel": "%s...> (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (dom, sa1_rows),
             # priced against the HBM roof (its algorithmic bytes dominate its FLOPs at either MFMA
             # rate); what actually limits it today is on-chip: VALU issue + latency at 2 waves/SIMD
             # (PMC pipe counters)
@@ -437,11 +574,27 @@ def main():
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,
             "avg_launch_ms": mlp_ms,
+            # this ONE kernel's share of the step: `frac` above is a statement about it, not about the step
+            "share_of_step": mlp_ms / ms_step,
             "mfma_frac": mlp_flop / (mlp_ms * 1e-3) / 1e12 / mfma_peak,
             "note": "also %.1f algorithmic GFLOP per launch; mfma_frac = of the %.1f TF/s the mode can "
-                    "issue (%s)" % (mlp_flop / 1e9, mfma_peak,
-                                    "dense bf16 MFMA peak" if args.dtype == "bf16" else
-                                    ("dense bf16 MFMA peak / 6: three-term split" if x3 else "dense fp32 MFMA peak"))}
+                    "issue (%s); the whole step: roofline_step, its five longest kernels: roofline_top5"
+                    % (mlp_flop / 1e9, mfma_peak,
+                       "dense bf16 MFMA peak" if args.dtype == "bf16" else
+                       ("dense bf16 MFMA peak / 6: three-term split" if x3 else "dense fp32 MFMA peak"))}
+        if tk is not None:
+            # the five kernels with the most time per step in the newest committed profile of this command
+            # (rocprofv3 kernel trace + PMC passes; builder-run, committed - not measured by this run):
+            # time, HBM bytes moved, achieved GB/s and fraction of the 8 TB/s roof, each
+            out["roofline_top5"] = {
+                "source": tk_src, "profiled_kernel_us_per_step": tk.get("kernel_us_per_step"),
+                "profiled_launches_per_step": tk.get("launches_per_step"),
+                "kernels": [dict(kernel=e["kernel"][:100], us_per_step=e["us_per_step"],
+                                 launches_per_step=e["launches_per_step"],
+                                 mb_per_step=(e["hbm_bytes_per_step"] / 1e6 if e.get("hbm_bytes_per_step") else None),
+                                 gbps=e.get("gbps"), frac=e.get("frac_of_hbm_peak"),
+                                 side_stream=e.get("side_stream", False))
+                            for e in tk["kernels"][:5]]}
         # ---- step level: what the metric asks for ("as achieved fraction of HBM roofline")
         step_bytes = ALGO_BYTES_PER_SCENE * args.batch
         step_flop = ALGO_FLOP_PER_SCENE * args.batch
@@ -450,7 +603,8 @@ def main():
             "bound": "mfma" if args.dtype != "bf16" else "hbm", "algorithmic_bytes": step_bytes,
             # HBM bytes the whole step actually moved (PMC, every kernel) and their ratio to the
             # algorithmic bytes: > 1 = re-reads of materialised intermediates (Y_l read by the next
-            # layer, the dx and the dW pass)
+            # layer, the dx and the dW pass).  Builder-run PMC passes of this command, committed under
+            # profiles/ (`traffic_source`) - not observed by this run.
             "traffic_step": traffic_step, "traffic_source": src_step,
             "traffic_over_algorithmic": (traffic_step / step_bytes) if traffic_step else None,
             "algorithmic_flop": step_flop,
@@ -461,20 +615,18 @@ def main():
             "note": "SURVEY 8(d) per-scene algorithmic figures (190 MB, 46 GFLOP fwd+bwd) x scenes/GPU "
                     "over the measured step time, per GPU; the path is fp32-MFMA / latency bound, "
                     "not HBM bound"}
-        # ---- the FPS chain (underneath the step): latency-bound, neither HBM nor MFMA
+        # ---- the FPS chain (underneath the step): latency-bound, neither HBM nor MFMA.  Reported as
+        # what it is - milliseconds and shader cycles per dependent round - not as a fraction of a floor.
         big = [ms for ms, shp in fps_timer.results() if shp is not None and shp[1] == 20000]
         if big:
             fps_ms = float(np.mean(big))
             rounds = 2047
-            cyc = fps_ms * 1e-3 / rounds * CLOCK_GHZ * 1e9
             out["roofline_fps"] = {
                 "kernel": "FPS 20000->2048 (one workgroup per scene, %d scenes)" % args.batch,
                 "bound": "latency", "avg_launch_ms": fps_ms, "dependent_rounds": rounds,
-                "cycles_per_round": cyc, "floor_cycles_per_round": FPS_FLOOR_CYCLES,
-                "frac": FPS_FLOOR_CYCLES / cyc,
-                "note": "floor = VALU issue of the distance update of 20000 points on one CU (4 waves per "
-                        "SIMD x ~105 packed instructions x 4 cycles, DESIGN.md section 7); HBM bytes are "
-                        "2 MB per launch by construction"}
+                "cycles_per_round": fps_ms * 1e-3 / rounds * CLOCK_GHZ * 1e9,
+                "note": "cycles at the %.1f GHz peak clock; HBM bytes are 2 MB per launch by construction "
+                        "(points read once, indices written once); DESIGN.md section 3.1" % CLOCK_GHZ}
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

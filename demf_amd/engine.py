@@ -288,7 +288,14 @@ class Trainer:
         if self.fused:
             world = dist.get_world_size() if dist.is_initialized() else 1
             if world > 1:
+                ev = getattr(self, "allreduce_events", None)   # bench.py: HIP events around the collective
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+                if ev is not None:
+                    e1.record()
+                    ev.append((e0, e1))
             norm = torch.linalg.vector_norm(self.flat.flat)      # of the SUM; scaled in-kernel
             self.opt.step(norm, self.max_grad_norm, 1.0 / world)
             return
@@ -329,7 +336,24 @@ class Trainer:
                 lab[i, 0] = 0
         return gt.to(device), lab.to(device)
 
-    def capture(self, batch, warmup=3, prefetch_geometry=True, max_gt=None):
+    def _snapshot_state(self):
+        """What a forward + backward WITHOUT an optimizer update still changes: BatchNorm running
+        statistics / counters and the dropout counter.  (-> restore closure)"""
+        bufs = [(b, b.clone()) for b in self.model.buffers()]
+        rng = None
+        if self.fused:
+            from . import fused
+            rng = fused.get_rng_state(self.flat.flat.device)
+
+        def restore():
+            for b, c in bufs:
+                b.copy_(c)
+            if rng is not None:
+                from . import fused
+                fused.set_rng_state(self.flat.flat.device, rng)
+        return restore
+
+    def capture(self, batch, warmup=3, prefetch_geometry=True, max_gt=None, dry=False, geo_pipe=None):
         """Capture forward + loss + backward of ``batch`` (static shapes, device-resident
         inputs) into one hipGraph; returns ``replay(next_points=None)`` = graph launch + eager
         all-reduce / clip / AdamW.  The path issues no host sync or host->device copy after
@@ -346,13 +370,23 @@ class Trainer:
                 if k: replay.load(batch_k)
                 loss = replay(next_points=batch_{k+1}["points"])
 
+        Batches whose SHAPES differ (padded image size, point count, batch size) need their own
+        graph: ``Trainer.bucketed()`` keeps one per shape.
+
         ``prefetch_geometry``: the coordinate-only pre-pass of the NEXT batch (every FPS level,
         the backbone ball queries, 3-NN - ``DeMFHotPath.index_geometry``) is issued on a side
         HIP stream in front of the current batch's fwd+bwd graph, so the latency-bound FPS chain
         (B workgroups on 256 CUs) runs underneath the current step's forward instead of in front
         of the next step (``DEMF_GEO_AT_BWD=1``: between a forward and a backward graph).  Every step still computes one full
         pre-pass; the graph reads it from static buffers that are refreshed by ONE ~6 MB multi-copy
-        launch at the step boundary."""
+        launch at the step boundary.
+
+        ``dry``: the warm-up passes run forward + backward only (no optimizer update) and the state
+        they touch (BatchNorm running statistics, dropout counter) is restored afterwards - a capture
+        in the middle of training leaves the model exactly as it found it.
+        ``geo_pipe``: the pre-pass pipeline (``replay.geo``) of another capture with the same cloud
+        shape (B, N, channels): both graphs then read the same index buffers and share one
+        pipelined pre-pass."""
         dev = batch["points"].device
         gt_list = isinstance(batch["gt_bboxes_3d"], (list, tuple))
         if gt_list and dev.type == "cuda":
@@ -371,14 +405,32 @@ class Trainer:
         if head is not None and hasattr(head, "pin_metas"):
             head.pin_metas(static["img_metas"])     # the graph holds raw pointers into its cache entry
         side = self.side_stream if getattr(self, "side_stream", None) is not None else torch.cuda.Stream()
+        if geo_pipe is not None:
+            side = geo_pipe.side
+        restore = self._snapshot_state() if dry else None
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.step(batch)
+                if dry:
+                    self._fwd_bwd(batch)
+                else:
+                    self.step(batch)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         can_prefetch = prefetch_geometry and hasattr(self.model, "index_geometry")
-        static_geo = self.model.index_geometry(batch["points"]) if can_prefetch else None
+        geo = None
+        if can_prefetch:
+            if geo_pipe is not None:
+                if tuple(geo_pipe.static_pts.shape) != tuple(batch["points"].shape):
+                    raise ValueError("geo_pipe was built for clouds of shape %s, this batch has %s"
+                                     % (tuple(geo_pipe.static_pts.shape), tuple(batch["points"].shape)))
+                geo = geo_pipe
+                # the shared index buffers must describe THIS batch's cloud while it is being captured
+                # (values do not matter to a capture, but the eager bookkeeping below assumes them)
+                geo.ensure(torch.cuda.current_stream(), batch["points"], static["points"])
+            else:
+                geo = _GeoPipe(self.model, batch["points"], side)
+        static_geo = geo.static_geo if geo is not None else None
         torch.cuda.synchronize()
         self.flat.reserve_table()
         graph = torch.cuda.CUDAGraph()
@@ -410,64 +462,10 @@ class Trainer:
             finally:
                 self.flat.captured_pack = False
         self.flat.finish_capture()
-
-        def flat_tensors(g):
-            """Every tensor of the (nested) geometry structure, in a deterministic order."""
-            if torch.is_tensor(g):
-                return [g]
-            if isinstance(g, dict):
-                return [t for k in sorted(g) for t in flat_tensors(g[k])]
-            return [t for v in g for t in flat_tensors(v)]
-
-        geo_graph, fresh, static_pts = None, None, None
-        if can_prefetch:
-            # the pre-pass is its own (small) hipGraph, replayed on the side stream: one launch
-            # call instead of ~30, so the main graph is not held up behind host launch latency
-            static_pts = batch["points"].clone()
+        if restore is not None:
+            restore()
             torch.cuda.synchronize()
-            geo_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(geo_graph, stream=side):
-                fresh = flat_tensors(self.model.index_geometry(static_pts))
-            torch.cuda.synchronize()
-        static_flat = flat_tensors(static_geo) if can_prefetch else None
-        refresh = None
-        if can_prefetch:
-            # one launch instead of one copy per index tensor (~30 of them)
-            from . import ops
-            pairs = [(d, s) for d, s in zip(static_flat, fresh) if d.numel()]
-            refresh = ops.MultiCopy([d for d, _ in pairs], [s for _, s in pairs])
-
-        # Which cloud the static geometry buffers hold and which cloud's pre-pass sits in `fresh`
-        # (in flight or finished).  Identity is the tensor OBJECT handed in (held here, so the caching
-        # allocator cannot hand its address to the next batch) plus its version counter; an address /
-        # shape tag would match a recycled buffer and silently pair new points with old indices.
-        class _Cloud:
-            __slots__ = ("t", "v")
-
-            def __init__(self, t):
-                self.t, self.v = t, t._version
-
-            def holds(self, t):
-                return self.t is t and self.v == t._version
-
-        captured = _Cloud(batch["points"])     # the static copy made above: never seen by callers
-        state = dict(static=captured, fresh=None, pts=captured)   # static_pts holds the captured cloud
         one_deep = not os.environ.get("DEMF_GEO_TWO_DEEP")         # A/B: see replay()
-
-        def take_fresh(main):
-            """fresh -> static (one launch), after the pre-pass that filled `fresh` has finished."""
-            main.wait_stream(side)
-            refresh()
-            state["static"], state["fresh"] = state["fresh"], None
-
-        def launch_prepass(main, next_points):
-            if next_points is not None:
-                static_pts.copy_(next_points)
-                state["pts"] = _Cloud(next_points)
-            side.wait_stream(main)                # the cloud is in place, `fresh` has been consumed
-            with torch.cuda.stream(side):
-                geo_graph.replay()
-            state["fresh"] = state["pts"]
 
         def replay(next_points=None):
             """One training step.  Default (one-deep): ``next_points`` is the cloud of the NEXT batch;
@@ -491,27 +489,27 @@ class Trainer:
                 return loss
             if graph_bwd is not None and one_deep:
                 graph.replay()
-                launch_prepass(main, next_points)
+                geo.launch_prepass(main, next_points)
                 graph_bwd.replay()
                 self._update()
-                take_fresh(main)
+                geo.take_fresh(main)
                 return loss
             if graph_bwd is not None:
                 graph.replay()
                 graph_bwd.replay()
-                if state["fresh"] is not None:
-                    take_fresh(main)              # no stall: that pre-pass had a whole step
-                launch_prepass(main, next_points)
+                if geo.state["fresh"] is not None:
+                    geo.take_fresh(main)              # no stall: that pre-pass had a whole step
+                geo.launch_prepass(main, next_points)
                 self._update()
                 return loss
             if can_prefetch:
                 # single-graph step (the default): the pre-pass goes first - enqueueing the
                 # ~900-node step graph takes the host about a millisecond
-                launch_prepass(main, next_points)
+                geo.launch_prepass(main, next_points)
             graph.replay()
             self._update()
             if can_prefetch:
-                take_fresh(main)
+                geo.take_fresh(main)
             return loss
 
         def load(new):
@@ -520,14 +518,8 @@ class Trainer:
             they do not hold THIS cloud's geometry, it is fetched from the finished / in-flight
             pre-pass (waiting for it) or recomputed here, so geometry and targets can never belong
             to different batches."""
-            if can_prefetch and not state["static"].holds(new["points"]):
-                main = torch.cuda.current_stream()
-                if state["fresh"] is not None and state["fresh"].holds(new["points"]):
-                    take_fresh(main)
-                else:
-                    # (an unrelated pre-pass in flight is left to finish; its result is dropped)
-                    launch_prepass(main, new["points"])
-                    take_fresh(main)
+            if can_prefetch:
+                geo.ensure(torch.cuda.current_stream(), new["points"], static["points"])
             static["points"].copy_(new["points"])
             nf = new["img_features"]
             if isinstance(nf, dict):
@@ -547,5 +539,175 @@ class Trainer:
 
         replay.load = load
         replay.static = static
+        replay.geo = geo
+        replay.max_gt = G
         self._graph = graph
         return replay
+
+    def bucketed(self, **kw):
+        """A step that keeps one captured graph per input SHAPE (``StepCache``)."""
+        return StepCache(self, **kw)
+
+
+def _flat_tensors(g):
+    """Every tensor of the (nested) geometry structure, in a deterministic order."""
+    if torch.is_tensor(g):
+        return [g]
+    if isinstance(g, dict):
+        return [t for k in sorted(g) for t in _flat_tensors(g[k])]
+    return [t for v in g for t in _flat_tensors(v)]
+
+
+class _Cloud:
+    """Which cloud a set of index buffers describes.  Identity is the tensor OBJECT handed in (held
+    here, so the caching allocator cannot hand its address to the next batch) plus its version
+    counter; an address / shape tag would match a recycled buffer and silently pair new points with
+    old indices."""
+    __slots__ = ("t", "v")
+
+    def __init__(self, t):
+        self.t, self.v = t, t._version
+
+    def holds(self, t):
+        return self.t is t and self.v == t._version
+
+
+class _GeoPipe:
+    """The pipelined coordinate pre-pass of ONE cloud shape (B, N, channels): static index buffers that
+    captured step graphs read, a small hipGraph that recomputes them for another cloud on a side stream
+    (``DeMFHotPath.index_geometry``: every FPS level, ball queries + inverse lists, 3-NN, the head's seed
+    FPS), and the one-launch refresh that moves a finished pre-pass into the static buffers.  Shared by
+    every step graph captured for that cloud shape (graphs for different padded image sizes read the
+    same index buffers)."""
+
+    def __init__(self, model, points, side):
+        from . import ops
+        self.side = side
+        self.static_geo = model.index_geometry(points)
+        torch.cuda.synchronize()
+        # the pre-pass is its own (small) hipGraph, replayed on the side stream: one launch
+        # call instead of ~30, so the main graph is not held up behind host launch latency
+        self.static_pts = points.clone()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            fresh = _flat_tensors(model.index_geometry(self.static_pts))
+        torch.cuda.synchronize()
+        static_flat = _flat_tensors(self.static_geo)
+        # one launch instead of one copy per index tensor (~30 of them)
+        pairs = [(d, s) for d, s in zip(static_flat, fresh) if d.numel()]
+        self.refresh = ops.MultiCopy([d for d, _ in pairs], [s for _, s in pairs])
+        # Which cloud the static geometry buffers hold and which cloud's pre-pass sits in `fresh`
+        # (in flight or finished).
+        captured = _Cloud(points)
+        self.state = dict(static=captured, fresh=None, pts=captured)   # static_pts holds the captured cloud
+
+    def take_fresh(self, main):
+        """fresh -> static (one launch), after the pre-pass that filled `fresh` has finished."""
+        main.wait_stream(self.side)
+        self.refresh()
+        self.state["static"], self.state["fresh"] = self.state["fresh"], None
+
+    def launch_prepass(self, main, next_points):
+        if next_points is not None:
+            self.static_pts.copy_(next_points)
+            self.state["pts"] = _Cloud(next_points)
+        self.side.wait_stream(main)                # the cloud is in place, `fresh` has been consumed
+        with torch.cuda.stream(self.side):
+            self.graph.replay()
+        self.state["fresh"] = self.state["pts"]
+
+    def ensure(self, main, points, static_points=None):
+        """Make the static index buffers describe ``points``: already there, taken from the finished /
+        in-flight pre-pass (waiting for it), or recomputed here."""
+        st = self.state
+        if st["static"].holds(points) or (static_points is not None and st["static"].holds(static_points)
+                                          and points is static_points):
+            return
+        if st["fresh"] is not None and st["fresh"].holds(points):
+            self.take_fresh(main)
+        else:
+            # (an unrelated pre-pass in flight is left to finish; its result is dropped)
+            self.launch_prepass(main, points)
+            self.take_fresh(main)
+
+
+class StepCache:
+    """Training step over batches of VARYING shape: one captured hipGraph per shape key
+
+        (scenes, points, point channels, image-pyramid shapes, GT slots)
+
+    in an LRU of ``max_graphs``, an eager step for shapes seen fewer than ``capture_on`` times.  The
+    reference rebuilds its masks and shapes per batch from ``img_metas[0]['batch_input_shape']``
+    (demf/modeling/heads/class_agnostic_vote_head.py:556-568) and its pipeline pads every batch to a
+    multiple of 32 after ``Resize((1333, 800), keep_ratio)`` (configs/demf/demf_votenet.py:194-197): SUN
+    RGB-D's four sensors give four padded image sizes, so a single static-shape graph would only ever
+    serve one of them.  GT slots are bucketed (8 / 16 / 32 / 64) so that box counts do not multiply the
+    graphs.  Graphs of the same cloud shape share one pipelined coordinate pre-pass (``_GeoPipe``).
+    Captures are ``dry``: they leave parameters, optimizer state, BatchNorm statistics and the dropout
+    counter untouched, so the sequence of updates equals that of eager steps."""
+
+    GT_BUCKETS = (8, 16, 32, 64)
+
+    def __init__(self, trainer, max_graphs=4, capture_on=2, warmup=2, prefetch_geometry=True):
+        import collections
+        self.trainer, self.max_graphs, self.capture_on = trainer, int(max_graphs), int(capture_on)
+        self.warmup, self.prefetch = int(warmup), prefetch_geometry
+        self.graphs = collections.OrderedDict()       # key -> replay
+        self.pipes = {}                               # cloud shape -> _GeoPipe
+        self.seen = collections.Counter()
+        self.stats = dict(eager=0, replayed=0, captured=0, evicted=0)
+
+    @classmethod
+    def gt_slots(cls, gt_boxes):
+        if not isinstance(gt_boxes, (list, tuple)):
+            return int(gt_boxes.shape[1])
+        n = max(1, max(int((b.tensor if hasattr(b, "tensor") else b).shape[0]) for b in gt_boxes))
+        for g in cls.GT_BUCKETS:
+            if n <= g:
+                return g
+        raise ValueError("a scene has %d ground-truth boxes; the target kernels hold %d" % (n, cls.GT_BUCKETS[-1]))
+
+    @classmethod
+    def key(cls, batch):
+        f = batch["img_features"]
+        if isinstance(f, dict):
+            img = (tuple(f["tokens"].shape), tuple(tuple(s) for s in f["spatial"]))
+        else:
+            img = tuple(tuple(t.shape) for t in f)
+        return (tuple(batch["points"].shape), img, cls.gt_slots(batch["gt_bboxes_3d"]))
+
+    def step(self, batch, next_points=None):
+        """One optimizer step on ``batch``.  ``next_points``: the cloud of the next batch (its
+        coordinate pre-pass then runs underneath this step if the next batch replays a graph of the
+        same cloud shape)."""
+        key = self.key(batch)
+        r = self.graphs.get(key)
+        if r is None:
+            self.seen[key] += 1
+            if self.seen[key] < self.capture_on:
+                self.stats["eager"] += 1
+                return self.trainer.step(batch)
+            while len(self.graphs) >= self.max_graphs:
+                old, dead = self.graphs.popitem(last=False)
+                self.stats["evicted"] += 1
+                if not any(k[0] == old[0] for k in self.graphs):
+                    self.pipes.pop(old[0], None)
+                del dead
+            pipe = self.pipes.get(key[0]) if self.prefetch else None
+            r = self.trainer.capture(batch, warmup=self.warmup, prefetch_geometry=self.prefetch,
+                                     max_gt=key[2] if isinstance(batch["gt_bboxes_3d"], (list, tuple)) else None,
+                                     dry=True, geo_pipe=pipe)
+            if self.prefetch and r.geo is not None:
+                self.pipes[key[0]] = r.geo
+            self.graphs[key] = r
+            self.stats["captured"] += 1
+        else:
+            self.graphs.move_to_end(key)
+        r.load(batch)
+        self.stats["replayed"] += 1
+        if next_points is not None and tuple(next_points.shape) != key[0]:
+            next_points = None                      # another cloud shape: its own pipeline fetches it
+        return r(next_points=next_points)
+
+    __call__ = step

@@ -18,13 +18,26 @@ def depth2img():
 
 
 def make_scene_batch(B, N, pyramid, batch_input_shape, channels, seed=0, n_gt=4,
-                     img_shape=None, scale_factor=None):
+                     img_shape=None, scale_factor=None, cloud="uniform", gt_counts=None):
     """Synthetic SUN RGB-D-like batch: points (B,N,4) (xyz + height) in front of the camera,
     image pyramid ~N(0,1), img_metas alternating an identity 3-D flow with a
     flip+rot+scale+trans flow (and a smaller valid image, so padding masks are exercised),
-    and n_gt-ish rotated GT boxes per scene."""
+    and n_gt-ish rotated GT boxes per scene.
+    ``cloud``: "uniform" in the room volume, or "clustered" = 20 Gaussian blobs (sigma 0.3 m) per scene
+    (a depth sensor sees surfaces, not a volume - the SA1 balls then
+    saturate at 64 neighbours and the neighbour lists are unbalanced).
+    ``gt_counts``: explicit number of GT boxes per scene (default: n_gt - b % 3)."""
     rng = np.random.default_rng(seed)
-    xyz = rng.uniform([-2.5, 0.8, -1.2], [2.5, 6.0, 1.6], size=(B, N, 3))
+    lo, hi = np.array([-2.5, 0.8, -1.2]), np.array([2.5, 6.0, 1.6])
+    if cloud == "clustered":
+        centres = rng.uniform(lo + 0.3, hi - 0.3, size=(B, 20, 3))
+        which = rng.integers(0, 20, size=(B, N))
+        xyz = np.take_along_axis(centres, which[..., None].repeat(3, -1), 1) + rng.normal(0, 0.3, size=(B, N, 3))
+        xyz = np.clip(xyz, lo - 0.5, hi + 0.5)
+    elif cloud == "uniform":
+        xyz = rng.uniform(lo, hi, size=(B, N, 3))
+    else:
+        raise ValueError("cloud must be 'uniform' or 'clustered'")
     height = xyz[..., 2:3] - xyz[..., 2:3].min(axis=1, keepdims=True)
     points = np.concatenate([xyz, height], -1).astype(np.float32)
     feats = [rng.standard_normal((B, channels, h, w)).astype(np.float32) for h, w in pyramid]
@@ -46,7 +59,7 @@ def make_scene_batch(B, N, pyramid, batch_input_shape, channels, seed=0, n_gt=4,
             pcd_rotation=rot.astype(np.float32), pcd_scale_factor=1.07 if aug else 1.0,
             pcd_trans=np.array([0.05, -0.1, 0.02], np.float32) if aug else np.zeros(3, np.float32),
             transformation_3d_flow=["HF", "R", "S", "T"] if aug else []))
-        k = max(0, n_gt - b % 3)
+        k = max(0, n_gt - b % 3) if gt_counts is None else int(gt_counts[b])
         ctr = rng.uniform([-2.0, 1.5, -1.0], [2.0, 5.0, 0.0], size=(k, 3))
         dims = rng.uniform([0.5, 0.5, 0.4], [1.8, 1.6, 1.2], size=(k, 3))
         yaw = rng.uniform(-np.pi, np.pi, size=(k, 1))

@@ -245,3 +245,84 @@ def test_three_training_steps_follow_the_fp64_oracle():
             worst = (k, rel)
     print(f"worst parameter / buffer after {steps} steps: {worst[0]} rel-L2 {worst[1]:.2e}")
     assert worst[1] <= 1.2e-3, worst                             # 2 x the observed 4.6e-4 .. 5.3e-4
+
+
+def _shape_batches(cfg, n, seed0=40):
+    """Batches of two padded image sizes (two pyramids) with differing per-scene GT counts."""
+    from demf_amd import synthetic
+    # (more tokens than the decoder samples - 32 queries x 4 levels x 2 points x 4 corners = 1 024 - so
+    # that the fusion layers take the one-node device path with its counter-based dropout)
+    pyr = [((32, 44), (16, 22), (8, 11), (4, 6)), ((32, 40), (16, 20), (8, 10), (4, 5))]
+    inp = [(256, 352), (256, 320)]
+    order = [0, 1, 0, 1, 1, 0, 0, 1, 0, 1]
+    out = []
+    for i in range(n):
+        w = order[i % len(order)]
+        counts = [(3 * i + 2 * b) % 7 for b in range(3)]          # 0 .. 6 boxes, never the same signature
+        if i == 6:
+            counts[1] = 11                                         # a one-off that needs the 16-slot bucket
+        raw = synthetic.make_scene_batch(3, 1024, pyr[w], inp[w], cfg.head.embed_dims, seed=seed0 + i,
+                                         gt_counts=counts)
+        out.append(dict(points=torch.from_numpy(raw["points"]).cuda(),
+                        img_features=[torch.from_numpy(f).cuda() for f in raw["img_features"]],
+                        img_metas=raw["img_metas"],
+                        gt_bboxes_3d=[torch.from_numpy(b).cuda() for b in raw["gt_boxes"]],
+                        gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]]))
+    return out
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+def test_shape_bucketed_capture_matches_eager_steps(dropout):
+    """Trainer.bucketed(): batches of two padded image sizes and varying GT counts cycle through one
+    captured graph per shape (class_agnostic_vote_head.py:556-568 rebuilds masks per batch from
+    batch_input_shape; demf_votenet.py:194-197 pads every batch to its own multiple of 32).  The
+    sequence of updates must equal that of plain eager steps on a twin: captures are dry (BatchNorm
+    statistics and the dropout counter restored), shapes seen once run eagerly, graphs of one cloud
+    shape share the pipelined pre-pass."""
+    import dataclasses
+    from demf_amd import engine
+    from demf_amd.modules import DeMFHotPath
+    cfg = fixtures.tiny_cfg()
+    cfg = dataclasses.replace(cfg, head=dataclasses.replace(cfg.head, attn_dropout=dropout, ffn_dropout=dropout))
+    batches = _shape_batches(cfg, 10)
+
+    def run(bucketed):
+        torch.manual_seed(11)
+        model = DeMFHotPath(cfg)
+        fixtures.seed_weights(model, 9)
+        model.cuda().train()
+        tr = engine.Trainer(model, lr=2e-4)           # (re)seeds the dropout counter
+        stepper = tr.bucketed(max_graphs=3, capture_on=2, warmup=1) if bucketed else None
+        losses = []
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1]["points"] if i + 1 < len(batches) else None
+            l = stepper.step(b, next_points=nxt) if bucketed else tr.step(b)
+            losses.append(float(l))
+        torch.cuda.synchronize()
+        bufs = torch.cat([b.detach().double().reshape(-1) for b in model.buffers()])
+        return losses, tr.opt.flat.clone().double(), bufs, stepper
+
+    la, pa, ba, _ = run(False)
+    lb, pb, bb, sc = run(True)
+    # shapes: two pyramids x the 8-slot bucket (+ one 16-slot one-off): first sight eager, then captured
+    assert sc.stats["captured"] == 2 and sc.stats["eager"] == 3, sc.stats
+    assert sc.stats["replayed"] == len(batches) - sc.stats["eager"]
+    assert len(sc.pipes) == 1, "both image sizes share the cloud shape's pre-pass pipeline"
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x - y) <= 2e-3 * abs(x), (i, x, y)
+    assert ((pa - pb).norm() / pa.norm()).item() < 2e-4
+    assert ((ba - bb).norm() / ba.norm()).item() < 1e-4       # BatchNorm statistics: no extra warm-up passes
+
+
+def test_step_cache_evicts_least_recently_used():
+    from demf_amd import engine
+    from demf_amd.modules import DeMFHotPath
+    cfg = fixtures.tiny_cfg()
+    batches = _shape_batches(cfg, 4)
+    model = DeMFHotPath(cfg)
+    fixtures.seed_weights(model, 9)
+    model.cuda().train()
+    sc = engine.Trainer(model, lr=1e-4).bucketed(max_graphs=1, capture_on=1, warmup=1)
+    for b in batches:                       # shapes 0 1 0 1 with room for one graph: every step re-captures
+        assert bool(torch.isfinite(sc.step(b)))
+    assert sc.stats["captured"] == 4 and sc.stats["evicted"] == 3 and len(sc.graphs) == 1

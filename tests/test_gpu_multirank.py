@@ -132,3 +132,32 @@ def test_plain_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU launch line, eight ranks sharing one GPU through gloo (one scene per rank):
+    JSON shape, n_gpus, the weak-scaling arithmetic (value = all ranks' scenes over the max-over-ranks
+    time), the all-reduce's own time, and that the eight replicas differ where they must - data seeds and
+    dropout streams - while the reference's launcher gives every rank its own shard
+    (tools/dist_train.sh:8-9, train.py:56-63)."""
+    env = dict(os.environ, DEMF_SHARE_DEVICE="1", DEMF_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "2",
+           "--batch", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["scenes_per_gpu"] == 1 and out["config"]["parallelism"] == "dp8"
+    assert abs(out["value"] - 8 * 1 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["allreduce_us"] > 0.0
+    assert "cpu_baseline" not in out and "secondary" not in out
+    ranks = out["ranks"]
+    assert [r_["rank"] for r_ in ranks] == list(range(8))
+    assert len({r_["dropout_seed"] for r_ in ranks}) == 8
+    seeds = [sd for r_ in ranks for sd in r_["batch_seeds"]]
+    assert len(set(seeds)) == len(seeds)

@@ -24,5 +24,7 @@ if [ -n "$PMC" ]; then
     [ -n "$f" ] && python $R/tools/pmc_summary.py $f $c > $out/pmc_$c.csv
   done
 fi
+pf=""; [ -n "$PMC" ] && pf="$out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv"
+[ -n "$tr" ] && python $R/tools/top_kernels.py $tr $pf 5 7 > $out/top_kernels.json 2>> $out/prof.log
 cd $R
 head -45 $out/steps_summary.txt; grep -A40 -e '^--- ' $out/steps_summary.txt | head -60
