@@ -153,17 +153,22 @@ def ball_margin(xyz, center, r):
     return np.abs(d2 - r * r).min() / (r * r)
 
 
-def oracle_run(cfg, batch, gtb, gtl, seed, dtype, truth_taps=None, tap=True):
+def oracle_run(cfg, batch, gtb, gtl, seed, dtype, truth_taps=None, tap=True, emulate_bf16=False):
+    """``emulate_bf16``: the oracle rounds where the product's bf16 compute mode rounds
+    (oracle/emulate.py); float64 = the emulated truth, float32 = the accumulation noise around it."""
+    import contextlib
+    from oracle import emulate
     ref = OracleDeMF(cfg)
     fixtures.seed_weights(ref, seed)
     ref.train().to(dtype)
-    taps = Taps(ref, truth_taps) if tap else None
+    taps = Taps(ref, truth_taps) if tap and not emulate_bf16 else None
     pts = torch.from_numpy(batch["points"]).to(dtype)
     feats = [torch.from_numpy(f).to(dtype) for f in batch["img_features"]]
-    losses, preds, targets = ref.forward_train(pts, feats, batch["img_metas"],
-                                               [torch.from_numpy(b).to(dtype) for b in gtb],
-                                               [torch.from_numpy(l) for l in gtl])
-    sum(losses.values()).backward()
+    with (emulate.bf16_emulation() if emulate_bf16 else contextlib.nullcontext()):
+        losses, preds, targets = ref.forward_train(pts, feats, batch["img_metas"],
+                                                   [torch.from_numpy(b).to(dtype) for b in gtb],
+                                                   [torch.from_numpy(l) for l in gtl])
+        sum(losses.values()).backward()
     if taps is not None:
         taps.close()
     grads = {n: p.grad.detach().double() for n, p in ref.named_parameters() if p.grad is not None}
@@ -240,6 +245,16 @@ def _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log):
         return dict(seed=seed, batch=batch, gtb=gtb, gtl=gtl, truth=truth, cpu32=cpu32,
                     risk=worst[1][0])
     raise AssertionError("no qualifying seed: " + "; ".join(why))
+
+
+def emulated_runs(cfg, case):
+    """The two bf16-emulating oracle runs of a qualified case (cached on the case): emu64 = emulated
+    truth, emu32 = the same rounding points with fp32 accumulation."""
+    if "emu64" not in case:
+        a = (cfg, case["batch"], case["gtb"], case["gtl"], case["seed"])
+        case["emu64"] = oracle_run(*a, torch.float64, tap=False, emulate_bf16=True)
+        case["emu32"] = oracle_run(*a, torch.float32, tap=False, emulate_bf16=True)
+    return case["emu64"], case["emu32"]
 
 
 def rel_l2(a, t):

@@ -217,3 +217,89 @@ def test_bf16_steps_reduce_the_loss(bf16_mode):
     tr = engine.Trainer(model, lr=1e-4)
     losses = [tr.step(batch).item() for _ in range(12)]
     assert all(np.isfinite(losses)) and min(losses[6:]) < losses[0], losses
+
+
+def test_bf16_training_trajectory_tracks_fp32():
+    """Thirty optimizer steps on the same four batches from the same initial weights in the bf16 compute
+    mode and - twice - in fp32 (mid-size configuration, dropout off so that all runs see the same
+    function).  Training this randomly initialised network is chaotic at the level of single steps even
+    between two fp32 runs (see the note under the test), so the yard-stick for the bf16 trajectory is the
+    distance between the two fp32 trajectories: its per-step deviation from the nearer fp32 run must be
+    within 3x the fp32 runs' own (medians; vote loss and total loss), the first step - same weights -
+    must agree to 3 % / 5 %, and the loss level after 30 steps must lie in the fp32 runs' band.  A bf16
+    backward that is finite but wrong (a transposed operand, a missing term) fails the level and the
+    medians within a few steps."""
+    from demf_amd import engine, ops, synthetic
+    from demf_amd.config import BackboneCfg, DeMFCfg, HeadCfg
+    from demf_amd.modules import DeMFHotPath
+    cfg = DeMFCfg(backbone=BackboneCfg(num_points=(1024, 512, 256, 128)),
+                  head=HeadCfg(num_proposal=128, attn_dropout=0.0, ffn_dropout=0.0))
+    pyr, ins, img = ((50, 70), (25, 35), (13, 18), (7, 9)), (400, 560), (400, 551)
+
+    def fresh_model():
+        model = DeMFHotPath(cfg)
+        fixtures.seed_weights(model, 21)
+        return model.cuda().train()
+    probe = fresh_model()
+    batches = []
+    for i in range(4):
+        raw = synthetic.make_scene_batch(4, 6000, pyr, ins, cfg.head.embed_dims, seed=70 + i, n_gt=4, img_shape=img)
+        pts = torch.from_numpy(raw["points"]).cuda()
+        feats = [torch.from_numpy(f).cuda() for f in raw["img_features"]]
+        with torch.no_grad():                      # GT boxes on top of initial proposals: positives exist
+            agg = probe.forward_head(pts, feats, raw["img_metas"])["aggregated_points"].cpu().numpy()
+        rng = np.random.default_rng(700 + i)
+        gtb, gtl = [], []
+        for b in range(4):
+            pick = rng.choice(agg.shape[1], 4, replace=False)
+            dims = rng.uniform(0.8, 1.6, size=(4, 3))
+            extra = np.concatenate([agg[b, pick] - [0, 0, 1] * dims * 0.5, dims, rng.uniform(-3, 3, (4, 1))], 1)
+            gtb.append(np.concatenate([raw["gt_boxes"][b], extra.astype(np.float32)], 0))
+            gtl.append(np.concatenate([raw["gt_labels"][b], rng.integers(0, 10, 4)]))
+        batches.append(dict(points=pts, img_features=feats, img_metas=raw["img_metas"],
+                            gt_bboxes_3d=[torch.from_numpy(x).cuda() for x in gtb],
+                            gt_labels_3d=[torch.from_numpy(x).cuda() for x in gtl]))
+    def run(mode):
+        ops.set_compute_dtype(mode)
+        try:
+            model = fresh_model()
+            tr = engine.Trainer(model, lr=1e-4)
+            rows = []
+            for k in range(30):
+                b = batches[k % 4]
+                tr._arena(True)
+                try:
+                    losses = model.forward_train(b["points"], b["img_features"], b["img_metas"],
+                                                 b["gt_bboxes_3d"], b["gt_labels_3d"])
+                    tr.flat.backward_into(losses["_total"])
+                finally:
+                    tr._arena(False)
+                tr._update()
+                rows.append((losses["vote_loss"].item(), losses["_total"].item()))
+            return np.asarray(rows)
+        finally:
+            ops.set_compute_dtype("f32")
+    a, a2, b = run("f32"), run("f32"), run("bf16")
+    dev = lambda x, y: np.abs(x - y) / np.abs(x)
+    self_med = np.median(dev(a, a2), axis=0)          # fp32 against itself: (vote, total)
+    bf_med = np.median(np.minimum(dev(a, b), dev(a2, b)), axis=0)
+    print("[bf16 trajectory] total loss fp32 %.2f -> %.2f / %.2f -> %.2f, bf16 %.2f -> %.2f; per-step deviation "
+          "(median; max) fp32-vs-fp32 vote %.3f; %.2f total %.3f; %.2f | bf16-vs-fp32 vote %.3f; %.2f total %.3f; %.2f"
+          % (a[:4, 1].mean(), a[-8:, 1].mean(), a2[:4, 1].mean(), a2[-8:, 1].mean(), b[:4, 1].mean(), b[-8:, 1].mean(),
+             self_med[0], dev(a, a2)[:, 0].max(), self_med[1], dev(a, a2)[:, 1].max(),
+             bf_med[0], dev(a, b)[:, 0].max(), bf_med[1], dev(a, b)[:, 1].max()))
+    assert np.isfinite(b).all()
+    assert dev(a, b)[0, 1] <= 0.05 and dev(a, b)[0, 0] <= 0.03          # the first step: same weights
+    assert bf_med[0] <= max(TRAJ_TOL_VOTE, 3.0 * self_med[0]), (bf_med, self_med)
+    assert bf_med[1] <= max(TRAJ_TOL_TOTAL, 3.0 * self_med[1]), (bf_med, self_med)
+    lo, hi = min(a[-8:, 1].mean(), a2[-8:, 1].mean()), max(a[-8:, 1].mean(), a2[-8:, 1].mean())
+    assert 0.6 * lo <= b[-8:, 1].mean() <= 1.4 * hi, (b[-8:, 1].mean(), lo, hi)
+
+
+# Measured on MI355X (tools runs of this test's loop, round 4): two fp32 runs of the SAME 30 steps differ
+# per step by 1.2-2.9 % (vote loss) and 6-9 % (total loss) in the median, and by up to 4.7x on single
+# steps (the number of positive proposals is a discrete function of the predicted votes; the order of
+# the fp32 atomics decides on which side of the 0.3 m threshold a proposal lands).  bf16 against fp32:
+# 1.6-2.8 % / 10-14 % - the band a second fp32 run would need as well, which is what is asserted.
+TRAJ_TOL_VOTE = 0.05
+TRAJ_TOL_TOTAL = 0.2

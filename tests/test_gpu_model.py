@@ -214,90 +214,110 @@ def test_hot_path_vs_oracle_full_config_batch_8():
             cap=GRAD_CAP["full8"])
 
 
-@pytest.fixture
-def bf16_mode():
+# ---- BASELINE configs[3]: the bf16 compute mode against the bf16-EMULATING oracle ------------------------
+# The reference has no such variant (fp16_enabled = False, class_agnostic_vote_head.py:384), so the burden
+# of proof is here.  Truth = oracle/emulate.py: the same oracle model rounding the operands of every dense
+# contraction to bf16 exactly where the kernels do (forward and backward, incl. the product's factored
+# first SA layer and sample-then-project attention), in float64 ("emu64").  Its float32 twin ("emu32")
+# measures what ANY fp32-accumulating implementation of those rounding points can be expected to deviate:
+# round-to-bf16 is discontinuous, an operand within fp32 noise d of a rounding boundary flips by one bf16
+# ulp e = 2^-8, so every rounding point turns d ~ 1e-7 into sqrt(d e) ~ 2e-5 of new noise, which the 30
+# train-mode BN layers then amplify like any other.  The HIP path must be no further from
+# emu64 than a small multiple of emu32 - tensor by tensor, forward and gradient - and emu64 must explain
+# most of its distance to the plain fp64 oracle (a wrong rounding point or a wrong-but-finite bf16
+# backward fails both).
+BF16_MULT = 2.5          # per tensor: err(HIP, emu64) <= max(floor, BF16_MULT x err(emu32, emu64))
+BF16_MEDIAN_MULT = 1.5   # medians over all gradient tensors
+
+
+def _bf16_parity(cfg, case, label):
     from demf_amd import ops
+    E64, E32 = P.emulated_runs(cfg, case)
+    T = case["truth"]
     ops.set_compute_dtype("bf16")
-    yield
-    ops.set_compute_dtype("f32")
+    try:
+        G = _gpu_run(cfg, case)
+    finally:
+        ops.set_compute_dtype("f32")
+    rel = lambda a, t: ((a.detach().double().cpu() - t.double()).norm() / t.double().norm()).item()
+    # coordinate-only stages are mode-independent: FPS / ball query / 3-NN see coordinates only, and with
+    # sample_mod = 'seed' so does the proposal FPS
+    for k in ("seed_indices", "aggregated_indices"):
+        np.testing.assert_array_equal(G["preds"][k].cpu().numpy(), E64["preds"][k].numpy())
+    assert rel(G["preds"]["seed_points"], E64["preds"]["seed_points"]) == 0.0
+    report, bad = [], []
+
+    def check(name, g, e32, e64, t, floor):
+        eg, ec, et = rel(g, e64), rel(e32, e64), rel(g, t)
+        report.append((name, eg, ec, et))
+        if eg > max(floor, BF16_MULT * ec):
+            bad.append("%s: HIP-vs-emu64 %.2e, emu32-vs-emu64 %.2e (x%.1f)" % (name, eg, ec, eg / max(ec, 1e-30)))
+    for k in ("vote_points", "vote_features", "aggregated_points"):
+        check(k, G["preds"][k], E32["preds"][k], E64["preds"][k], T["preds"][k], 2e-3)
+    for i, d in enumerate(E64["preds"]["decode_res_all"]):
+        for k in d:
+            check("decode%d.%s" % (i, k), G["preds"]["decode_res_all"][i][k], E32["preds"]["decode_res_all"][i][k],
+                  d[k], T["preds"]["decode_res_all"][i][k], 2e-3)
+    fwd = list(report)
+    for k in E64["losses"]:
+        lg, l64, l32 = G["losses"][k].item(), E64["losses"][k].item(), E32["losses"][k].item()
+        if abs(lg - l64) > max(1e-3 * abs(l64), BF16_MULT * abs(l32 - l64)):
+            bad.append("loss %s: HIP %.6f emu64 %.6f emu32 %.6f" % (k, lg, l64, l32))
+    gmax = max(v.norm().item() for v in E64["grads"].values())
+    assert sorted(E64["grads"]) == sorted(G["grads"])
+    grows = []
+    for n, g in E64["grads"].items():
+        if g.norm().item() < 1e-6 * gmax:               # conv biases shadowed by BatchNorm: exact zeros + noise
+            assert G["grads"][n].double().norm().item() <= 1e-3 * gmax, n
+            continue
+        eg, ec = rel(G["grads"][n], g), rel(E32["grads"][n], g)
+        grows.append((n, eg, ec, rel(G["grads"][n], T["grads"][n])))
+        if eg > max(1e-2, BF16_MULT * ec):
+            bad.append("grad %s: HIP-vs-emu64 %.2e, emu32-vs-emu64 %.2e (x%.1f)" % (n, eg, ec, eg / max(ec, 1e-30)))
+    med = [float(np.median([r[i] for r in grows])) for i in (1, 2, 3)]
+
+    def cos(A, B):
+        a = torch.cat([A[n].double().cpu().reshape(-1) for n in B])
+        b = torch.cat([B[n].double().reshape(-1) for n in B])
+        return (a @ b / (a.norm() * b.norm())).item()
+    c_ge, c_ce, c_gt = cos(G["grads"], E64["grads"]), cos(E32["grads"], E64["grads"]), cos(G["grads"], T["grads"])
+    worst = sorted(grows, key=lambda r: -r[1] / max(r[2], 1e-30))[:5]
+    print("[bf16 %s] seed %d: forward (name, HIP-vs-emu64, emu32-vs-emu64, HIP-vs-fp64) %s" %
+          (label, case["seed"], [(n, "%.1e" % a, "%.1e" % b_, "%.1e" % c) for n, a, b_, c in fwd[:3]]))
+    print("[bf16 %s] gradients: median rel-L2 HIP-vs-emu64 %.2e, emu32-vs-emu64 %.2e, HIP-vs-fp64 %.2e; "
+          "whole-gradient cosine HIP.emu64 %.3f, emu32.emu64 %.3f, HIP.fp64 %.3f; worst ratios %s" %
+          (label, med[0], med[1], med[2], c_ge, c_ce, c_gt,
+           [(n, "%.2e" % a, "%.2e" % b_) for n, a, b_, _ in worst]))
+    assert all(torch.isfinite(g).all() for g in G["grads"].values())
+    assert not bad, "bf16 parity vs the emulating oracle (%s):\n  " % label + "\n  ".join(bad)
+    assert med[0] <= max(1e-2, BF16_MEDIAN_MULT * med[1]), med
+    # the direction of the whole gradient survives at least as well as in the fp32-accumulating twin
+    assert c_ge >= c_ce - 0.08, (c_ge, c_ce)
+    # and the emulation explains the bulk of the mode's deviation from the fp64 oracle
+    vp = [r for r in fwd if r[0] == "vote_points"][0]
+    assert vp[1] <= 0.5 * vp[3], vp
+    # (for the gradients too - unless the fp32-accumulating twin itself is decorrelated from emu64, as at
+    # the full size: median rel-L2 ~ sqrt(2) for ANY pair of implementations, nothing left to explain)
+    assert med[0] <= 0.75 * med[2] or med[2] <= 1e-2 or med[1] >= 1.0, med
 
 
-# Measured on MI355X for the qualified full-size B=8 seed (round 3, printed by the test below); the
-# asserted bounds are 2x these.  bf16 operands carry 8 significand bits: a shared-MLP output is
-# ~2e-3 relative per layer, and the 30 train-mode BN layers of the untrained, randomly weighted
-# network amplify input noise ~400x towards the heads.
-def test_hot_path_bf16_full_config_batch_8(bf16_mode):
-    """BASELINE configs[3] per GPU at full size: bf16 compute mode, 8 scenes x 20 000 points x
-    18 609 image tokens, against the fp64 oracle on the SAME qualified input as the fp32 test above
-    (the oracle runs are shared through parity_tools' session cache): coordinate-only indices
-    bit-exact, every tensor up to the vote stage, the losses and EVERY gradient tensor within a
-    stated bf16 bound (2x the measured deviation, printed)."""
+def test_hot_path_bf16_vs_emulating_oracle_mid_size():
+    from demf_amd.config import BackboneCfg, DeMFCfg, HeadCfg
+    cfg = DeMFCfg(backbone=BackboneCfg(num_points=(1024, 512, 256, 128)),
+                  head=HeadCfg(num_proposal=128, attn_dropout=0.0, ffn_dropout=0.0))
+    case = P.qualified_case(cfg, 2, 6000, *MID, seeds=SEEDS["mid"])
+    _bf16_parity(cfg, case, "mid")
+
+
+def test_hot_path_bf16_vs_emulating_oracle_full_config_batch_8():
+    """BASELINE configs[3] per GPU at full size: 8 scenes x 20 000 points x 18 609 image tokens, on the
+    SAME qualified input as the fp32 B=8 test above (the plain oracle runs are shared through
+    parity_tools' session cache)."""
     from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
     cfg = DeMFCfg(head=HeadCfg(attn_dropout=0.0, ffn_dropout=0.0))
     case = P.qualified_case(cfg, 8, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2],
                             seeds=SEEDS["full8"])
-    T = case["truth"]
-    G = _gpu_run(cfg, case)
-    # FPS / ball-query / 3-NN see coordinates only: the backbone's index lists are mode-independent
-    np.testing.assert_array_equal(G["preds"]["seed_indices"].cpu().numpy(), T["preds"]["seed_indices"].numpy())
-    rel = lambda a, t: ((a.detach().double().cpu() - t.double()).norm() / t.double().norm()).item()
-    stage = {k: rel(G["preds"][k], T["preds"][k]) for k in ("seed_points", "vote_points", "vote_features")}
-    # the vote-aggregation FPS runs on PREDICTED coordinates (vote_points): its picks may differ in
-    # bf16, so tensors behind it are compared through the loss / gradients only
-    same_agg = bool((G["preds"]["aggregated_indices"].cpu() == T["preds"]["aggregated_indices"]).all())
-    loss_g = sum(v.item() for v in G["losses"].values())
-    loss_t = sum(v.item() for v in T["losses"].values())
-    per_loss = {k: abs(G["losses"][k].item() - T["losses"][k].item()) / max(abs(T["losses"][k].item()), 1e-6)
-                for k in T["losses"]}
-    grads = {n: rel(G["grads"][n], g) for n, g in T["grads"].items()
-             if g.norm().item() > 1e-6 * max(v.norm().item() for v in T["grads"].values())}
-    worst = sorted(grads.items(), key=lambda kv: -kv[1])[:8]
-    gn_g = np.sqrt(sum(v.double().pow(2).sum().item() for v in G["grads"].values()))
-    gn_t = np.sqrt(sum(v.pow(2).sum().item() for v in T["grads"].values()))
-    dot = sum((G["grads"][n].double().cpu() * g.double()).sum().item() for n, g in T["grads"].items())
-    cosine = dot / (gn_g * gn_t)
-    # per stage: how far the gradient direction survives (cosine of the concatenated tensors)
-    def stage_cos(prefix):
-        names = [n for n in T["grads"] if n.startswith(prefix)]
-        a = torch.cat([G["grads"][n].double().cpu().reshape(-1) for n in names])
-        b = torch.cat([T["grads"][n].double().reshape(-1) for n in names])
-        return (a @ b / (a.norm() * b.norm())).item()
-    stages = {k: stage_cos(k) for k in ("pts_backbone.SA_modules.0", "pts_backbone.SA_modules.3",
-                                        "pts_backbone.FP_modules", "pts_bbox_head.vote_module",
-                                        "pts_bbox_head.vote_aggregation", "pts_bbox_head.decoder",
-                                        "pts_bbox_head.conv_pred")}
-    print("[bf16 full B=8] gradient cosine vs fp64: whole %.4f; per stage %s"
-          % (cosine, {k: "%.3f" % v for k, v in stages.items()}))
-    print("[bf16 full B=8] seed %d; vote-stage rel-L2 %s; aggregated_indices identical: %s; total loss "
-          "%.5f vs %.5f; per-loss rel %s; gradient norm %.4e vs %.4e; median gradient rel-L2 %.3e; worst %s"
-          % (case["seed"], {k: "%.2e" % v for k, v in stage.items()}, same_agg, loss_g, loss_t,
-             {k: "%.2e" % v for k, v in per_loss.items()}, gn_g, gn_t,
-             float(np.median(list(grads.values()))), [(n, "%.2e" % v) for n, v in worst]))
-    assert all(torch.isfinite(g).all() for g in G["grads"].values())
-    assert stage["seed_points"] == 0.0                        # gathered coordinates: exact
-    assert stage["vote_points"] <= BF16_BOUNDS["vote_points"], stage
-    assert stage["vote_features"] <= BF16_BOUNDS["vote_features"], stage
-    assert abs(loss_g - loss_t) <= BF16_BOUNDS["loss"] * abs(loss_t), (loss_g, loss_t)
-    assert max(per_loss.values()) <= BF16_BOUNDS["per_loss"], per_loss
-    assert abs(gn_g - gn_t) <= BF16_BOUNDS["grad_norm"] * gn_t, (gn_g, gn_t)
-    assert float(np.median(list(grads.values()))) <= BF16_BOUNDS["grad_median"], worst
-    assert worst[0][1] <= BF16_BOUNDS["grad_worst"], worst
-    assert stages["pts_bbox_head.conv_pred"] >= BF16_BOUNDS["conv_pred_cosine"], stages
-
-
-# 2x the deviations measured on MI355X in round 3 (two runs; the print above; DESIGN.md section 4):
-# vote_points 4.1e-2, vote_features 1.18e-1, total loss -2.5 / -2.6 %, worst single loss 6.6 / 6.8 %,
-# gradient norm -7 / -18 / -9 %.  PER-TENSOR GRADIENTS (three runs): median rel-L2 1.31-1.43, worst
-# 1.63-2.26, cosine of the whole gradient vs fp64 = -0.03 ... -0.07 (conv_pred heads 0.64-0.69, decoder
-# 0.03-0.08, everything upstream ~0): with
-# seeded RANDOM weights this 30-BN-layer network amplifies forward noise into the gradient by ~1e6 (fp32
-# itself: 6e-8 -> up to 5e-2, test above), so bf16's 4e-3 operand rounding decorrelates every gradient
-# upstream of the prediction heads - a property of the untrained network, the bf16 kernels themselves
-# are pinned against bf16-emulating references in tests/test_gpu_bf16.py.  rel-L2 of two unrelated
-# vectors of equal norm is sqrt(2): the per-tensor bounds below only exclude blow-ups; the direction
-# is asserted where it exists (the heads).
-BF16_BOUNDS = dict(vote_points=8.7e-2, vote_features=0.26, loss=0.06, per_loss=0.14, grad_norm=0.4,
-                   grad_median=2.9, grad_worst=4.6, conv_pred_cosine=0.32)
+    _bf16_parity(cfg, case, "full B=8")
 
 
 # Seeds to try, in order.  The first entries were found by running the (oracle-only) qualification
