@@ -1071,6 +1071,13 @@ __device__ __forceinline__ void fr_mfma(f32x16& acc, const bf16x8 (&a)[P], const
 template <int NTN, int KT, bool POOL, int CM, int ST = 0>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three-term
 __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   constexpr bool XB = (ST & 1) != 0, YB = (ST & 2) != 0;
+  // ST bit 2 (pooled launches): the raw output is NOT stored at all - the backward of a pooled last
+  // layer can be written without it (csrc/mlp_bwd.hip mlp_bwd_pool_kernel): what leaves the kernel is the
+  // column statistics and, per group and channel, the selected extremum + its row.  Channels with
+  // gamma == 0 (constant activation: upstream's max-pool picks slot 0) then report slot 0 and ITS raw
+  // value, which the BN backward needs for dgamma and could otherwise only gather from Y.
+  constexpr bool NOY = (ST & 4) != 0;
+  static_assert(!NOY || (POOL && !YB), "no-store form: pooled launches, fp32 bookkeeping");
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32, KB = K * 2;
   constexpr int KS = K / 16;                       // MFMA K steps
@@ -1105,11 +1112,14 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   const float4 sc = *reinterpret_cast<const float4*>(s_vec + 4 * c4);
   const float4 sh = *reinterpret_cast<const float4*>(s_vec + K + 4 * c4);
   char* my_a = s_a + wave * P * 32 * KB;
-  unsigned selbits = 0;
+  unsigned selbits = 0, zbits = 0;
   if constexpr (POOL) {
 #pragma unroll
-    for (int nt = 0; nt < NTN; ++nt)
-      if (p.fin.gamma[nt * 32 + lr] < 0.f) selbits |= 1u << nt;
+    for (int nt = 0; nt < NTN; ++nt) {
+      const float gm = p.fin.gamma[nt * 32 + lr];
+      if (gm < 0.f) selbits |= 1u << nt;
+      if (NOY && gm == 0.f) zbits |= 1u << nt;
+    }
   }
   float cs1[NTN], cs2[NTN];
 #pragma unroll
@@ -1192,7 +1202,9 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
 #pragma unroll
       for (int nt = 0; nt < NTN; ++nt) {
         const int col = nt * 32 + lr;
-        if constexpr (YB) {
+        if constexpr (NOY) {
+          // (nothing to store)
+        } else if constexpr (YB) {
           // lanes (2c, 2c+1): the even lane stores row r, the odd lane row r+1 of the register pair
           const bool odd = lane & 1;
           unsigned* yp = reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(p.Y) +
@@ -1241,6 +1253,13 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
               const float v = flip_sign(acc[0][nt][r], flip);
               const bool up = v > mx;
               mx = up ? v : mx; ax = up ? rho : ax;
+            }
+            if constexpr (NOY) {
+              if ((zbits >> nt) & 1u) {              // gamma == 0: slot 0 of the group and its raw value
+                const bool has0 = half == 0 && lh == 0;
+                mx = has0 ? flip_sign(acc[0][nt][0], flip) : -__builtin_inff();
+                ax = has0 ? 0 : 64;
+              }
             }
             const float omx = __shfl_xor(mx, 32);
             const int oax = __shfl_xor(ax, 32);
@@ -1362,13 +1381,13 @@ __global__ __launch_bounds__(256) void pool_select_k(long long RC, int C,
                                                      const float* __restrict__ ss,
                                                      float* __restrict__ out,
                                                      int* __restrict__ arg,
-                                                     float* __restrict__ yraw) {
+                                                     float* __restrict__ yraw, int slot0) {
   long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; t < RC; t += stride) {
     const int c = (int)(t % C);
     const float sc = ss[c], sh = ss[C + c];
-    const bool up = sc > 0.f;
+    const bool up = sc > 0.f || (slot0 && sc == 0.f);     // slot0: zero-scale channels carry slot 0 in pmax
     const float y = up ? pmax[t] : pmin[t];
     out[t] = fmaxf(0.f, __builtin_fmaf(y, sc, sh));
     const int a = sc == 0.f ? 0 : (up ? amax[t] : amin[t]);  // constant activation: first slot wins
@@ -1376,7 +1395,9 @@ __global__ __launch_bounds__(256) void pool_select_k(long long RC, int C,
     // the raw output AT the selected row (what the sparse BN-backward reduce would otherwise gather
     // from Y).  Zero scale: the selected row is slot 0, whose value is not among the extrema - NaN
     // tells the consumer to gather it (dgamma = sum dZ*xhat needs it even though gamma is 0).
-    if (yraw) yraw[t] = sc == 0.f ? __builtin_nanf("") : y;
+    // (``slot0``: the producer tracked slot 0 and its raw value for zero-gamma channels itself - the no-store
+    // forward, which has no Y to gather from)
+    if (yraw) yraw[t] = (sc == 0.f && !slot0) ? __builtin_nanf("") : y;
   }
 }
 
@@ -1863,6 +1884,10 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
         if constexpr (BF16 == 1 && POOL) {
           if (a.st == 3 && ntn == 4) { FRGO(4, 3); done = true; }
         }
+        if constexpr (POOL) {
+          // no-store form (either mode): SA1's last layer, 64-row groups
+          if (a.st == 4 && ntn == 4 && a.ns == 64) { FRGO(4, 4); done = true; }
+        }
         if (!done) {
           set_error("mlp_fwd_res: bf16 storage form st=%d N=%d pool=%d mode=%d not built", a.st, a.N, (int)POOL, BF16);
           return DEMF_EUNSUPPORTED;
@@ -2120,7 +2145,7 @@ static int mlp_gemm_fwd_pool_bn_impl(int R, int K, int N, int ldx, const float* 
     set_error("mlp_gemm_fwd_pool_bn: ns=%d with R=%d N=%d is not fused", ns, R, N);
     return DEMF_EUNSUPPORTED;
   }
-  DEMF_REQUIRE(X && Wt && Y && pro_scale_shift && pmax && amax && (pmin == nullptr) == (amin == nullptr),
+  DEMF_REQUIRE(X && Wt && (Y || st == 4) && pro_scale_shift && pmax && amax && (pmin == nullptr) == (amin == nullptr),
                "mlp_gemm_fwd_pool_bn: null pointer");
   if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
   MlpArgs a{};
@@ -2155,16 +2180,16 @@ extern "C" int demf_mlp_gemm_fwd_pool_bn_st(int R, int K, int N, int ldx, const 
                                             long long* num_batches_tracked, float* scale_shift,
                                             float* mean_invstd, const float* conv_bias, int store_flags,
                                             demf_stream_t stream) {
-  DEMF_REQUIRE(store_flags >= 1 && store_flags <= 3, "mlp_gemm_fwd_pool_bn_st: store_flags in 1..3");
+  DEMF_REQUIRE(store_flags >= 1 && store_flags <= 4, "mlp_gemm_fwd_pool_bn_st: store_flags in 1..4");
   return mlp_gemm_fwd_pool_bn_impl(R, K, N, ldx, (const float*)X, pro_scale_shift, Wt, (float*)Y, stats, ns,
                                    pmax, nullptr, amax, nullptr, gamma, beta, eps, momentum, running_mean,
                                    running_var, num_batches_tracked, scale_shift, mean_invstd, conv_bias,
                                    store_flags, stream);
 }
 
-extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,
-                                const int* amax, const int* amin, const float* scale_shift,
-                                float* out, int* arg, float* yraw, demf_stream_t stream) {
+static int pool_select_impl(int Rp, int C, const float* pmax, const float* pmin, const int* amax, const int* amin,
+                            const float* scale_shift, float* out, int* arg, float* yraw, int slot0,
+                            demf_stream_t stream) {
   DEMF_REQUIRE(Rp >= 0 && C >= 1, "pool_select: bad sizes");
   if (Rp == 0) return DEMF_OK;
   DEMF_REQUIRE(pmax && pmin && amax && amin && scale_shift && out && arg, "pool_select: null pointer");
@@ -2172,8 +2197,22 @@ extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* p
   long long g = (RC + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(pool_select_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, RC, C, pmax,
-                     pmin, amax, amin, scale_shift, out, arg, yraw);
+                     pmin, amax, amin, scale_shift, out, arg, yraw, slot0);
   return check_launch("pool_select");
+}
+
+extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,
+                                const int* amax, const int* amin, const float* scale_shift,
+                                float* out, int* arg, float* yraw, demf_stream_t stream) {
+  return pool_select_impl(Rp, C, pmax, pmin, amax, amin, scale_shift, out, arg, yraw, 0, stream);
+}
+
+// The same behind the no-store pooled forward (demf_mlp_gemm_fwd_pool_bn_st, store_flags = 4): channels
+// with a zero BN scale arrive with slot 0 and its raw value in pmax / amax, so yraw is complete (no NaN).
+extern "C" int demf_pool_select_slot0(int Rp, int C, const float* pmax, const int* amax,
+                                      const float* scale_shift, float* out, int* arg, float* yraw,
+                                      demf_stream_t stream) {
+  return pool_select_impl(Rp, C, pmax, pmax, amax, amax, scale_shift, out, arg, yraw, 1, stream);
 }
 
 extern "C" int demf_bn_finalize(int N, long long count, double* stats, const float* gamma,
@@ -2212,7 +2251,9 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
                               const BnVecFin& vf, demf_stream_t stream, int y_bf16 = 0) {
   DEMF_REQUIRE(R >= 0 && N >= 1, "bn_bwd_reduce: bad sizes R=%d N=%d", R, N);
   if (R == 0) return DEMF_OK;
-  DEMF_REQUIRE(Y && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
+  // (Y may be NULL in the pooled form when yraw is complete - the no-store forward, whose yraw never holds
+  // the NaN that asks for a gather from Y)
+  DEMF_REQUIRE((Y || (!G && yraw)) && scale_shift && mean_invstd && g12 && (G || (dP && arg && ns >= 1)),
                "bn_bwd_reduce: null pointer");
   // (a "pooled" layer with one sample per group - the row MLPs of the FP / vote / head modules - is the
   // dense case: dP is the upstream gradient of every row and the selected row is the row itself)

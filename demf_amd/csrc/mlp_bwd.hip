@@ -518,6 +518,434 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   }
 }
 
+// ---- backward of a POOLED last layer without its output -------------------------------------------
+// The last layer of a set-abstraction stack is  Y = A.W^T -> BN -> ReLU -> max over ns rows  with
+// A = act(Y_{L-1}) (R x K).  Its upstream gradient is sparse (one selected row per group and channel):
+// dZ[r,c] = dP[g,c] at r = arg[g,c] (gated by the ReLU), and the train-mode BN backward is
+// dY = gi*dZ + a*y + b per channel.  Everything the layer's backward needs from the dense part is a
+// function of A alone, because y = A.W^T:
+//     dA = dY.W        = (gi*dZ).W  +  A.M  +  v         M = W^T diag(a) W  (K x K),  v = b^T W
+//     dW = dY^T.A      = (gi*dZ)^T.A  +  diag(a) W (A^T A)  +  b (x) colsum(A)
+// so the (R x N) output - 537 MB at SA1, written once by the forward and read once here - is neither
+// stored nor read: the forward keeps the selected extremum, its row and its raw value per (group,
+// channel) only (mlp_fwd_res_kernel ST bit 2), and this kernel walks Y_{L-1} once.  Per 32-row slab:
+//   * A = relu(y*scale + shift), split once, as bf16 planes in both orientations ([row][k] for A.M,
+//     [k][row] for the Gram matrix A^T A) + an fp32 copy (the sparse products read single rows of it);
+//   * the slab's share of the sparse gradient (arg rows that fall into it) is scattered into zeroed
+//     [row][channel] planes and contracted with the register-resident W fragments on the MFMA as well
+//     (32 x 64 x 128: the same tile shape as before, but with no row of Y behind it); the entries are
+//     wiped again after the MFMA phase instead of re-zeroing 24 KB per slab;
+//   * S = (gi*dZ)^T.A is 128 row-AXPYs per group: 16 fp32 accumulators per thread, VALU;
+//   * half the MFMA work of mlp_bwd_fused_kernel: A.M (K x K) and A^T A (K x K) replace dY.W and dY^T.A
+//     (N x K each); the M fragments are formed once per workgroup from W and the vector a;
+//   * epilogue as mlp_bwd_fused_kernel's RED: dA rows out of the LDS tile + v, stored, and layer L-1's
+//     BN-backward sums taken on the way;
+//   * the workgroup's Gram tiles, S and colsum(A) leave as PLAIN stores into its own slot of a workspace
+//     (same-address fp32 atomics from 240 workgroups serialise: ~30 G/s chip-wide); pool_bwd_finish_k
+//     sums the slots and forms dW.
+// Shapes: N = 128, K = 64 (SA1), ns a multiple of 32 (a slab lies inside one group), R % 32 == 0.
+struct PoolBwdArgs {
+  int R, ns;
+  const float* Xp;    // (R x K) pre-BN output of layer L-1
+  const float* pss;   // [scale|shift] of layer L-1 (2K)
+  const float* pmi;   // [mean|invstd] of layer L-1 (2K)
+  const float* W;     // (N x K) weight of layer L
+  const float* vec;   // 5 x N backward vectors of layer L (scale, shift, gi, a, b)
+  const float* dP;    // (R/ns x N) gradient of the pooled output
+  const int* arg;     // (R/ns x N) selected row inside the group
+  const float* yraw;  // (R/ns x N) raw output at the selected row
+  float* dX;          // (R x K) gradient of layer L-1's activation
+  float* part;        // (gridDim.x x PB_NACC) per-workgroup partial sums: Gm (K x K) | S (N x K) | cs (K)
+  double* g12;        // layer L-1: sum dZ | sum dZ*xhat (2K), accumulated
+  BnVecFin vfin;      // layer L-1's backward vectors by the last workgroup (ticket != null)
+  int dbg;            // DEMF_PB_DBG phase-skip bits (measurement only)
+};
+constexpr int PB_N = 128, PB_K = 64, PB_RS = 64;       // rows per slab = rows per group
+constexpr int PB_NACC = PB_K * PB_K + PB_N * PB_K + PB_K;
+constexpr int PB_LDA = PB_K + 4;      // fp32 A copy: row stride (floats)
+constexpr int PB_LDM = PB_K + 4;      // fp32 M in LDS during the prologue
+
+// 128-byte LDS rows (64 bf16): 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7) (as fr_swz<128> in
+// csrc/mlp.hip: a ds_read_b128 lane group then touches every bank once)
+__device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// One 8-wave workgroup per CU on 64-row slabs (= one group at ns = 64): half the fold rounds per row and twice
+// the bytes in flight of a 32-row slab.  Measured alternatives (tools/pool_bwd_micro.py, SA1 shape, f32 mode):
+// 32-row slabs / 8 waves 476 us (one-slab prefetch of 8 KB: latency-bound), this form 384 us, two 4-wave
+// workgroups per CU with a two-deep register prefetch 395-431 us (the phases of a slab still add up: with
+// the three-term split the transform + fold + epilogue VALU work is as long as the MFMA work).
+template <int CM>
+__global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
+  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int N = PB_N, K = PB_K, NTN = N / 32, RS = PB_RS, NT = 512, NW = 8;
+  constexpr int QK = K / 4;                 // float4 per dX row (16): thread -> (row = tid / 16 (+32), col4 = tid % 16)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_vy = reinterpret_cast<float*>(smem);              // 5N
+  float* s_px = s_vy + 5 * N;                                // pss (2K) | pmi (2K)
+  float* s_v = s_px + 4 * K;                                 // v = b^T W (K)
+  char* s_base = reinterpret_cast<char*>(s_v + K);           // everything below is also prologue / flush scratch
+  char* s_dz = s_base;                                       // [NTN][P][64 rows x 64 B]   gi*dZ, [row][channel]
+  char* s_ar = s_dz + NTN * P * 4096;                        // [2 k-halves][P][64 rows x 64 B]  A, [row][k]
+  char* s_at = s_ar + 2 * P * 4096;                          // [P][64 k x 128 B]          A, [k][row]
+  float* s_yf = reinterpret_cast<float*>(s_at + P * 8192);   // [2 buffers][64][PB_LDA] fp32 RAW rows of Y_{L-1}
+  float* s_dx = s_yf + 2 * RS * PB_LDA;                      // [64][K] fp32 dA tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int drt = wave & 1, dct = (wave >> 1) & 1, dkh = wave >> 2;   // dA: tile (row half drt, column half dct), reduction half dkh
+  const int gti = (wave & 3) >> 1, gtj = wave & 1, gs = wave >> 2;    // Gram: tile (gti, gtj), row half gs of the slab
+  for (int i = tid; i < 5 * N; i += NT) s_vy[i] = p.vec[i];
+  for (int i = tid; i < 2 * K; i += NT) { s_px[i] = p.pss[i]; s_px[2 * K + i] = p.pmi[i]; }
+  // ---- prologue: M = W^T diag(a) W and v = b^T W from an fp32 copy of W in LDS (the plane regions serve
+  // as scratch: 32 KB of W + 17 KB of M) ---------------------------------------------------------------
+  float* s_w = reinterpret_cast<float*>(s_base);             // [N][K]
+  float* s_m = s_w + N * K;                                  // [K][PB_LDM]
+  for (int i = tid; i < N * K / 4; i += NT)
+    reinterpret_cast<float4*>(s_w)[i] = reinterpret_cast<const float4*>(p.W)[i];
+  __syncthreads();
+  {
+    const int k = tid >> 3, j0 = (tid & 7) * 8;
+    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float vk = 0.f;
+    for (int c = 0; c < ((p.dbg & 32) ? 1 : N); ++c) {
+      const float wa = s_w[c * K + k] * s_vy[3 * N + c];
+      const float4 w0 = *reinterpret_cast<const float4*>(s_w + c * K + j0);
+      const float4 w1 = *reinterpret_cast<const float4*>(s_w + c * K + j0 + 4);
+      m[0] = __builtin_fmaf(wa, w0.x, m[0]); m[1] = __builtin_fmaf(wa, w0.y, m[1]);
+      m[2] = __builtin_fmaf(wa, w0.z, m[2]); m[3] = __builtin_fmaf(wa, w0.w, m[3]);
+      m[4] = __builtin_fmaf(wa, w1.x, m[4]); m[5] = __builtin_fmaf(wa, w1.y, m[5]);
+      m[6] = __builtin_fmaf(wa, w1.z, m[6]); m[7] = __builtin_fmaf(wa, w1.w, m[7]);
+      if ((tid & 7) == 0) vk = __builtin_fmaf(s_vy[4 * N + c], s_w[c * K + k], vk);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_m[k * PB_LDM + j0 + e] = m[e];
+    if ((tid & 7) == 0) s_v[k] = vk;
+  }
+  __syncthreads();
+  // B fragments, resident for the whole launch.  A.M: B^T[col j][red k] = M[k][j], this wave's k half (two steps)
+  bf16x8 mf[2][P];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    __bf16 t[8][P];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_planes<P>(s_m[(32 * dkh + 16 * u + 8 * lh + e) * PB_LDM + 32 * dct + lr], t[e]);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mf[u][q][e] = t[e][q];
+  }
+  // (gi*dZ).W: B^T[col j = k][red = channel], this wave's channel half (four 16-channel steps)
+  bf16x8 wf[4][P];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    __bf16 t[8][P];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_planes<P>(s_w[(64 * dkh + 16 * u + 8 * lh + e) * K + 32 * dct + lr], t[e]);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wf[u][q][e] = t[e][q];
+  }
+  __syncthreads();
+  // the gi*dZ planes start (and are kept) all-zero
+  for (int i = tid; i < NTN * P * 4096 / 16; i += NT)
+    reinterpret_cast<uint4*>(s_dz)[i] = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 gacc;                                               // this wave's share of its Gram tile
+#pragma unroll
+  for (int r = 0; r < 16; ++r) gacc[r] = 0.f;
+  float sacc[16];                                            // S[c][16*part ..): channel c = tid / 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sacc[i] = 0.f;
+  const int s_c = tid >> 2, s_part = tid & 3;
+  // transform map: thread -> channel pair (2*t_k2, +1) of rows 4*t_rq .. 4*t_rq + 3
+  const int t_k2 = tid & 31, t_rq = tid >> 5;
+  const int e_cq = tid % QK, e_rl = tid / QK;                // epilogue: float4 column e_cq of rows e_rl, e_rl + 32
+  float es1[4] = {0.f, 0.f, 0.f, 0.f}, es2[4] = {0.f, 0.f, 0.f, 0.f}, ecs[4] = {0.f, 0.f, 0.f, 0.f};
+  float2 rx[4];
+  int r_arg = 0;                                             // channel s_c of the slab's group: selected row,
+  float r_y = 0.f, r_dp = 0.f;                               // raw output there, pooled gradient
+  // (all of a slab's operands are requested one slab ahead: the sparse entry's three words would
+  // otherwise be two dependent global-load latencies in front of every slab's barrier)
+  auto fetch = [&](int slab) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      rx[j] = *reinterpret_cast<const float2*>(p.Xp + (size_t)(slab * RS + 4 * t_rq + j) * K + 2 * t_k2);
+    const size_t o = (size_t)slab * N + s_c;                 // slab == group (ns == 64)
+    r_arg = p.arg[o];
+    r_y = p.yraw[o];
+    r_dp = p.dP[o];
+  };
+  const int nslab = p.R / RS;
+  int slab = blockIdx.x;
+  if (slab < nslab) fetch(slab);
+  __syncthreads();
+
+  for (int it = 0; slab < nslab; slab += gridDim.x, ++it) {
+    const int row0 = slab * RS;
+    float* yf = s_yf + (it & 1) * RS * PB_LDA;               // raw rows: two buffers, so that the next slab's [A]
+    //                                                          does not wait for this slab's epilogue
+    // ---- [A] raw rows (fp32) + A = relu(y*scale + shift), split ONCE (pairs along rows), planes in both
+    // orientations: [k][row] takes the pairs as they are, [row][k] re-pairs two channels with one v_perm --------
+    if (!(p.dbg & 1)) {
+      const int kk = 2 * t_k2;
+      unsigned pr[2][2][P];                                  // [channel e][row pair][plane]
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float sc = s_px[kk + e], sh = s_px[K + kk + e];
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = fmaxf(0.f, __builtin_fmaf(e == 0 ? rx[j].x : rx[j].y, sc, sh));
+        split_pair<P>(a[0], a[1], pr[e][0]);
+        split_pair<P>(a[2], a[3], pr[e][1]);
+        const int r = 4 * t_rq;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          *reinterpret_cast<uint2*>(s_at + q * 8192 + sw128(kk + e, r >> 3) + 2 * (r & 7)) = make_uint2(pr[e][0][q], pr[e][1][q]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * t_rq + j, jp = j >> 1;
+        *reinterpret_cast<float2*>(yf + r * PB_LDA + kk) = rx[j];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          *reinterpret_cast<unsigned*>(s_ar + ((kk >> 5) * P + q) * 4096 + swz(r, (kk & 31) >> 3) + 2 * (kk & 7)) =
+              (j & 1) ? pair_hi(pr[0][jp][q], pr[1][jp][q]) : pair_lo(pr[0][jp][q], pr[1][jp][q]);
+      }
+    }
+    // ---- the group's sparse entries: channel s_c's selected row ------------------------------------------
+    const int e_row = r_arg;
+    const float dzv = __builtin_fmaf(r_y, s_vy[s_c], s_vy[N + s_c]) > 0.f ? s_vy[2 * N + s_c] * r_dp : 0.f;
+    if (s_part == 0) {
+      __bf16 t[P];
+      split_planes<P>(dzv, t);
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        *reinterpret_cast<__bf16*>(s_dz + ((s_c >> 5) * P + q) * 4096 + swz(e_row, (s_c & 31) >> 3) + 2 * (s_c & 7)) = t[q];
+    }
+    // ---- [B] next slab's operands in flight underneath the MFMA phase --------------------------------------
+    if (slab + (int)gridDim.x < nslab) fetch(slab + (int)gridDim.x);
+    lds_barrier();
+    // ---- [C] S += (gi*dZ)^T.A (VALU, one raw row -> activation on the fly); dA partial and Gram tile (MFMA)
+    if (!(p.dbg & 16)) {
+      const float* yr = yf + e_row * PB_LDA + 16 * s_part;
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const float4 v = *reinterpret_cast<const float4*>(yr + 4 * i4);
+        const float4 sc = *reinterpret_cast<const float4*>(s_px + 16 * s_part + 4 * i4);
+        const float4 sh = *reinterpret_cast<const float4*>(s_px + K + 16 * s_part + 4 * i4);
+        sacc[4 * i4 + 0] = __builtin_fmaf(dzv, fmaxf(0.f, __builtin_fmaf(v.x, sc.x, sh.x)), sacc[4 * i4 + 0]);
+        sacc[4 * i4 + 1] = __builtin_fmaf(dzv, fmaxf(0.f, __builtin_fmaf(v.y, sc.y, sh.y)), sacc[4 * i4 + 1]);
+        sacc[4 * i4 + 2] = __builtin_fmaf(dzv, fmaxf(0.f, __builtin_fmaf(v.z, sc.z, sh.z)), sacc[4 * i4 + 2]);
+        sacc[4 * i4 + 3] = __builtin_fmaf(dzv, fmaxf(0.f, __builtin_fmaf(v.w, sc.w, sh.w)), sacc[4 * i4 + 3]);
+      }
+    }
+    f32x16 pa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pa[r] = 0.f;
+    if (!(p.dbg & 2)) {
+      bf16x8 a[P];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                          // A.M: k half dkh, steps 16u: region dkh, chunk 2u + lh
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          a[q] = *reinterpret_cast<const bf16x8*>(s_ar + (dkh * P + q) * 4096 + swz(32 * drt + lr, 2 * u + lh));
+        mfma_planes<P>(pa, a, mf[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                          // (gi*dZ).W: channel half dkh = slices 2dkh, 2dkh + 1
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          a[q] = *reinterpret_cast<const bf16x8*>(s_dz + ((2 * dkh + (u >> 1)) * P + q) * 4096 + swz(32 * drt + lr, 2 * (u & 1) + lh));
+        mfma_planes<P>(pa, a, wf[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                          // Gram tile: slab rows 32 * gs + 16u .. + 15
+        bf16x8 ga[P], gb[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          ga[q] = *reinterpret_cast<const bf16x8*>(s_at + q * 8192 + sw128(32 * gti + lr, 4 * gs + 2 * u + lh));
+          gb[q] = *reinterpret_cast<const bf16x8*>(s_at + q * 8192 + sw128(32 * gtj + lr, 4 * gs + 2 * u + lh));
+        }
+        mfma_planes<P>(gacc, ga, gb);
+      }
+    }
+    // the two partial tiles of a (row half, column half) meet in the fp32 LDS tile in two ordered rounds: in
+    // round j wave (.., dkh) owns row chunk (dkh + j) % 2 = 8 accumulator registers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = (dkh + j) & 1;
+      float* d = s_dx + (size_t)(32 * drt + 4 * lh) * K + 32 * dct + lr;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        if (cc != c) continue;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = cc * 8 + i;
+          float* q = d + ((r & 3) + 8 * (r >> 2)) * K;
+          if (j == 0) *q = pa[r];
+          else *q += pa[r];
+        }
+      }
+      lds_barrier();
+    }
+    // wipe this slab's entries: the gi*dZ planes are all-zero again (nobody reads them before the next barrier)
+    if (s_part == 0) {
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        *reinterpret_cast<unsigned short*>(s_dz + ((s_c >> 5) * P + q) * 4096 + swz(e_row, (s_c & 31) >> 3) + 2 * (s_c & 7)) = 0;
+    }
+    // ---- [D] dA rows out of the LDS tile (+ v), stored; layer L-1's sums and colsum(A) on the way ---------
+    {
+      const float4 vv = *reinterpret_cast<const float4*>(s_v + 4 * e_cq);
+      const float4 sc0 = *reinterpret_cast<const float4*>(s_px + 4 * e_cq);
+      const float4 sh0 = *reinterpret_cast<const float4*>(s_px + K + 4 * e_cq);
+      const float4 mu0 = *reinterpret_cast<const float4*>(s_px + 2 * K + 4 * e_cq);
+      const float4 is0 = *reinterpret_cast<const float4*>(s_px + 3 * K + 4 * e_cq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int rl = e_rl + 32 * i;
+        float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
+        dx.x += vv.x; dx.y += vv.y; dx.z += vv.z; dx.w += vv.w;
+        const float4 y = *reinterpret_cast<const float4*>(yf + rl * PB_LDA + 4 * e_cq);
+        const float z[4] = {__builtin_fmaf(y.x, sc0.x, sh0.x), __builtin_fmaf(y.y, sc0.y, sh0.y),
+                            __builtin_fmaf(y.z, sc0.z, sh0.z), __builtin_fmaf(y.w, sc0.w, sh0.w)};
+        const float dxa[4] = {dx.x, dx.y, dx.z, dx.w};
+        const float xh[4] = {(y.x - mu0.x) * is0.x, (y.y - mu0.y) * is0.y, (y.z - mu0.z) * is0.z, (y.w - mu0.w) * is0.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float dz = z[c] > 0.f ? dxa[c] : 0.f;
+          es1[c] += dz;
+          es2[c] = __builtin_fmaf(dz, xh[c], es2[c]);
+          ecs[c] += fmaxf(z[c], 0.f);
+        }
+        if (!(p.dbg & 8)) *reinterpret_cast<float4*>(p.dX + (size_t)(row0 + rl) * K + 4 * e_cq) = dx;
+      }
+    }
+    // (no barrier here: the next slab writes the OTHER raw-row buffer and planes that nobody reads before its
+    // barrier; the dA tile is only written again after that barrier; this slab's raw rows are overwritten two
+    // slabs on, behind three more barriers)
+  }
+
+  // ---- flush: plain stores into this workgroup's slot; column sums through LDS ---------------------------
+  __syncthreads();
+  float* slot = p.part + (size_t)blockIdx.x * PB_NACC;
+  {
+    // Gram tile (gti, gtj), this wave's row half: two waves share a tile -> fold through LDS first
+    float* s_g = reinterpret_cast<float*>(s_base);           // [2 halves][4 tiles][16][64]
+    float* mine = s_g + ((gs * 4 + (wave & 3)) * 16) * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = gacc[r];
+  }
+  __syncthreads();
+  {
+    const float* s_g = reinterpret_cast<const float*>(s_base);
+    if (gs == 0) {
+      const float* a0 = s_g + ((wave & 3) * 16) * 64;
+      const float* a1 = s_g + ((4 + (wave & 3)) * 16) * 64;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * gti + (r & 3) + 8 * (r >> 2) + 4 * lh, j = 32 * gtj + lr;
+        slot[i * K + j] = a0[r * 64 + lane] + a1[r * 64 + lane];
+      }
+    }
+  }
+#pragma unroll
+  for (int i4 = 0; i4 < 4; ++i4)
+    *reinterpret_cast<float4*>(slot + K * K + (size_t)s_c * K + 16 * s_part + 4 * i4) =
+        make_float4(sacc[4 * i4], sacc[4 * i4 + 1], sacc[4 * i4 + 2], sacc[4 * i4 + 3]);
+  // column sums: lanes l, l + 16, l + 32, l + 48 of a wave hold the same float4 column at different rows
+  constexpr int NV = 12;
+  float v[NV];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { v[c] = es1[c]; v[4 + c] = es2[c]; v[8 + c] = ecs[c]; }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int m = QK; m < 64; m <<= 1) v[i] += __shfl_xor(v[i], m);
+  __syncthreads();
+  float* s_red = reinterpret_cast<float*>(s_base);
+  if (lane < QK) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s_red[(wave * QK + lane) * NV + i] = v[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < QK * NV; i += NT) {
+    const int cq = i / NV, q = i % NV;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += s_red[(w * QK + cq) * NV + q];
+    const int col = 4 * cq + (q & 3);
+    if (q < 8) atomicAdd(p.g12 + (q >> 2) * K + col, (double)t);
+    else slot[K * K + N * K + col] = t;
+  }
+  if (p.vfin.ticket != nullptr) {          // layer L-1's backward vectors by the last workgroup (csrc/bn_fin.h)
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) s_last = last_workgroup(p.vfin.ticket, (int)gridDim.x, (int)blockIdx.x);
+    __syncthreads();
+    if (s_last) bn_vec_finalize(p.vfin, K, 0, K, p.g12, tid, NT);
+  }
+}
+
+// Sum the workgroups' slots and form the layer's weight gradient:
+//   dW = S + diag(a) W Gm + b (x) cs      (S already carries gi)
+// Blocks first reduce disjoint element ranges of the slots into ``tot`` (plain stores + a device fence),
+// the last block to finish then forms dW from the totals.
+__global__ __launch_bounds__(256) void pool_bwd_finish_k(int nslots, const float* __restrict__ part,
+                                                         float* __restrict__ tot, const float* __restrict__ W,
+                                                         const float* __restrict__ vec, float* __restrict__ dW,
+                                                         int* __restrict__ ticket) {
+  constexpr int N = PB_N, K = PB_K;
+  // 32 consecutive elements x 8 slot lanes per block: a thread adds every 8th slot (8 loads in flight), the
+  // slot lanes fold through LDS.  (One thread per element walking all ~480 slots was a chain of dependent
+  // cache misses: ~120 us for 24 MB.)
+  {
+    __shared__ float s_f[8][32];
+    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    for (int e0 = blockIdx.x * 32; e0 < PB_NACC; e0 += gridDim.x * 32) {
+      const int e = e0 + el;
+      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (e < PB_NACC) {
+        int s = sl;
+        for (; s + 56 < nslots; s += 64) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] += part[(size_t)(s + 8 * u) * PB_NACC + e];
+        }
+        for (; s < nslots; s += 8) t[0] += part[(size_t)s * PB_NACC + e];
+      }
+      s_f[sl][el] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+      __syncthreads();
+      if (sl == 0 && e < PB_NACC)
+        tot[e] = ((s_f[0][el] + s_f[1][el]) + (s_f[2][el] + s_f[3][el])) + ((s_f[4][el] + s_f[5][el]) + (s_f[6][el] + s_f[7][el]));
+      __syncthreads();
+    }
+  }
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int n = atomicAdd(ticket, 1);
+    s_last = n == (int)gridDim.x - 1;
+    if (s_last) atomicExch(ticket, 0);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  __shared__ float s_gm[K * (K + 1)];
+  __shared__ float s_cs[K];
+  for (int i = threadIdx.x; i < K * K; i += 256) s_gm[(i / K) * (K + 1) + i % K] = tot[i];
+  for (int i = threadIdx.x; i < K; i += 256) s_cs[i] = tot[K * K + N * K + i];
+  __syncthreads();
+  const float* va = vec + 3 * N;
+  const float* vb = vec + 4 * N;
+  for (int o = threadIdx.x; o < N * K; o += 256) {
+    const int c = o / K, k = o % K;
+    float t = 0.f;
+    for (int j = 0; j < K; ++j) t = __builtin_fmaf(W[c * K + j], s_gm[j * (K + 1) + k], t);
+    dW[o] = tot[K * K + o] + va[c] * t + vb[c] * s_cs[k];
+  }
+}
+
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
 static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int P = CM == 2 ? 3 : 1;
@@ -637,4 +1065,73 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   if (N == 256 && Kc == 128) { if (sparse) { FGO(8, 4, 1, true); } else { FGO(8, 4, 1, false); } }
   if (sparse) { FGO(2, 2, 2, true); } else { FGO(2, 2, 2, false); }
 #undef FGO
+}
+
+static int pool_bwd_grid(int R) {
+  static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
+  const int nslab = R / PB_RS;
+  return nslab < cus ? (nslab > 0 ? nslab : 1) : cus;
+}
+
+// floats of workspace demf_mlp_bwd_pool needs: one slot per workgroup + the totals
+extern "C" int demf_mlp_bwd_pool_ws(int R, long long* floats) {
+  DEMF_REQUIRE(R >= 0 && floats, "mlp_bwd_pool_ws: bad arguments");
+  *floats = (long long)(pool_bwd_grid(R) + 1) * PB_NACC;
+  return DEMF_OK;
+}
+
+// Backward of a pooled last layer WITHOUT its (R x N) output (see mlp_bwd_pool_kernel): N = 128, K = 64,
+// ns in {32, 64}, R a multiple of ns, compute modes 1 (bf16) / 2 (three-term fp32).  dX (R x K) and dW
+// (N x K) are written (not accumulated); g12_prev (2K doubles) is accumulated and - with gamma_prev - turned
+// into layer L-1's backward vectors by the last workgroup; ``workspace`` holds demf_mlp_bwd_pool_ws(R)
+// floats (scratch, no initialisation needed).  ``counter`` is one zero-initialised int that the call leaves
+// zeroed (the finish kernel's exit count).
+extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, const int* arg,
+                                 const float* yraw, const float* vec6, const float* W, const float* Yprev,
+                                 const float* scale_shift_prev, const float* mean_invstd_prev, float* dX,
+                                 float* dW, double* g12_prev, const float* gamma_prev, float* vec6_prev,
+                                 float* dgamma_prev, float* dbeta_prev, float* workspace, int* counter,
+                                 demf_stream_t stream) {
+  const int cm = compute_mode();
+  DEMF_REQUIRE((cm == 1 || cm == 2) && N == PB_N && K == PB_K && ns == PB_RS && R >= ns && R % ns == 0,
+               "mlp_bwd_pool: unsupported shape / mode R=%d N=%d K=%d ns=%d mode=%d", R, N, K, ns, cm);
+  DEMF_REQUIRE(dP && arg && yraw && vec6 && W && Yprev && scale_shift_prev && mean_invstd_prev && dX && dW &&
+                   g12_prev && workspace && counter, "mlp_bwd_pool: null pointer");
+  PoolBwdArgs a{};
+  a.R = R; a.ns = ns; a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.vec = vec6;
+  a.dP = dP; a.arg = arg; a.yraw = yraw; a.dX = dX; a.part = workspace; a.g12 = g12_prev;
+  { static const int dbg = [] { const char* v = getenv("DEMF_PB_DBG"); return v ? atoi(v) : 0; }(); a.dbg = dbg; }
+  if (gamma_prev != nullptr) {
+    DEMF_REQUIRE(vec6_prev && dgamma_prev && dbeta_prev, "mlp_bwd_pool: vectors of layer l-1 need all three outputs");
+    a.vfin = BnVecFin{(double)R, gamma_prev, scale_shift_prev, mean_invstd_prev, vec6_prev, dgamma_prev,
+                      dbeta_prev, sched_slot()};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int gx = pool_bwd_grid(R);
+  const int P = cm == 2 ? 3 : 1;
+  const size_t head = sizeof(float) * (5 * PB_N + 4 * PB_K + PB_K);                           // vectors
+  const size_t main = (size_t)(PB_N / 32) * P * 4096 + 2 * P * 4096 + (size_t)P * 8192 +       // planes
+                      sizeof(float) * (2 * PB_RS * PB_LDA + PB_RS * PB_K);                     // 2 x fp32 rows + dA tile
+  const size_t scratch = sizeof(float) * ((size_t)PB_N * PB_K + (size_t)PB_K * PB_LDM);      // prologue: W + M
+  const size_t fold = sizeof(float) * 8 * 16 * 64;                                            // flush: Gram fold
+  // (the prologue's W + M scratch and the flush's folds overlay the plane regions + the fp32 tiles)
+  size_t body = main > scratch ? main : scratch;
+  if (body < fold) body = fold;
+  const size_t bytes = head + body;
+  static bool configured[3] = {false, false, false};
+  if (!configured[cm]) {
+    const void* fn = cm == 1 ? reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<1>)
+                             : reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<2>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+      set_error("mlp_bwd_pool: cannot reserve %zu bytes of LDS", bytes);
+      return DEMF_ELAUNCH;
+    }
+    configured[cm] = true;
+  }
+  if (cm == 1) hipLaunchKernelGGL(mlp_bwd_pool_kernel<1>, dim3(gx), dim3(512), bytes, s, a);
+  else hipLaunchKernelGGL(mlp_bwd_pool_kernel<2>, dim3(gx), dim3(512), bytes, s, a);
+  if (int e = check_launch("mlp_bwd_pool")) return e;
+  float* tot = workspace + (size_t)gx * PB_NACC;
+  hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, tot, W, vec6, dW, counter);
+  return check_launch("pool_bwd_finish");
 }

@@ -785,6 +785,28 @@ def _bwd_fused_cols_ok(R, N, K, ns, sparse):
     return N == 256 and K > 128 and K % 128 == 0 and K <= 512
 
 
+# SA1's pooled last layer without its (R x 128) output: the forward does not store it, the backward is
+# written in terms of the layer's INPUT activations (csrc/mlp_bwd.hip mlp_bwd_pool_kernel).  A/B switch.
+_POOL_NOY = bool(int(os.environ.get("DEMF_POOL_NOY", "1")))
+_COUNTERS = {}
+
+
+def _zero_counter(device):
+    """One persistent zero-initialised int32 per device for kernels that leave their exit count zeroed."""
+    key = str(device)
+    if key not in _COUNTERS:
+        _COUNTERS[key] = torch.zeros(4, dtype=torch.int32, device=device)
+    return _COUNTERS[key]
+
+
+def _pool_noy_ok(R, ns, shapes, training, fuse_pool):
+    """Shapes / modes of the no-store pooled last layer (N = 128 <- K = 64, 64-row groups, enough rows for
+    the weight-resident forward)."""
+    return (_POOL_NOY and training and fuse_pool and _COMPUTE_MODE in (1, 2) and ns == 64 and R >= 16384
+            and R % 64 == 0 and len(shapes) >= 2 and shapes[-1] == (128, 64) and shapes[-2][0] == 64
+            and not _NO_BWD_FUSE and (_VEC_FIN & 1))
+
+
 _NO_GROUP_FIRST = bool(int(__import__('os').environ.get('DEMF_NO_GROUP_FIRST', '0')))  # A/B switch
 _NO_FUSED_POOL = bool(int(__import__('os').environ.get('DEMF_NO_FUSED_POOL', '0')))   # A/B switch
 
@@ -842,6 +864,9 @@ class _SharedMLPPool(Function):
                    and ld == 4 and not x.requires_grad and R >= 16384 and R % 64 == 0
                    and ns in (16, 32, 64) and not _NO_FUSED_POOL and not _NO_BWD_FUSE and not _NO_FIRST_FUSE
                    and [tuple(tensors[7 * l].shape) for l in range(3)] == [(64, 4), (64, 64), (128, 64)])
+        noy = geo is None and not store16 and L >= 2 and ld % 4 == 0 and _pool_noy_ok(
+            R, ns, [tuple(tensors[7 * l].shape) for l in range(L)], training,
+            training and not _NO_FUSED_POOL and ns in (16, 32, 64))
         # the self-cleaning fp64 accumulator holds every layer's statistics (no fill launches)
         ws = _accum64(2 * sum(tensors[7 * l].shape[0] for l in range(L)), dev) if training else None
         woff = 0
@@ -888,7 +913,14 @@ class _SharedMLPPool(Function):
                 pm = torch.empty((R // ns, N), dtype=torch.float32, device=dev)
                 am = torch.empty((R // ns, N), dtype=torch.int32, device=dev)
                 # (+ the BN bookkeeping, in the GEMM's last workgroup)
-                if store16:
+                if noy:
+                    # the raw (R x N) output is never written: its backward needs the layer's INPUT only
+                    Y = torch.empty((0, N), dtype=torch.float32, device=dev)
+                    _ffi.call("demf_mlp_gemm_fwd_pool_bn_st", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), None,
+                              _p(stats), ns, _p(pm), _p(am), _p(gamma), _p(beta), float(eps),
+                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi),
+                              _p(tensors[7 * l + 5]), 4, st)
+                elif store16:
                     _ffi.call("demf_mlp_gemm_fwd_pool_bn_st", R, K, N, cur_ld, _p(cur), _p(pro), _p(W), _p(Y),
                               _p(stats), ns, _p(pm), _p(am), _p(gamma), _p(beta), float(eps),
                               float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi),
@@ -929,8 +961,12 @@ class _SharedMLPPool(Function):
             # + the raw output at the selected rows: the sparse BN-backward reduce reads it
             # instead of gathering 2 M scattered values from the (R x C) output
             yraw = torch.empty((R // ns, C), dtype=torch.float32, device=dev)
-            _ffi.call("demf_pool_select", R // ns, C, _p(pm), _p(pm), _p(am), _p(am),
-                      _p(sss[-1]), _p(out), _p(arg), _p(yraw), st)
+            if noy:
+                _ffi.call("demf_pool_select_slot0", R // ns, C, _p(pm), _p(am), _p(sss[-1]), _p(out), _p(arg),
+                          _p(yraw), st)
+            else:
+                _ffi.call("demf_pool_select", R // ns, C, _p(pm), _p(pm), _p(am), _p(am),
+                          _p(sss[-1]), _p(out), _p(arg), _p(yraw), st)
         else:
             _ffi.call("demf_bnrelu_maxpool_fwd", R // ns, ns, C, _p(Ys[-1]), _p(sss[-1]), _p(out),
                       _p(arg), st)
@@ -941,6 +977,7 @@ class _SharedMLPPool(Function):
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
         ctx.store16 = store16
+        ctx.noy = noy
         ctx.geo = None
         if geo is not None:
             ctx.geo = (g_xyz, g_center, g_off, g_rows, float(g_radius), int(bool(g_norm)))
@@ -997,7 +1034,8 @@ class _SharedMLPPool(Function):
                 o64 += 2 * N
                 if G is None and (_VEC_FIN & 1):
                     # pooled last layer: sums + vectors in one launch
-                    _ffi.call("demf_bn_bwd_reduce_vectors", R, N, ns, _p(dP), _p(arg), _p(Ys[l]), _p(yraw),
+                    _ffi.call("demf_bn_bwd_reduce_vectors", R, N, ns, _p(dP), _p(arg),
+                              _p(Ys[l]) if Ys[l].numel() else None, _p(yraw),
                               _p(sss[l]), _p(mis[l]), _p(g12), _p(gammas[l]), _p(vec6), _p(dgamma),
                               _p(dbeta), int(Ys[l].dtype == torch.bfloat16), st)
                 else:
@@ -1049,6 +1087,30 @@ class _SharedMLPPool(Function):
             sparse = G is None
             first_here = l == 1 and fuse_first
             s16 = getattr(ctx, "store16", False)
+            if l == L - 1 and getattr(ctx, "noy", False):
+                # pooled last layer whose output was never stored: dX, dW and layer l-1's sums from its
+                # INPUT activations and the sparse pooled gradient (csrc/mlp_bwd.hip mlp_bwd_pool_kernel)
+                grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
+                if ctx.bias_shapes[l] is not None:
+                    grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])
+                    o32 += N
+                dX = torch.empty((R, K), dtype=torch.float32, device=dev)
+                g12p = ws64[o64:o64 + 2 * K]
+                o64 += 2 * K
+                vec_ready = (torch.empty(5 * K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev),
+                             torch.empty(K, dtype=torch.float32, device=dev))
+                nws = ctypes.c_longlong()
+                _ffi.call("demf_mlp_bwd_pool_ws", R, ctypes.addressof(nws))
+                wsp = torch.empty(nws.value, dtype=torch.float32, device=dev)
+                _ffi.call("demf_mlp_bwd_pool", R, N, K, ns, _p(dP), _p(arg), _p(yraw), _p(vec6), _p(W),
+                          _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p),
+                          _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]), _p(vec_ready[1]),
+                          _p(vec_ready[2]), _p(wsp), _p(_zero_counter(dev)), st)
+                if not (_VEC_FIN & 2):
+                    g12_pending = g12p
+                G = dX
+                continue
             if l > 0 and ldx == K and _bwd_fused_ok(N, K, ns, sparse, first_here):
                 # ONE pass over Y_l: dX (or, for SA1's layer 1, the raw sums of layer 0's whole
                 # backward instead of dX), dW and layer l-1's BN-backward sums (csrc/mlp_bwd.hip)

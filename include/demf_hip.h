@@ -289,6 +289,12 @@ int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin, const 
                      const int* amin, const float* scale_shift, float* out, int* arg, float* yraw,
                      demf_stream_t stream);
 
+/* demf_pool_select behind the NO-STORE pooled forward (demf_mlp_gemm_fwd_pool_bn_st with store_flags = 4:
+ * the raw (R x N) output of the pooled last layer is not written; zero-scale channels arrive with slot 0
+ * and its raw value in pmax / amax, so yraw is complete).                                              */
+int demf_pool_select_slot0(int Rp, int C, const float* pmax, const int* amax, const float* scale_shift,
+                           float* out, int* arg, float* yraw, demf_stream_t stream);
+
 /* stats (2N fp64) over `count` rows -> scale_shift (2N), mean_invstd (2N); updates the
  * running statistics (momentum, unbiased variance) and increments *num_batches_tracked when
  * they are non-NULL (BatchNorm's train-mode bookkeeping).  The consumed accumulator is left
@@ -433,6 +439,24 @@ int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, const float*
                             const float* mean_invstd_prev, float* dX, float* dW, double* g12_prev,
                             const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
                             float* dbeta_prev, demf_stream_t stream);
+
+/* Backward of a POOLED last layer without its (R x N) output (SA1: 537 MB neither written by the forward
+ * nor read here).  With y = A.W^T and dY = gi*dZ + a*y + b (train-mode BN), A = act(Y_{L-1}):
+ *     dA = (gi*dZ).W + A.(W^T diag(a) W) + b^T W,    dW = (gi*dZ)^T.A + diag(a) W (A^T A) + b (x) colsum(A)
+ * - functions of A and of the sparse pooled gradient (dP at the selected rows ``arg``, gated by the ReLU on
+ * ``yraw`` = the raw output at the selected row, from demf_pool_select_slot0) alone.
+ * N = 128, K = 64, ns = 64, R % 64 == 0, compute modes 1 / 2.  dX (R x K), dW (N x K) written;
+ * g12_prev (2K doubles, zeroed accumulator) accumulated and, with gamma_prev, turned into layer L-1's
+ * backward vectors by the last workgroup.  workspace: *floats of demf_mlp_bwd_pool_ws(R, &floats), scratch;
+ * counter: one zero-initialised int, left zeroed.  Replaces demf_mlp_bwd_fused for that layer
+ * (mmdet3d PointSAModule's shared MLP, demf/modeling/heads/class_agnostic_vote_head.py:383,
+ * configs/demf/demf_votenet.py:48-62).                                                                  */
+int demf_mlp_bwd_pool_ws(int R, long long* floats);
+int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, const int* arg, const float* yraw,
+                      const float* vec6, const float* W, const float* Yprev,
+                      const float* scale_shift_prev, const float* mean_invstd_prev, float* dX, float* dW,
+                      double* g12_prev, const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
+                      float* dbeta_prev, float* workspace, int* counter, demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */

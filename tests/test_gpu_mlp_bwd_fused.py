@@ -73,6 +73,9 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
     try:
         _ffi.call = spy
         ops._NO_BWD_FUSE = False
+        # (the no-store pooled last layer re-associates the backward: in the bf16 mode it rounds A and
+        # W^T diag(a) W where this comparison assumes dY and W - it has its own test below)
+        ops._POOL_NOY = mode == "f32"
         ops._FUSED_COLS_MIN_R = 16384          # (opt-in: DEMF_FUSED_COLS_MIN_R, measured neutral on the step)
         out_f, g_f = _run(x, layers, go, ns, xgrad)
         n_fused = calls.count("demf_mlp_bwd_fused")
@@ -84,6 +87,7 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
     finally:
         _ffi.call = orig
         ops._NO_BWD_FUSE = False
+        ops._POOL_NOY = True
         ops._FUSED_COLS_MIN_R = cols_min
         ops.set_compute_dtype("f32")
     assert n_fused + n_cols >= 1, "the case must exercise the fused kernel"
@@ -143,6 +147,7 @@ def test_bf16_row_storage_of_the_sa1_stack():
     def spy(name, *a):
         calls.append(name)
         return orig(name, *a)
+    no_store_default = ops._NO_BF16_STORE
     try:
         _ffi.call = spy
         ops._NO_BF16_STORE = False
@@ -150,11 +155,13 @@ def test_bf16_row_storage_of_the_sa1_stack():
         st_calls = [c for c in calls if c.endswith("_st")]
         calls.clear()
         ops._NO_BF16_STORE = True
+        ops._POOL_NOY = False            # fp32 rows, stored: the form the bf16 rows differ from by one rounding
         out_f, g_f = _run(x, layers, go, ns, False)
         assert not [c for c in calls if c.endswith("_st")]
     finally:
         _ffi.call = orig
-        ops._NO_BF16_STORE = False
+        ops._NO_BF16_STORE = no_store_default
+        ops._POOL_NOY = True
         ops.set_compute_dtype("f32")
     assert sorted(st_calls) == ["demf_mlp_gemm_fwd_bn_st", "demf_mlp_gemm_fwd_pool_bn_st"], st_calls
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
@@ -164,3 +171,62 @@ def test_bf16_row_storage_of_the_sa1_stack():
           % (rel(out_s, out_f), worst))
     assert worst <= 0.15, worst
     assert all(torch.isfinite(g).all() for g in g_s)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("Rp", [256, 700])
+def test_pooled_last_layer_without_its_output(Rp, mode):
+    """SA1's last layer (R x 64 -> 128, BN, ReLU, max over 64 rows) WITHOUT its (R x 128) output: the
+    forward does not store it (demf_mlp_gemm_fwd_pool_bn_st, store_flags 4), the backward
+    (demf_mlp_bwd_pool) is  dA = (gi dZ).W + A.(W^T diag(a) W) + b^T W,  dW = (gi dZ)^T.A + diag(a) W (A^T A)
+    + b (x) colsum(A) - algebraically the layer's backward, re-associated.  Against the stored-output path
+    (same forward arithmetic: identical outputs; gradients to fp32 re-association) and, in the fp32-grade
+    mode, against fp64 autograd.  Pooled-layer scales: positive, negative (minimum selected) and ZERO
+    (constant channel: slot 0 is the selected row and its raw value feeds dgamma)."""
+    from demf_amd import _ffi, ops
+    ns, ld, chans = 64, 4, (64, 64, 128)
+    x, layers, go = _make(Rp, ns, ld, chans, seed=900 + Rp)
+    layers[2][1][5] = -0.8
+    layers[2][1][9] = 0.0
+    layers[2][1][77] = 0.0
+    ops.set_compute_dtype(mode)
+    calls = []
+    orig = _ffi.call
+
+    def spy(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+    try:
+        _ffi.call = spy
+        ops._POOL_NOY = True
+        out_n, g_n = _run(x, layers, go, ns, False)
+        assert calls.count("demf_mlp_bwd_pool") == 1 and "demf_pool_select_slot0" in calls
+        calls.clear()
+        ops._POOL_NOY = False
+        out_s, g_s = _run(x, layers, go, ns, False)
+        assert "demf_mlp_bwd_pool" not in calls
+    finally:
+        _ffi.call = orig
+        ops._POOL_NOY = True
+        ops.set_compute_dtype("f32")
+    assert torch.equal(out_n, out_s)
+    names = [f"layer{l}.{n}" for l in range(3) for n in ("W", "gamma", "beta")]
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    tol = 1e-4 if mode == "f32" else 2e-2      # bf16: M = W^T diag(a) W and A are rounded where dY and W were
+    worst = max((rel(a, b), n) for n, a, b in zip(names, g_n, g_s))
+    print("no-store pooled layer vs stored (%s): worst gradient rel-L2 %.2e at %s" % (mode, *worst))
+    for n, a, b in zip(names, g_n, g_s):
+        assert rel(a, b) <= tol, (n, rel(a, b))
+    if mode == "f32":
+        xr = x.clone()
+        lr_ = [(W.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_())
+               for W, g, b in layers]
+        h = xr
+        for W, g, b in lr_:
+            h = F.relu(F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, 1e-5))
+        ref = h.view(Rp, ns, -1).max(1)[0]
+        ref.backward(go)
+        want = [t.grad for l in lr_ for t in l]
+        assert float((out_n.double().cpu() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.detach().abs().max()))
+        for n, a, b in zip(names, g_n, want):
+            assert rel(a.cpu(), b) <= 5e-3, (n, rel(a.cpu(), b))
