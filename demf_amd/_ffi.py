@@ -49,6 +49,7 @@ SIGNATURES = {
     "demf_proposal_targets": [_c_int] * 4 + [_c_float] * 3 + [_ptr] * 18,
     "demf_gt_prep": [_c_int] * 3 + [_ptr] * 10,
     "demf_pad_gt": [_c_int] * 2 + [_ptr] * 8,
+    "demf_query_pos_rows": [_c_int] * 2 + [_ptr] * 4,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
@@ -63,7 +64,7 @@ SIGNATURES = {
     "demf_mlp_gemm_fwd_pool_bn_st": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 4 + [_c_float, _c_float] + [_ptr] * 6 + [_c_int, _ptr],
     "demf_pool_select": [_c_int] * 2 + [_ptr] * 9,
     "demf_pool_select_slot0": [_c_int] * 2 + [_ptr] * 7,
-    "demf_mlp_bwd_pool": [_c_int] * 4 + [_ptr] * 18,
+    "demf_mlp_bwd_pool": [_c_int] * 4 + [_ptr] * 17,
     "demf_mlp_bwd_pool_ws": [_c_int, _ptr],
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 7,
     "demf_l2norm_rows_fwd": [_c_int] * 2 + [_ptr] * 4,

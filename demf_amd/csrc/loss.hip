@@ -467,6 +467,18 @@ __global__ void pad_gt_k(PadGtArgs a, float* __restrict__ gt, long long* __restr
   if (valid != nullptr) valid[i] = g < (n > 1 ? n : 1) ? 1 : 0;
 }
 
+// position-embedding input of a decoder layer: [base + reg[0:3] | reg[3:6] | 0 0] per proposal row
+__global__ void query_pos_rows_k(int R, int nreg, const float* __restrict__ reg, const float* __restrict__ base,
+                                 float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* g = reg + (size_t)r * nreg;
+  const float* b = base + (size_t)r * 3;
+  float4* o = reinterpret_cast<float4*>(out + (size_t)r * 8);
+  o[0] = make_float4(b[0] + g[0], b[1] + g[1], b[2] + g[2], g[3]);
+  o[1] = make_float4(g[4], g[5], 0.f, 0.f);
+}
+
 // objectness_weights = masks / (sum(masks) + 1e-6); box_loss_weights = obj / (sum(obj) + 1e-6)
 // (class_agnostic_vote_head.py:797-816), R <= a few thousand proposals: one workgroup.
 __global__ __launch_bounds__(1024) void target_weights_k(int R, const float* __restrict__ obj_mask,
@@ -659,6 +671,16 @@ extern "C" int demf_pad_gt(int B, int G, const int* counts, const int* box_dims,
   hipLaunchKernelGGL(pad_gt_k, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, gt_padded,
                      (long long*)labels_padded, valid);
   return check_launch("pad_gt");
+}
+
+extern "C" int demf_query_pos_rows(int R, int nreg, const float* reg_rows, const float* base_xyz,
+                                   float* out8, demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 0 && nreg >= 6, "query_pos_rows: bad sizes R=%d nreg=%d", R, nreg);
+  if (R == 0) return DEMF_OK;
+  DEMF_REQUIRE(reg_rows && base_xyz && out8, "query_pos_rows: null pointer");
+  hipLaunchKernelGGL(query_pos_rows_k, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, R, nreg, reg_rows,
+                     base_xyz, out8);
+  return check_launch("query_pos_rows");
 }
 
 extern "C" int demf_target_weights(int R, const float* objectness_masks,

@@ -555,13 +555,13 @@ struct PoolBwdArgs {
   const int* arg;     // (R/ns x N) selected row inside the group
   const float* yraw;  // (R/ns x N) raw output at the selected row
   float* dX;          // (R x K) gradient of layer L-1's activation
-  float* part;        // (gridDim.x x PB_NACC) per-workgroup partial sums: Gm (K x K) | S (N x K) | cs (K)
+  float* part;        // (gridDim.x x PB_NACC) per-workgroup contribution to dW (N x K)
   double* g12;        // layer L-1: sum dZ | sum dZ*xhat (2K), accumulated
   BnVecFin vfin;      // layer L-1's backward vectors by the last workgroup (ticket != null)
   int dbg;            // DEMF_PB_DBG phase-skip bits (measurement only)
 };
 constexpr int PB_N = 128, PB_K = 64, PB_RS = 64;       // rows per slab = rows per group
-constexpr int PB_NACC = PB_K * PB_K + PB_N * PB_K + PB_K;
+constexpr int PB_NACC = PB_N * PB_K;      // floats per workgroup slot
 constexpr int PB_LDA = PB_K + 4;      // fp32 A copy: row stride (floats)
 constexpr int PB_LDM = PB_K + 4;      // fp32 M in LDS during the prologue
 
@@ -826,33 +826,23 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
     // slabs on, behind three more barriers)
   }
 
-  // ---- flush: plain stores into this workgroup's slot; column sums through LDS ---------------------------
+  // ---- flush.  The layer's weight gradient is linear in this workgroup's sums:
+  //     dW_wg = S + diag(a) W Gm + b (x) cs        (S already carries gi)
+  // formed here and stored PLAINLY into the workgroup's slot (same-address fp32 atomics from 240 workgroups
+  // serialise: ~30 G/s chip-wide); pool_bwd_finish_k adds the slots up.  Column sums go through LDS.
   __syncthreads();
   float* slot = p.part + (size_t)blockIdx.x * PB_NACC;
+  float* s_g = reinterpret_cast<float*>(s_base);             // [2 halves][4 tiles][16][64]: the two row halves of a Gram tile
+  float* s_gm = s_g + 8 * 16 * 64;                           // [K][K + 1] Gm
+  float* s_cs = s_gm + K * (K + 1);                          // [K] colsum(A)
+  float* s_w2 = s_cs + K;                                    // [N][K] W
   {
-    // Gram tile (gti, gtj), this wave's row half: two waves share a tile -> fold through LDS first
-    float* s_g = reinterpret_cast<float*>(s_base);           // [2 halves][4 tiles][16][64]
     float* mine = s_g + ((gs * 4 + (wave & 3)) * 16) * 64;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = gacc[r];
   }
-  __syncthreads();
-  {
-    const float* s_g = reinterpret_cast<const float*>(s_base);
-    if (gs == 0) {
-      const float* a0 = s_g + ((wave & 3) * 16) * 64;
-      const float* a1 = s_g + ((4 + (wave & 3)) * 16) * 64;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = 32 * gti + (r & 3) + 8 * (r >> 2) + 4 * lh, j = 32 * gtj + lr;
-        slot[i * K + j] = a0[r * 64 + lane] + a1[r * 64 + lane];
-      }
-    }
-  }
-#pragma unroll
-  for (int i4 = 0; i4 < 4; ++i4)
-    *reinterpret_cast<float4*>(slot + K * K + (size_t)s_c * K + 16 * s_part + 4 * i4) =
-        make_float4(sacc[4 * i4], sacc[4 * i4 + 1], sacc[4 * i4 + 2], sacc[4 * i4 + 3]);
+  for (int i = tid; i < N * K / 4; i += NT)
+    reinterpret_cast<float4*>(s_w2)[i] = reinterpret_cast<const float4*>(p.W)[i];
   // column sums: lanes l, l + 16, l + 32, l + 48 of a wave hold the same float4 column at different rows
   constexpr int NV = 12;
   float v[NV];
@@ -862,13 +852,21 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int m = QK; m < 64; m <<= 1) v[i] += __shfl_xor(v[i], m);
-  __syncthreads();
-  float* s_red = reinterpret_cast<float*>(s_base);
+  float* s_red = s_w2 + N * K;                               // [NW][QK][NV]
   if (lane < QK) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) s_red[(wave * QK + lane) * NV + i] = v[i];
   }
   __syncthreads();
+  if (gs == 0) {
+    const float* a0 = s_g + ((wave & 3) * 16) * 64;
+    const float* a1 = s_g + ((4 + (wave & 3)) * 16) * 64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * gti + (r & 3) + 8 * (r >> 2) + 4 * lh, j = 32 * gtj + lr;
+      s_gm[i * (K + 1) + j] = a0[r * 64 + lane] + a1[r * 64 + lane];
+    }
+  }
   for (int i = tid; i < QK * NV; i += NT) {
     const int cq = i / NV, q = i % NV;
     float t = 0.f;
@@ -876,7 +874,31 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
     for (int w = 0; w < NW; ++w) t += s_red[(w * QK + cq) * NV + q];
     const int col = 4 * cq + (q & 3);
     if (q < 8) atomicAdd(p.g12 + (q >> 2) * K + col, (double)t);
-    else slot[K * K + N * K + col] = t;
+    else s_cs[col] = t;
+  }
+  __syncthreads();
+  {
+    // thread (c = tid / 4, part): dW_wg[c][16 part ..) = sacc + a_c * sum_j W[c][j] Gm[j][k] + b_c * cs[k]
+    const float va = s_vy[3 * N + s_c], vb = s_vy[4 * N + s_c];
+    float t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0.f;
+    for (int j = 0; j < K; ++j) {
+      const float w = s_w2[s_c * K + j];
+      const float* gr = s_gm + j * (K + 1) + 16 * s_part;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = __builtin_fmaf(w, gr[i], t[i]);
+    }
+#pragma unroll
+    for (int i4 = 0; i4 < 4; ++i4) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * i4 + e;
+        o[e] = sacc[i] + va * t[i] + vb * s_cs[16 * s_part + i];
+      }
+      *reinterpret_cast<float4*>(slot + (size_t)s_c * K + 16 * s_part + 4 * i4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
   if (p.vfin.ticket != nullptr) {          // layer L-1's backward vectors by the last workgroup (csrc/bn_fin.h)
     __shared__ int s_last;
@@ -887,63 +909,27 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
   }
 }
 
-// Sum the workgroups' slots and form the layer's weight gradient:
-//   dW = S + diag(a) W Gm + b (x) cs      (S already carries gi)
-// Blocks first reduce disjoint element ranges of the slots into ``tot`` (plain stores + a device fence),
-// the last block to finish then forms dW from the totals.
+// dW = the sum of the workgroups' slots.  32 consecutive elements x 8 slot lanes per block: a thread adds every
+// 8th slot (8 loads in flight), the slot lanes fold through LDS.  (One thread per element walking all the
+// slots was a chain of dependent cache misses: ~60 us.)
 __global__ __launch_bounds__(256) void pool_bwd_finish_k(int nslots, const float* __restrict__ part,
-                                                         float* __restrict__ tot, const float* __restrict__ W,
-                                                         const float* __restrict__ vec, float* __restrict__ dW,
-                                                         int* __restrict__ ticket) {
-  constexpr int N = PB_N, K = PB_K;
-  // 32 consecutive elements x 8 slot lanes per block: a thread adds every 8th slot (8 loads in flight), the
-  // slot lanes fold through LDS.  (One thread per element walking all ~480 slots was a chain of dependent
-  // cache misses: ~120 us for 24 MB.)
-  {
-    __shared__ float s_f[8][32];
-    const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    for (int e0 = blockIdx.x * 32; e0 < PB_NACC; e0 += gridDim.x * 32) {
-      const int e = e0 + el;
-      float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (e < PB_NACC) {
-        int s = sl;
-        for (; s + 56 < nslots; s += 64) {
+                                                         float* __restrict__ dW) {
+  __shared__ float s_f[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int e = blockIdx.x * 32 + el;
+  float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < PB_NACC) {
+    int s = sl;
+    for (; s + 56 < nslots; s += 64) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] += part[(size_t)(s + 8 * u) * PB_NACC + e];
-        }
-        for (; s < nslots; s += 8) t[0] += part[(size_t)s * PB_NACC + e];
-      }
-      s_f[sl][el] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-      __syncthreads();
-      if (sl == 0 && e < PB_NACC)
-        tot[e] = ((s_f[0][el] + s_f[1][el]) + (s_f[2][el] + s_f[3][el])) + ((s_f[4][el] + s_f[5][el]) + (s_f[6][el] + s_f[7][el]));
-      __syncthreads();
+      for (int u = 0; u < 8; ++u) t[u] += part[(size_t)(s + 8 * u) * PB_NACC + e];
     }
+    for (; s < nslots; s += 8) t[0] += part[(size_t)s * PB_NACC + e];
   }
-  __shared__ int s_last;
-  __threadfence();
+  s_f[sl][el] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int n = atomicAdd(ticket, 1);
-    s_last = n == (int)gridDim.x - 1;
-    if (s_last) atomicExch(ticket, 0);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  __shared__ float s_gm[K * (K + 1)];
-  __shared__ float s_cs[K];
-  for (int i = threadIdx.x; i < K * K; i += 256) s_gm[(i / K) * (K + 1) + i % K] = tot[i];
-  for (int i = threadIdx.x; i < K; i += 256) s_cs[i] = tot[K * K + N * K + i];
-  __syncthreads();
-  const float* va = vec + 3 * N;
-  const float* vb = vec + 4 * N;
-  for (int o = threadIdx.x; o < N * K; o += 256) {
-    const int c = o / K, k = o % K;
-    float t = 0.f;
-    for (int j = 0; j < K; ++j) t = __builtin_fmaf(W[c * K + j], s_gm[j * (K + 1) + k], t);
-    dW[o] = tot[K * K + o] + va[c] * t + vb[c] * s_cs[k];
-  }
+  if (sl == 0 && e < PB_NACC)
+    dW[e] = ((s_f[0][el] + s_f[1][el]) + (s_f[2][el] + s_f[3][el])) + ((s_f[4][el] + s_f[5][el]) + (s_f[6][el] + s_f[7][el]));
 }
 
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
@@ -1076,7 +1062,7 @@ static int pool_bwd_grid(int R) {
 // floats of workspace demf_mlp_bwd_pool needs: one slot per workgroup + the totals
 extern "C" int demf_mlp_bwd_pool_ws(int R, long long* floats) {
   DEMF_REQUIRE(R >= 0 && floats, "mlp_bwd_pool_ws: bad arguments");
-  *floats = (long long)(pool_bwd_grid(R) + 1) * PB_NACC;
+  *floats = (long long)pool_bwd_grid(R) * PB_NACC;
   return DEMF_OK;
 }
 
@@ -1084,19 +1070,18 @@ extern "C" int demf_mlp_bwd_pool_ws(int R, long long* floats) {
 // ns in {32, 64}, R a multiple of ns, compute modes 1 (bf16) / 2 (three-term fp32).  dX (R x K) and dW
 // (N x K) are written (not accumulated); g12_prev (2K doubles) is accumulated and - with gamma_prev - turned
 // into layer L-1's backward vectors by the last workgroup; ``workspace`` holds demf_mlp_bwd_pool_ws(R)
-// floats (scratch, no initialisation needed).  ``counter`` is one zero-initialised int that the call leaves
-// zeroed (the finish kernel's exit count).
+// floats (scratch, no initialisation needed).
 extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, const int* arg,
                                  const float* yraw, const float* vec6, const float* W, const float* Yprev,
                                  const float* scale_shift_prev, const float* mean_invstd_prev, float* dX,
                                  float* dW, double* g12_prev, const float* gamma_prev, float* vec6_prev,
-                                 float* dgamma_prev, float* dbeta_prev, float* workspace, int* counter,
+                                 float* dgamma_prev, float* dbeta_prev, float* workspace,
                                  demf_stream_t stream) {
   const int cm = compute_mode();
   DEMF_REQUIRE((cm == 1 || cm == 2) && N == PB_N && K == PB_K && ns == PB_RS && R >= ns && R % ns == 0,
                "mlp_bwd_pool: unsupported shape / mode R=%d N=%d K=%d ns=%d mode=%d", R, N, K, ns, cm);
   DEMF_REQUIRE(dP && arg && yraw && vec6 && W && Yprev && scale_shift_prev && mean_invstd_prev && dX && dW &&
-                   g12_prev && workspace && counter, "mlp_bwd_pool: null pointer");
+                   g12_prev && workspace, "mlp_bwd_pool: null pointer");
   PoolBwdArgs a{};
   a.R = R; a.ns = ns; a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.vec = vec6;
   a.dP = dP; a.arg = arg; a.yraw = yraw; a.dX = dX; a.part = workspace; a.g12 = g12_prev;
@@ -1113,7 +1098,7 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   const size_t main = (size_t)(PB_N / 32) * P * 4096 + 2 * P * 4096 + (size_t)P * 8192 +       // planes
                       sizeof(float) * (2 * PB_RS * PB_LDA + PB_RS * PB_K);                     // 2 x fp32 rows + dA tile
   const size_t scratch = sizeof(float) * ((size_t)PB_N * PB_K + (size_t)PB_K * PB_LDM);      // prologue: W + M
-  const size_t fold = sizeof(float) * 8 * 16 * 64;                                            // flush: Gram fold
+  const size_t fold = sizeof(float) * (8 * 16 * 64 + PB_K * (PB_K + 1) + PB_K + PB_N * PB_K + 8 * 16 * 12);   // flush
   // (the prologue's W + M scratch and the flush's folds overlay the plane regions + the fp32 tiles)
   size_t body = main > scratch ? main : scratch;
   if (body < fold) body = fold;
@@ -1131,7 +1116,6 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   if (cm == 1) hipLaunchKernelGGL(mlp_bwd_pool_kernel<1>, dim3(gx), dim3(512), bytes, s, a);
   else hipLaunchKernelGGL(mlp_bwd_pool_kernel<2>, dim3(gx), dim3(512), bytes, s, a);
   if (int e = check_launch("mlp_bwd_pool")) return e;
-  float* tot = workspace + (size_t)gx * PB_NACC;
-  hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, tot, W, vec6, dW, counter);
+  hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, dW);
   return check_launch("pool_bwd_finish");
 }

@@ -6,33 +6,36 @@ import torch
 
 
 class _Preds(dict):
-    """split_pred's result dict.  The reference also stores ``dir_res`` (coder.py:233); nothing on the
-    training path reads it (the losses take ``dir_res_norm``), so it is computed when first asked for
-    (decode, tests) instead of costing a launch + an autograd node per prediction head and step.
-    Every read access of the dict contract sees the key - ``d["dir_res"]``, ``.get``, ``in``, iteration,
-    ``keys / items / values``, ``dict(d)`` / ``{**d}`` and ``.copy()`` (which also keeps the scale)."""
-    dir_res_scale = None
+    """split_pred's result dict.  Two of the reference's entries are materialised on first access instead
+    of by split_pred itself: ``dir_res`` = dir_res_norm * (pi / num_dir_bins) (coder.py:233) and ``center``
+    = base_xyz + reg[..., 0:3] (coder.py:214).  Nothing on the fused training path reads them (the loss
+    kernels take the raw rows, the decoder's position embedding is built by ops.query_pos_rows), so they
+    would only cost a launch + an autograd node per prediction head and step.
+    Every read access of the dict contract sees the keys - ``d[k]``, ``.get``, ``in``, iteration,
+    ``keys / items / values``, ``dict(d)`` / ``{**d}`` and ``.copy()`` (which keeps the recipes)."""
 
-    def _lazy(self):
-        if self.dir_res_scale is not None and not dict.__contains__(self, "dir_res") \
-                and dict.__contains__(self, "dir_res_norm"):
-            dict.__setitem__(self, "dir_res", dict.__getitem__(self, "dir_res_norm") * self.dir_res_scale)
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.lazy = {}                 # key -> zero-argument callable
+
+    def _lazy(self, only=None):
+        for key in ([only] if only is not None else list(self.lazy)):
+            fn = self.lazy.get(key)
+            if fn is not None and not dict.__contains__(self, key):
+                dict.__setitem__(self, key, fn())
 
     def __missing__(self, key):
-        if key == "dir_res":
-            self._lazy()
-            if dict.__contains__(self, key):
-                return dict.__getitem__(self, key)
+        self._lazy(key)
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
         raise KeyError(key)
 
     def get(self, key, default=None):
-        if key == "dir_res":
-            self._lazy()
+        self._lazy(key)
         return dict.get(self, key, default)
 
     def __contains__(self, key):
-        if key == "dir_res":
-            self._lazy()
+        self._lazy(key)
         return dict.__contains__(self, key)
 
     def __iter__(self):
@@ -57,7 +60,7 @@ class _Preds(dict):
 
     def copy(self):
         out = _Preds(dict.items(self))
-        out.dir_res_scale = self.dir_res_scale
+        out.lazy = dict(self.lazy)
         return out
 
 
@@ -123,13 +126,14 @@ class DeMFClassAgnosticBBoxCoder:
         nb = self.num_dir_bins
         # (the reference materialises every slice with .contiguous(); here they stay views of the
         # raw conv rows - same values, no copy kernels; consumers that need dense memory copy)
-        results["center"] = base_xyz + reg_t[..., 0:3]
+        # "center" = base_xyz + reg[..., 0:3]: materialised on first access (see _Preds)
+        results.lazy["center"] = lambda: base_xyz + reg_t[..., 0:3]
         results["size"] = reg_t[..., 3:6]
         results["dir_class"] = reg_t[..., 6:6 + nb]
         dir_res_norm = reg_t[..., 6 + nb:6 + 2 * nb]
         results["dir_res_norm"] = dir_res_norm
         # "dir_res" = dir_res_norm * (pi / nb) is only read by decode(): materialised on first access
-        results.dir_res_scale = np.pi / nb
+        results.lazy["dir_res"] = lambda: dir_res_norm * (np.pi / nb)
         results["obj_scores"] = cls_t[..., 0:2]
         if with_sem:
             results["sem_scores"] = cls_t[..., 2:]

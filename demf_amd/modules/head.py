@@ -166,9 +166,7 @@ class DeMFVoteHead(nn.Module):
             for i in range(self.num_decoder_layers):
                 # (center | size | zero columns up to a multiple of 4: the row width the position
                 # embedding's first GEMM stages, written by this one concatenation)
-                zpad = self._zero_cols(B, Q, (-6) % 4, features)
-                query_pos = torch.cat([decode_res["center"], decode_res["size"], zpad], dim=-1).detach() \
-                    .reshape(B * Q, -1)
+                query_pos = ops.query_pos_rows(decode_res["_rows"][1], aggregated_points)
                 rows = self.decoder[i].forward_rows(
                     rows, query_pos, pts, image_inputs["value_tokens"], spatial_shapes,
                     level_start_index, (mt["M"], mt["ab"]), valid_ratios, B, layer_index=i)
@@ -298,6 +296,9 @@ class DeMFVoteHead(nn.Module):
             ab=np.asarray([c[1:] for c in comp]).astype(fdt),
             hw=hw,
             mask_flatten=None if empty else np.ascontiguousarray(flat),
+            # (the same mask as bytes: what the token transposes read - converted here once per metas object
+            # instead of by a launch per step)
+            mask_u8=None if empty else np.ascontiguousarray(flat).astype(np.uint8),
             # (converted to float in numpy: torch's bool -> float32 copy of this 0.6 M-element array costs
             # 60-75 ms on the host, numpy's 0.5 ms - it is on the per-batch path of replay.load)
             keep4=None if empty else np.stack([(~flat).astype(fdt)] + [np.zeros(flat.shape, fdt)] * 3, -1),
@@ -350,7 +351,7 @@ class DeMFVoteHead(nn.Module):
         sample_first = on_gpu and samples < S and C0 % 4 == 0 and C0 <= 256
         if feat_flatten is None:
             if on_gpu:           # tiled transposes; the padding mask rides along when wanted
-                feat_flatten = ops.pyramid_to_tokens(mlvl_feats, mask_flatten if sample_first else None)
+                feat_flatten = ops.pyramid_to_tokens(mlvl_feats, mt["mask_u8"] if sample_first else None)
             else:
                 feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         elif sample_first:

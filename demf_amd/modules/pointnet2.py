@@ -108,15 +108,20 @@ class PointSAModule(nn.Module):
                                  geo=(points_xyz, new_xyz, idx, inv_off, inv_rows, self.radius,
                                       self.normalize_xyz))
         else:
+            # Rows without padding (SA1: xyz + one feature = 4 floats) are written in the REFERENCE column
+            # order [xyz | feat]: the first conv's weight is then used as stored - no concatenation of its
+            # permuted columns per step, no slice-and-copy of its gradient in the backward.
+            ref_order = self.use_xyz and C + 3 == ld and C < 4
             grouped = ops.group_concat_cl(points_xyz, new_xyz, feat, idx, self.radius,
                                           self.normalize_xyz, ldo=ld,
-                                          xyz_col=C if self.use_xyz else 0, feat_col=0,
+                                          xyz_col=(0 if ref_order else C) if self.use_xyz else 0,
+                                          feat_col=3 if ref_order else 0,
                                           inverse=group_inv) \
                 if self.use_xyz else ops.gather_rows_cl(
                     feat, idx.view(B, M * self.num_sample)).view(B, M, self.num_sample, C)
             x = grouped.view(B * M * self.num_sample, ld)
             # shared MLP + BN + ReLU + max over the ns neighbours: one fused chain (csrc/mlp.hip)
-            x = mlp.forward_rows(x, self._first_weight(ld), ns=self.num_sample)
+            x = mlp.forward_rows(x, None if ref_order else self._first_weight(ld), ns=self.num_sample)
         new_features = x.view(B, M, -1).transpose(1, 2)  # (B,C',M) view of point-major
         return new_xyz, new_features, indices
 

@@ -788,15 +788,6 @@ def _bwd_fused_cols_ok(R, N, K, ns, sparse):
 # SA1's pooled last layer without its (R x 128) output: the forward does not store it, the backward is
 # written in terms of the layer's INPUT activations (csrc/mlp_bwd.hip mlp_bwd_pool_kernel).  A/B switch.
 _POOL_NOY = bool(int(os.environ.get("DEMF_POOL_NOY", "1")))
-_COUNTERS = {}
-
-
-def _zero_counter(device):
-    """One persistent zero-initialised int32 per device for kernels that leave their exit count zeroed."""
-    key = str(device)
-    if key not in _COUNTERS:
-        _COUNTERS[key] = torch.zeros(4, dtype=torch.int32, device=device)
-    return _COUNTERS[key]
 
 
 def _pool_noy_ok(R, ns, shapes, training, fuse_pool):
@@ -1106,7 +1097,7 @@ class _SharedMLPPool(Function):
                 _ffi.call("demf_mlp_bwd_pool", R, N, K, ns, _p(dP), _p(arg), _p(yraw), _p(vec6), _p(W),
                           _p(Ys[l - 1]), _p(sss[l - 1]), _p(mis[l - 1]), _p(dX), _p(dW), _p(g12p),
                           _p(gammas[l - 1]) if (_VEC_FIN & 2) else None, _p(vec_ready[0]), _p(vec_ready[1]),
-                          _p(vec_ready[2]), _p(wsp), _p(_zero_counter(dev)), st)
+                          _p(vec_ready[2]), _p(wsp), st)
                 if not (_VEC_FIN & 2):
                     g12_pending = g12p
                 G = dX
@@ -1465,6 +1456,22 @@ def pad_gt_lists(boxes, labels, G):
     return gt, lab, valid.view(torch.bool)
 
 
+@torch.no_grad()
+def query_pos_rows(reg_rows, base_xyz):
+    """The decoder layer's position-embedding input from a prediction head's raw regression rows:
+    reg_rows (B,Q,nreg) point-major conv_reg output, base_xyz (B,Q,3) -> (B*Q, 8) rows
+    [base + reg[:3] (centre) | reg[3:6] (size) | 0 0], detached - what the reference builds as
+    ``torch.cat([decode_res['center'], decode_res['size']], -1).detach().clone()``
+    (class_agnostic_vote_head.py:497-498), zero-padded to the 8 columns the first GEMM stages.  One launch."""
+    _chk(base_xyz, "base_xyz")
+    B, Q, nreg = reg_rows.shape
+    reg = reg_rows if reg_rows.is_contiguous() else reg_rows.contiguous()
+    _chk(reg, "reg_rows")
+    out = torch.empty((B * Q, 8), dtype=torch.float32, device=reg.device)
+    _ffi.call("demf_query_pos_rows", B * Q, nreg, _p(reg), _p(base_xyz), _p(out), _stream())
+    return out
+
+
 def target_weights(objectness_masks, objectness_targets):
     """-> (objectness_weights, box_loss_weights): each tensor divided by (its sum + 1e-6)
     (class_agnostic_vote_head.py:797-816), one launch."""
@@ -1564,7 +1571,8 @@ def pyramid_to_tokens(mlvl_feats, zero_mask=None):
     sizes = [f.shape[2] * f.shape[3] for f in mlvl_feats]
     S = sum(sizes)
     out = torch.empty((B, S, C), dtype=torch.float32, device=mlvl_feats[0].device)
-    m = None if zero_mask is None else zero_mask.to(torch.uint8).contiguous()
+    m = None if zero_mask is None else \
+        (zero_mask if zero_mask.dtype == torch.uint8 else zero_mask.to(torch.uint8)).contiguous()
     for f in mlvl_feats:
         _chk(f, "feature map")
     if len(sizes) <= 8:                  # every level in one launch

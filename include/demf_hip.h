@@ -447,8 +447,8 @@ int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, const float*
  * ``yraw`` = the raw output at the selected row, from demf_pool_select_slot0) alone.
  * N = 128, K = 64, ns = 64, R % 64 == 0, compute modes 1 / 2.  dX (R x K), dW (N x K) written;
  * g12_prev (2K doubles, zeroed accumulator) accumulated and, with gamma_prev, turned into layer L-1's
- * backward vectors by the last workgroup.  workspace: *floats of demf_mlp_bwd_pool_ws(R, &floats), scratch;
- * counter: one zero-initialised int, left zeroed.  Replaces demf_mlp_bwd_fused for that layer
+ * backward vectors by the last workgroup.  workspace: *floats of demf_mlp_bwd_pool_ws(R, &floats), scratch.
+ * Replaces demf_mlp_bwd_fused for that layer
  * (mmdet3d PointSAModule's shared MLP, demf/modeling/heads/class_agnostic_vote_head.py:383,
  * configs/demf/demf_votenet.py:48-62).                                                                  */
 int demf_mlp_bwd_pool_ws(int R, long long* floats);
@@ -456,7 +456,7 @@ int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, const int* a
                       const float* vec6, const float* W, const float* Yprev,
                       const float* scale_shift_prev, const float* mean_invstd_prev, float* dX, float* dW,
                       double* g12_prev, const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
-                      float* dbeta_prev, float* workspace, int* counter, demf_stream_t stream);
+                      float* dbeta_prev, float* workspace, demf_stream_t stream);
 
 /* dW (N,K) += dY^T @ A_prev, A_prev = act_prev(Xprev (R,K; stride ldx)) or Xprev itself
  * when prev_scale_shift is NULL (first layer).  dW accumulated (fp32 atomics).        */
@@ -563,6 +563,13 @@ int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, floa
                           float* dir_res_targets, float* dir_targets, int64_t* mask_targets,
                           float* distance_targets, int64_t* objectness_targets,
                           float* objectness_masks, demf_stream_t stream);
+
+/* Position-embedding input of a fusion decoder layer from a prediction head's raw regression rows
+ * (reg_rows (R, nreg >= 6) point-major, base_xyz (R,3)): out8 (R,8) = [base + reg[0:3] | reg[3:6] | 0 0] -
+ * the reference's torch.cat([center, size], -1).detach() (class_agnostic_vote_head.py:497-498), padded
+ * to the 8 columns the first GEMM of the position embedding stages.                                  */
+int demf_query_pos_rows(int R, int nreg, const float* reg_rows, const float* base_xyz, float* out8,
+                        demf_stream_t stream);
 
 /* Per-scene ground-truth lists -> the static-shape padded form the target kernels read: gt_padded
  * (B,G,7) fp32, labels_padded (B,G) int64 with -1 on padding slots, valid (B,G) u8 or NULL.  An empty

@@ -17,6 +17,8 @@ parameters, same state dict) round at exactly the places the kernels round, forw
     the gradient summed per source point (dU), as the kernels do, not the per-neighbour rows;
   * SA1's first layer (4-float rows): forward rounded, but its weight gradient comes out of the fp32
     epilogue sums of the layer above (the FIRST epilogue): NOT rounded;
+  * SA1's pooled last layer in the no-store form (``_PooledLast``): same forward values, backward re-associated
+    around the layer's INPUT, A and W^T diag(a) W rounded where dY and W were before round 4;
   * self attention with the kernels' operand order: S = q(Q) q(K)^T * (1/sqrt(Dh)) (scale after the
     product), O = q(dropout(softmax S)) q(V);
   * the fusion cross-attention as sample-then-project (demf_amd/ops.py msda_sample_then_project):
@@ -100,6 +102,58 @@ class _RowBias(Function):
         return (gq * q(bias).unsqueeze(0)).sum(-1), (gq * q(ks).unsqueeze(-1)).sum(0)
 
 
+class _PooledLast(Function):
+    """Conv1x1 -> train-mode BN -> ReLU -> max over ns rows of an SA1-shaped last layer (64 -> 128 channels,
+    64-row groups, >= 16 384 rows) the way the product runs it since round 4 (csrc/mlp_bwd.hip
+    mlp_bwd_pool_kernel): the raw output is never stored, and the backward is written in terms of the
+    layer's input A:   dA = q(gi dZ) q(W) + q(A) q(M) + b^T W,   M = W^T diag(a) W  (formed in full precision),
+    dW = (gi dZ)^T A + diag(a) W (q(A)^T q(A)) + b (x) colsum(A)   (sparse product and column sums in full
+    precision).  Forward values equal the plain rounded layer's."""
+
+    @staticmethod
+    def forward(ctx, A, W, gamma, beta, ns, eps):
+        R, K = A.shape
+        y = q(A) @ q(W).t()
+        mean = y.mean(0)
+        invstd = torch.rsqrt(y.var(0, unbiased=False) + eps)
+        sc = gamma * invstd
+        sh = beta - mean * sc
+        z = torch.relu(y * sc + sh).view(R // ns, ns, -1)
+        out = z.max(1)[0]
+        first = (z == out.unsqueeze(1)).to(torch.int64).argmax(1)       # the FIRST maximal row (upstream's max-pool)
+        yraw = torch.gather(y.view(R // ns, ns, -1), 1, first.unsqueeze(1)).squeeze(1)
+        ctx.save_for_backward(A, W, gamma, mean, invstd, sh, first, yraw)
+        ctx.ns = ns
+        return out
+
+    @staticmethod
+    def backward(ctx, dP):
+        A, W, gamma, mean, invstd, sh, arg, yraw = ctx.saved_tensors
+        ns = ctx.ns
+        R, K = A.shape
+        G, N = dP.shape
+        gi = gamma * invstd
+        dz = torch.where(yraw * gi + sh > 0, dP, torch.zeros_like(dP))
+        g1, g2 = dz.sum(0), (dz * ((yraw - mean) * invstd)).sum(0)
+        a = -gi * invstd * (g2 / R)
+        b = -gi * (g1 / R) - a * mean
+        dzs = torch.zeros(G, ns, N, dtype=A.dtype)
+        dzs.scatter_(1, arg.unsqueeze(1), (gi * dz).unsqueeze(1))
+        dzs = dzs.view(R, N)
+        M = W.t() @ (a.unsqueeze(1) * W)
+        dA = q(dzs) @ q(W) + q(A) @ q(M) + (b @ W)
+        dW = dzs.t() @ A + a.unsqueeze(1) * (W @ (q(A).t() @ q(A))) + b.unsqueeze(1) * A.sum(0).unsqueeze(0)
+        return dA, dW, g2, g1, None, None
+
+
+def _no_store_last(R, ns, mlp):
+    """demf_amd/ops.py _pool_noy_ok: the stacks whose last layer runs without its stored output."""
+    if len(mlp) < 2 or ns != 64 or R < 16384 or R % 64:
+        return False
+    last, prev = mlp[len(mlp) - 1].conv, mlp[len(mlp) - 2].conv
+    return last.out_channels == 128 and last.in_channels == 64 and prev.out_channels == 64
+
+
 _STATE = {"on": False, "first_no_round_dw": False}
 _ORIG = {}
 
@@ -168,6 +222,15 @@ def _sa_forward(self, points_xyz, features=None, indices=None, target_xyz=None):
             x = layer0(x)
         finally:
             _STATE["first_no_round_dw"] = False
+        Bx, _, Mx, nsx = x.shape
+        if _no_store_last(Bx * Mx * nsx, nsx, mlp) and self.training:
+            for blk in list(mlp)[1:-1]:
+                x = blk(x)
+            last = mlp[len(mlp) - 1]
+            rows = x.permute(0, 2, 3, 1).reshape(Bx * Mx * nsx, x.shape[1])
+            Wl = last.conv.weight.reshape(last.conv.out_channels, -1)
+            pooled = _PooledLast.apply(rows, Wl, last.bn.weight, last.bn.bias, nsx, last.bn.eps)
+            return new_xyz, pooled.view(Bx, Mx, -1).transpose(1, 2), indices
         for blk in list(mlp)[1:]:
             x = blk(x)
     new_features = F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)

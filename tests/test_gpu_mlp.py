@@ -84,11 +84,21 @@ def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
     for l in range(L):
         Yg, ssg = saved[2 + l].double().cpu(), saved[2 + L + l].double().cpu()
         n = Yg.shape[1]
-        masks_g.append(Yg * ssg[:n] + ssg[n:] > 0)        # exact sign of the kernels' one fma
+        if Yg.numel() == 0:
+            # the no-store pooled last layer (SA1 shape): its raw output does not exist; the only ReLU
+            # decisions that reach the result are those at the selected rows, kept as ``yraw``
+            yraw = saved[2 + 5 * L].double().cpu()
+            masks_g.append(("selected", yraw * ssg[:n] + ssg[n:] > 0))
+        else:
+            masks_g.append(Yg * ssg[:n] + ssg[n:] > 0)        # exact sign of the kernels' one fma
     # they may differ from the fp64 reference's only at round-off-level pre-activations
     h = x
     for l, (W, g, b) in enumerate(layers64):
         z = F.batch_norm(F.linear(h, W), None, None, g, b, True, 0.1, 1e-5)
+        if isinstance(masks_g[l], tuple):
+            m = (z > 0).view(Rp, ns, -1).clone()
+            m.scatter_(1, arg_g.view(Rp, 1, -1), masks_g[l][1].view(Rp, 1, -1))
+            masks_g[l] = m.view(Rp * ns, -1)
         diff = masks_g[l] != (z > 0)
         assert int(diff.sum()) <= 4 + z.numel() // 10 ** 6, f"layer {l}: {int(diff.sum())} ReLU masks differ"
         assert not bool(diff.any()) or z[diff].abs().max().item() < 2e-5, f"layer {l}: mask differs at |z| = {z[diff].abs().max().item():.2e}"

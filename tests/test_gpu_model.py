@@ -261,7 +261,9 @@ def _bf16_parity(cfg, case, label):
     fwd = list(report)
     for k in E64["losses"]:
         lg, l64, l32 = G["losses"][k].item(), E64["losses"][k].item(), E32["losses"][k].item()
-        if abs(lg - l64) > max(1e-3 * abs(l64), BF16_MULT * abs(l32 - l64)):
+        # (a scalar against ONE sample of the twin's noise: floor 1 % - the losses are sums over a few
+        # positive proposals)
+        if abs(lg - l64) > max(1e-2 * abs(l64), BF16_MULT * abs(l32 - l64)):
             bad.append("loss %s: HIP %.6f emu64 %.6f emu32 %.6f" % (k, lg, l64, l32))
     gmax = max(v.norm().item() for v in E64["grads"].values())
     assert sorted(E64["grads"]) == sorted(G["grads"])

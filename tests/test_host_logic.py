@@ -136,6 +136,7 @@ def test_pad_gt_slots_and_lazy_dir_res():
                  {**coder.split_pred(cls, reg, torch.zeros(2, 5, 3))},
                  coder.split_pred(cls, reg, torch.zeros(2, 5, 3)).copy()):
         assert torch.equal(view["dir_res"], want)
+        assert torch.equal(view["center"], reg.transpose(2, 1)[..., 0:3])      # base_xyz = 0
     assert "dir_res" in list(coder.split_pred(cls, reg, torch.zeros(2, 5, 3)))
     assert torch.equal(res["dir_res"], want) and "dir_res" in res
     with pytest.raises(KeyError):

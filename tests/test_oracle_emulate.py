@@ -81,3 +81,28 @@ def test_primitive_gradient_rules():
     # q is round-to-nearest-even onto 8 significand bits
     v = torch.tensor([1.0, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -9, 1.0 + 2.0 ** -7], dtype=torch.float64)
     assert q(v).tolist() == [1.0, 1.0, 1.0 + 2.0 ** -7, 1.0 + 2.0 ** -7]
+
+
+def test_pooled_last_layer_emulation_equals_autograd_when_rounding_is_identity(monkeypatch):
+    """``_PooledLast`` (the no-store form of SA1's last layer: backward written around the layer's input) is
+    algebraically the layer's backward: with identity rounding it must equal torch autograd of
+    conv -> BN(train) -> ReLU -> max over 64 rows, incl. a negative and a zero BN scale."""
+    import torch.nn.functional as F
+    monkeypatch.setattr(emulate, "q", lambda x: x)
+    g = torch.Generator().manual_seed(3)
+    G, ns, K, N = 40, 64, 64, 128
+    A = torch.relu(torch.randn(G * ns, K, generator=g, dtype=torch.float64)).requires_grad_()
+    W = (torch.randn(N, K, generator=g, dtype=torch.float64) / 8).requires_grad_()
+    gamma = (1.0 + 0.2 * torch.randn(N, generator=g, dtype=torch.float64))
+    gamma[5], gamma[9] = -0.8, 0.0
+    gamma.requires_grad_()
+    beta = (0.1 * torch.randn(N, generator=g, dtype=torch.float64)).requires_grad_()
+    dP = torch.randn(G, N, generator=g, dtype=torch.float64)
+    out = emulate._PooledLast.apply(A, W, gamma, beta, ns, 1e-5)
+    got = torch.autograd.grad(out, [A, W, gamma, beta], dP)
+    A2, W2, g2, b2 = (t.detach().clone().requires_grad_() for t in (A, W, gamma, beta))
+    ref = F.relu(F.batch_norm(A2 @ W2.t(), None, None, g2, b2, True, 0.1, 1e-5)).view(G, ns, N).max(1)[0]
+    want = torch.autograd.grad(ref, [A2, W2, g2, b2], dP)
+    assert torch.allclose(out, ref, rtol=0, atol=1e-12)
+    for a, b, n in zip(got, want, ("dA", "dW", "dgamma", "dbeta")):
+        assert ((a - b).norm() / b.norm()).item() < 1e-10, n

@@ -28,7 +28,7 @@ nws = ctypes.c_longlong(); _ffi.call("demf_mlp_bwd_pool_ws", R, ctypes.addressof
 ws = torch.empty(nws.value, device="cuda"); cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
 def pool():
     _ffi.call("demf_mlp_bwd_pool", R, N, K, ns, p(dP), p(arg), p(yraw), p(vec), p(W), p(Yp), p(pss), p(pmi), p(dX), p(dW), p(g12),
-              None, None, None, None, p(ws), p(cnt), st)
+              None, None, None, None, p(ws), st)
 def fused():
     _ffi.call("demf_mlp_bwd_fused", R, N, K, None, p(dP), p(arg), ns, p(Y), p(vec), p(W), p(Yp), p(pss), p(pmi),
               p(dX), p(dW), p(g12), None, None, None, None, None, None, 0, st)
