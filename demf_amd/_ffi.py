@@ -64,6 +64,9 @@ SIGNATURES = {
     "demf_mlp_gemm_fwd_pool_bn_st": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 4 + [_c_float, _c_float] + [_ptr] * 6 + [_c_int, _ptr],
     "demf_pool_select": [_c_int] * 2 + [_ptr] * 9,
     "demf_pool_select_slot0": [_c_int] * 2 + [_ptr] * 7,
+    "demf_mlp_first_stats": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _c_float] + [_ptr] * 7,
+    "demf_mlp_gemm_fwd_bn_x4": [_c_int] * 2 + [_ptr] * 8 + [_c_float, _c_float] + [_ptr] * 7,
+    "demf_mlp_bwd_fused_x4": [_c_int] * 3 + [_ptr] * 11,
     "demf_mlp_bwd_pool": [_c_int] * 4 + [_ptr] * 17,
     "demf_mlp_bwd_pool_ws": [_c_int, _ptr],
     "demf_bn_finalize": [_c_int, ctypes.c_longlong] + [_ptr] * 3 + [_c_float, _c_float] + [_ptr] * 7,

@@ -174,6 +174,8 @@ struct MlpArgs {
   // FIRST epilogue (backward of a stack whose first layer has a 4-float input and no input
   // gradient): the output tile IS the gradient of layer 0's activation; instead of storing it, the
   // raw sums of layer 0's whole backward are taken from it (see mlp_first_finish_k)
+  const float* W0;             // weight-resident forward, ST bit 3: (K x 4) weight of the layer BELOW, whose raw
+                               // output is recomputed from its 4-float input rows X instead of being loaded
   const float* fX;             // (R x 4) input rows of layer 0
   const float* fY;             // (R x N) pre-BN output of layer 0
   const float* fss;            // layer 0 [scale|shift] (2N)
@@ -1078,6 +1080,12 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   // value, which the BN backward needs for dgamma and could otherwise only gather from Y.
   constexpr bool NOY = (ST & 4) != 0;
   static_assert(!NOY || (POOL && !YB), "no-store form: pooled launches, fp32 bookkeeping");
+  // ST bit 3: X holds the 4-float input rows of the layer BELOW (SA1's first layer, 4 -> K channels): that
+  // layer's raw output - 256 bytes per row - is never materialised; the 16 fma per lane and row that rebuild
+  // the lane's four channels of it are free next to a 16-fold cut of the bytes read.  In the bf16 mode the
+  // products are taken on bf16-rounded operands, as the MFMA kernel that used to produce the rows did.
+  constexpr bool XR = (ST & 8) != 0;
+  static_assert(!XR || !XB, "recomputed rows have no storage type");
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32, KB = K * 2;
   constexpr int KS = K / 16;                       // MFMA K steps
@@ -1111,6 +1119,17 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   const int c4 = lane % LPR, rq = lane / LPR;
   const float4 sc = *reinterpret_cast<const float4*>(s_vec + 4 * c4);
   const float4 sh = *reinterpret_cast<const float4*>(s_vec + K + 4 * c4);
+  float4 w0r[XR ? 4 : 1];                              // XR: rows 4*c4 .. +3 of the lower layer's (K x 4) weight
+  if constexpr (XR) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float4 w = *reinterpret_cast<const float4*>(p.W0 + (size_t)(4 * c4 + e) * 4);
+      if constexpr (CM == 1) {
+        w.x = (float)(__bf16)w.x; w.y = (float)(__bf16)w.y; w.z = (float)(__bf16)w.z; w.w = (float)(__bf16)w.w;
+      }
+      w0r[e] = w;
+    }
+  }
   char* my_a = s_a + wave * P * 32 * KB;
   unsigned selbits = 0, zbits = 0;
   if constexpr (POOL) {
@@ -1133,7 +1152,9 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
     for (int j = 0; j < NLD; ++j) {
       int row = row0 + rq + RPI * j;
       row = row < p.R ? row : p.R - 1;                     // valid address; zeroed by the transform
-      if constexpr (XB) {
+      if constexpr (XR) {
+        raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)row * 4);       // the 4-float INPUT row
+      } else if constexpr (XB) {
         const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(p.X) + (size_t)row * p.ldx + 4 * c4);
         raw[j] = make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
                              __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
@@ -1159,6 +1180,16 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
       for (int j = 0; j < NLD; ++j) {
         const int rl = rq + RPI * j;
         float4 x = raw[j];
+        if constexpr (XR) {                                  // the lane's four channels of the lower layer's output
+          float4 r = x;
+          if constexpr (CM == 1) {
+            r.x = (float)(__bf16)r.x; r.y = (float)(__bf16)r.y; r.z = (float)(__bf16)r.z; r.w = (float)(__bf16)r.w;
+          }
+          x.x = __builtin_fmaf(r.w, w0r[0].w, __builtin_fmaf(r.z, w0r[0].z, __builtin_fmaf(r.y, w0r[0].y, r.x * w0r[0].x)));
+          x.y = __builtin_fmaf(r.w, w0r[1].w, __builtin_fmaf(r.z, w0r[1].z, __builtin_fmaf(r.y, w0r[1].y, r.x * w0r[1].x)));
+          x.z = __builtin_fmaf(r.w, w0r[2].w, __builtin_fmaf(r.z, w0r[2].z, __builtin_fmaf(r.y, w0r[2].y, r.x * w0r[2].x)));
+          x.w = __builtin_fmaf(r.w, w0r[3].w, __builtin_fmaf(r.z, w0r[3].z, __builtin_fmaf(r.y, w0r[3].y, r.x * w0r[3].x)));
+        }
         x.x = fmaxf(0.f, __builtin_fmaf(x.x, sc.x, sh.x));
         x.y = fmaxf(0.f, __builtin_fmaf(x.y, sc.y, sh.y));
         x.z = fmaxf(0.f, __builtin_fmaf(x.z, sc.z, sh.z));
@@ -1848,7 +1879,8 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     // weight-resident, barrier-free forward (mlp_fwd_res_kernel): 64-channel inputs, N = 64 / 128
     static const int fr_on = env_int("DEMF_FWD_RES", 1);
     const bool sel = !POOL || (a.pmin == nullptr && a.fin.gamma != nullptr);
-    if ((fr_on || a.st) && a.K == 64 && (a.N == 64 || a.N == 128) && a.ldx == 64 && a.ldy == a.N && a.ldb == 0 && sel &&
+    if ((fr_on || a.st) && a.K == 64 && (a.N == 64 || a.N == 128) && (a.ldx == 64 || (a.st == 8 && a.ldx == 4)) &&
+        a.ldy == a.N && a.ldb == 0 && sel &&
         a.R >= 64 * 256 && (!POOL || ((a.ns == 16 || a.ns == 32 || a.ns == 64) && a.R % 64 == 0)) &&
         (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
       constexpr int P = BF16 == 2 ? 3 : 1;
@@ -1887,6 +1919,10 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
         if constexpr (POOL) {
           // no-store form (either mode): SA1's last layer, 64-row groups
           if (a.st == 4 && ntn == 4 && a.ns == 64) { FRGO(4, 4); done = true; }
+        }
+        if constexpr (!POOL) {
+          // input rows of the layer below instead of its output (either mode): SA1's second layer
+          if (a.st == 8 && ntn == 2 && a.W0 != nullptr) { FRGO(2, 8); done = true; }
         }
         if (!done) {
           set_error("mlp_fwd_res: bf16 storage form st=%d N=%d pool=%d mode=%d not built", a.st, a.N, (int)POOL, BF16);
@@ -2187,6 +2223,82 @@ extern "C" int demf_mlp_gemm_fwd_pool_bn_st(int R, int K, int N, int ldx, const 
                                    store_flags, stream);
 }
 
+// ---- first layer of an SA1-shaped stack (4-float rows -> N0 channels) WITHOUT its output -----------------
+// y = x.W0^T is linear in a 4-float row: the train-mode BN statistics of all N0 channels follow from the 14
+// second moments of x alone,  sum y_c = w_c . sum x,   sum y_c^2 = w_c^T (sum x x^T) w_c,  taken in one pass
+// over the 16-byte rows (fp32 per thread, fp64 across threads); the last workgroup turns them into
+// scale / shift, mean / invstd and the running statistics (bn_finalize_channel).  The 268 MB of raw
+// outputs the GEMM kernel wrote for the consumers are recomputed by them from the rows (ST bit 3 of
+// mlp_fwd_res_kernel, mlp_bwd_fused_kernel).  bf16 mode: moments of the bf16-rounded rows, rounded weights.
+__global__ __launch_bounds__(256) void mlp_first_stats_k(int R, int N0, const float* __restrict__ X,
+                                                         const float* __restrict__ W0, double* __restrict__ mom,
+                                                         BnFin fin, int bf16) {
+  float m[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) m[i] = 0.f;
+  double acc[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] = 0.0;
+  int n = 0;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * 4);
+    if (bf16) { x.x = (float)(__bf16)x.x; x.y = (float)(__bf16)x.y; x.z = (float)(__bf16)x.z; x.w = (float)(__bf16)x.w; }
+    const float v[4] = {x.x, x.y, x.z, x.w};
+    int t = 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m[i] += v[i];
+#pragma unroll
+      for (int j = i; j < 4; ++j) { m[t] = __builtin_fmaf(v[i], v[j], m[t]); ++t; }
+    }
+    if (++n == 64) {                       // fp32 partial sums of at most 64 rows, then fp64
+#pragma unroll
+      for (int i = 0; i < 14; ++i) { acc[i] += (double)m[i]; m[i] = 0.f; }
+      n = 0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 14; ++i) acc[i] += (double)m[i];
+  __shared__ double s_m[4][14];
+  __shared__ int s_last;
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    double v = acc[i];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 14)
+    atomicAdd(mom + threadIdx.x, (s_m[0][threadIdx.x] + s_m[1][threadIdx.x]) + (s_m[2][threadIdx.x] + s_m[3][threadIdx.x]));
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
+  __syncthreads();
+  if (!s_last) return;
+  __shared__ double s_t[14];
+  if (threadIdx.x < 14)
+    s_t[threadIdx.x] = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(mom + threadIdx.x), 0ull));
+  __syncthreads();
+  if (threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
+  for (int c = threadIdx.x; c < N0; c += 256) {
+    double w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float wk = W0[c * 4 + k];
+      w[k] = bf16 ? (double)(float)(__bf16)wk : (double)wk;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    int t = 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s1 += w[i] * s_t[i];
+#pragma unroll
+      for (int j = i; j < 4; ++j) { s2 += (i == j ? 1.0 : 2.0) * w[i] * w[j] * s_t[t]; ++t; }
+    }
+    bn_finalize_channel(c, N0, fin.count, s1, s2, fin.gamma, fin.beta, fin.eps, fin.momentum, fin.rmean, fin.rvar,
+                        fin.ss, fin.mi, fin.conv_bias);
+  }
+}
+
 static int pool_select_impl(int Rp, int C, const float* pmax, const float* pmin, const int* amax, const int* amin,
                             const float* scale_shift, float* out, int* arg, float* yraw, int slot0,
                             demf_stream_t stream) {
@@ -2199,6 +2311,48 @@ static int pool_select_impl(int Rp, int C, const float* pmax, const float* pmin,
   hipLaunchKernelGGL(pool_select_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, RC, C, pmax,
                      pmin, amax, amin, scale_shift, out, arg, yraw, slot0);
   return check_launch("pool_select");
+}
+
+// First layer of an SA1-shaped stack without its output: BN statistics + bookkeeping from the 4-float rows
+// alone (mlp_first_stats_k).  ``moments``: >= 14 doubles of a zeroed accumulator, left zeroed.
+extern "C" int demf_mlp_first_stats(int R, int N0, const float* X, const float* W0, double* moments,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    float* scale_shift, float* mean_invstd, const float* conv_bias,
+                                    demf_stream_t stream) {
+  DEMF_REQUIRE(R >= 1 && N0 >= 1 && X && W0 && moments, "mlp_first_stats: bad arguments");
+  if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, moments)) return e;
+  BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+            num_batches_tracked, scale_shift, mean_invstd, sched_slot()};
+  DEMF_REQUIRE(fin.ticket != nullptr, "mlp_first_stats: needs the counter ring (DEMF_STATIC_TILES=1 is set)");
+  int grid = cdiv(R, 256 * 16);
+  if (grid > 256) grid = 256;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(mlp_first_stats_k, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N0, X, W0, moments, fin,
+                     compute_mode() == 1 ? 1 : 0);
+  return check_launch("mlp_first_stats");
+}
+
+// Second layer of that stack (K = 64 -> N = 64): demf_mlp_gemm_fwd_bn with the prologue's input rebuilt from the
+// 4-float rows X4 and the first layer's weight W0 (64 x 4) instead of loaded from a stored (R x 64) output;
+// prev_scale_shift = the first layer's [scale|shift] from demf_mlp_first_stats.  Modes 1 / 2, R >= 16384.
+extern "C" int demf_mlp_gemm_fwd_bn_x4(int R, int N, const float* X4, const float* W0,
+                                       const float* prev_scale_shift, const float* Wt, float* Y, double* stats,
+                                       const float* gamma, const float* beta, float eps, float momentum,
+                                       float* running_mean, float* running_var, long long* num_batches_tracked,
+                                       float* scale_shift, float* mean_invstd, const float* conv_bias,
+                                       demf_stream_t stream) {
+  const int cm = compute_mode();
+  DEMF_REQUIRE((cm == 1 || cm == 2) && N == 64 && R >= 64 * 256 && X4 && W0 && prev_scale_shift && Wt && Y,
+               "mlp_gemm_fwd_bn_x4: unsupported shape / mode R=%d N=%d mode=%d (or null pointer)", R, N, cm);
+  if (int e = fin_check(R, gamma, beta, scale_shift, mean_invstd, stats)) return e;
+  MlpArgs a{};
+  a.R = R; a.K = 64; a.N = N; a.ldx = 4; a.ldy = N; a.X = X4; a.W0 = W0; a.vec = prev_scale_shift; a.Bt = Wt;
+  a.Y = Y; a.stats = stats; a.st = 8;
+  hipStream_t s = (hipStream_t)stream;
+  BnFin fin{(double)R, gamma, beta, conv_bias, eps, momentum, running_mean, running_var,
+            num_batches_tracked, scale_shift, mean_invstd, nullptr};
+  return launch_with_finalize(a, fin, [s](const MlpArgs& b) { return launch_gemm<PRO_BNRELU, true>(b, s); }, s);
 }
 
 extern "C" int demf_pool_select(int Rp, int C, const float* pmax, const float* pmin,

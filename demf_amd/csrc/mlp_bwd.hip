@@ -59,6 +59,7 @@ struct FusedBwdArgs {
   // A launch may cover K of the fld >= K channels of layer l-1 (columns fc0 .. fc0 + K): Xp, dX, W, dW
   // then arrive offset by fc0 with row strides ldk / ldw; pss, pmi, g12 and vfin are the WHOLE layer's.
   int ldk, ldw, fld, fc0;
+  const float* W0;    // FIRST with ST bit 2: (K x 4) weight of layer 0 - Y_0 = fX.W0^T is recomputed, Xp is not read
 };
 
 // one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
@@ -144,6 +145,12 @@ __device__ __forceinline__ auto load_row(const float* __restrict__ base, size_t 
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>   // CM 1 bf16 / 2 three-term ; EPI 0 RED / 1 FIRST
 __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_fused_kernel(FusedBwdArgs p) {
   constexpr bool XB = (ST & 1) != 0, YB = (ST & 2) != 0;
+  // ST bit 2 (FIRST only): layer 0's raw output is not stored - its 4-float input rows fX and its (K x 4) weight
+  // W0 rebuild the values this kernel needs (two channels of four rows per lane for the staged activation,
+  // four channels of a row in the epilogue): 268 MB less to read at SA1.  bf16 mode: products of bf16-rounded
+  // operands, as the forward kernels compute them.
+  constexpr bool XR = (ST & 4) != 0;
+  static_assert(!XR || (EPI == 1 && !XB), "recomputed rows: FIRST epilogue, no storage type");
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32;
   constexpr int NW = NTN * KG;              // waves per workgroup
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   float* s_dx = reinterpret_cast<float*>(s_xat + XATB);     // [RS][K] fp32
   float* s_vy = s_dx + RS * K;                              // 5N
   float* s_px = s_vy + 5 * N;                               // pss (2K) | pmi (2K)
+  float* s_w0 = s_px + 4 * K;                               // XR: W0 (K x 4), bf16-rounded in the bf16 mode
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
   const int lr = lane & 31, lh = lane >> 5;
@@ -179,6 +187,12 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
     const int g = (i < K ? i : p.fld + i - K) + p.fc0;           // [scale | shift], [mean | invstd] of the chunk
     s_px[i] = p.pss[g];
     s_px[2 * K + i] = p.pmi[g];
+  }
+  if constexpr (XR) {
+    for (int i = tid; i < 4 * K; i += NT) {
+      const float w = p.W0[i];
+      s_w0[i] = CM == 1 ? (float)(__bf16)w : w;
+    }
   }
 
   // ---- the weight as B fragments of dX = dY.W, resident for the whole launch --------------------
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   vecT rdp;                                          // sparse: pooled gradient of the lane's group
   ivecT rarg;                                        //         and its arg-max slots
   float2 rx[4];                                      // raw Y_{l-1}
+  float4 rq[XR ? 4 : 1];                             // XR: the 4-float input rows instead
   int r_slot = 0;
   char* reg_base = s_reg + nt * REGB;
   char* xat_base = s_xat;
@@ -239,7 +254,9 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
       ry[j] = load_row<CW, YB>(p.Yl, (size_t)row * N + t_col);
       if constexpr (!SPARSE) rg[j] = load_row<CW, YB>(p.G, (size_t)row * N + t_col);
       const int xrow = min(row0 + x_rl + j, last);
-      {
+      if constexpr (XR) {
+        rq[j] = *reinterpret_cast<const float4*>(p.fX + (size_t)xrow * 4);      // rebuilt in the transform
+      } else {
         const auto xv = load_row<2, XB>(p.Xp, (size_t)xrow * p.ldk + 2 * x_c2);
         rx[j] = make_float2(xv[0], xv[1]);
       }
@@ -319,6 +336,19 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         }
       }
       // act(Y_{l-1}) = relu(y*scale + shift) as [k][row] planes
+      if constexpr (XR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float4 r = rq[j];
+          if constexpr (CM == 1) {
+            r.x = (float)(__bf16)r.x; r.y = (float)(__bf16)r.y; r.z = (float)(__bf16)r.z; r.w = (float)(__bf16)r.w;
+          }
+          const float4 wa = *reinterpret_cast<const float4*>(s_w0 + 4 * (2 * x_c2));
+          const float4 wb = *reinterpret_cast<const float4*>(s_w0 + 4 * (2 * x_c2 + 1));
+          rx[j].x = __builtin_fmaf(r.w, wa.w, __builtin_fmaf(r.z, wa.z, __builtin_fmaf(r.y, wa.y, r.x * wa.x)));
+          rx[j].y = __builtin_fmaf(r.w, wb.w, __builtin_fmaf(r.z, wb.z, __builtin_fmaf(r.y, wb.y, r.x * wb.x)));
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int k = 2 * x_c2 + e;
@@ -407,8 +437,21 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         const int rl = e_r0 + i * ER, row = srow0 + rl;
         const float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
         if (row < p.R) {
-          const auto yv = load_row<4, XB>(p.Xp, (size_t)row * p.ldk + 4 * e_cq);
-          const float4 y = make_float4(yv[0], yv[1], yv[2], yv[3]);
+          float4 y;
+          if constexpr (XR) {
+            float4 r = *reinterpret_cast<const float4*>(p.fX + (size_t)row * 4);
+            if constexpr (CM == 1) {
+              r.x = (float)(__bf16)r.x; r.y = (float)(__bf16)r.y; r.z = (float)(__bf16)r.z; r.w = (float)(__bf16)r.w;
+            }
+            const float4* w4 = reinterpret_cast<const float4*>(s_w0 + 16 * e_cq);
+            y.x = __builtin_fmaf(r.w, w4[0].w, __builtin_fmaf(r.z, w4[0].z, __builtin_fmaf(r.y, w4[0].y, r.x * w4[0].x)));
+            y.y = __builtin_fmaf(r.w, w4[1].w, __builtin_fmaf(r.z, w4[1].z, __builtin_fmaf(r.y, w4[1].y, r.x * w4[1].x)));
+            y.z = __builtin_fmaf(r.w, w4[2].w, __builtin_fmaf(r.z, w4[2].z, __builtin_fmaf(r.y, w4[2].y, r.x * w4[2].x)));
+            y.w = __builtin_fmaf(r.w, w4[3].w, __builtin_fmaf(r.z, w4[3].z, __builtin_fmaf(r.y, w4[3].y, r.x * w4[3].x)));
+          } else {
+            const auto yv = load_row<4, XB>(p.Xp, (size_t)row * p.ldk + 4 * e_cq);
+            y = make_float4(yv[0], yv[1], yv[2], yv[3]);
+          }
           float dz[4];
           dz[0] = __builtin_fmaf(y.x, sc0.x, sh0.x) > 0.f ? dx.x : 0.f;
           dz[1] = __builtin_fmaf(y.y, sc0.y, sh0.y) > 0.f ? dx.y : 0.f;
@@ -936,7 +979,7 @@ template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
 static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int P = CM == 2 ? 3 : 1;
   constexpr int N = NTN * 32, K = KT * 32, NW = NTN * KG;
-  const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K);
+  const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K + 4 * K);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI, ST>),
@@ -1118,4 +1161,25 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   if (int e = check_launch("mlp_bwd_pool")) return e;
   hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, dW);
   return check_launch("pool_bwd_finish");
+}
+
+// SA1's second layer (64 -> 64, dense upstream gradient G) with the FIRST epilogue, layer 0's raw output NOT
+// stored: its 4-float input rows X0 and weight W0 (64 x 4) rebuild what demf_mlp_bwd_fused reads from Yprev.
+// Otherwise as demf_mlp_bwd_fused with first_sums != NULL (dW accumulated, first_sums as demf_mlp_first_finish
+// reads them).  Compute modes 1 / 2.
+extern "C" int demf_mlp_bwd_fused_x4(int R, int N, int K, const float* G, const float* Y, const float* vec6,
+                                     const float* W, const float* X0, const float* W0,
+                                     const float* scale_shift_prev, const float* mean_invstd_prev, float* dW,
+                                     double* first_sums, demf_stream_t stream) {
+  DEMF_REQUIRE(fused_supported(R, N, K, 1, 0, 1), "mlp_bwd_fused_x4: unsupported shape / mode R=%d N=%d K=%d mode=%d",
+               R, N, K, compute_mode());
+  DEMF_REQUIRE(G && Y && vec6 && W && X0 && W0 && scale_shift_prev && mean_invstd_prev && dW && first_sums,
+               "mlp_bwd_fused_x4: null pointer");
+  FusedBwdArgs a{};
+  a.R = R; a.N = N; a.K = K; a.ns = 1; a.Yl = Y; a.G = G; a.vec = vec6; a.Xp = nullptr; a.pss = scale_shift_prev;
+  a.pmi = mean_invstd_prev; a.W = W; a.dW = dW; a.fX = X0; a.fsum = first_sums; a.W0 = W0;
+  a.ldk = K; a.ldw = K; a.fld = K; a.fc0 = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (compute_mode() == 1) return launch_fused<2, 2, 2, false, 1, 1, 4>(a, s);
+  return launch_fused<2, 2, 2, false, 2, 1, 4>(a, s);
 }

@@ -790,6 +790,19 @@ def _bwd_fused_cols_ok(R, N, K, ns, sparse):
 _POOL_NOY = bool(int(os.environ.get("DEMF_POOL_NOY", "1")))
 
 
+# SA1's first layer (4-float rows -> 64 channels) without its (R x 64) output: statistics from the rows'
+# second moments, the consumers rebuild the values they need (csrc/mlp.hip mlp_first_stats_k, ST bit 3 of
+# mlp_fwd_res_kernel; csrc/mlp_bwd.hip ST bit 2).  A/B switch.
+_SA1_X4 = bool(int(os.environ.get("DEMF_SA1_X4", "1")))
+
+
+def _sa1_x4_ok(R, ld, shapes, training, x_grad, ns):
+    return (_SA1_X4 and training and not x_grad and _COMPUTE_MODE in (1, 2) and ld == 4 and len(shapes) >= 3
+            and shapes[0] == (64, 4) and shapes[1] == (64, 64) and R >= 16384 and not _NO_BWD_FUSE
+            and not _NO_FIRST_FUSE and int(os.environ.get("DEMF_FWD_RES", "1") or 0) and
+            not int(os.environ.get("DEMF_STATIC_TILES", "0") or 0))
+
+
 def _pool_noy_ok(R, ns, shapes, training, fuse_pool):
     """Shapes / modes of the no-store pooled last layer (N = 128 <- K = 64, 64-row groups, enough rows for
     the weight-resident forward)."""
@@ -858,6 +871,8 @@ class _SharedMLPPool(Function):
         noy = geo is None and not store16 and L >= 2 and ld % 4 == 0 and _pool_noy_ok(
             R, ns, [tuple(tensors[7 * l].shape) for l in range(L)], training,
             training and not _NO_FUSED_POOL and ns in (16, 32, 64))
+        x4 = geo is None and not store16 and _sa1_x4_ok(
+            R, ld, [tuple(tensors[7 * l].shape) for l in range(L)], training, x.requires_grad, ns)
         # the self-cleaning fp64 accumulator holds every layer's statistics (no fill launches)
         ws = _accum64(2 * sum(tensors[7 * l].shape[0] for l in range(L)), dev) if training else None
         woff = 0
@@ -869,7 +884,9 @@ class _SharedMLPPool(Function):
             first_geo = geo is not None and l == 0
             assert first_geo or K == cur_ld, \
                 f"layer {l}: weight has {K} input columns, rows have {cur_ld}"
-            Y = torch.empty((R, N), dtype=torch.bfloat16 if (store16 and l >= 1) else torch.float32, device=dev)
+            # (x4: layer 0's output is never written - an empty placeholder keeps the saved-tensor layout)
+            Y = torch.empty((0 if (x4 and l == 0) else R, N),
+                            dtype=torch.bfloat16 if (store16 and l >= 1) else torch.float32, device=dev)
             ss = torch.empty(2 * N, dtype=torch.float32, device=dev)
             mi = torch.empty(2 * N, dtype=torch.float32, device=dev)
             fuse_pool = training and l == L - 1 and l > 0 and not _NO_FUSED_POOL and \
@@ -921,6 +938,18 @@ class _SharedMLPPool(Function):
                               _p(stats), ns, _p(pm), None, _p(am), None, _p(gamma),
                               _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss),
                               _p(mi), _p(tensors[7 * l + 5]), st)
+            elif training and x4 and l == 0:
+                # statistics of y = x.W0^T from the second moments of the 16-byte rows; no output
+                stats = ws[woff:woff + 2 * N]
+                woff += 2 * N
+                _ffi.call("demf_mlp_first_stats", R, N, _p(cur), _p(W), _p(stats), _p(gamma), _p(beta), float(eps),
+                          float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
+            elif training and x4 and l == 1:
+                stats = ws[woff:woff + 2 * N]
+                woff += 2 * N
+                _ffi.call("demf_mlp_gemm_fwd_bn_x4", R, N, _p(x), _p(tensors[0]), _p(pro), _p(W), _p(Y), _p(stats),
+                          _p(gamma), _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt),
+                          _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
             elif training:
                 stats = ws[woff:woff + 2 * N]
                 woff += 2 * N
@@ -969,6 +998,7 @@ class _SharedMLPPool(Function):
         ctx.meta = (R, ld, ns, L, training)
         ctx.store16 = store16
         ctx.noy = noy
+        ctx.x4 = x4
         ctx.geo = None
         if geo is not None:
             ctx.geo = (g_xyz, g_center, g_off, g_rows, float(g_radius), int(bool(g_norm)))
@@ -1113,9 +1143,13 @@ class _SharedMLPPool(Function):
                     N0 = K
                     sums = ws64[o64:o64 + 10 * N0 + 4]
                     o64 += 10 * N0 + 4
-                    _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), None, None, ns, _p(Ys[l]), _p(vec6),
-                              _p(W), _p(Ys[0]), _p(sss[0]), _p(mis[0]), None, _p(dW), None, _p(x),
-                              _p(sums), None, None, None, None, 2 if s16 else 0, st)
+                    if getattr(ctx, "x4", False):
+                        _ffi.call("demf_mlp_bwd_fused_x4", R, N, K, _p(G), _p(Ys[l]), _p(vec6), _p(W), _p(x),
+                                  _p(Ws[0]), _p(sss[0]), _p(mis[0]), _p(dW), _p(sums), st)
+                    else:
+                        _ffi.call("demf_mlp_bwd_fused", R, N, K, _p(G), None, None, ns, _p(Ys[l]), _p(vec6),
+                                  _p(W), _p(Ys[0]), _p(sss[0]), _p(mis[0]), None, _p(dW), None, _p(x),
+                                  _p(sums), None, None, None, None, 2 if s16 else 0, st)
                     dW0 = ws32[o32:o32 + N0 * 4].view(N0, 4)
                     o32 += N0 * 4
                     dgamma0 = torch.empty(N0, dtype=torch.float32, device=dev)

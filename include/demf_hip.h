@@ -440,6 +440,29 @@ int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, const float*
                             const float* gamma_prev, float* vec6_prev, float* dgamma_prev,
                             float* dbeta_prev, demf_stream_t stream);
 
+/* SA1-shaped stacks (4-float grouped rows -> N0 <= 64 channels -> ...): the first layer WITHOUT its (R x N0)
+ * output.  y = x.W0^T is linear in the 16-byte row, so
+ *   demf_mlp_first_stats      the layer's train-mode BN statistics + bookkeeping from the 14 second moments of the
+ *                             rows (one pass over 16 MB instead of a GEMM writing 268 MB); ``moments``: >= 14
+ *                             doubles of a zeroed accumulator, left zeroed;
+ *   demf_mlp_gemm_fwd_bn_x4   the second layer (64 -> 64): demf_mlp_gemm_fwd_bn with its BN + ReLU prologue
+ *                             fed by rows rebuilt from X4 and W0 (R >= 16384, compute modes 1 / 2);
+ *   demf_mlp_bwd_fused_x4     the second layer's one-pass backward with the FIRST epilogue
+ *                             (demf_mlp_bwd_fused, first_sums != NULL), likewise rebuilding layer 0's output.
+ * mmdet3d PointSAModule's shared MLP at SA1 (configs/demf/demf_votenet.py:48-62).                          */
+int demf_mlp_first_stats(int R, int N0, const float* X, const float* W0, double* moments, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* scale_shift,
+                         float* mean_invstd, const float* conv_bias, demf_stream_t stream);
+int demf_mlp_gemm_fwd_bn_x4(int R, int N, const float* X4, const float* W0, const float* prev_scale_shift,
+                            const float* Wt, float* Y, double* stats, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var,
+                            long long* num_batches_tracked, float* scale_shift, float* mean_invstd,
+                            const float* conv_bias, demf_stream_t stream);
+int demf_mlp_bwd_fused_x4(int R, int N, int K, const float* G, const float* Y, const float* vec6,
+                          const float* W, const float* X0, const float* W0, const float* scale_shift_prev,
+                          const float* mean_invstd_prev, float* dW, double* first_sums, demf_stream_t stream);
+
 /* Backward of a POOLED last layer without its (R x N) output (SA1: 537 MB neither written by the forward
  * nor read here).  With y = A.W^T and dY = gi*dZ + a*y + b (train-mode BN), A = act(Y_{L-1}):
  *     dA = (gi*dZ).W + A.(W^T diag(a) W) + b^T W,    dW = (gi*dZ)^T.A + diag(a) W (A^T A) + b (x) colsum(A)

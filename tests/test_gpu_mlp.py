@@ -84,7 +84,17 @@ def test_shared_mlp_pool_fwd_bwd(Rp, ns, ld, chans, xgrad):
     for l in range(L):
         Yg, ssg = saved[2 + l].double().cpu(), saved[2 + L + l].double().cpu()
         n = Yg.shape[1]
-        if Yg.numel() == 0:
+        if Yg.numel() == 0 and l == 0:
+            # SA1's first layer without its output (ops._SA1_X4): every consumer rebuilds y = x.W0^T from the
+            # 4-float row with the same fp32 fma chain - restated here (fp64 products are exact, one rounding
+            # per fma) to read the kernels' ReLU decisions
+            xf, wf = xg.detach().cpu().double(), lg[0][0].detach().cpu().double()
+            f32 = lambda t: t.float().double()
+            y0 = f32(xf[:, 0:1] * wf[:, 0])
+            for k_ in (1, 2, 3):
+                y0 = f32(xf[:, k_:k_ + 1] * wf[:, k_] + y0)
+            masks_g.append(y0 * ssg[:n] + ssg[n:] > 0)
+        elif Yg.numel() == 0:
             # the no-store pooled last layer (SA1 shape): its raw output does not exist; the only ReLU
             # decisions that reach the result are those at the selected rows, kept as ``yraw``
             yraw = saved[2 + 5 * L].double().cpu()

@@ -76,6 +76,7 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
         # (the no-store pooled last layer re-associates the backward: in the bf16 mode it rounds A and
         # W^T diag(a) W where this comparison assumes dY and W - it has its own test below)
         ops._POOL_NOY = mode == "f32"
+        ops._SA1_X4 = False                    # (rebuilds layer 0's output with an fma chain: not bit-equal to the MFMA's)
         ops._FUSED_COLS_MIN_R = 16384          # (opt-in: DEMF_FUSED_COLS_MIN_R, measured neutral on the step)
         out_f, g_f = _run(x, layers, go, ns, xgrad)
         n_fused = calls.count("demf_mlp_bwd_fused")
@@ -88,6 +89,7 @@ def test_fused_backward_equals_the_two_launch_path(Rp, ns, ld, chans, xgrad, mod
         _ffi.call = orig
         ops._NO_BWD_FUSE = False
         ops._POOL_NOY = True
+        ops._SA1_X4 = True
         ops._FUSED_COLS_MIN_R = cols_min
         ops.set_compute_dtype("f32")
     assert n_fused + n_cols >= 1, "the case must exercise the fused kernel"
@@ -198,18 +200,30 @@ def test_pooled_last_layer_without_its_output(Rp, mode):
         return orig(name, *a)
     try:
         _ffi.call = spy
-        ops._POOL_NOY = True
+        ops._POOL_NOY, ops._SA1_X4 = True, False
         out_n, g_n = _run(x, layers, go, ns, False)
         assert calls.count("demf_mlp_bwd_pool") == 1 and "demf_pool_select_slot0" in calls
         calls.clear()
         ops._POOL_NOY = False
         out_s, g_s = _run(x, layers, go, ns, False)
         assert "demf_mlp_bwd_pool" not in calls
+        # + the first layer without ITS output (statistics from the rows' moments, consumers rebuild it)
+        calls.clear()
+        ops._POOL_NOY, ops._SA1_X4 = True, True
+        out_x, g_x = _run(x, layers, go, ns, False)
+        assert {"demf_mlp_first_stats", "demf_mlp_gemm_fwd_bn_x4", "demf_mlp_bwd_fused_x4"} <= set(calls)
     finally:
         _ffi.call = orig
-        ops._POOL_NOY = True
+        ops._POOL_NOY, ops._SA1_X4 = True, True
         ops.set_compute_dtype("f32")
     assert torch.equal(out_n, out_s)
+    relx = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    tolx = 2e-5 if mode == "f32" else 2e-2
+    assert relx(out_x, out_s) <= tolx, relx(out_x, out_s)
+    worst_x = max(relx(a, b) for a, b in zip(g_x, g_s))
+    print("first layer without its output vs stored (%s): output rel-L2 %.2e, worst gradient rel-L2 %.2e"
+          % (mode, relx(out_x, out_s), worst_x))
+    assert worst_x <= (2e-4 if mode == "f32" else 3e-2), worst_x
     names = [f"layer{l}.{n}" for l in range(3) for n in ("W", "gamma", "beta")]
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
     tol = 1e-4 if mode == "f32" else 2e-2      # bf16: M = W^T diag(a) W and A are rounded where dY and W were
@@ -230,3 +244,5 @@ def test_pooled_last_layer_without_its_output(Rp, mode):
         assert float((out_n.double().cpu() - ref.detach()).abs().max()) <= 1e-4 * max(1.0, float(ref.detach().abs().max()))
         for n, a, b in zip(names, g_n, want):
             assert rel(a.cpu(), b) <= 5e-3, (n, rel(a.cpu(), b))
+        for n, a, b in zip(names, g_x, want):
+            assert rel(a.cpu(), b) <= 5e-3, ("x4 " + n, rel(a.cpu(), b))
