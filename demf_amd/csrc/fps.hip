@@ -23,6 +23,7 @@
 //   * thread t owns points t, t+BS, t+2BS, ... with BS = min(1024, 2^floor(log2 N))
 //     - the same ownership as the upstream block reduction - so "first maximum in
 //     the thread, then lowest thread id" reproduces upstream tie-breaking exactly.
+#include <type_traits>
 #include "common.h"
 
 namespace demf {
@@ -324,6 +325,298 @@ __global__ __launch_bounds__(BS) void fps_reg_kernel(int N, int M,
   for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
 }
 
+// ---- exact spatially pruned FPS for large clouds -------------------------------------------------------
+// A round of fps_reg_kernel costs ~3 200 cycles, of which ~1 700 are the SIMDs' VALU issue: every one of the
+// 16 waves updates its 20 x 64 points although, once a few hundred samples exist, a new sample can only
+// lower the running distance of points within the current maximum of it.  Here the scene's points are first
+// binned into 16^3 cells in Hilbert order (fps_sort_k) and a wave owns a CONTIGUOUS run of the cell order, i.e. a
+// compact block of space.  Per round a wave evaluates the canonical squared distance from the new sample to
+// its block's bounding box, lb - with the same operations in the same order as dist2(), so by the monotonicity
+// of IEEE rounding lb <= d(p) for every point p of the block - and if lb >= the block's cached maximum of the
+// running distances, then min(d, tmp) == tmp for all of them: the wave skips the update and contributes its
+// cached maximum.  Picks are bit-identical to the full update.  What the spatial order destroys is the upstream
+// tie rule "first maximum in the thread, then lowest thread" = lowest (k mod 1024, k / 1024); every point
+// therefore carries that key (15 bits, two per register) and ties are resolved by it explicitly: inside a wave
+// by a min-key chain over the slots that hold the maximum, across waves by a second exchange among the waves
+// whose maxima tie (usually one).  Two barriers per round, as before.
+constexpr int FPS_CELLS = 4096;
+
+// 12-bit Hilbert index of a cell (x, y, z in 0..15) - Skilling's axes-to-transpose transform.  A Morton
+// (Z-order) run of equal point COUNT jumps across space wherever it crosses a high-level cell boundary
+// (measured: 3 of 16 waves with a bounding box as large as the scene, updating in 55-80 % of the rounds);
+// consecutive Hilbert cells are always face neighbours, so every run is one connected, compact region.
+__device__ __forceinline__ unsigned hilbert12(unsigned x, unsigned y, unsigned z) {
+  unsigned X[3] = {x, y, z};
+#pragma unroll
+  for (unsigned Q = 8; Q > 1; Q >>= 1) {
+    const unsigned P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) X[0] ^= P;
+      else { const unsigned t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0;
+#pragma unroll
+  for (unsigned Q = 8; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  unsigned idx = 0;
+#pragma unroll
+  for (int j = 3; j >= 0; --j)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) idx = (idx << 1) | ((X[i] >> j) & 1u);
+  return idx;
+}
+
+// perm[b][i] = original index of the i-th point of scene b in Hilbert-cell order (order inside a cell
+// arbitrary: the sampling result does not depend on it)
+__global__ __launch_bounds__(1024) void fps_sort_k(int N, const float* __restrict__ xyz, int* __restrict__ perm) {
+  __shared__ int s_cnt[FPS_CELLS];
+  __shared__ float s_red[6][16];
+  __shared__ int s_part[16];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  xyz += (size_t)b * N * 3;
+  perm += (size_t)b * N;
+  float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+  for (int k = tid; k < N; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const float v = xyz[3 * k + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float mn = -wave_allmax(-lo[a]), mx = wave_allmax(hi[a]);
+    if (lane == 0) { s_red[a][wave] = mn; s_red[3 + a][wave] = mx; }
+  }
+  for (int i = tid; i < FPS_CELLS; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  float inv[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float mn = s_red[a][0], mx = s_red[3 + a][0];
+    for (int w = 1; w < 16; ++w) { mn = fminf(mn, s_red[a][w]); mx = fmaxf(mx, s_red[3 + a][w]); }
+    lo[a] = mn;
+    inv[a] = mx > mn ? 16.0f / (mx - mn) : 0.f;
+  }
+  auto cell_of = [&](int k) {
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int v = (int)((xyz[3 * k + a] - lo[a]) * inv[a]);
+      q[a] = (unsigned)(v < 0 ? 0 : (v > 15 ? 15 : v));
+    }
+    return (int)hilbert12(q[0], q[1], q[2]);
+  };
+  for (int k = tid; k < N; k += 1024) atomicAdd(&s_cnt[cell_of(k)], 1);
+  __syncthreads();
+  // exclusive scan of the 4096 counters: 4 per thread, wave scan, 16 wave totals
+  int c4[4], run = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c4[i] = s_cnt[4 * tid + i]; run += c4[i]; }
+  int inc = run;
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+  if (lane == 63) s_part[wave] = inc;
+  __syncthreads();
+  int base = inc - run;
+  for (int w = 0; w < wave; ++w) base += s_part[w];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s_cnt[4 * tid + i] = base; base += c4[i]; }
+  __syncthreads();
+  for (int k = tid; k < N; k += 1024) perm[atomicAdd(&s_cnt[cell_of(k)], 1)] = k;
+}
+
+// unsigned minimum over the wave / over each 16-lane row, on DPP (a __shfl_xor butterfly is six LDS-crossbar
+// round trips: ~700 cycles per reduction, measured as +1 200 cycles per round)
+__device__ __forceinline__ unsigned umin(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+// wave64 minimum, returned wave-uniform (lane 63 holds it after the two row broadcasts)
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = row16_min_u32(v);
+  asm volatile(
+      "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct __attribute__((aligned(32))) FpsCand { float v; unsigned tk; float x, y, z; };
+
+// Exact farthest point sampling with bounding-box pruning.  The points of a scene arrive in Hilbert-cell
+// order (perm); wave w owns positions [w*64*PPT, (w+1)*64*PPT), two register slots (a PAIR, 128 consecutive
+// positions of the curve = one compact region) per packed register.  Lane g of the wave keeps the bounding
+// box of pair g, so ONE pass of the distance arithmetic tests all pairs of the wave:
+//   * a new sample can lower a running distance of a pair only if its distance to the pair's box is below
+//     the wave's maximum running distance cv.  The box distance is the same rounded operations as dist2()
+//     on offsets no larger in magnitude than any point's, so it is <= every computed point distance
+//     (rounding is monotone); a pair that is skipped would have changed nothing.
+//   * the wave's candidate (cv, the lowest tie key that holds it, that point's coordinates) is cached.
+//     Lane 63 carries the candidate point itself as a degenerate box, whose "box distance" IS the
+//     candidate's distance to the new sample, bit for bit: while that stays >= cv the candidate keeps its
+//     value, still holds the maximum (no distance ever grows) and is still the lowest key that holds it -
+//     so the wave reduces and searches again only in the rounds that lower its own candidate.
+// One barrier per round: waves publish their candidate (double-buffered by round parity, rewritten only
+// for two rounds after a change), every wave reduces the 16.  Picks are bit-identical to the full update.
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const float* __restrict__ xyz,
+                                                         const int* __restrict__ perm, int* __restrict__ idx) {
+  constexpr int BS = 1024, NW = 16, PP = PPT / 2;
+  static_assert(PPT % 2 == 0 && PP < 63, "pairs of slots, lane 63 is the candidate's");
+  asm volatile("" ::: "v127");                   // the CU's whole register file, as fps_reg_kernel
+  __shared__ FpsCand s_cand[2][16];
+  __shared__ int s_idx[FPS_IDX_CHUNK];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * N * 3;
+  perm += (size_t)b * N;
+  idx += (size_t)b * M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f2 px[PP], py[PP], pz[PP];
+  float tmp[PPT];
+  unsigned kp[PPT];                               // (tie key << 5) | slot
+  float blx = 1e30f, bly = 1e30f, blz = 1e30f, bhx = -1e30f, bhy = -1e30f, bhz = -1e30f;
+  // a valid point of the wave for its padding slots
+  const int first = wave * 64 * PPT;
+  const int kf = perm[first < N ? first : 0];
+  const float fx = xyz[3 * kf], fy = xyz[3 * kf + 1], fz = xyz[3 * kf + 2];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * i + q;
+      const int pos = first + p * 64 + lane;
+      const bool ok = pos < N;
+      const int k = ok ? perm[pos] : 0;
+      const float x = ok ? xyz[3 * k] : fx, y = ok ? xyz[3 * k + 1] : fy, z = ok ? xyz[3 * k + 2] : fz;
+      px[i][q] = x; py[i][q] = y; pz[i][q] = z;
+      tmp[p] = ok ? 1e10f : -2.f;                 // pad slots can never reach the maximum
+      const unsigned key = ok ? (((unsigned)k & 1023u) << 5) | ((unsigned)k >> 10) : 0x7FFFu;
+      kp[p] = (key << 5) | (unsigned)p;
+      if (ok) {
+        l[0] = fminf(l[0], x); h[0] = fmaxf(h[0], x);
+        l[1] = fminf(l[1], y); h[1] = fmaxf(h[1], y);
+        l[2] = fminf(l[2], z); h[2] = fmaxf(h[2], z);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { l[a] = -wave_allmax(-l[a]); h[a] = wave_allmax(h[a]); }
+    if (lane == i) { blx = l[0]; bly = l[1]; blz = l[2]; bhx = h[0]; bhy = h[1]; bhz = h[2]; }
+  }
+  if (lane == 63) { blx = bly = blz = bhx = bhy = bhz = 0.f; }     // any finite point: round 1 searches
+  float cv = first < N ? 1e10f : -2.f;
+  unsigned ctk = 0xFFFFFFFFu;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  int dirty = 2;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (tid == 0) s_idx[0] = 0;
+
+  for (int j = 1; j < M; ++j) {
+    // ---- every pair's box (and the candidate) against the new sample, one lane each
+    const float ex = raw_max3(blx - x1, x1 - bhx, 0.f);
+    const float ey = raw_max3(bly - y1, y1 - bhy, 0.f);
+    const float ez = raw_max3(blz - z1, z1 - bhz, 0.f);
+    const float lb = dist2(ex, ey, ez);
+    const unsigned long long need = __ballot(!(lb >= cv));
+    if (need) {                                           // (wave-uniform)
+      const f2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
+#pragma unroll
+      for (int i = 0; i < PP; ++i) {
+        if ((need >> i) & 1ull) {
+          const f2 dx = px[i] - X1, dy = py[i] - Y1, dz = pz[i] - Z1;
+          f2 d = dy * dy;                               // dist2(): fma(dz,dz,fma(dx,dx,dy*dy))
+          d = __builtin_elementwise_fma(dx, dx, d);
+          d = __builtin_elementwise_fma(dz, dz, d);
+          tmp[2 * i] = raw_min(d[0], tmp[2 * i]);
+          tmp[2 * i + 1] = raw_min(d[1], tmp[2 * i + 1]);
+        }
+      }
+      if (need >> 63) {                                   // the candidate's own distance fell: search again
+        float best = -1.f;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) best = raw_max3(best, tmp[2 * i], tmp[2 * i + 1]);
+        cv = wave_max_dpp(best);
+        // lowest (tie key, slot) among the wave's points that hold the maximum
+        unsigned bt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) bt = tmp[p] == cv ? umin(bt, kp[p]) : bt;
+        const unsigned btmin = wave_min_u32(bt);
+        const int wl = __builtin_ctzll(__ballot(bt == btmin));
+        ctk = btmin >> 5;
+        // its coordinates: a scalar branch on the (wave-uniform) slot, one v_readlane per coordinate
+#define DEMF_FPS_PICK(P)                                                                       \
+  case P:                                                                                      \
+    if constexpr ((P) < PPT) {                                                                 \
+      cx = readlane_f(px[(P) / 2][(P) % 2], wl);                                               \
+      cy = readlane_f(py[(P) / 2][(P) % 2], wl);                                               \
+      cz = readlane_f(pz[(P) / 2][(P) % 2], wl);                                               \
+    }                                                                                          \
+    break;
+        switch ((int)(btmin & 31u)) {
+          DEMF_FPS_PICK(0) DEMF_FPS_PICK(1) DEMF_FPS_PICK(2) DEMF_FPS_PICK(3) DEMF_FPS_PICK(4) DEMF_FPS_PICK(5)
+          DEMF_FPS_PICK(6) DEMF_FPS_PICK(7) DEMF_FPS_PICK(8) DEMF_FPS_PICK(9) DEMF_FPS_PICK(10) DEMF_FPS_PICK(11)
+          DEMF_FPS_PICK(12) DEMF_FPS_PICK(13) DEMF_FPS_PICK(14) DEMF_FPS_PICK(15) DEMF_FPS_PICK(16)
+          DEMF_FPS_PICK(17) DEMF_FPS_PICK(18) DEMF_FPS_PICK(19) DEMF_FPS_PICK(20) DEMF_FPS_PICK(21)
+          DEMF_FPS_PICK(22) DEMF_FPS_PICK(23)
+          default: break;
+        }
+#undef DEMF_FPS_PICK
+        if (lane == 63) { blx = bhx = cx; bly = bhy = cy; blz = bhz = cz; }
+        dirty = 2;
+      }
+    }
+    // ---- block maximum, lowest tie key among the waves that hold it
+    FpsCand* slot = s_cand[j & 1];
+    if (dirty) {
+      if (lane == 0) slot[wave] = FpsCand{cv, ctk, cx, cy, cz};
+      --dirty;
+    }
+    lds_barrier();
+    {
+      const FpsCand c = slot[lane & (NW - 1)];           // every 16-lane row: all 16 waves
+      const float gmax = readlane_f(row16_max_dpp(c.v), 0);
+      const unsigned long long held = __ballot(c.v == gmax) & 0xFFFFull;
+      int wv = __builtin_ctzll(held);
+      if (held & (held - 1)) {                           // several waves hold it: lowest tie key
+        const unsigned key = c.v == gmax ? c.tk : 0xFFFFFFFFu;
+        const unsigned tmin = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_min_u32(key));
+        wv = __builtin_ctzll(__ballot(key == tmin));
+      }
+      x1 = readlane_f(c.x, wv);
+      y1 = readlane_f(c.y, wv);
+      z1 = readlane_f(c.z, wv);
+      if (tid == 0) {
+        const unsigned tk = (unsigned)__builtin_amdgcn_readlane((int)c.tk, wv);
+        s_idx[j & (FPS_IDX_CHUNK - 1)] = (int)(((tk & 31u) << 10) | (tk >> 5));
+      }
+    }
+    if (((j + 1) & (FPS_IDX_CHUNK - 1)) == 0) {
+      lds_barrier();
+      const int base = j + 1 - FPS_IDX_CHUNK;
+      for (int t = tid; t < FPS_IDX_CHUNK; t += BS) idx[base + t] = s_idx[t];
+      lds_barrier();
+    }
+  }
+  lds_barrier();
+  const int base = M & ~(FPS_IDX_CHUNK - 1);
+  for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
+}
+
 struct __attribute__((aligned(32))) FpsSlot {
   float v;
   int i;
@@ -412,6 +705,18 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
   if (temp != nullptr && M >= 2 && M <= FPS_PREFIX_MAX && N <= 4 * M && bs >= 64 && ppt <= 24) {
     hipLaunchKernelGGL(fps_ordered_check_k, dim3(B), dim3(1024), 0, s, N, M, xyz, idx, (int*)temp);
     skip = (const int*)temp;
+  }
+  // large clouds with the (B, N) scratch at hand: Hilbert-cell order + the exact box-pruned kernel
+  static const int prune_on = [] { const char* v = getenv("DEMF_FPS_PRUNE"); return v ? atoi(v) : 1; }();
+  if (prune_on && skip == nullptr && temp != nullptr && bs == 1024 && N >= 4096 && N <= 20 * 1024 && M >= 64 &&
+      M <= N) {
+    int* perm = (int*)temp;
+    hipLaunchKernelGGL(fps_sort_k, dim3(B), dim3(1024), 0, s, N, xyz, perm);
+#define PRUNE(P) hipLaunchKernelGGL((fps_prune_kernel<P>), dim3(B), dim3(1024), 0, s, N, M, xyz, perm, idx)
+    if (ppt <= 4) PRUNE(4); else if (ppt <= 8) PRUNE(8); else if (ppt <= 12) PRUNE(12);
+    else if (ppt <= 16) PRUNE(16); else PRUNE(20);          // 24 slots + their keys spill
+#undef PRUNE
+    return check_launch("fps_prune");
   }
   bool done = true;
   if (bs == 1024) {

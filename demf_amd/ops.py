@@ -178,7 +178,8 @@ class _FurthestPointSampling(Function):
         # the register-resident kernel covers 64 <= N <= 24576; outside it the library
         # needs the (B,N) running-distance scratch the upstream ABI always carries
         temp = None
-        if N < 64 or N > 24 * 1024:
+        if N < 64 or N > 24 * 1024 or (N >= 4096 and num_points >= 64 and not (N <= 4 * num_points)):
+            # (large clouds: the scratch holds the Hilbert-cell order of the exact box-pruned kernel)
             temp = torch.empty((B, N), dtype=torch.float32, device=points_xyz.device)
         elif 2 <= num_points <= 1024 and N <= 4 * num_points and not _NO_FPS_CHECK:
             # B flags for the ordered-input check (every SA level after the first samples a cloud

@@ -207,19 +207,20 @@ def make_case(cfg, B, N, pyramid, in_shape, img_shape, seed):
 _CASES = {}      # qualified cases of this pytest session: the B=8 oracle runs take minutes of CPU
 
 
-def qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=range(1, 12), log=print):
-    """The first seed whose discrete events all keep their distance (module docstring).
+def qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=range(1, 12), log=print, risk_max=RISK_MAX):
+    """The first seed whose discrete events all keep their distance (module docstring); ``risk_max``
+    tightens the flip-risk bound for a test whose gradient cap is below 2 x RISK_MAX.
     -> dict(seed, batch, gtb, gtl, truth, cpu32) ; raises if none of ``seeds`` qualifies.
     Cached per argument set for the session (the fp32 and the bf16 whole-path tests of the same
     configuration share the oracle runs; the choice still depends on the oracle alone)."""
     key = (repr(cfg), B, N, tuple(pyramid), tuple(in_shape), tuple(img_shape) if img_shape else None,
-           tuple(seeds))
+           tuple(seeds), risk_max)
     if key not in _CASES:
-        _CASES[key] = _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log)
+        _CASES[key] = _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log, risk_max)
     return _CASES[key]
 
 
-def _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log):
+def _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log, risk_max=RISK_MAX):
     why = []
     for seed in seeds:
         case = make_case(cfg, B, N, pyramid, in_shape, img_shape, seed)
@@ -235,7 +236,7 @@ def _qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds, log):
         cpu32 = oracle_run(cfg, batch, gtb, gtl, seed, torch.float32, truth_taps=truth["taps"])
         risks = flip_risks(truth["taps"], cpu32["taps"].noise)
         worst = max(risks.items(), key=lambda kv: kv[1][0])
-        if worst[1][0] > RISK_MAX:
+        if worst[1][0] > risk_max:
             why.append(f"seed {seed}: flip risk {worst[1][0]:.1e} at {worst[0]} "
                        f"({worst[1][2]} elements within {worst[1][1]:.1e})")
             continue

@@ -138,9 +138,9 @@ TARGET_NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_r
 GRAD_CAP = dict(mid=2e-2, full2=6e-2, full2p4=8e-2, full8=1e-1)
 
 
-def _parity(cfg, B, N, pyramid, in_shape, img_shape, seeds, cap=None):
+def _parity(cfg, B, N, pyramid, in_shape, img_shape, seeds, cap=None, risk_max=P.RISK_MAX):
     """One input (the first seed of ``seeds`` that the oracle qualifies), every check, no retry."""
-    case = P.qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=seeds)
+    case = P.qualified_case(cfg, B, N, pyramid, in_shape, img_shape, seeds=seeds, risk_max=risk_max)
     T, C = case["truth"], case["cpu32"]
     G = _gpu_run(cfg, case)
     for k in ("seed_indices", "aggregated_indices"):
@@ -194,7 +194,10 @@ def test_hot_path_vs_oracle_full_config():
     """configs/demf/demf_votenet.py sizes: 20 000 points, 800x1120 pyramid, 256 queries."""
     from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
     cfg = DeMFCfg(head=HeadCfg(attn_dropout=0.0, ffn_dropout=0.0))
-    _parity(cfg, 2, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2], seeds=SEEDS["full2"], cap=GRAD_CAP["full2"])
+    # a flip the qualification PREDICTS (risk 8.7e-2 at conv_pred0.shared_convs.layer1 for seed 1) is as
+    # large as the cap: the input must keep its worst flip below the cap it is held to
+    _parity(cfg, 2, 20000, PYRAMID_SHAPES, BATCH_INPUT_SHAPE, IMG_SHAPE[:2], seeds=SEEDS["full2"],
+            cap=GRAD_CAP["full2"], risk_max=5e-2)
 
 
 def test_hot_path_vs_oracle_full_config_four_sampling_points():
@@ -326,5 +329,5 @@ def test_hot_path_bf16_vs_emulating_oracle_full_config_batch_8():
 # of tests/parity_tools.py in the build container - tools/qualify_seeds.py - so that the GPU tier
 # does not spend minutes of CPU time rejecting seeds; qualification is re-evaluated at test time
 # and the search simply continues if the host's BLAS rounds differently.
-SEEDS = dict(mid=tuple(range(1, 12)), full2=tuple(range(1, 12)), full2p4=tuple(range(1, 12)),
+SEEDS = dict(mid=tuple(range(1, 12)), full2=(4, 5, 6, 8, 11, 1, 2, 3, 7, 9, 10), full2p4=tuple(range(1, 12)),
              full8=tuple(range(1, 12)))

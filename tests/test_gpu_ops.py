@@ -27,7 +27,10 @@ def dev(a):
 # SA levels of configs/demf/demf_votenet.py:51-53 + the head's 1024->256 (cfg:157)
 FPS_CASES = [(20000, 2048), (2048, 1024), (1024, 512), (512, 256), (1024, 256),
              (1, 1), (3, 3), (63, 10), (64, 64), (100, 37), (1500, 700), (5000, 64),
-             (24576, 32), (30000, 40)]
+             (24576, 32), (30000, 40),
+             # the box-pruned kernel (N >= 4096, M >= 64, no ordered-input shortcut): every points-per-lane form,
+             # a ragged last wave, the largest cloud the register-resident kernels hold
+             (4097, 64), (8192, 1024), (12000, 500), (15000, 3000), (20480, 2048), (24576, 3000)]
 
 
 @pytest.mark.parametrize("n,m", FPS_CASES)
@@ -39,6 +42,15 @@ def test_fps_bit_exact(ops, n, m, kind):
     x = dev(xyz)
     idx = ops.furthest_point_sample(x, m)
     np.testing.assert_array_equal(idx.cpu().numpy(), want)
+
+
+def test_fps_pruned_ties_everywhere(ops):
+    """Coarsely grid-snapped clustered clouds: almost every round has several points at exactly the maximal
+    distance, in different spatial cells / waves of the box-pruned kernel - the upstream tie rule (lowest
+    k mod 1024, then lowest k) must still decide."""
+    for grid in (2, 4):
+        xyz = scene_points(2, 20000, seed=31 + grid, grid=grid, clustered=True)
+        np.testing.assert_array_equal(ops.furthest_point_sample(dev(xyz), 1024).cpu().numpy(), ok.fps(xyz, 1024))
 
 
 def test_fps_clustered_and_duplicates(ops):
