@@ -33,14 +33,19 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 CLOCK_GHZ = 2.4
-# The kernel the headline `roofline` object prices: SA1's last shared-MLP layer (R = B*2048*64 grouped
-# rows, 64 -> 128 channels, BN statistics + max-pool in the epilogue).  `prefix`: how rocprofv3 prints the
-# instantiation - matched BY PREFIX against the committed PMC / stats files (trailing template
-# arguments come and go with the kernel's options).
-DOMINANT_KERNEL = {"f32_native": "mlp_gemm_kernel<4, 1, 1, true, true, false, false, 0, true>",
-                   "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2",       # weight-resident forward (csrc/mlp.hip)
-                   "bf16": "mlp_fwd_res_kernel<4, 2, true, 1"}
+# The kernel the headline `roofline` object prices: the single longest launch on the step's main stream -
+# since round 4 the BACKWARD of SA1's last shared-MLP layer (R = B*2048*64 grouped rows, 128 -> 64
+# channels; csrc/mlp_bwd.hip mlp_bwd_pool_kernel: the pooled layer's input gradient, weight gradient and
+# the previous layer's BN sums without the layer's (R,128) output ever stored).  `prefix`: how rocprofv3
+# prints the instantiation - matched BY PREFIX against the committed PMC / stats files.
+DOMINANT_KERNEL = {"f32_native": "mlp_bwd_pool_kernel<0>", "f32x3": "mlp_bwd_pool_kernel<2>",
+                   "bf16": "mlp_bwd_pool_kernel<1>"}
 DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
+    "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
+# its forward twin (the round-3 headline): SA1 layer 3, 64 -> 128 + BN statistics + max-pool, no output store
+SA1_FWD_KERNEL = {"f32_native": "mlp_fwd_res_kernel<4, 2, true, 0", "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2",
+                  "bf16": "mlp_fwd_res_kernel<4, 2, true, 1"}
+SA1_FWD_KERNEL["f32"] = SA1_FWD_KERNEL[
     "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
 MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
              "f32x3": "fp32 operands split exactly into 3 bf16 terms, 6 products on "
@@ -355,12 +360,12 @@ def main():
     batch = batches[0]
 
     fps_timer = KernelTimer(ops, "furthest_point_sample")
-    # the largest FORWARD kernel on the critical path (the FPS chain runs underneath the step on a side
-    # stream): SA1's last shared-MLP layer, 64 -> 128 channels over B*2048*64 grouped rows, with
-    # BN statistics and the max-pool fused into its epilogue
+    # the longest launch on the critical path (the FPS chain runs underneath the step on a side stream):
+    # SA1's last shared-MLP layer backward, and its forward twin
     from demf_amd import _ffi
     sa1_rows = args.batch * 2048 * 64
-    mlp_timer = FfiTimer(_ffi, "demf_mlp_gemm_fwd_pool_bn", (sa1_rows, 64, 128))
+    mlp_timer = FfiTimer(_ffi, "demf_mlp_bwd_pool", (sa1_rows, 128, 64, 64))
+    fwd_timer = FfiTimer(_ffi, "demf_mlp_gemm_fwd_pool_bn_st", (sa1_rows, 64, 128))
 
     def sync():
         if world > 1:
@@ -430,11 +435,14 @@ def main():
     # dominant-kernel duration: HIP events around the same launches, same inputs, same stream,
     # in an eager pass right after the timed region (a graph replay cannot host per-kernel
     # events); profiles/ holds the rocprofv3 figure for the same kernel inside the replays
-    fps_timer.enabled = mlp_timer.enabled = True
+    fps_timer.enabled = mlp_timer.enabled = fwd_timer.enabled = True
     for _ in range(min(args.steps, 5)):
         trainer.step(batch)
     torch.cuda.synchronize()
-    fps_timer.enabled = mlp_timer.enabled = False
+    fps_timer.enabled = mlp_timer.enabled = fwd_timer.enabled = False
+    if not mlp_timer.events:
+        raise RuntimeError("bench: demf_mlp_bwd_pool was not launched with R=%d - the roofline object would "
+                           "describe a kernel this step does not run" % sa1_rows)
 
     def time_steps(fn, n):
         for _ in range(3):
@@ -545,31 +553,33 @@ def main():
         if rank_info is not None:
             out["ranks"] = [dict(rank=r["rank"], batch_seeds=r["batch_seeds"], dropout_seed=r["dropout_seed"])
                             for r in rank_info]
-        # ---- headline roofline: the largest forward kernel ON the step's critical path.  Algorithmic
-        # bytes of that GEMM = read the (R,64) input rows once, write the (R,128) raw output once, write
-        # the pooled extremum that the sign of gamma selects + its row offset (2 x (R/64,128) words);
-        # weights < 1 %.
+        # ---- headline roofline: the longest launch ON the step's main stream - SA1's last layer backward.
+        # Algorithmic bytes of that layer's backward = read the (R,64) input rows once, write their (R,64)
+        # gradient once, read the pooled gradient, its argmax rows and the raw pooled values (3 x (R/64,128)
+        # words); weights and the (128,64) weight gradient < 1 %.  Algorithmic FLOPs: dX = dZ W and
+        # dW = dZ^T A, 2 x 2 R 128 64.
         x3 = args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"]
         # MFMA budget of the mode: native fp32 -> the fp32 MFMA peak; bf16 -> the bf16 peak; the
         # three-term split issues 6 bf16 MFMAs per algorithmic product -> bf16 peak / 6
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else \
             (MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS)
         mlp_ms = mlp_timer.mean_ms()
-        mlp_bytes = sa1_rows * (64 + 128) * 4 + 2 * (sa1_rows // 64) * 128 * 4
-        mlp_flop = 2.0 * sa1_rows * 64 * 128
+        mlp_bytes = 2 * sa1_rows * 64 * 4 + 3 * (sa1_rows // 64) * 128 * 4
+        mlp_flop = 2 * 2.0 * sa1_rows * 64 * 128
         dom = DOMINANT_KERNEL[args.dtype]
         # (the committed PMC passes are B = 8 runs of the default mode; no row for this kernel in the
         # newest pair is an error there, not a silent fall-back to an older round's file)
-        traffic, src = pmc_per_launch(dom, required=(args.batch == 8 and args.dtype == "f32"
-                                                      and not os.environ.get("DEMF_F32_NATIVE"))) \
-            if args.batch == 8 else (None, None)
+        strict = args.batch == 8 and args.dtype == "f32" and not os.environ.get("DEMF_F32_NATIVE")
+        traffic, src = pmc_per_launch(dom, required=strict) if args.batch == 8 else (None, None)
         tk, tk_src = top_kernels()
         out["roofline"] = {
-            "kernel": "%s...> (SA1 layer 3: 64->128 + BN stats + max-pool epilogue, R=%d)" % (dom, sa1_rows),
+            "kernel": "%s (SA1 layer 3 backward: dX, dW and layer 2's BN sums from the pooled gradient; the "
+                      "layer's (R,128) output is never stored; R=%d)" % (dom, sa1_rows),
             # priced against the HBM roof (its algorithmic bytes dominate its FLOPs at either MFMA
-            # rate); what actually limits it today is on-chip: VALU issue + latency at 2 waves/SIMD
-            # (PMC pipe counters)
-            "bound": "hbm", "limited_by": "valu-issue/latency (2 waves per SIMD), not HBM bytes",
+            # rate); what limits it today is on-chip: MFMA issue of the three-term products (44 % of its
+            # time, tools/pool_bwd_micro.py phase skips) + latency at 2 waves/SIMD
+            "bound": "hbm", "limited_by": "mfma issue of the split products + latency (2 waves per SIMD), "
+                                          "not HBM bytes",
             "achieved": mlp_bytes / (mlp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": mlp_bytes / (mlp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": src, "algorithmic_bytes": mlp_bytes,
@@ -582,6 +592,20 @@ def main():
                     % (mlp_flop / 1e9, mfma_peak,
                        "dense bf16 MFMA peak" if args.dtype == "bf16" else
                        ("dense bf16 MFMA peak / 6: three-term split" if x3 else "dense fp32 MFMA peak"))}
+        # the forward twin (round 3's headline kernel): reads the (R,64) rows, writes only the pooled
+        # (R/64,128) extremum + its row; since round 4 the (R,128) output is not stored
+        fwd_ms = fwd_timer.mean_ms()
+        if fwd_ms == fwd_ms:
+            fwd_bytes = sa1_rows * 64 * 4 + 2 * (sa1_rows // 64) * 128 * 4
+            ftraffic, fsrc = pmc_per_launch(SA1_FWD_KERNEL[args.dtype]) if args.batch == 8 else (None, None)
+            out["roofline_sa1_fwd"] = {
+                "kernel": "%s...> (SA1 layer 3 forward: 64->128 + BN stats + max-pool, no output store, R=%d)"
+                          % (SA1_FWD_KERNEL[args.dtype], sa1_rows),
+                "bound": "hbm", "achieved": fwd_bytes / (fwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": fwd_bytes / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": ftraffic, "traffic_source": fsrc, "algorithmic_bytes": fwd_bytes,
+                "avg_launch_ms": fwd_ms, "share_of_step": fwd_ms / ms_step,
+                "mfma_frac": 2.0 * sa1_rows * 64 * 128 / (fwd_ms * 1e-3) / 1e12 / mfma_peak}
         if tk is not None:
             # the five kernels with the most time per step in the newest committed profile of this command
             # (rocprofv3 kernel trace + PMC passes; builder-run, committed - not measured by this run):

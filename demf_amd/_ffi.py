@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdemf_hip.so")
+LIB_PATH = os.environ.get("DEMF_LIB_PATH") or os.path.join(_HERE, "lib", "libdemf_hip.so")     # (A/B builds)
 
 _c_int = ctypes.c_int
 _c_float = ctypes.c_float
