@@ -50,6 +50,8 @@ SIGNATURES = {
     "demf_gt_prep": [_c_int] * 3 + [_ptr] * 10,
     "demf_pad_gt": [_c_int] * 2 + [_ptr] * 8,
     "demf_query_pos_rows": [_c_int] * 2 + [_ptr] * 4,
+    "demf_loss_total": [_c_int] + [_ptr] * 4,
+    "demf_loss_total_bwd": [_c_int] + [_ptr] * 4,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,

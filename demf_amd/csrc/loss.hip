@@ -500,7 +500,32 @@ __global__ __launch_bounds__(1024) void target_weights_k(int R, const float* __r
   }
 }
 
+// mean of n (<= 4) seven-vectors of per-decode-layer losses and the grand total (+ the vote loss), one thread
+struct LossTotalArgs { const float* v[4]; };
+__global__ void loss_total_k(int n, LossTotalArgs a, const float* __restrict__ vote, float* __restrict__ out8) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float tot = 0.f;
+  for (int i = 0; i < 7; ++i) {
+    float m = a.v[0][i];
+    for (int j = 1; j < n; ++j) m = m + a.v[j][i];      // the order of the reference's Python sum()
+    m = m / (float)n;
+    out8[i] = m;
+    tot = i == 0 ? m : tot + m;                           // torch's 7-element sum: sequential
+  }
+  out8[7] = tot + (vote ? vote[0] : 0.f);
+}
+// gradients: every seven-vector gets (g_mean7[i] + g_total) / n, the vote loss g_total
+__global__ void loss_total_bwd_k(int n, const float* __restrict__ g8, float* __restrict__ gv, float* __restrict__ gvote) {
+  const int t = threadIdx.x;
+  if (t < 7) {
+    const float g = (g8[t] + g8[7]) / (float)n;
+    for (int j = 0; j < n; ++j) gv[7 * j + t] = g;
+  }
+  if (t == 7 && gvote) gvote[0] = g8[7];
+}
+
 }  // namespace demf
+
 
 using namespace demf;
 
@@ -693,4 +718,21 @@ extern "C" int demf_target_weights(int R, const float* objectness_masks,
   hipLaunchKernelGGL(target_weights_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, R, objectness_masks,
                      (const long long*)objectness_targets, objectness_weights, box_loss_weights);
   return check_launch("target_weights");
+}
+
+extern "C" int demf_loss_total(int n, const float* const* vecs, const float* vote, float* out8, demf_stream_t stream) {
+  DEMF_REQUIRE(n >= 1 && n <= 4 && vecs && out8, "loss_total: 1..4 seven-vectors");
+  LossTotalArgs a{};
+  for (int i = 0; i < n; ++i) {
+    DEMF_REQUIRE(vecs[i], "loss_total: null vector %d", i);
+    a.v[i] = vecs[i];
+  }
+  hipLaunchKernelGGL(loss_total_k, dim3(1), dim3(64), 0, (hipStream_t)stream, n, a, vote, out8);
+  return check_launch("loss_total");
+}
+
+extern "C" int demf_loss_total_bwd(int n, const float* g8, float* gvecs, float* gvote, demf_stream_t stream) {
+  DEMF_REQUIRE(n >= 1 && n <= 4 && g8 && gvecs, "loss_total_bwd: 1..4 seven-vectors");
+  hipLaunchKernelGGL(loss_total_bwd_k, dim3(1), dim3(64), 0, (hipStream_t)stream, n, g8, gvecs, gvote);
+  return check_launch("loss_total_bwd");
 }

@@ -224,29 +224,28 @@ class DeMFVoteHead(nn.Module):
             if mid != id(static_metas):
                 continue
             found = True
-            fresh = self._build_meta_arrays(new_metas, shapes, entry["M"].dtype)
-            if not entry["M"].is_cuda:
-                for k, v in fresh.items():
-                    if v is not None and torch.is_tensor(entry.get(k)):
-                        entry[k].copy_(torch.as_tensor(v))
+            fresh, layout = self._pack_meta_arrays(self._build_meta_arrays(new_metas, shapes, entry["M"].dtype))
+            if [(k, o, n, str(d), tuple(sh)) for k, o, n, d, sh in layout] != entry["_layout"]:
+                raise RuntimeError("refresh_metas: the new metas do not have the captured batch's shapes")
+            if not entry["_blob"].is_cuda:
+                entry["_blob"].copy_(torch.as_tensor(fresh))
                 continue
-            # Device entries: uploaded on a SIDE stream into fresh device tensors, then copied device to
-            # device on the current stream.  A pageable host -> device copy makes the host wait for everything
-            # queued on ITS stream; on the stream of the training step that is the step in flight, and the
-            # per-batch input path would run behind the GPU instead of underneath it (measured: the host
-            # spent 5.3 ms per load in these copies; pinned staging + non-blocking copies on the step's own
-            # stream were worse still - the DMA copies between graph launches cost milliseconds).
+            # Device entries are views of one byte blob: ONE upload on a SIDE stream into a fresh device
+            # tensor, then ONE device-to-device copy on the current stream.  A pageable host -> device copy
+            # makes the host wait for everything queued on ITS stream; on the stream of the training step that
+            # is the step in flight, and the per-batch input path would run behind the GPU instead of
+            # underneath it (measured: the host spent 5.3 ms per load in these copies; pinned staging +
+            # non-blocking copies on the step's own stream were worse still - the DMA copies between graph
+            # launches cost milliseconds).  (Round 3 moved every array on its own: 24 copy launches per batch.)
             cur = torch.cuda.current_stream()
             up = self.__dict__.get("_meta_upload_stream")
             if up is None:
                 up = self.__dict__.setdefault("_meta_upload_stream", torch.cuda.Stream())
             with torch.cuda.stream(up):
-                dev_fresh = {k: torch.as_tensor(v, device=entry["M"].device)
-                             for k, v in fresh.items() if v is not None and torch.is_tensor(entry.get(k))}
+                dev_fresh = torch.as_tensor(fresh, device=entry["_blob"].device)
             cur.wait_stream(up)
-            for k, v in dev_fresh.items():
-                v.record_stream(cur)
-                entry[k].copy_(v.view(entry[k].shape) if v.numel() == entry[k].numel() else v)
+            dev_fresh.record_stream(cur)
+            entry["_blob"].copy_(dev_fresh)
         if not found:
             raise RuntimeError("refresh_metas: no cached device constants for this metas object "
                                "(it was never used in a forward, or its entry was evicted)")
@@ -306,9 +305,32 @@ class DeMFVoteHead(nn.Module):
             spatial_shapes=np.asarray(list(mlvl_shapes), dtype=np.int64).reshape(-1, 2),
             level_start_index=np.asarray([0] + list(np.cumsum(sizes)[:-1]), dtype=np.int64))
 
+    @staticmethod
+    def _pack_meta_arrays(arrays):
+        """name -> ndarray as ONE byte blob (64-byte aligned pieces) + its layout [(name, offset, nbytes,
+        dtype, shape)]: a batch's constants travel as one upload and one device copy instead of two per array."""
+        layout, off = [], 0
+        for k, v in arrays.items():
+            if v is None:
+                continue
+            v = np.ascontiguousarray(v)
+            layout.append((k, off, v.nbytes, v.dtype, v.shape))
+            off += (v.nbytes + 63) // 64 * 64
+        blob = np.zeros(max(off, 64), np.uint8)
+        for (k, o, n, _, _) in layout:
+            blob[o:o + n] = np.ascontiguousarray(arrays[k]).reshape(-1).view(np.uint8)
+        return blob, layout
+
     def _build_meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
-        return {k: None if v is None else torch.as_tensor(v, device=dev)
-                for k, v in self._build_meta_arrays(img_metas, mlvl_shapes, dt).items()}
+        arrays = self._build_meta_arrays(img_metas, mlvl_shapes, dt)
+        blob, layout = self._pack_meta_arrays(arrays)
+        dblob = torch.as_tensor(blob, device=dev)
+        out = {k: None for k in arrays}
+        for (k, o, n, ndt, shp) in layout:
+            tdt = torch.as_tensor(np.zeros(0, ndt)).dtype
+            out[k] = dblob[o:o + n].view(tdt).view(shp)
+        out["_blob"], out["_layout"] = dblob, [(k, o, n, str(ndt), tuple(shp)) for k, o, n, ndt, shp in layout]
+        return out
 
     # ---- :524-547 ------------------------------------------------------------
     def get_reference_points(self, seeds_3d_batch, img_metas, mlvl_shapes=()):
@@ -390,14 +412,19 @@ class DeMFVoteHead(nn.Module):
             vecs, vote = zip(*[self._loss_fused(bbox_preds, targets, d["_rows"],
                                                  with_vote=(i == 0))
                                for i, d in enumerate(decode_res_all)])
-            mean7 = vecs[0]
-            for v in vecs[1:]:
-                mean7 = mean7 + v
-            mean7 = mean7 / len(vecs)
+            if vecs[0].is_cuda and len(vecs) <= 4:
+                out8 = ops.loss_total(list(vecs), vote[0])            # one launch each way
+                mean7, total = out8[:7], out8[7]
+            else:
+                mean7 = vecs[0]
+                for v in vecs[1:]:
+                    mean7 = mean7 + v
+                mean7 = mean7 / len(vecs)
+                total = mean7.sum() + vote[0]
             losses = dict(vote_loss=vote[0])
             for i, name in enumerate(ops.HEAD_LOSS_NAMES):
                 losses[name] = mean7[i]
-            losses["_total"] = mean7.sum() + vote[0]
+            losses["_total"] = total
             return losses
         losses_all = [self._loss({**bbox_preds, **d}, targets) for d in decode_res_all]
         return {k: sum(l[k] for l in losses_all) / (self.num_fusion_layers + 1)

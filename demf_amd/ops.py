@@ -1507,6 +1507,35 @@ def query_pos_rows(reg_rows, base_xyz):
     return out
 
 
+class _LossTotal(Function):
+    @staticmethod
+    def forward(ctx, vote, *vecs):
+        n = len(vecs)
+        vecs = [v.contiguous() for v in vecs]
+        out = torch.empty(8, dtype=torch.float32, device=vecs[0].device)
+        tab = (ctypes.c_void_p * n)(*[v.data_ptr() for v in vecs])
+        _ffi.call("demf_loss_total", n, ctypes.addressof(tab), _p(vote), _p(out), _stream())
+        ctx.n, ctx.has_vote = n, vote is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g8):
+        g8 = g8.contiguous()
+        gv = torch.empty((ctx.n, 7), dtype=torch.float32, device=g8.device)
+        gvote = torch.empty(1, dtype=torch.float32, device=g8.device) if ctx.has_vote else None
+        _ffi.call("demf_loss_total_bwd", ctx.n, _p(g8), _p(gv), _p(gvote), _stream())
+        return (gvote,) + tuple(gv[i] for i in range(ctx.n))
+
+
+def loss_total(vecs, vote=None):
+    """Tail of DeMFVoteHead.loss: (7,) loss vectors of the decode results -> (8,) = [their mean | sum of the
+    mean + vote loss]; one launch each way instead of add / div / sum / add and their backward nodes."""
+    assert 1 <= len(vecs) <= 4
+    for v in vecs:
+        _chk(v, "loss vector")
+    return _LossTotal.apply(None if vote is None else vote.reshape(1), *vecs)
+
+
 def target_weights(objectness_masks, objectness_targets):
     """-> (objectness_weights, box_loss_weights): each tensor divided by (its sum + 1e-6)
     (class_agnostic_vote_head.py:797-816), one launch."""

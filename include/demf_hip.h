@@ -594,6 +594,13 @@ int demf_proposal_targets(int B, int Q, int G, int with_rot, float pos_thr, floa
 int demf_query_pos_rows(int R, int nreg, const float* reg_rows, const float* base_xyz, float* out8,
                         demf_stream_t stream);
 
+/* Tail of DeMFVoteHead.loss (class_agnostic_vote_head.py:604-612: the losses of the num_fusion_layers + 1
+ * decode results are averaged, the training loop sums the dict): vecs[0..n) are the (7,) per-decode-layer
+ * loss vectors, vote the (1,) vote loss or NULL -> out8 = [mean of the vectors (7) | their sum + vote].
+ * n <= 4.  demf_loss_total_bwd: g8 = gradient of out8 -> gvecs (n,7) = (g8[i] + g8[7]) / n, gvote = g8[7]. */
+int demf_loss_total(int n, const float* const* vecs, const float* vote, float* out8, demf_stream_t stream);
+int demf_loss_total_bwd(int n, const float* g8, float* gvecs, float* gvote, demf_stream_t stream);
+
 /* Per-scene ground-truth lists -> the static-shape padded form the target kernels read: gt_padded
  * (B,G,7) fp32, labels_padded (B,G) int64 with -1 on padding slots, valid (B,G) u8 or NULL.  An empty
  * scene gets the reference's single all-zero fake box with label 0

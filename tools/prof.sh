@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- p
 st=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 tr=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 [ -n "$st" ] && cp $st $out/kernel_stats.csv
-[ -n "$tr" ] && TOPN=${TOPN:-45} DETAIL=${DETAIL:-demf::gemm_kernel} python $R/tools/trace_summary.py $tr 5 40 7 > $out/steps_summary.txt 2>&1
+[ -n "$tr" ] && LIBSEQ=1 TOPN=${TOPN:-45} DETAIL=${DETAIL:-demf::gemm_kernel} python $R/tools/trace_summary.py $tr 5 40 7 > $out/steps_summary.txt 2>&1
 [ -n "$tr" ] && python $R/tools/step_timeline.py $tr > $out/step_timeline.txt 2>&1
 tail -1 $out/prof.log | head -c 400 > $out/bench_under_profiler.txt
 if [ -n "$PMC" ]; then

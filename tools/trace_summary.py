@@ -42,3 +42,18 @@ if os.environ.get("TOPN"):
     print(f"--- the {n} longest launches of one step (start offset us, duration us, name)")
     for r in sorted(one, key=lambda r: int(r["Start_Timestamp"]) - int(r["End_Timestamp"]))[:n]:
         print(f"  @{(int(r['Start_Timestamp'])-t0)/1e3:8.1f}  {(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3:7.1f} us  {r['Kernel_Name'][:110]}")
+
+if os.environ.get("LIBSEQ"):
+    # every library (non-demf) launch of one step, in order, with the demf kernel in front of it for context
+    one = rows[marks[-2 - SKIP]:marks[-1 - SKIP]]
+    t0 = int(one[0]["Start_Timestamp"])
+    print("--- library launches of one step (offset us, duration us, grid, name | previous demf kernel)")
+    prev = "-"
+    for r in one:
+        n = r["Kernel_Name"]
+        if "demf::" in n:
+            prev = n.split("demf::")[1][:40]
+            continue
+        print("  @%8.1f %7.1f us  grid %-9s %-70s | %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3,
+              (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?")),
+              n[:70], prev))
