@@ -102,6 +102,8 @@ SIGNATURES = {
     "demf_multi_copy": [_c_int, _ptr, _c_int, _ptr],
     "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
     "demf_add_dropout_ln_bwd": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _ptr, _c_int, _ptr, _c_int] + [_ptr] * 4,
+    "demf_attn_core_fwd": [_c_int] * 4 + [_ptr, _c_float, _c_float, _ptr, _c_int] + [_ptr] * 5,
+    "demf_attn_core_bwd": [_c_int] * 4 + [_ptr] * 4 + [_c_float, _c_float, _ptr, _c_int] + [_ptr] * 2,
     "demf_softmax_dropout_fwd": [_c_int] * 2 + [_ptr, _c_float, _ptr, _c_int] + [_ptr] * 3,
     "demf_softmax_dropout_bwd": [_c_int] * 2 + [_ptr, _c_float, _ptr, _c_int] + [_ptr] * 2,
     "demf_msda_prep_fwd": [_c_int] * 5 + [_ptr] * 10,

@@ -40,6 +40,7 @@ RELU, DROPOUT, GATE, ACCUM, ROWBIAS, ACCUM2 = 1, 2, 4, 8, 16, 32
 OP_ATTN, OP_LN1, OP_LN2, OP_FFN, OP_LN3 = 1, 2, 3, 4, 5
 
 _RNG = {}
+ATTN_CORE = True  # the one-launch attention core (csrc/attn.hip); False: QK^T / softmax / PV as three launches
 _DEBUG = None     # tools/debug_fused.py: a dict that FusedDecoderLayer.backward fills with its intermediates
 
 
@@ -199,16 +200,29 @@ class FusedDecoderLayer(Function):
         qkv = new(R, 3 * E)
         gemm(R, 3 * E, E, _p(x), (E, 1), _p(in_w), (E, 1), _p(qkv), 3 * E, A2=_p(pos), a2_cols=2 * E,
              bias=_p(in_b))
-        sc = new(B * H, Q, Q)
-        zb = (Q * 3 * E, Dh)                                     # (scene, head) -> offset into qkv
-        gemm(Q, Q, Dh, _p(qkv), (3 * E, 1), _p(qkv, E), (3 * E, 1), _p(sc), Q, batch=B * H, zdiv=H,
-             sab=zb, sbb=zb, scb=(H * Q * Q, Q * Q), alpha=1.0 / math.sqrt(Dh))
-        prob, pd = new(B * H, Q, Q), sc                          # dropout(prob) overwrites the scores
-        _ffi.call("demf_softmax_dropout_fwd", B * H * Q, Q, _p(sc), p_attn, rng, OP_ATTN, _p(prob),
-                  _p(pd), st)
         att = new(R, E)
-        gemm(Q, Dh, Q, _p(pd), (Q, 1), _p(qkv, 2 * E), (1, 3 * E), _p(att), E, batch=B * H, zdiv=H,
-             sab=(H * Q * Q, Q * Q), sbb=zb, scb=(Q * E, Dh))
+        core = ATTN_CORE and Q == 256 and Dh == 32
+        if core:
+            # QK^T -> softmax -> dropout -> PV as ONE launch per direction (csrc/attn.hip); the backward
+            # recomputes the probabilities from two floats per query
+            prob = pd = new(0)
+            ast = new(B * H * Q, 2)
+            dbg = _DEBUG is not None
+            if dbg:
+                prob, pd = new(B * H, Q, Q), new(B * H, Q, Q)
+            _ffi.call("demf_attn_core_fwd", B, H, Q, Dh, _p(qkv), 1.0 / math.sqrt(Dh), p_attn, rng, OP_ATTN,
+                      _p(att), _p(ast), _p(prob) if dbg else None, _p(pd) if dbg else None, st)
+        else:
+            ast = new(0)
+            sc = new(B * H, Q, Q)
+            zb = (Q * 3 * E, Dh)                                     # (scene, head) -> offset into qkv
+            gemm(Q, Q, Dh, _p(qkv), (3 * E, 1), _p(qkv, E), (3 * E, 1), _p(sc), Q, batch=B * H, zdiv=H,
+                 sab=zb, sbb=zb, scb=(H * Q * Q, Q * Q), alpha=1.0 / math.sqrt(Dh))
+            prob, pd = new(B * H, Q, Q), sc                          # dropout(prob) overwrites the scores
+            _ffi.call("demf_softmax_dropout_fwd", B * H * Q, Q, _p(sc), p_attn, rng, OP_ATTN, _p(prob),
+                      _p(pd), st)
+            gemm(Q, Dh, Q, _p(pd), (Q, 1), _p(qkv, 2 * E), (1, 3 * E), _p(att), E, batch=B * H, zdiv=H,
+                 sab=(H * Q * Q, Q * Q), sbb=zb, scb=(Q * E, Dh))
         s1 = linear_fwd(att, out_w, out_b)
         x1, st1 = new(R, E), new(R, 2)
         _ffi.call("demf_add_dropout_ln_fwd", R, E, _p(s1), _p(x), _p(g1), _p(b1), eps, p_attn, rng,
@@ -246,7 +260,8 @@ class FusedDecoderLayer(Function):
         _ffi.call("demf_add_dropout_ln_fwd", R, E, _p(s3), _p(x2), _p(g3), _p(b3), eps, p_ffn, rng,
                   OP_LN3, _p(s3), _p(x3), _p(st3), st)
         ctx.dims = (B, Q, H, L, P, p_attn, p_ffn, eps, salt)
-        ctx.save_for_backward(snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att,
+        ctx.core = core
+        ctx.save_for_backward(snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att, ast,
                               s1, st1, x1, w, loc, uvw, z, ks4, mo, s2, st2, x2, hid, s3, st3,
                               in_w, out_w, g1, off_w, aw_w, vp_w, vp_b, op_w, g2, f0_w, f1_w, g3)
         return x3
@@ -254,7 +269,7 @@ class FusedDecoderLayer(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dx3):
-        (snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att, s1, st1, x1, w, loc,
+        (snap, x, pos, pts, tokens, keep4, shapes, lsi, M, ab, vr, qkv, prob, pd, att, ast, s1, st1, x1, w, loc,
          uvw, z, ks4, mo, s2, st2, x2, hid, s3, st3, in_w, out_w, g1, off_w, aw_w, vp_w, vp_b, op_w,
          g2, f0_w, f1_w, g3) = ctx.saved_tensors
         B, Q, H, L, P, p_attn, p_ffn, eps, salt = ctx.dims
@@ -330,19 +345,25 @@ class FusedDecoderLayer(Function):
         weight_grad(dao, att, d_out_w, d_out_b, group=wg)
         datt = new(R, E)
         gemm(R, E, E, _p(dao), (E, 1), _p(out_w), (1, E), _p(datt), E)
-        dqkv, ds = new(R, 3 * E), new(B * H, Q, Q)
-        zb, zs, za = (Q * 3 * E, Dh), (H * Q * Q, Q * Q), (Q * E, Dh)
-        # dPd = dO v^T ; dv = Pd^T dO
-        gemm(Q, Q, Dh, _p(datt), (E, 1), _p(qkv, 2 * E), (3 * E, 1), _p(ds), Q, batch=B * H, zdiv=H,
-             sab=za, sbb=zb, scb=zs)
-        gemm(Q, Dh, Q, _p(pd), (1, Q), _p(datt), (1, E), _p(dqkv, 2 * E), 3 * E, batch=B * H, zdiv=H,
-             sab=zs, sbb=za, scb=zb)
-        _ffi.call("demf_softmax_dropout_bwd", B * H * Q, Q, _p(prob), p_attn, rng, OP_ATTN, _p(ds), st)
-        a = 1.0 / math.sqrt(Dh)
-        gemm(Q, Dh, Q, _p(ds), (Q, 1), _p(qkv, E), (1, 3 * E), _p(dqkv), 3 * E, batch=B * H, zdiv=H,
-             sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dq = a dS k
-        gemm(Q, Dh, Q, _p(ds), (1, Q), _p(qkv), (1, 3 * E), _p(dqkv, E), 3 * E, batch=B * H, zdiv=H,
-             sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dk = a dS^T q
+        dqkv = new(R, 3 * E)
+        ds = None
+        if ctx.core:
+            _ffi.call("demf_attn_core_bwd", B, H, Q, Dh, _p(qkv), _p(att), _p(datt), _p(ast), 1.0 / math.sqrt(Dh),
+                      p_attn, rng, OP_ATTN, _p(dqkv), st)
+        else:
+            ds = new(B * H, Q, Q)
+            zb, zs, za = (Q * 3 * E, Dh), (H * Q * Q, Q * Q), (Q * E, Dh)
+            # dPd = dO v^T ; dv = Pd^T dO
+            gemm(Q, Q, Dh, _p(datt), (E, 1), _p(qkv, 2 * E), (3 * E, 1), _p(ds), Q, batch=B * H, zdiv=H,
+                 sab=za, sbb=zb, scb=zs)
+            gemm(Q, Dh, Q, _p(pd), (1, Q), _p(datt), (1, E), _p(dqkv, 2 * E), 3 * E, batch=B * H, zdiv=H,
+                 sab=zs, sbb=za, scb=zb)
+            _ffi.call("demf_softmax_dropout_bwd", B * H * Q, Q, _p(prob), p_attn, rng, OP_ATTN, _p(ds), st)
+            a = 1.0 / math.sqrt(Dh)
+            gemm(Q, Dh, Q, _p(ds), (Q, 1), _p(qkv, E), (1, 3 * E), _p(dqkv), 3 * E, batch=B * H, zdiv=H,
+                 sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dq = a dS k
+            gemm(Q, Dh, Q, _p(ds), (1, Q), _p(qkv), (1, 3 * E), _p(dqkv, E), 3 * E, batch=B * H, zdiv=H,
+                 sab=zs, sbb=zb, scb=zb, alpha=a)                                    # dk = a dS^T q
         weight_grad(dqkv, x, d_in_w, d_in_b, x2=pos, x2_rows=2 * E, group=wg)
         gemm(R, E, 2 * E, _p(dqkv), (3 * E, 1), _p(in_w), (1, E), _p(dx), E, C2=_p(dpos),
              flags=ACCUM | ACCUM2)                                               # q, k see x + pos

@@ -718,6 +718,26 @@ int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stream_t stream
  * Process-wide setting (the one piece of host-side mutable state besides the counter ring).     */
 int demf_set_compute_dtype(int mode);
 
+/* Self-attention core of the fusion decoder layer (nn.MultiheadAttention inside mmcv's
+ * DetrTransformerDecoderLayer; demf/modeling/layers/transformer.py:55-80, configs/demf/demf_votenet.py:71-91):
+ * out[b, q, h] = dropout(softmax(scale * q_h k_h^T)) v_h for the packed projections qkv (B*Q, 3*H*Dh) =
+ * [q | k | v], one launch, the (B*H, Q, Q) score / probability tensors never stored.  stats (B*H*Q, 2) = row
+ * maximum of the scaled scores and 1 / sum of exponentials, all the backward needs besides qkv, out and dout.
+ * Dropout element ((b*H + h)*Q + q)*Q + k of stream (rng, op_id), as demf_softmax_dropout_fwd draws it.
+ * prob / prob_dropped: optional (B*H, Q, Q) outputs for tests (both or neither).
+ * Built for the reference's head shape Q = 256, Dh = 32: DEMF_EUNSUPPORTED otherwise (callers keep the
+ * demf_gemm_f32 + demf_softmax_dropout_* form).  Compute mode 1 rounds the operands to bf16 where those
+ * launches did; modes 0 / 2 are fp32 FMAs. */
+int demf_attn_core_fwd(int B, int H, int Q, int Dh, const float* qkv, float scale, float p, const void* rng,
+                       int op_id, float* out, float* stats, float* prob, float* prob_dropped,
+                       demf_stream_t stream);
+/* dqkv (B*Q, 3*H*Dh) = gradients of [q | k | v] for dout (B*Q, H*Dh): probabilities are recomputed from
+ * stats bit for bit, D = dout . out per query; per (scene, head) four query blocks produce dq and four key
+ * blocks dk, dv - no atomics, every element written once. */
+int demf_attn_core_bwd(int B, int H, int Q, int Dh, const float* qkv, const float* out, const float* dout,
+                       const float* stats, float scale, float p, const void* rng, int op_id, float* dqkv,
+                       demf_stream_t stream);
+
 /* s = identity + dropout(x) ; y = LayerNorm(s) over rows of C channels (C in 64..1024, power of two
  * multiples of 64).  s_out may alias x; stats (R,2) = mean, rstd.  nn.LayerNorm + the
  * `identity + dropout(out)` tails of mmcv MultiheadAttention / MultiScaleDeformableAttention / FFN. */

@@ -490,3 +490,58 @@ def test_gemm_group_and_bias_row_sums():
         _close(dw, want, 1e-4, "grouped dW")
         _close(db, wb, 1e-4, "bias gradient = row sums of the A operand")
     _close(ya, xa.double() @ wa.double().t(), 1e-4, "ungroupable member")
+
+
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_attention_core_one_launch_each_way(p, mode):
+    """demf_attn_core_{fwd,bwd} (softmax(q k^T / sqrt d) -> dropout -> . v without the score tensors in memory)
+    against the fp64 statement with the library's own dropout mask; in bf16 mode against the same statement
+    with the operands rounded where the kernel rounds them (q, k, v, dO, dropout(P), dS)."""
+    from demf_amd import _ffi, fused, ops
+    from demf_amd.fused import _p
+    dev = torch.device("cuda")
+    fused.rng_state(dev, seed=5)
+    B, H, Q, Dh = 2, 8, 256, 32
+    E, R = H * Dh, B * Q
+    qkv, dout = _r(R, 3 * E, seed=3, scale=1.5), _r(R, E, seed=4)
+    rng, st = fused.rng_state(dev).data_ptr(), torch.cuda.current_stream().cuda_stream
+    out, stats = torch.empty(R, E, device="cuda"), torch.empty(B * H * Q, 2, device="cuda")
+    prob, pd = torch.empty(B * H, Q, Q, device="cuda"), torch.empty(B * H, Q, Q, device="cuda")
+    dqkv = torch.full((R, 3 * E), float("nan"), device="cuda")
+    a = 1.0 / np.sqrt(Dh)
+    ops.set_compute_dtype(mode)
+    try:
+        _ffi.call("demf_attn_core_fwd", B, H, Q, Dh, _p(qkv), a, p, rng, 7, _p(out), _p(stats), _p(prob), _p(pd), st)
+        out2 = torch.empty_like(out)                 # the product path: no debug outputs
+        _ffi.call("demf_attn_core_fwd", B, H, Q, Dh, _p(qkv), a, p, rng, 7, _p(out2), _p(stats), None, None, st)
+        _ffi.call("demf_attn_core_bwd", B, H, Q, Dh, _p(qkv), _p(out), _p(dout), _p(stats), a, p, rng, 7, _p(dqkv), st)
+    finally:
+        ops.set_compute_dtype("f32")
+    assert torch.equal(out, out2)
+    mask = fused.dropout_mask(B * H * Q * Q, p, 7, dev).view(B * H, Q, Q).double() if p > 0 else \
+        torch.ones(B * H, Q, Q, device="cuda", dtype=torch.float64)
+    q_ = (lambda t: t.float().bfloat16().double()) if mode == "bf16" else (lambda t: t)
+
+    x = qkv.double().view(B, Q, 3, H, Dh).permute(2, 0, 3, 1, 4).reshape(3, B * H, Q, Dh).requires_grad_()
+    qh, kh, vh = q_(x[0]), q_(x[1]), q_(x[2])
+    pr = torch.softmax(a * (qh @ kh.transpose(1, 2)), -1)
+    pdr = pr * mask
+    o = q_(pdr) @ vh
+    tol = 2e-2 if mode == "bf16" else 1e-5
+    _close(prob, pr, 1e-5 if mode == "f32" else 1e-2, "prob")
+    want = o.view(B, H, Q, Dh).permute(0, 2, 1, 3).reshape(R, E)
+    _close(out, want, tol, "out")
+    if mode == "f32":
+        _close(pd, pdr, 1e-5, "dropout(prob)")
+        o.backward(dout.double().view(B, Q, H, Dh).permute(0, 2, 1, 3).reshape(B * H, Q, Dh))
+        g = x.grad.view(3, B, H, Q, Dh).permute(1, 3, 0, 2, 4).reshape(R, 3 * E)
+        _close(dqkv, g, 2e-5, "dqkv")
+    else:
+        assert torch.isfinite(dqkv).all()
+        # bf16: the gradient against the fp64 statement of the UNROUNDED problem, at bf16 operand precision
+        x2 = qkv.double().view(B, Q, 3, H, Dh).permute(2, 0, 3, 1, 4).reshape(3, B * H, Q, Dh).requires_grad_()
+        o2 = (torch.softmax(a * (x2[0] @ x2[1].transpose(1, 2)), -1) * mask) @ x2[2]
+        o2.backward(dout.double().view(B, Q, H, Dh).permute(0, 2, 1, 3).reshape(B * H, Q, Dh))
+        g = x2.grad.view(3, B, H, Q, Dh).permute(1, 3, 0, 2, 4).reshape(R, 3 * E)
+        _close(dqkv, g, 3e-2, "dqkv (bf16 operands)")
