@@ -96,9 +96,17 @@ SIGNATURES = {
     "demf_vote_loss_fwd": [_c_int] * 4 + [_c_float] + [_ptr] * 8,
     "demf_msda_fwd_f32": [_c_int] * 7 + [_ptr] * 7,
     "demf_msda_bwd_f32": [_c_int] * 7 + [_ptr] * 10,
+    "demf_msda_fwd_bf16": [_c_int] * 7 + [_ptr] * 7,
+    "demf_msda_bwd_bf16": [_c_int] * 7 + [_ptr] * 10,
     "demf_gemm_f32": [_ptr, _ptr],
     "demf_gemm_group_f32": [_ptr, _c_int, _ptr],
     "demf_set_compute_dtype": [_c_int],
+    "demf_get_compute_dtype": [],
+    "demf_ctx_push": [_ptr],
+    "demf_ctx_pop": [],
+    "demf_gemm_f32_ctx": [_ptr] * 3,
+    "demf_gemm_group_f32_ctx": [_ptr, _ptr, _c_int, _ptr],
+    "demf_mlp_gemm_fwd_ctx": [_ptr] + [_c_int] * 4 + [_ptr] * 6,
     "demf_multi_copy": [_c_int, _ptr, _c_int, _ptr],
     "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
     "demf_add_dropout_ln_bwd": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _ptr, _c_int, _ptr, _c_int] + [_ptr] * 4,

@@ -50,7 +50,14 @@ static int env_int(const char* name, int dflt) {
 
 // Until demf_set_compute_dtype is called the mode is 2, or 0 with DEMF_F32_NATIVE=1 in the environment.
 static std::atomic<int> g_compute_mode{-1};
+// demf_ctx_push / demf_ctx_pop: the calling THREAD's mode for the calls in between (a stack, so library code
+// may nest them); -1 = the process default below.  Two host threads driving two models in different modes do
+// not see each other's setting.
+constexpr int CTX_DEPTH = 8;
+static thread_local int tl_mode_stack[CTX_DEPTH];
+static thread_local int tl_mode_top = 0;
 int compute_mode() {
+  if (tl_mode_top > 0 && tl_mode_stack[tl_mode_top - 1] >= 0) return tl_mode_stack[tl_mode_top - 1];
   int m = g_compute_mode.load(std::memory_order_relaxed);
   if (m < 0) {
     const char* v = getenv("DEMF_F32_NATIVE");
@@ -2058,6 +2065,58 @@ extern "C" int demf_set_compute_dtype(int mode) {
   DEMF_REQUIRE(mode >= 0 && mode <= 2, "set_compute_dtype: 0 = fp32, 1 = bf16, 2 = fp32 as three bf16 terms");
   g_compute_mode.store(mode);
   return DEMF_OK;
+}
+
+extern "C" int demf_ctx_push(const demf_ctx* ctx) {
+  DEMF_REQUIRE(ctx != nullptr, "ctx_push: null context");
+  DEMF_REQUIRE(ctx->compute_mode >= -1 && ctx->compute_mode <= 2,
+               "ctx_push: compute_mode -1 (process default), 0 fp32, 1 bf16, 2 fp32 as three bf16 terms");
+  DEMF_REQUIRE(tl_mode_top < CTX_DEPTH, "ctx_push: more than %d nested contexts on this thread", CTX_DEPTH);
+  tl_mode_stack[tl_mode_top++] = ctx->compute_mode;
+  return DEMF_OK;
+}
+
+extern "C" int demf_ctx_pop(void) {
+  DEMF_REQUIRE(tl_mode_top > 0, "ctx_pop: no context pushed on this thread");
+  --tl_mode_top;
+  return DEMF_OK;
+}
+
+extern "C" int demf_get_compute_dtype(void) { return compute_mode(); }
+
+namespace {
+struct CtxScope {          // the *_ctx entry points: the context for exactly one call
+  bool pushed;
+  explicit CtxScope(const demf_ctx* c) : pushed(c != nullptr && demf_ctx_push(c) == DEMF_OK) {}
+  ~CtxScope() { if (pushed) demf_ctx_pop(); }
+};
+}  // namespace
+
+extern "C" int demf_mlp_gemm_fwd(int, int, int, int, const float*, const float*, const float*, float*, double*,
+                                 demf_stream_t);
+extern "C" int demf_mlp_gemm_fwd_ctx(const demf_ctx* ctx, int R, int K, int N, int ldx, const float* X,
+                                     const float* pro_scale_shift, const float* Wt, float* Y, double* stats,
+                                     demf_stream_t stream) {
+  DEMF_REQUIRE(ctx != nullptr, "mlp_gemm_fwd_ctx: null context");
+  CtxScope scope(ctx);
+  if (!scope.pushed) return DEMF_EINVAL;
+  return demf_mlp_gemm_fwd(R, K, N, ldx, X, pro_scale_shift, Wt, Y, stats, stream);
+}
+
+extern "C" int demf_gemm_f32(const demf_gemm_desc*, demf_stream_t);
+extern "C" int demf_gemm_f32_ctx(const demf_ctx* ctx, const demf_gemm_desc* desc, demf_stream_t stream) {
+  DEMF_REQUIRE(ctx != nullptr, "gemm_f32_ctx: null context");
+  CtxScope scope(ctx);
+  if (!scope.pushed) return DEMF_EINVAL;
+  return demf_gemm_f32(desc, stream);
+}
+
+extern "C" int demf_gemm_group_f32(const demf_gemm_desc*, int, demf_stream_t);
+extern "C" int demf_gemm_group_f32_ctx(const demf_ctx* ctx, const demf_gemm_desc* descs, int n, demf_stream_t stream) {
+  DEMF_REQUIRE(ctx != nullptr, "gemm_group_f32_ctx: null context");
+  CtxScope scope(ctx);
+  if (!scope.pushed) return DEMF_EINVAL;
+  return demf_gemm_group_f32(descs, n, stream);
 }
 
 extern "C" int demf_mlp_gemm_fwd(int R, int K, int N, int ldx, const float* X,

@@ -74,10 +74,29 @@ __device__ __forceinline__ float f4_dot(float4 a, float4 b) {
 
 constexpr int MAX_L = 8;
 
+// four consecutive channels of a value row: fp32 rows, or bf16 rows (2 bytes per element: the gather moves
+// half the bytes; demf_msda_{fwd,bwd}_bf16) widened exactly
+template <typename VT>
+__device__ __forceinline__ float4 ld4(const VT* p);
+template <>
+__device__ __forceinline__ float4 ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 ld4<uint16_t>(const uint16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xFFFF0000u));
+}
+template <typename VT>
+__device__ __forceinline__ float ld1(const VT* p);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld1<uint16_t>(const uint16_t* p) { return __uint_as_float((unsigned)*p << 16); }
+
 // TL,TP > 0: compile-time levels/points (fully unrolled); 0: runtime loop.
-template <int G, int TL, int TP>
+template <int G, int TL, int TP, typename VT = float>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(
-    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attw, float* __restrict__ out,
     long long items) {
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   const int sub = (int)(t - item * G);
   const int h = (int)(item % H);
   const int b = (int)(item / ((long long)Q * H));
-  const float* vb = value + (size_t)b * S * H * Dh + sub * 4;
+  const VT* vb = value + (size_t)b * S * H * Dh + sub * 4;
   if constexpr (TL > 0) {
     L = TL;
     P = TP;
@@ -106,15 +125,15 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      v = f4_fma(c.cw[k], *reinterpret_cast<const float4*>(vb + c.off[k]), v);
+      v = f4_fma(c.cw[k], ld4<VT>(vb + c.off[k]), v);
     acc = f4_fma(aw, v, acc);
   }
   *reinterpret_cast<float4*>(out + item * Dh + sub * 4) = acc;
 }
 
-template <int G, int TL, int TP>
+template <int G, int TL, int TP, typename VT = float>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
-    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ gout, float* __restrict__ gvalue, float* __restrict__ gloc,
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
   const int h = (int)(item % H);
   const int b = (int)(item / ((long long)Q * H));
   const size_t boff = (size_t)b * S * H * Dh + sub * 4;
-  const float* vb = value + boff;
+  const VT* vb = value + boff;
   float* gvb = gvalue + boff;
   if constexpr (TL > 0) {
     L = TL;
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
     float4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      v[k] = *reinterpret_cast<const float4*>(vb + c.off[k]);
+      v[k] = ld4<VT>(vb + c.off[k]);
       v[k].x *= c.ok[k]; v[k].y *= c.ok[k]; v[k].z *= c.ok[k]; v[k].w *= c.ok[k];
     }
     // d(sample)/d(h), d(sample)/d(w), and the sample itself, per channel
@@ -187,8 +206,9 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(
 }
 
 // Any Dh (multiple of nothing): one thread per (b,q,h), serial over channels.
+template <typename VT = float>
 __global__ __launch_bounds__(256) void msda_fwd_generic(
-    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attw, float* __restrict__ out,
     long long items) {
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(256) void msda_fwd_generic(
   if (item >= items) return;
   const int h = (int)(item % H);
   const int b = (int)(item / ((long long)Q * H));
-  const float* vb = value + (size_t)b * S * H * Dh;
+  const VT* vb = value + (size_t)b * S * H * Dh;
   const int nlp = L * P;
   for (int ch = 0; ch < Dh; ++ch) {
     float acc = 0.f;
@@ -206,15 +226,16 @@ __global__ __launch_bounds__(256) void msda_fwd_generic(
                                    (int)shapes[2 * l], (int)shapes[2 * l + 1], (int)lsi[l], H,
                                    Dh, h);
       float v = 0.f;
-      for (int k = 0; k < 4; ++k) v = __builtin_fmaf(c.cw[k], vb[c.off[k] + ch], v);
+      for (int k = 0; k < 4; ++k) v = __builtin_fmaf(c.cw[k], ld1<VT>(vb + c.off[k] + ch), v);
       acc = __builtin_fmaf(attw[item * nlp + i], v, acc);
     }
     out[item * Dh + ch] = acc;
   }
 }
 
+template <typename VT = float>
 __global__ __launch_bounds__(256) void msda_bwd_generic(
-    int S, int H, int Dh, int L, int Q, int P, const float* __restrict__ value,
+    int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attw,
     const float* __restrict__ gout, float* __restrict__ gvalue, float* __restrict__ gloc,
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
     for (int ch = 0; ch < Dh; ++ch) {
       const float top = gout[item * Dh + ch];
       float v[4];
-      for (int k = 0; k < 4; ++k) v[k] = value[boff + c.off[k] + ch] * c.ok[k];
+      for (int k = 0; k < 4; ++k) v[k] = ld1<VT>(value + boff + c.off[k] + ch) * c.ok[k];
       const float gh = c.hw * (v[2] - v[0]) + c.lw * (v[3] - v[1]);
       const float gw = c.hh * (v[1] - v[0]) + c.lh * (v[3] - v[2]);
       const float val = c.hh * c.hw * v[0] + c.hh * c.lw * v[1] + c.lh * c.hw * v[2] +
@@ -253,34 +274,34 @@ __global__ __launch_bounds__(256) void msda_bwd_generic(
   }
 }
 
-template <int G>
+template <int G, typename VT>
 static void launch_fwd(dim3 grid, hipStream_t s, int S, int H, int Dh, int L, int Q,
-                       int P, const float* value, const int64_t* shapes, const int64_t* lsi,
+                       int P, const VT* value, const int64_t* shapes, const int64_t* lsi,
                        const float* loc, const float* w, float* out, long long items) {
   if (L == 4 && P == 2)
-    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 2>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 2, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
                        shapes, lsi, loc, w, out, items);
   else if (L == 4 && P == 4)
-    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 4, 4, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
                        value, shapes, lsi, loc, w, out, items);
   else
-    hipLaunchKernelGGL((msda_fwd_kernel<G, 0, 0>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+    hipLaunchKernelGGL((msda_fwd_kernel<G, 0, 0, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
                        shapes, lsi, loc, w, out, items);
 }
 
-template <int G>
+template <int G, typename VT>
 static void launch_bwd(dim3 grid, hipStream_t s, int S, int H, int Dh, int L, int Q,
-                       int P, const float* value, const int64_t* shapes, const int64_t* lsi,
+                       int P, const VT* value, const int64_t* shapes, const int64_t* lsi,
                        const float* loc, const float* w, const float* gout, float* gvalue,
                        float* gloc, float* gw, long long items) {
   if (L == 4 && P == 2)
-    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 2>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 2, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
                        shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
   else if (L == 4 && P == 4)
-    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 4, 4, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P,
                        value, shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
   else
-    hipLaunchKernelGGL((msda_bwd_kernel<G, 0, 0>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
+    hipLaunchKernelGGL((msda_bwd_kernel<G, 0, 0, VT>), grid, dim3(256), 0, s, S, H, Dh, L, Q, P, value,
                        shapes, lsi, loc, w, gout, gvalue, gloc, gw, items);
 }
 
@@ -295,10 +316,11 @@ static int msda_check(int B, int S, int H, int Dh, int L, int Q, int P) {
 
 using namespace demf;
 
-extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
-                                 const float* value, const int64_t* spatial_shapes,
-                                 const int64_t* level_start_index, const float* sampling_loc,
-                                 const float* attn_weight, float* out, demf_stream_t stream) {
+template <typename VT>
+static int msda_fwd_impl(int B, int S, int H, int Dh, int L, int Q, int P,
+                         const VT* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const float* sampling_loc,
+                         const float* attn_weight, float* out, demf_stream_t stream) {
   if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
   if (B == 0 || Q == 0) return DEMF_OK;
   DEMF_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
@@ -308,16 +330,16 @@ extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   const int G = Dh / 4;
   const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 ||
                                       G == 64) &&
-                    (((uintptr_t)value | (uintptr_t)out) % 16 == 0);
+                    (((uintptr_t)value % (4 * sizeof(VT))) == 0 && (uintptr_t)out % 16 == 0);
   if (!fast) {
-    hipLaunchKernelGGL(msda_fwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(msda_fwd_generic<VT>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
                        S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
                        attn_weight, out, items);
     return check_launch("msda_fwd_generic");
   }
   const dim3 grid((unsigned)((items * G + 255) / 256));
 #define GO(g)                                                                              \
-  launch_fwd<g>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
+  launch_fwd<g, VT>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
                 sampling_loc, attn_weight, out, items)
   switch (G) {
     case 1: GO(1); break;
@@ -332,12 +354,13 @@ extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   return check_launch("msda_fwd");
 }
 
-extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
-                                 const float* value, const int64_t* spatial_shapes,
-                                 const int64_t* level_start_index, const float* sampling_loc,
-                                 const float* attn_weight, const float* grad_out,
-                                 float* grad_value, float* grad_sampling_loc,
-                                 float* grad_attn_weight, demf_stream_t stream) {
+template <typename VT>
+static int msda_bwd_impl(int B, int S, int H, int Dh, int L, int Q, int P,
+                         const VT* value, const int64_t* spatial_shapes,
+                         const int64_t* level_start_index, const float* sampling_loc,
+                         const float* attn_weight, const float* grad_out,
+                         float* grad_value, float* grad_sampling_loc,
+                         float* grad_attn_weight, demf_stream_t stream) {
   if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
   if (B == 0 || Q == 0) return DEMF_OK;
   DEMF_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight &&
@@ -348,9 +371,9 @@ extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   const int G = Dh / 4;
   const bool fast = (Dh % 4 == 0) && (G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 ||
                                       G == 64) &&
-                    (((uintptr_t)value | (uintptr_t)grad_out) % 16 == 0);
+                    (((uintptr_t)value % (4 * sizeof(VT))) == 0 && (uintptr_t)grad_out % 16 == 0);
   if (!fast) {
-    hipLaunchKernelGGL(msda_bwd_generic, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(msda_bwd_generic<VT>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s,
                        S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
                        attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight,
                        items);
@@ -358,7 +381,7 @@ extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   }
   const dim3 grid((unsigned)((items * G + 255) / 256));
 #define GO(g)                                                                              \
-  launch_bwd<g>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
+  launch_bwd<g, VT>(grid, s, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, \
                 sampling_loc, attn_weight, grad_out, grad_value, grad_sampling_loc,        \
                 grad_attn_weight, items)
   switch (G) {
@@ -372,4 +395,38 @@ extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int 
   }
 #undef GO
   return check_launch("msda_bwd");
+}
+
+extern "C" int demf_msda_fwd_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,
+                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* sampling_loc, const float* attn_weight, float* out,
+                                 demf_stream_t stream) {
+  return msda_fwd_impl<float>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                              attn_weight, out, stream);
+}
+
+extern "C" int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,
+                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                 float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                                 demf_stream_t stream) {
+  return msda_bwd_impl<float>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                              attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+extern "C" int demf_msda_fwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P, const uint16_t* value,
+                                  const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* sampling_loc, const float* attn_weight, float* out,
+                                  demf_stream_t stream) {
+  return msda_fwd_impl<uint16_t>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                                 attn_weight, out, stream);
+}
+
+extern "C" int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P, const uint16_t* value,
+                                  const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                  const float* sampling_loc, const float* attn_weight, const float* grad_out,
+                                  float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
+                                  demf_stream_t stream) {
+  return msda_bwd_impl<uint16_t>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
+                                 attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight, stream);
 }

@@ -562,6 +562,21 @@ int demf_msda_bwd_f32(int B, int S, int H, int Dh, int L, int Q, int P,
                       float* grad_value, float* grad_sampling_loc,
                       float* grad_attn_weight, demf_stream_t stream);
 
+/* The same two entry points over bf16 VALUE rows (B,S,H,Dh) of 2-byte elements (the upper halves of the fp32
+ * bit patterns): the gather - the dominant traffic of the operator - moves half the bytes; sampling locations,
+ * weights, every accumulation, the output and all gradients (grad_value too: fp32, same layout) stay fp32.
+ * BASELINE.json configs[3]: a bf16 image-token buffer halves the 152 MB token tensor. */
+int demf_msda_fwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P,
+                       const uint16_t* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, float* out, demf_stream_t stream);
+int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P,
+                       const uint16_t* value, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* sampling_loc,
+                       const float* attn_weight, const float* grad_out,
+                       float* grad_value, float* grad_sampling_loc,
+                       float* grad_attn_weight, demf_stream_t stream);
+
 /* Per-point vote targets of DeMFVoteHead.get_targets_single (class_agnostic_vote_head.py:828-858),
  * batched: points (B,N,point_stride>=3), gt_boxes (B,G,7) = (x,y,z_bottom,dx,dy,dz,yaw) padded to
  * G <= 64 with valid (B,G) bytes, cos/sin of -yaw (B,G) -> vote_targets (B,N,9) = votes to the
@@ -715,8 +730,29 @@ int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stream_t stream
  * 2 = fp32 emulated on the bf16 MFMA in the demf_mlp_gemm_* kernels: each fp32 operand is split
  * exactly into three bf16 terms (3 x 8 significand bits) and the six products of weight >= 2^-16
  * are accumulated in fp32 (dropped terms <= 2^-23 relative); demf_gemm_f32 stays on the fp32 MFMA.
- * Process-wide setting (the one piece of host-side mutable state besides the counter ring).     */
+ * demf_set_compute_dtype sets the PROCESS DEFAULT; a caller that runs several models / threads in different
+ * modes passes the mode with the call instead (demf_ctx below).  demf_get_compute_dtype: the mode a dense
+ * call made by this thread right now would run in.                                                 */
 int demf_set_compute_dtype(int mode);
+int demf_get_compute_dtype(void);
+
+/* The compute mode as a PARAMETER.  compute_mode: 0 / 1 / 2 as above, -1 = the process default; reserved
+ * must be zero.  Two ways to hand it over:
+ *   - demf_*_ctx(ctx, ...) variants of the generic dense entry points: the context applies to that call;
+ *   - demf_ctx_push(ctx) ... demf_ctx_pop(): every dense call THIS THREAD makes in between (all demf_mlp_*,
+ *     demf_gemm_*, demf_attn_core_*, demf_linear_* entry points) - a per-thread stack of depth 8, so two host
+ *     threads in different modes never see each other's setting and nothing process-global is written. */
+typedef struct demf_ctx {
+  int compute_mode;
+  int reserved[7];
+} demf_ctx;
+int demf_ctx_push(const demf_ctx* ctx);
+int demf_ctx_pop(void);
+int demf_gemm_f32_ctx(const demf_ctx* ctx, const demf_gemm_desc* desc, demf_stream_t stream);
+int demf_gemm_group_f32_ctx(const demf_ctx* ctx, const demf_gemm_desc* descs, int n, demf_stream_t stream);
+int demf_mlp_gemm_fwd_ctx(const demf_ctx* ctx, int R, int K, int N, int ldx, const float* X,
+                          const float* pro_scale_shift, const float* Wt, float* Y, double* stats,
+                          demf_stream_t stream);
 
 /* Self-attention core of the fusion decoder layer (nn.MultiheadAttention inside mmcv's
  * DetrTransformerDecoderLayer; demf/modeling/layers/transformer.py:55-80, configs/demf/demf_votenet.py:71-91):

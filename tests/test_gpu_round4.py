@@ -100,3 +100,102 @@ def test_gemm_asum_fallback_through_the_c_abi():
             fused.gemm_group(grp)
         torch.testing.assert_close(dw.double(), want_w, rtol=1e-4, atol=2e-3)
         torch.testing.assert_close(db.double(), want_b, rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("Dh", [32, 6])          # the 4-channel-per-lane kernels and the any-width form
+def test_msda_bf16_value_rows_are_the_fp32_operator_on_widened_rows(Dh):
+    """demf_msda_{fwd,bwd}_bf16: value rows stored as bf16 (2-byte elements) - BIT-identical to the fp32 entry
+    points on the same rows widened to fp32 (forward; the backward's scalar gradients likewise), because the
+    widening is exact and everything after the load is the same fp32 code."""
+    from demf_amd import _ffi
+    B, Q, H, L, P = 2, 100, 4, 4, 2
+    shapes = [(20, 28), (10, 14), (5, 7), (3, 4)]
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(Dh)
+    v16 = torch.randn(B, S, H, Dh, generator=g).bfloat16().cuda()
+    v32 = v16.float()
+    ss = torch.tensor(shapes, dtype=torch.long).cuda()
+    lsi = torch.cat((ss.new_zeros(1), ss.prod(1).cumsum(0)[:-1]))
+    loc = torch.rand(B, Q, H, L, P, 2, generator=g).cuda() * 1.2 - 0.1
+    w = torch.softmax(torch.randn(B, Q, H, L * P, generator=g), -1).view(B, Q, H, L, P).cuda()
+    go = torch.randn(B, Q, H * Dh, generator=g).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: t.data_ptr()
+    outs = {}
+    for name, v in (("f32", v32), ("bf16", v16)):
+        out = torch.empty(B, Q, H * Dh, device="cuda")
+        gv, gl, gw = torch.zeros(B, S, H, Dh, device="cuda"), torch.empty_like(loc), torch.empty_like(w)
+        _ffi.call("demf_msda_fwd_" + name, B, S, H, Dh, L, Q, P, p(v), p(ss), p(lsi), p(loc), p(w), p(out), st)
+        _ffi.call("demf_msda_bwd_" + name, B, S, H, Dh, L, Q, P, p(v), p(ss), p(lsi), p(loc), p(w), p(go), p(gv), p(gl),
+                  p(gw), st)
+        outs[name] = (out, gl, gw, gv)
+    for a, b, what in zip(outs["f32"][:3], outs["bf16"][:3], ("out", "grad_loc", "grad_weight")):
+        assert torch.equal(a, b), what
+    torch.testing.assert_close(outs["f32"][3], outs["bf16"][3], rtol=1e-5, atol=1e-5)      # (atomics order)
+    assert outs["f32"][0].abs().max() > 0
+
+
+def test_compute_mode_is_a_parameter_per_thread():
+    """demf_ctx: two host threads run the same dense call in DIFFERENT modes at the same time (their own
+    streams), each through its own context - results equal the single-threaded runs under the process default
+    set to that mode, and the process default itself is never touched."""
+    import ctypes
+    import threading
+    from demf_amd import _ffi, ops
+    lib = _ffi.load()
+
+    class Ctx(ctypes.Structure):
+        _fields_ = [("compute_mode", ctypes.c_int), ("reserved", ctypes.c_int * 7)]
+
+    R, K, N = 4096, 64, 128
+    g = torch.Generator().manual_seed(3)
+    X, Wt = torch.randn(R, K, generator=g).cuda(), (torch.randn(N, K, generator=g) / 8).cuda()
+
+    def run(mode, use_ctx, stream, reps=1):
+        Y = torch.empty(R, N, device="cuda")
+        with torch.cuda.stream(stream):
+            for _ in range(reps):
+                if use_ctx:
+                    c = Ctx(mode, (ctypes.c_int * 7)())
+                    _ffi.call("demf_mlp_gemm_fwd_ctx", ctypes.addressof(c), R, K, N, K, X.data_ptr(), None, Wt.data_ptr(),
+                              Y.data_ptr(), None, stream.cuda_stream)
+                else:
+                    _ffi.call("demf_mlp_gemm_fwd", R, K, N, K, X.data_ptr(), None, Wt.data_ptr(), Y.data_ptr(), None,
+                              stream.cuda_stream)
+        stream.synchronize()
+        return Y
+    s0 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    want = {}
+    for mode, name in ((1, "bf16"), (2, "f32")):
+        ops.set_compute_dtype(name)
+        want[mode] = run(mode, False, s0)
+    ops.set_compute_dtype("f32")
+    default = lib.demf_get_compute_dtype()
+    assert not torch.equal(want[1], want[2])                     # the modes really differ
+    got, errs = {}, []
+
+    def worker(mode):
+        try:
+            got[mode] = run(mode, True, torch.cuda.Stream(), reps=200)
+            # the scoped form: every dense call of THIS thread between push and pop
+            c = Ctx(mode, (ctypes.c_int * 7)())
+            _ffi.call("demf_ctx_push", ctypes.addressof(c))
+            try:
+                assert lib.demf_get_compute_dtype() == mode
+                got[("scoped", mode)] = run(mode, False, torch.cuda.Stream(), reps=50)
+            finally:
+                _ffi.call("demf_ctx_pop")
+        except Exception as e:          # noqa: BLE001 - reported below
+            errs.append(e)
+    ts = [threading.Thread(target=worker, args=(m,)) for m in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for m in (1, 2):
+        assert torch.equal(got[m], want[m]) and torch.equal(got[("scoped", m)], want[m]), m
+    assert lib.demf_get_compute_dtype() == default
+    with pytest.raises(RuntimeError, match="no context pushed"):
+        _ffi.call("demf_ctx_pop")
