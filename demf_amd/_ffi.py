@@ -43,6 +43,7 @@ SIGNATURES = {
     "demf_colsum_f32": [_c_int] * 3 + [_ptr] * 3,
     "demf_nchw_to_tokens": [_c_int] * 5 + [_ptr] * 4,
     "demf_pyramid_to_tokens": [_c_int] * 4 + [_ptr] * 5,
+    "demf_pyramid_to_tokens_bf16": [_c_int] * 4 + [_ptr] * 5,
     "demf_vote_targets": [_c_int] * 4 + [_ptr] * 8,
     "demf_box_extent_count": [_c_int] * 4 + [_ptr] * 8,
     "demf_aligned_nms": [_c_int, _c_int, _c_float] + [_ptr] * 6,

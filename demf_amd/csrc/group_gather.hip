@@ -455,16 +455,19 @@ struct TokLevels {
   int hw[8], row0[8], tile0[9];
   int n;
 };
+template <bool OB>     // OB: bf16 token rows (2-byte elements, round to nearest even) - C % 4 == 0
 __global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLevels lv,
                                                            const unsigned char* __restrict__ mask,
-                                                           float* __restrict__ dst) {
+                                                           void* __restrict__ dst_) {
   __shared__ float tile[64][65];
   const int bx = blockIdx.x, b = blockIdx.z, t = threadIdx.x;
   int l = 0;
   while (l + 1 < lv.n && bx >= lv.tile0[l + 1]) ++l;
   const int HW = lv.hw[l], p0 = (bx - lv.tile0[l]) * 64, c0 = blockIdx.y * 64;
   const float* __restrict__ src = lv.src[l] + (size_t)b * C * HW;
-  float* __restrict__ d = dst + ((size_t)b * S + lv.row0[l]) * C;
+  const size_t drow = ((size_t)b * S + lv.row0[l]) * C;
+  float* __restrict__ d = reinterpret_cast<float*>(dst_) + drow;
+  unsigned short* __restrict__ d16 = reinterpret_cast<unsigned short*>(dst_) + drow;
   const unsigned char* m = mask != nullptr ? mask + (size_t)b * S + lv.row0[l] : nullptr;
   const int q = t & 15, r = t >> 4;
 #pragma unroll
@@ -491,6 +494,11 @@ __global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLeve
     const bool z = m != nullptr && m[pp];                       // padding token
     float4 v = make_float4(tile[4 * q][pl], tile[4 * q + 1][pl], tile[4 * q + 2][pl], tile[4 * q + 3][pl]);
     if (z) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (OB) {
+      const __bf16 h[4] = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<uint2*>(d16 + (size_t)pp * C + c) = *reinterpret_cast<const uint2*>(h);
+      continue;
+    }
     float* o = d + (size_t)pp * C + c;
     if (c + 3 < C) {
       *reinterpret_cast<float4*>(o) = v;
@@ -507,9 +515,10 @@ __global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLeve
 
 using namespace demf;
 
-extern "C" int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
-                                      const unsigned char* mask, float* dst, demf_stream_t stream) {
+static int pyramid_to_tokens_impl(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                                  const unsigned char* mask, void* dst, bool bf16, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && C >= 1 && nlev >= 1 && nlev <= 8 && srcs && hws, "pyramid_to_tokens: bad arguments");
+  DEMF_REQUIRE(!bf16 || C % 4 == 0, "pyramid_to_tokens_bf16: C = %d is not a multiple of 4", C);
   if (B == 0) return DEMF_OK;
   DEMF_REQUIRE(dst, "pyramid_to_tokens: null pointer");
   TokLevels lv{};
@@ -523,9 +532,20 @@ extern "C" int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float
   lv.tile0[nlev] = tiles;
   lv.n = nlev;
   DEMF_REQUIRE(row == S, "pyramid_to_tokens: the levels hold %d tokens, S = %d", row, S);
-  hipLaunchKernelGGL(pyramid_to_tokens_k, dim3(tiles, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
-                     C, S, lv, mask, dst);
+  const dim3 grid(tiles, (C + 63) / 64, B);
+  if (bf16) hipLaunchKernelGGL(pyramid_to_tokens_k<true>, grid, dim3(256), 0, (hipStream_t)stream, C, S, lv, mask, dst);
+  else hipLaunchKernelGGL(pyramid_to_tokens_k<false>, grid, dim3(256), 0, (hipStream_t)stream, C, S, lv, mask, dst);
   return check_launch("pyramid_to_tokens");
+}
+
+extern "C" int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                                      const unsigned char* mask, float* dst, demf_stream_t stream) {
+  return pyramid_to_tokens_impl(B, C, S, nlev, srcs, hws, mask, dst, false, stream);
+}
+
+extern "C" int demf_pyramid_to_tokens_bf16(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                                           const unsigned char* mask, uint16_t* dst, demf_stream_t stream) {
+  return pyramid_to_tokens_impl(B, C, S, nlev, srcs, hws, mask, dst, true, stream);
 }
 
 extern "C" int demf_group_points_fwd(int B, int C, int N, int M, int ns,

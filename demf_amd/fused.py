@@ -239,8 +239,9 @@ class FusedDecoderLayer(Function):
         z, ks4 = new(R * H, Ct), new(R * H, 4)
         # sample-then-project (ops.msda_sample_then_project): every (query, head) is one item of a
         # single-head MSDA over the unprojected tokens / the keep mask
-        _ffi.call("demf_msda_fwd_f32", B, S, 1, Ct, L, Q * H, P, _p(tokens), shapes.data_ptr(),
-                  lsi.data_ptr(), _p(loc), _p(w), _p(z), st)
+        # (bf16 token rows in the bf16 compute mode: ops.pyramid_to_tokens(bf16=True), half the gather's bytes)
+        _ffi.call("demf_msda_fwd_bf16" if tokens.dtype == torch.bfloat16 else "demf_msda_fwd_f32", B, S, 1, Ct, L,
+                  Q * H, P, _p(tokens), shapes.data_ptr(), lsi.data_ptr(), _p(loc), _p(w), _p(z), st)
         _ffi.call("demf_msda_fwd_f32", B, S, 1, 4, L, Q * H, P, _p(keep4), shapes.data_ptr(),
                   lsi.data_ptr(), _p(loc), _p(w), _p(ks4), st)
         mo = new(R, E)
@@ -325,8 +326,9 @@ class FusedDecoderLayer(Function):
              sbb=(Dh, 0), scb=(4, 0))
         dloc, dw = new(R, H, L, P, 2), new(R, H, L, P)
         dloc2, dw2 = new(R, H, L, P, 2), new(R, H, L, P)
-        _ffi.call("demf_msda_bwd_f32", B, S, 1, Ct, L, Q * H, P, _p(tokens), shapes.data_ptr(),
-                  lsi.data_ptr(), _p(loc), _p(w), _p(dz), None, _p(dloc), _p(dw), st)
+        _ffi.call("demf_msda_bwd_bf16" if tokens.dtype == torch.bfloat16 else "demf_msda_bwd_f32", B, S, 1, Ct, L,
+                  Q * H, P, _p(tokens), shapes.data_ptr(), lsi.data_ptr(), _p(loc), _p(w), _p(dz), None, _p(dloc),
+                  _p(dw), st)
         _ffi.call("demf_msda_bwd_f32", B, S, 1, 4, L, Q * H, P, _p(keep4), shapes.data_ptr(),
                   lsi.data_ptr(), _p(loc), _p(w), _p(dks4), None, _p(dloc2), _p(dw2), st)
         draw, dpts = new(R, 3 * HLP), new(R, 3)

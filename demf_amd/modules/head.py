@@ -25,6 +25,9 @@ from .transformer import DeMFTransformerDecoderLayer
 from .vote import BaseConvBboxHead, VoteModule
 
 
+BF16_TOKENS = True     # bf16 compute mode: image tokens as bf16 rows (False: fp32 rows as in the fp32 modes)
+
+
 def compose_projection(img_meta):
     """Host-side (float64) composition of DeMFVoteHead.get_reference_points
     (class_agnostic_vote_head.py:524-547) for one scene:
@@ -373,7 +376,11 @@ class DeMFVoteHead(nn.Module):
         sample_first = on_gpu and samples < S and C0 % 4 == 0 and C0 <= 256
         if feat_flatten is None:
             if on_gpu:           # tiled transposes; the padding mask rides along when wanted
-                feat_flatten = ops.pyramid_to_tokens(mlvl_feats, mt["mask_u8"] if sample_first else None)
+                # (bf16 compute mode, sample-then-project: the tokens are an operand of nothing but the gather
+                # in front of the bf16 value projection - bf16 rows, half of the 152 MB)
+                feat_flatten = ops.pyramid_to_tokens(mlvl_feats, mt["mask_u8"] if sample_first else None,
+                                                     bf16=sample_first and BF16_TOKENS and
+                                                     ops.get_compute_dtype() == "bf16")
             else:
                 feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
         elif sample_first:

@@ -1627,14 +1627,16 @@ def aligned_nms(extent, scores, classes, valid, iou_thr):
     return keep.bool()
 
 
-def pyramid_to_tokens(mlvl_feats, zero_mask=None):
+def pyramid_to_tokens(mlvl_feats, zero_mask=None, bf16=False):
     """list of (B,C,H_l,W_l) -> (B, sum H_l W_l, C) channels-last tokens (no gradient: the image
     pyramid is an input of the hot path).  ``zero_mask`` (B,S) bool: tokens to write as zeros
-    (image padding), fused into the transposes."""
+    (image padding), fused into the transposes.  ``bf16``: bf16 token rows (the bf16 compute mode's
+    sample-then-project attention gathers them with demf_msda_*_bf16: half the bytes)."""
     B, C = mlvl_feats[0].shape[:2]
     sizes = [f.shape[2] * f.shape[3] for f in mlvl_feats]
     S = sum(sizes)
-    out = torch.empty((B, S, C), dtype=torch.float32, device=mlvl_feats[0].device)
+    bf16 = bool(bf16) and C % 4 == 0 and len(sizes) <= 8
+    out = torch.empty((B, S, C), dtype=torch.bfloat16 if bf16 else torch.float32, device=mlvl_feats[0].device)
     m = None if zero_mask is None else \
         (zero_mask if zero_mask.dtype == torch.uint8 else zero_mask.to(torch.uint8)).contiguous()
     for f in mlvl_feats:
@@ -1642,8 +1644,8 @@ def pyramid_to_tokens(mlvl_feats, zero_mask=None):
     if len(sizes) <= 8:                  # every level in one launch
         srcs = (ctypes.c_void_p * len(sizes))(*[f.data_ptr() for f in mlvl_feats])
         hws = (ctypes.c_int * len(sizes))(*sizes)
-        _ffi.call("demf_pyramid_to_tokens", B, C, S, len(sizes), ctypes.addressof(srcs), ctypes.addressof(hws),
-                  _p(m), _p(out), _stream())
+        _ffi.call("demf_pyramid_to_tokens_bf16" if bf16 else "demf_pyramid_to_tokens", B, C, S, len(sizes),
+                  ctypes.addressof(srcs), ctypes.addressof(hws), _p(m), _p(out), _stream())
         return out
     row0 = 0
     for f, hw in zip(mlvl_feats, sizes):
@@ -1670,6 +1672,8 @@ def msda_sample_then_project(tokens, keep4, spatial_shapes, level_start_index, s
     Dh = weight.shape[0] // H
     loc = sampling_locations.reshape(B, Q * H, 1, L, P, 2)
     aw = attention_weights.reshape(B, Q * H, 1, L, P)
+    if tokens.dtype == torch.bfloat16:            # (the unfused module path gathers fp32 rows)
+        tokens = tokens.float()
     z = MultiScaleDeformableAttnFunction.apply(tokens.view(B, S, 1, C), spatial_shapes,
                                                level_start_index, loc, aw)          # (B,Q*H,C)
     ksum = MultiScaleDeformableAttnFunction.apply(keep4.view(B, S, 1, 4), spatial_shapes,

@@ -230,6 +230,10 @@ int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const float* src,
  * ranges of dst (B,S,C), S = sum hws (nlev <= 8; srcs / hws are HOST arrays of device pointers / sizes). */
 int demf_pyramid_to_tokens(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
                            const unsigned char* mask, float* dst, demf_stream_t stream);
+/* The same transposes into bf16 token rows (2-byte elements, round to nearest even; C % 4 == 0): what
+ * demf_msda_{fwd,bwd}_bf16 gather from - BASELINE configs[3], half the bytes of the 152 MB token tensor. */
+int demf_pyramid_to_tokens_bf16(int B, int C, int S, int nlev, const float* const* srcs, const int* hws,
+                                const unsigned char* mask, uint16_t* dst, demf_stream_t stream);
 
 /* out (N) += column sums of x (R,N; row stride ld).  out arrives zeroed.  The bias gradient of the
  * path's linear layers (mmcv FFN / MultiheadAttention / MultiScaleDeformableAttention projections,

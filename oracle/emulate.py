@@ -278,7 +278,9 @@ def _msda_forward(self, query, key=None, value=None, identity=None, query_pos=No
     if not (samples < nv and key_padding_mask is not None):
         raise NotImplementedError("bf16 emulation covers the sample-then-project form only (decoder layers)")
     keep = (~key_padding_mask).to(value.dtype)                                    # (bs, nv)
-    tokens = value * keep.unsqueeze(-1)
+    # (the product keeps the image tokens as bf16 rows in this mode - ops.pyramid_to_tokens(bf16=True): the
+    # gather reads rounded tokens; no gradient flows to them)
+    tokens = q(value * keep.unsqueeze(-1))
     off = _linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(bs, nq, H, L, P, 2)
     aw = _linear(query, self.attention_weights.weight, self.attention_weights.bias) \
         .view(bs, nq, H, L * P).softmax(-1).view(bs, nq, H, L, P)
