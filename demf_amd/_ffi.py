@@ -55,6 +55,8 @@ SIGNATURES = {
     "demf_loss_total_bwd": [_c_int] + [_ptr] * 4,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
+    "demf_sa_index_chain": [_c_int] * 3 + [_ptr] * 4,
+    "demf_split_points": [ctypes.c_longlong, _c_int] + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
     "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 5 + [_c_int] + [_ptr] * 3,
     "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 9 + [_c_int, _ptr, _c_int] + [_ptr] * 3,

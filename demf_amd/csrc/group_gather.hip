@@ -510,6 +510,40 @@ __global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLeve
   }
 }
 
+// sa_indices of the backbone (PointNet2SASSG.forward, mmdet3d pointnet2_sa_ssg.py: indices into the INPUT cloud
+// of every level's samples): out_0 = arange(N), out_l[b][i] = out_{l-1}[b][idx_l[b][i]].  One workgroup per
+// scene walks the levels (their sizes shrink 20 000 -> 2 048 -> ... -> 256), one launch instead of
+// arange + repeat + 4 x (int64 conversion + torch.gather).
+struct IndexChain {
+  const int* idx[8];
+  long long* out[9];
+  int m[9];              // m[0] = N, m[l] = samples of level l
+  int n;
+};
+__global__ __launch_bounds__(1024) void index_chain_k(IndexChain c) {
+  const int b = blockIdx.x;
+  long long* o0 = c.out[0] + (size_t)b * c.m[0];
+  for (int i = threadIdx.x; i < c.m[0]; i += blockDim.x) o0[i] = i;
+  for (int l = 1; l <= c.n; ++l) {
+    __syncthreads();
+    const long long* prev = c.out[l - 1] + (size_t)b * c.m[l - 1];
+    const int* id = c.idx[l - 1] + (size_t)b * c.m[l];
+    long long* o = c.out[l] + (size_t)b * c.m[l];
+    for (int i = threadIdx.x; i < c.m[l]; i += blockDim.x) o[i] = prev[id[i]];
+  }
+}
+
+// points (rows, 3 + C) -> xyz (rows, 3) and the feature columns (rows, C): the two strided copies of the
+// pre-pass in one launch
+__global__ __launch_bounds__(256) void split_points_k(long long rows, int C, const float* __restrict__ pts,
+                                                      float* __restrict__ xyz, float* __restrict__ feat) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = pts + r * (3 + C);
+  xyz[3 * r] = p[0]; xyz[3 * r + 1] = p[1]; xyz[3 * r + 2] = p[2];
+  for (int c = 0; c < C; ++c) feat[r * C + c] = p[3 + c];
+}
+
 }  // namespace demf
 
 
@@ -782,4 +816,31 @@ extern "C" int demf_nchw_to_tokens(int B, int C, int HW, int S, int row0, const 
   hipLaunchKernelGGL(nchw_to_tokens_k, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
                      (hipStream_t)stream, C, HW, S, row0, src, mask, dst);
   return check_launch("nchw_to_tokens");
+}
+
+extern "C" int demf_sa_index_chain(int B, int N, int nlev, const int* const* idx, const int* samples,
+                                   int64_t* const* out, demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && nlev >= 0 && nlev <= 8 && out && (nlev == 0 || (idx && samples)),
+               "sa_index_chain: bad arguments");
+  if (B == 0) return DEMF_OK;
+  IndexChain c{};
+  c.n = nlev; c.m[0] = N;
+  DEMF_REQUIRE(out[0], "sa_index_chain: null pointer");
+  c.out[0] = (long long*)out[0];
+  for (int l = 1; l <= nlev; ++l) {
+    DEMF_REQUIRE(idx[l - 1] && out[l] && samples[l - 1] >= 1, "sa_index_chain: level %d", l);
+    c.idx[l - 1] = idx[l - 1]; c.out[l] = (long long*)out[l]; c.m[l] = samples[l - 1];
+  }
+  hipLaunchKernelGGL(index_chain_k, dim3(B), dim3(1024), 0, (hipStream_t)stream, c);
+  return check_launch("sa_index_chain");
+}
+
+extern "C" int demf_split_points(long long rows, int C, const float* points, float* xyz, float* feat,
+                                 demf_stream_t stream) {
+  DEMF_REQUIRE(rows >= 0 && C >= 0, "split_points: bad sizes");
+  if (rows == 0) return DEMF_OK;
+  DEMF_REQUIRE(points && xyz && (C == 0 || feat), "split_points: null pointer");
+  hipLaunchKernelGGL(split_points_k, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, C,
+                     points, xyz, feat);
+  return check_launch("split_points");
 }

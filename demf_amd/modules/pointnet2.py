@@ -206,21 +206,30 @@ class PointNet2SASSG(nn.Module):
         input cloud, so a training loop can run it for batch k+1 on a side stream while batch k
         trains (demf_amd/engine.py) - FPS is a latency-bound chain that occupies only B of the
         256 CUs."""
-        xyz = points[..., 0:3].contiguous()
+        on_dev = points.is_cuda and points.dtype == torch.float32
+        if on_dev:
+            xyz, feat_rows = ops.split_points(points)          # one launch instead of two strided copies
+        else:
+            xyz = points[..., 0:3].contiguous()
+            feat_rows = points[..., 3:].contiguous() if points.shape[-1] > 3 else None
         B, N = xyz.shape[:2]
         sa, cur = [], xyz
-        chain = [torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()]
         for i, m in enumerate(self.SA_modules):
             lvl = m.index_geometry(cur, with_inverse=i > 0)   # level 0 gathers the raw input
             sa.append(lvl)
             cur = lvl[1]
-            chain.append(torch.gather(chain[-1], 1, lvl[0].long()))   # indices into the input cloud
+        if on_dev and len(sa) <= 8:
+            chain = ops.sa_index_chain(N, [lvl[0] for lvl in sa])     # indices into the input cloud, one launch
+        else:
+            chain = [torch.arange(N, device=xyz.device).unsqueeze(0).repeat(B, 1).long()]
+            for lvl in sa:
+                chain.append(torch.gather(chain[-1], 1, lvl[0].long()))
         sa_xyz = [xyz] + [t[1] for t in sa]
         fp = [PointFPModule.index_geometry(sa_xyz[self.num_sa - i - 1], sa_xyz[self.num_sa - i])
               for i in range(self.num_fp)]
         geo = dict(sa=sa, fp=fp, xyz=xyz, sa_indices=chain)
-        if points.shape[-1] > 3:
-            geo["feat_rows"] = points[..., 3:].contiguous()        # (B,N,C0) point-major input features
+        if feat_rows is not None:
+            geo["feat_rows"] = feat_rows                           # (B,N,C0) point-major input features
         return geo
 
     def forward(self, points, geometry=None):

@@ -1627,6 +1627,35 @@ def aligned_nms(extent, scores, classes, valid, iou_thr):
     return keep.bool()
 
 
+def sa_index_chain(N, level_indices):
+    """[arange(N) per scene] + every SA level's samples as int64 indices into the input cloud (the
+    ``sa_indices`` of PointNet2SASSG.forward) from the levels' int32 FPS indices, one launch."""
+    B, dev = level_indices[0].shape[0], level_indices[0].device
+    for t in level_indices:
+        _chk(t, "fps indices", torch.int32)
+    outs = [torch.empty((B, N), dtype=torch.int64, device=dev)] + \
+        [torch.empty(tuple(t.shape), dtype=torch.int64, device=dev) for t in level_indices]
+    n = len(level_indices)
+    idx = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in level_indices])
+    ms = (ctypes.c_int * max(n, 1))(*[t.shape[1] for t in level_indices])
+    op = (ctypes.c_void_p * (n + 1))(*[t.data_ptr() for t in outs])
+    _ffi.call("demf_sa_index_chain", B, N, n, ctypes.addressof(idx), ctypes.addressof(ms), ctypes.addressof(op),
+              _stream())
+    return outs
+
+
+def split_points(points):
+    """(B,N,3+C) -> (xyz (B,N,3), feature rows (B,N,C) or None), contiguous, one launch."""
+    _chk(points, "points")
+    B, N, D = points.shape
+    C = D - 3
+    pts = points if points.is_contiguous() else points.contiguous()
+    xyz = torch.empty((B, N, 3), dtype=torch.float32, device=points.device)
+    feat = torch.empty((B, N, C), dtype=torch.float32, device=points.device) if C > 0 else None
+    _ffi.call("demf_split_points", B * N, C, _p(pts), _p(xyz), _p(feat), _stream())
+    return xyz, feat
+
+
 def pyramid_to_tokens(mlvl_feats, zero_mask=None, bf16=False):
     """list of (B,C,H_l,W_l) -> (B, sum H_l W_l, C) channels-last tokens (no gradient: the image
     pyramid is an input of the hot path).  ``zero_mask`` (B,S) bool: tokens to write as zeros

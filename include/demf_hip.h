@@ -184,6 +184,15 @@ int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out, const int* 
  * list.  N <= 16384.  Coordinate-only (QueryAndGroup's idx, class_agnostic_vote_head.py:383). */
 int demf_invert_index(int B, int N, int E, const int* idx, int* off, int* rows, demf_stream_t stream);
 
+/* sa_indices of the backbone (mmdet3d PointNet2SASSG.forward as used by demf/modeling: every level's samples as
+ * indices into the INPUT cloud): out[0] (B,N) = arange(N), out[l] (B, samples[l-1]) = out[l-1] gathered by the
+ * level's FPS indices idx[l-1] (B, samples[l-1]) int32; int64 outputs as the reference returns them.  nlev <= 8. */
+int demf_sa_index_chain(int B, int N, int nlev, const int* const* idx, const int* samples, int64_t* const* out,
+                        demf_stream_t stream);
+/* points (rows, 3 + C) -> xyz (rows, 3) | feat (rows, C): `points[..., :3]`, `points[..., 3:]` of the backbone
+ * input as contiguous tensors, one launch. */
+int demf_split_points(long long rows, int C, const float* points, float* xyz, float* feat, demf_stream_t stream);
+
 /* grad_feat (B,N,C) of demf_group_concat_cl_fwd through the inverse lists: every source point sums
  * the grad_out rows (B,E,ldo)[.., feat_col:feat_col+C] that gathered it.  No atomics; grad_feat is
  * fully written (need not arrive zeroed).  C % 4 == 0.  Same result as demf_group_concat_cl_bwd's

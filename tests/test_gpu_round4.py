@@ -199,3 +199,28 @@ def test_compute_mode_is_a_parameter_per_thread():
     assert lib.demf_get_compute_dtype() == default
     with pytest.raises(RuntimeError, match="no context pushed"):
         _ffi.call("demf_ctx_pop")
+
+
+def test_prepass_bookkeeping_kernels_match_torch():
+    """demf_sa_index_chain / demf_split_points (the pre-pass's arange + int64 conversions + gathers, and the two
+    strided input copies) against the torch statements they replace."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, N = 3, 5000
+    sizes = [2048, 1024, 512, 256]
+    idx, prev = [], N
+    for m in sizes:
+        idx.append(torch.stack([torch.randperm(prev, generator=g)[:m] for _ in range(B)]).int().cuda())
+        prev = m
+    got = ops.sa_index_chain(N, idx)
+    want = [torch.arange(N).unsqueeze(0).repeat(B, 1).cuda()]
+    for t in idx:
+        want.append(torch.gather(want[-1], 1, t.long()))
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a.dtype == torch.int64 and torch.equal(a, b)
+    for C in (1, 0, 5):
+        pts = torch.randn(B, N, 3 + C, generator=g).cuda()
+        xyz, feat = ops.split_points(pts)
+        assert torch.equal(xyz, pts[..., :3]) and xyz.is_contiguous()
+        assert (feat is None) if C == 0 else (torch.equal(feat, pts[..., 3:]) and feat.is_contiguous())
