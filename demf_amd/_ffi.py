@@ -55,6 +55,7 @@ SIGNATURES = {
     "demf_loss_total_bwd": [_c_int] + [_ptr] * 4,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
+    "demf_mlp_gemm_bwd_dw_group": [_c_int, _ptr, _ptr],
     "demf_sa_index_chain": [_c_int] * 3 + [_ptr] * 4,
     "demf_split_points": [ctypes.c_longlong, _c_int] + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
@@ -123,6 +124,13 @@ SIGNATURES = {
     "demf_rng_next": [_ptr, _ptr, _ptr],
     "demf_dropout_mask": [ctypes.c_longlong, _c_float, _ptr, _c_int, _ptr, _ptr],
 }
+
+
+class DwJob(ctypes.Structure):
+    """include/demf_hip.h: demf_dw_job (field order and types must match)."""
+    _fields_ = [("R", _c_int), ("N", _c_int), ("K", _c_int), ("ldx", _c_int), ("G", _ptr), ("dP", _ptr), ("arg", _ptr),
+                ("ns", _c_int), ("Y", _ptr), ("vec6", _ptr), ("Xprev", _ptr), ("prev_scale_shift", _ptr), ("dW", _ptr),
+                ("lddw", _c_int)]
 
 
 class GemmDesc(ctypes.Structure):

@@ -23,6 +23,7 @@
 // k = k0 + 4*(lane>>5) .. +3, and feeds component m to MFMA m: MFMA m then contracts over
 // k in {k0+m, k0+4+m} on both operands consistently - four MFMAs consume the two float4.
 #include "common.h"
+#include <vector>
 #include "bn_fin.h"
 #include <atomic>
 #include <type_traits>
@@ -1656,12 +1657,12 @@ struct DwArgs {
 // (8 ds_read_b32, conflict-free: consecutive lanes read consecutive columns), splits them into three
 // bf16 terms and issues the six significant products on v_mfma_f32_32x32x16_bf16.
 template <int TN, int TK, bool SPARSE, int X3 = 0>   // 0 fp32 MFMA, 1 three-term split, 2 one bf16 term
-__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
+__device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by, const int gx) {
   constexpr int PROY = SPARSE ? PRO_DY_SPARSE : PRO_DY_DENSE;
   {  // this block's (<= 2TN x 2TK tiles) corner of the N x K output
     const int TNt = (p.N + 31) / 32, TKt = (p.K + 31) / 32;
-    p.n0 = ((int)blockIdx.y / p.nsub_k) * 2 * TN;
-    p.k0 = ((int)blockIdx.y % p.nsub_k) * 2 * TK;
+    p.n0 = (by / p.nsub_k) * 2 * TN;
+    p.k0 = (by % p.nsub_k) * 2 * TK;
     p.NTn = TNt - p.n0 < 2 * TN ? TNt - p.n0 : 2 * TN;
     p.NTk = TKt - p.k0 < 2 * TK ? TKt - p.k0 : 2 * TK;
   }
@@ -1710,19 +1711,19 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
     }
   };
   // Rows are handed out in chunks of p.chunk 32-row slabs: the first chunk by block index, every
-  // further one from a device counter per sub-block column (blockIdx.y), claimed a chunk ahead.
+  // further one from a device counter per sub-block column (by), claimed a chunk ahead.
   const int nslab = (p.R + 31) / 32;
   const int nchunk = (nslab + p.chunk - 1) / p.chunk;
   __shared__ int s_next;
   const bool dyn = p.sched != nullptr;
   int claimed = 0;
-  int chunk = blockIdx.x, si = 0;
+  int chunk = bx, si = 0;
   if (chunk < nchunk) prefetch(chunk * p.chunk);
   while (chunk < nchunk) {
     const int slab = chunk * p.chunk + si;
     const bool last = si == p.chunk - 1 || slab + 1 >= nslab;
     if (dyn && threadIdx.x == 0) {
-      if (si == 0) claimed = (int)gridDim.x + atomicAdd(p.sched + blockIdx.y, 1);
+      if (si == 0) claimed = gx + atomicAdd(p.sched + by, 1);
       if (last) s_next = claimed;
     }
     __syncthreads();                                 // previous slab fully consumed (and s_v* ready)
@@ -1746,7 +1747,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
       }
     }
     __syncthreads();
-    const int next_chunk = last ? (dyn ? s_next : chunk + (int)gridDim.x) : chunk;
+    const int next_chunk = last ? (dyn ? s_next : chunk + gx) : chunk;
     const int next_si = last ? 0 : si + 1;
     if (next_chunk < nchunk) prefetch(next_chunk * p.chunk + next_si);
     if constexpr (X3 == 2) {
@@ -1818,9 +1819,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
   if (dyn && threadIdx.x == 0) {
     // re-arm the counters for the next launch that is handed this set: column-lasts, then the last
     int* done = p.sched + DW_MAX_SUB;
-    if (atomicAdd(done + blockIdx.y, 1) == (int)gridDim.x - 1) {
-      atomicExch(done + blockIdx.y, 0);
-      atomicExch(p.sched + blockIdx.y, 0);
+    if (atomicAdd(done + by, 1) == gx - 1) {
+      atomicExch(done + by, 0);
+      atomicExch(p.sched + by, 0);
     }
   }
 #pragma unroll
@@ -1837,6 +1838,31 @@ __global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
         }
       }
     }
+}
+
+template <int TN, int TK, bool SPARSE, int X3 = 0>
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(DwArgs p) {
+  mlp_dw_body<TN, TK, SPARSE, X3>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// Several weight-gradient launches of ONE template variant as one grid: nothing in a backward depends on a
+// layer's dW, so the few-row stacks (FP modules, vote module, prediction heads: 15-20 launches of ~20 us)
+// queue theirs and issue them together at the end (demf_mlp_gemm_bwd_dw_group) - the launches' ramps and tails
+// overlap and the graph has that many fewer dependent nodes.
+constexpr int DW_GROUP_MAX = 12;
+struct DwGroup {
+  int n;
+  int start[DW_GROUP_MAX + 1];     // first block of job j
+  int gx[DW_GROUP_MAX];            // its grid.x (row chunks); grid.y = (start[j+1] - start[j]) / gx
+  DwArgs job[DW_GROUP_MAX];
+};
+template <int TN, int TK, bool SPARSE, int X3 = 0>
+__global__ __launch_bounds__(256, 2) void mlp_dw_group_kernel(DwGroup g) {
+  const int b = (int)blockIdx.x;
+  int j = 0;
+  while (j + 1 < g.n && b >= g.start[j + 1]) ++j;
+  const int local = b - g.start[j], gx = g.gx[j];
+  mlp_dw_body<TN, TK, SPARSE, X3>(g.job[j], local % gx, local / gx, gx);
 }
 
 // Counter sets {next tile per group, finished blocks} of the dynamically scheduled persistent
@@ -2725,16 +2751,24 @@ extern "C" int demf_mlp_gemm_bwd_dw(int R, int N, int K, int ldx, const float* G
                                  stream);
 }
 
-extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float* G, const float* dP,
-                                       const int* arg, int ns, const float* Y, const float* vec6,
-                                       const float* Xprev, const float* prev_scale_shift, float* dW,
-                                       int lddw, demf_stream_t stream) {
+namespace {
+struct DwPlan {
+  DwArgs a;
+  int gx, nsub, tn, tk, x3;      // x3: 0 fp32 MFMA, 1 three-term split, 2 bf16
+  bool sparse;
+  size_t lds;
+};
+
+// argument checks + launch geometry of one weight-gradient product (shared by the single and the grouped entry)
+int dw_plan(int R, int N, int K, int ldx, const float* G, const float* dP, const int* arg, int ns, const float* Y,
+            const float* vec6, const float* Xprev, const float* prev_scale_shift, float* dW, int lddw, bool allow_dyn,
+            DwPlan& pl) {
   DEMF_REQUIRE(R >= 0 && N >= 4 && N % 4 == 0 && K >= 4 && K % 4 == 0 && ldx >= K && ldx % 4 == 0 &&
                    lddw >= K,
                "mlp_gemm_bwd_dw: bad sizes R=%d N=%d K=%d lddw=%d", R, N, K, lddw);
+  pl.gx = 0;
   if (R == 0) return DEMF_OK;
   DEMF_REQUIRE(Y && vec6 && Xprev && dW && (G || (dP && arg && ns >= 1)), "mlp_gemm_bwd_dw: null pointer");
-  hipStream_t s = (hipStream_t)stream;
   const int TNt = cdiv(N, 32), TKt = cdiv(K, 32);
   // one launch: grid.x strides the 32-row slabs, grid.y enumerates the (<= 4x4-tile) sub-blocks
   // of the N x K output, so even a 4 k-row layer spreads over the whole chip
@@ -2750,7 +2784,7 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
   const int nsub_n = cdiv(TNt, 2 * tn);
   a.nsub_k = cdiv(TKt, 2 * tk);
   const int nsub = nsub_n * a.nsub_k;
-  const size_t lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
+  pl.lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
   int gx = cdiv(R, 32 * 4);
   const int tot = env_int("DEMF_DW_GRID", 512);
   const int cap = tot / nsub > 16 ? tot / nsub : 16;
@@ -2759,7 +2793,7 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
   // dynamic chunk claims (DEMF_DW_DYN=1): measured neutral on the training step, so the default
   // stays the static slab striding (chunk = 1)
   a.chunk = 1;
-  if (env_int("DEMF_DW_DYN", 0)) {
+  if (allow_dyn && env_int("DEMF_DW_DYN", 0)) {
     const int nslab = cdiv(R, 32);
     a.chunk = nslab / (gx * 4);                  // >= 4 claims per block, at most DW_CHUNK slabs each
     a.chunk = a.chunk < 1 ? 1 : (a.chunk > DW_CHUNK ? DW_CHUNK : a.chunk);
@@ -2767,39 +2801,92 @@ extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float
     if (gx > nchunk) gx = nchunk;
     if (nchunk > 2 * gx && nsub <= DW_MAX_SUB) a.sched = sched_slot();
   }
-  const dim3 grid(gx, nsub);
-  if (compute_bf16() && !env_int("DEMF_DW_F32", 0)) {
-#define DWG(TNv, TKv)                                                                            \
-  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, 2>), grid, dim3(256), lds, s, a);    \
-  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, 2>), grid, dim3(256), lds, s, a)
-    if (tn == 1 && tk == 1) { DWG(1, 1); }
-    else if (tn == 1) { DWG(1, 2); }
-    else if (tk == 1) { DWG(2, 1); }
-    else { DWG(2, 2); }
-#undef DWG
-    return check_launch("mlp_gemm_bwd_dw(bf16 gather)");
-  }
   static const int x3mask = env_int("DEMF_X3_MASK", 7);          // bit 2: weight-gradient launches
-  if (compute_mode() == 2 && (x3mask & 4)) {
-#define DWX(TNv, TKv)                                                                            \
-  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, 1>), grid, dim3(256), lds, s, a); \
-  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, 1>), grid, dim3(256), lds, s, a)
-    if (tn == 1 && tk == 1) { DWX(1, 1); }
-    else if (tn == 1) { DWX(1, 2); }
-    else if (tk == 1) { DWX(2, 1); }
-    else { DWX(2, 2); }
-#undef DWX
-    return check_launch("mlp_gemm_bwd_dw(x3)");
-  }
-#define DW(TNv, TKv)                                                                             \
-  if (G) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false>), grid, dim3(256), lds, s, a);       \
-  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true>), grid, dim3(256), lds, s, a)
-  if (tn == 1 && tk == 1) { DW(1, 1); }
-  else if (tn == 1) { DW(1, 2); }
-  else if (tk == 1) { DW(2, 1); }
-  else { DW(2, 2); }
-#undef DW
+  pl.a = a; pl.gx = gx; pl.nsub = nsub; pl.tn = tn; pl.tk = tk; pl.sparse = G == nullptr;
+  pl.x3 = (compute_bf16() && !env_int("DEMF_DW_F32", 0)) ? 2 : ((compute_mode() == 2 && (x3mask & 4)) ? 1 : 0);
+  return DEMF_OK;
+}
+
+template <int X3>
+void dw_launch_one(const DwPlan& pl, hipStream_t s) {
+  const dim3 grid(pl.gx, pl.nsub);
+#define DWV(TNv, TKv)                                                                                       \
+  if (pl.sparse) hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, true, X3>), grid, dim3(256), pl.lds, s, pl.a); \
+  else hipLaunchKernelGGL((mlp_dw_kernel<TNv, TKv, false, X3>), grid, dim3(256), pl.lds, s, pl.a)
+  if (pl.tn == 1 && pl.tk == 1) { DWV(1, 1); }
+  else if (pl.tn == 1) { DWV(1, 2); }
+  else if (pl.tk == 1) { DWV(2, 1); }
+  else { DWV(2, 2); }
+#undef DWV
+}
+
+template <int X3>
+void dw_launch_group(const DwGroup& g, int tn, int tk, bool sparse, size_t lds, hipStream_t s) {
+  const dim3 grid(g.start[g.n]);
+#define DWG(TNv, TKv)                                                                                        \
+  if (sparse) hipLaunchKernelGGL((mlp_dw_group_kernel<TNv, TKv, true, X3>), grid, dim3(256), lds, s, g);     \
+  else hipLaunchKernelGGL((mlp_dw_group_kernel<TNv, TKv, false, X3>), grid, dim3(256), lds, s, g)
+  if (tn == 1 && tk == 1) { DWG(1, 1); }
+  else if (tn == 1) { DWG(1, 2); }
+  else if (tk == 1) { DWG(2, 1); }
+  else { DWG(2, 2); }
+#undef DWG
+}
+}  // namespace
+
+extern "C" int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float* G, const float* dP,
+                                       const int* arg, int ns, const float* Y, const float* vec6,
+                                       const float* Xprev, const float* prev_scale_shift, float* dW,
+                                       int lddw, demf_stream_t stream) {
+  DwPlan pl;
+  if (int e = dw_plan(R, N, K, ldx, G, dP, arg, ns, Y, vec6, Xprev, prev_scale_shift, dW, lddw, true, pl)) return e;
+  if (pl.gx == 0) return DEMF_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (pl.x3 == 2) dw_launch_one<2>(pl, s);
+  else if (pl.x3 == 1) dw_launch_one<1>(pl, s);
+  else dw_launch_one<0>(pl, s);
   return check_launch("mlp_gemm_bwd_dw");
+}
+
+extern "C" int demf_mlp_gemm_bwd_dw_group(int n, const demf_dw_job* jobs, demf_stream_t stream) {
+  DEMF_REQUIRE(n >= 0 && (n == 0 || jobs), "mlp_gemm_bwd_dw_group: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<DwPlan> plans;
+  plans.reserve(n);
+  for (int i = 0; i < n; ++i) {
+    const demf_dw_job& j = jobs[i];
+    DwPlan pl;
+    if (int e = dw_plan(j.R, j.N, j.K, j.ldx, j.G, j.dP, j.arg, j.ns, j.Y, j.vec6, j.Xprev, j.prev_scale_shift, j.dW,
+                        j.lddw, false, pl))
+      return e;
+    if (pl.gx) plans.push_back(pl);
+  }
+  std::vector<char> done(plans.size(), 0);
+  for (size_t i = 0; i < plans.size(); ++i) {
+    if (done[i]) continue;
+    // every not yet issued job of the same kernel variant, DW_GROUP_MAX at a time
+    DwGroup g{};
+    size_t lds = 0;
+    const DwPlan& f = plans[i];
+    for (size_t k = i; k < plans.size() && g.n < DW_GROUP_MAX; ++k) {
+      const DwPlan& q = plans[k];
+      if (done[k] || q.tn != f.tn || q.tk != f.tk || q.sparse != f.sparse || q.x3 != f.x3) continue;
+      g.job[g.n] = q.a; g.gx[g.n] = q.gx;
+      g.start[g.n + 1] = g.start[g.n] + q.gx * q.nsub;
+      lds = q.lds > lds ? q.lds : lds;
+      ++g.n;
+      done[k] = 1;
+    }
+    if (g.n == 1) {
+      if (f.x3 == 2) dw_launch_one<2>(f, s);
+      else if (f.x3 == 1) dw_launch_one<1>(f, s);
+      else dw_launch_one<0>(f, s);
+    } else if (f.x3 == 2) dw_launch_group<2>(g, f.tn, f.tk, f.sparse, lds, s);
+    else if (f.x3 == 1) dw_launch_group<1>(g, f.tn, f.tk, f.sparse, lds, s);
+    else dw_launch_group<0>(g, f.tn, f.tk, f.sparse, lds, s);
+    if (int e = check_launch("mlp_gemm_bwd_dw_group")) return e;
+  }
+  return DEMF_OK;
 }
 
 #ifdef DEMF_MLP_PROFILE

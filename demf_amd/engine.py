@@ -77,7 +77,12 @@ class FlatGrads:
     def backward_into(self, loss):
         """d(loss)/d(params) straight into the flat buffer: one autograd.grad + multi-tensor
         copies, instead of 119 per-parameter accumulate kernels (and no zero-fill dependence)."""
-        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        if self.flat.is_cuda:
+            from . import ops
+            with ops.deferred_weight_grads():       # the few-row stacks' dW products as one grouped launch at the end
+                grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        else:
+            grads = torch.autograd.grad(loss, self.params, allow_unused=True)
         dst = [v for v, g in zip(self.views, grads) if g is not None]
         src = [g for g in grads if g is not None]
         if len(src) != len(grads):

@@ -26,6 +26,70 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _DeferredDW:
+    """Weight-gradient products of the few-row stacks, queued and issued together.  Nothing in a backward depends
+    on a layer's dW (only the optimizer does), but one at a time each is a node of the step's dependency chain:
+    15-20 launches of ~20 us whose ramps and tails do not overlap.  Inside ``deferred_weight_grads()`` the
+    callers queue their job (pointers + sizes of demf_mlp_gemm_bwd_dw_ld) and keep its operands referenced; the
+    context's exit issues everything as demf_mlp_gemm_bwd_dw_group on the current stream: one launch per kernel
+    variant.  Outside the context a job is launched at once."""
+
+    def __init__(self):
+        self.on, self.jobs, self.keep = False, [], []
+
+
+DEFER = _DeferredDW()
+_DEFER_DW = int(os.environ.get("DEMF_DEFER_DW", "1") or 0)
+
+
+def _plain_parameter(w):
+    """True if ``w`` is a leaf or a contiguous view of one (conv.weight.view(N, K)): its gradient reaches the
+    parameter through alias-only backward nodes."""
+    try:
+        if w.is_leaf:
+            return True
+        return bool(w._is_view() and w._base is not None and w._base.is_leaf and w.is_contiguous() and
+                    w._base.is_contiguous() and w.numel() == w._base.numel())
+    except Exception:          # noqa: BLE001 - unknown tensor kinds are simply not deferred
+        return False
+
+
+def dw_job(R, N, K, ldx, G, dP, arg, ns, Y, vec6, xprev, pss, dW, lddw, dw_off=0, defer=True):
+    """One dW = dZ^T A product (arguments of demf_mlp_gemm_bwd_dw_ld; tensors, ``dw_off`` floats into dW)."""
+    j = _ffi.DwJob(R, N, K, ldx, _p(G), _p(dP), _p(arg), ns, _p(Y), _p(vec6), _p(xprev), _p(pss),
+                   dW.data_ptr() + 4 * dw_off, lddw)
+    if DEFER.on and _DEFER_DW and defer:
+        DEFER.jobs.append(j)
+        DEFER.keep.extend(t for t in (G, dP, arg, Y, vec6, xprev, pss, dW) if t is not None)
+        return
+    _ffi.call("demf_mlp_gemm_bwd_dw_group", 1, ctypes.addressof(j), _stream())
+
+
+def flush_dw():
+    if DEFER.jobs:
+        arr = (_ffi.DwJob * len(DEFER.jobs))(*DEFER.jobs)
+        DEFER.jobs = []
+        try:
+            _ffi.call("demf_mlp_gemm_bwd_dw_group", len(arr), ctypes.addressof(arr), _stream())
+        finally:
+            DEFER.keep.clear()
+
+
+class deferred_weight_grads:
+    def __enter__(self):
+        DEFER.on = True
+        return self
+
+    def __exit__(self, *exc):
+        DEFER.on = False
+        if exc[0] is None:
+            flush_dw()
+        else:
+            DEFER.jobs, DEFER.keep = [], []
+        return False
+
+
+
 class MultiCopy:
     """dst[i].copy_(src[i]) (src[i] None: dst[i].zero_()) for a FIXED list of contiguous tensor pairs
     as one kernel launch (demf_multi_copy); the address table is built once."""
@@ -997,6 +1061,10 @@ class _SharedMLPPool(Function):
         ctx.bias_shapes = [None if tensors[7 * l + 5] is None else tensors[7 * l + 5].shape
                            for l in range(L)]
         ctx.meta = (R, ld, ns, L, training)
+        # a layer's dW may be queued (dw_job) only if nothing but view ops sits between this node and the
+        # parameter: a torch.cat / index op in between (padded first-layer weights) would read the still empty
+        # gradient when the node returns
+        ctx.defer_ok = [_plain_parameter(tensors[7 * l]) for l in range(L)]
         ctx.store16 = store16
         ctx.noy = noy
         ctx.x4 = x4
@@ -1090,8 +1158,8 @@ class _SharedMLPPool(Function):
                           _p(dW0), K, _p(W), K, _p(dxyz), _p(dcenter), st)
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3
-                _ffi.call("demf_mlp_gemm_bwd_dw_ld", gB * gN, N, C0, C0, _p(dU), None, None, 1, _p(dU),
-                          _p(_identity_dy_vectors(N, dev)), _p(x), None, dW0.data_ptr() + 12, K, st)
+                dw_job(gB * gN, N, C0, C0, dU, None, None, 1, dU, _identity_dy_vectors(N, dev), x, None, dW0, K,
+                       dw_off=3, defer=ctx.defer_ok[0])
                 grads[0] = dW0
                 grads[1], grads[2] = dgamma, dbeta
                 if ctx.bias_shapes[0] is not None:
@@ -1201,9 +1269,8 @@ class _SharedMLPPool(Function):
                     g12_pending = g12p
                 G = dX
                 continue
-            _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, ldx, _p(G), _p(dP if sparse else None),
-                      _p(arg if sparse else None), ns, _p(Ys[l]), _p(vec6), _p(xprev),
-                      _p(sss[l - 1] if l > 0 else None), _p(dW), st)
+            dw_job(R, N, K, ldx, G, dP if sparse else None, arg if sparse else None, ns, Ys[l], vec6, xprev,
+                   sss[l - 1] if l > 0 else None, dW, K, defer=ctx.defer_ok[l])
             grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
             if ctx.bias_shapes[l] is not None:
                 grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])

@@ -507,6 +507,25 @@ int demf_mlp_gemm_bwd_dw_ld(int R, int N, int K, int ldx, const float* G, const 
                             const float* Xprev, const float* prev_scale_shift, float* dW, int lddw,
                             demf_stream_t stream);
 
+/* Several demf_mlp_gemm_bwd_dw_ld products in as few launches as their kernel variants allow (one per variant,
+ * twelve jobs at a time).  Nothing in a backward depends on a layer's weight gradient, so a caller may queue the
+ * jobs of many layers and issue them together once the operands exist; fields as the arguments of
+ * demf_mlp_gemm_bwd_dw_ld. */
+typedef struct demf_dw_job {
+  int R, N, K, ldx;
+  const float* G;
+  const float* dP;
+  const int* arg;
+  int ns;
+  const float* Y;
+  const float* vec6;
+  const float* Xprev;
+  const float* prev_scale_shift;
+  float* dW;
+  int lddw;
+} demf_dw_job;
+int demf_mlp_gemm_bwd_dw_group(int n, const demf_dw_job* jobs, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Fused head losses: DeMFVoteHead._loss (class_agnostic_vote_head.py:622-712)
  * over the raw conv-head rows  cls (R,12) = [objectness 2 | semantic 10],

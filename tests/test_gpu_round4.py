@@ -224,3 +224,84 @@ def test_prepass_bookkeeping_kernels_match_torch():
         xyz, feat = ops.split_points(pts)
         assert torch.equal(xyz, pts[..., :3]) and xyz.is_contiguous()
         assert (feat is None) if C == 0 else (torch.equal(feat, pts[..., 3:]) and feat.is_contiguous())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_grouped_weight_gradients_equal_the_single_launches(mode):
+    """demf_mlp_gemm_bwd_dw_group: many dW = dZ^T A products of different shapes (dense and pooled upstream
+    gradients, raw and BN+ReLU'd inputs, a strided destination) in a handful of launches - the same numbers as
+    one demf_mlp_gemm_bwd_dw_ld each (fp32 atomics order aside)."""
+    import ctypes
+    from demf_amd import _ffi, ops
+    g = torch.Generator().manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    shapes = [(2048, 128, 128, 1, True), (8192, 256, 256, 1, True), (4096, 256, 512, 1, False), (2048, 12, 128, 1, True),
+              (32768, 128, 128, 16, True), (8192, 256, 384, 1, True), (2048, 32, 128, 1, False), (65536, 128, 64, 32, True),
+              (1024, 64, 64, 1, True), (16384, 256, 256, 1, True), (20000, 128, 128, 1, True), (512, 256, 128, 1, True),
+              (4096, 128, 256, 1, True), (2048, 128, 128, 1, True)]
+    ops.set_compute_dtype(mode)
+    try:
+        jobs, keep, want, got = [], [], [], []
+        for (R, N, K, ns, pro) in shapes:
+            Y = torch.randn(R, N, generator=g).cuda()
+            X = torch.randn(R, K, generator=g).cuda()
+            vec = torch.randn(5 * N, generator=g).cuda()
+            pss = torch.randn(2 * K, generator=g).cuda() if pro else None
+            if ns > 1:
+                G, dP = None, torch.randn(R // ns, N, generator=g).cuda()
+                arg = torch.randint(0, ns, (R // ns, N), generator=g).int().cuda()
+            else:
+                G, dP, arg = torch.randn(R, N, generator=g).cuda(), None, None
+            ld = K + 4
+            w1, w2 = torch.zeros(N, ld, device="cuda"), torch.zeros(N, ld, device="cuda")
+            _ffi.call("demf_mlp_gemm_bwd_dw_ld", R, N, K, K, p(G), p(dP), p(arg), ns, p(Y), p(vec), p(X), p(pss), p(w1),
+                      ld, st)
+            jobs.append(_ffi.DwJob(R, N, K, K, p(G), p(dP), p(arg), ns, p(Y), p(vec), p(X), p(pss), p(w2), ld))
+            keep.append((Y, X, vec, pss, G, dP, arg))
+            want.append(w1)
+            got.append(w2)
+        arr = (_ffi.DwJob * len(jobs))(*jobs)
+        _ffi.call("demf_mlp_gemm_bwd_dw_group", len(jobs), ctypes.addressof(arr), st)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_compute_dtype("f32")
+    for i, (a, b) in enumerate(zip(want, got)):
+        scale = a.abs().max().item()
+        assert scale > 0 and (a - b).abs().max().item() <= 2e-5 * scale, (i, shapes[i], (a - b).abs().max().item(), scale)
+        assert torch.equal(a[:, shapes[i][2]:], b[:, shapes[i][2]:])         # the padding columns stay untouched
+
+
+def test_deferred_weight_gradients_reach_every_parameter():
+    """engine.FlatGrads.backward_into queues the few-row stacks' dW products (ops.deferred_weight_grads) and issues
+    them as grouped launches at the end of the backward: every parameter's gradient equals the immediate form -
+    including first-layer weights that reach the kernel through a torch.cat (padded columns), whose gradient
+    autograd slices the moment the node returns and which therefore must NOT be queued."""
+    from oracle import fixtures
+    from demf_amd import engine, ops, synthetic
+    from demf_amd.modules import DeMFHotPath
+
+    def run(defer):
+        old, ops._DEFER_DW = ops._DEFER_DW, defer
+        try:
+            cfg = fixtures.tiny_cfg()
+            model = DeMFHotPath(cfg)
+            fixtures.seed_weights(model, 7)
+            model.cuda().train()
+            raw = synthetic.make_scene_batch(2, 1024, fixtures.TINY_PYRAMID, fixtures.TINY_INPUT, cfg.head.embed_dims,
+                                             seed=50, n_gt=4)
+            batch = dict(points=torch.from_numpy(raw["points"]).cuda(),
+                         img_features=[torch.from_numpy(f).cuda() for f in raw["img_features"]],
+                         img_metas=raw["img_metas"], gt_bboxes_3d=[torch.from_numpy(b).cuda() for b in raw["gt_boxes"]],
+                         gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]])
+            tr = engine.Trainer(model, lr=1e-3)
+            tr._fwd_bwd(batch)
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        finally:
+            ops._DEFER_DW = old
+    a, b = run(0), run(1)
+    assert a.keys() == b.keys() and not ops.DEFER.jobs and not ops.DEFER.keep
+    for n in a:
+        s = a[n].abs().max().item()
+        assert (a[n] - b[n]).abs().max().item() <= 1e-4 * max(s, 1e-6), n
