@@ -1366,6 +1366,201 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   }
 }
 
+// ---- forward GEMM for 128-channel inputs: producer and consumer waves ------------------------------------
+// The layers behind SA1 (SA2-4, the vote aggregation: 128 -> 128 and 128 -> 256, 32 k ... 262 k rows) ran on
+// mlp_gemm_kernel at ~82 TF/s = 20 % of what the three-term mode can issue: every K step of 32 restages both
+// operands behind two workgroup barriers, and the loads of a step are in flight for one step's MFMAs only.
+// Their weight does not fit LDS as split planes next to per-wave slabs (256 x 128 x 6 B = 196 KB), so the
+// barrier-free form of mlp_fwd_res_kernel does not carry over.  Here a workgroup is 8 waves with two ROLES:
+//   waves 0-3  PRODUCERS: stream 64-row slabs of the input (full 512-byte rows, three slabs in flight in
+//              registers), apply the previous layer's BN + ReLU, split ONCE into bf16 planes in LDS (two stages);
+//   waves 4-7  CONSUMERS: each owns 32 output columns for the whole launch with ITS weight fragments in
+//              registers (8 K-steps x P planes x 4 VGPRs = 96), runs the slab's MFMAs straight from the planes,
+//              stores the raw output, accumulates the column statistics and the pooled extremum.
+// One LDS-only barrier per slab; each SIMD hosts one producer and one consumer, so VALU / memory work and the
+// matrix pipe overlap by construction.  128 columns per workgroup: a 256-column layer runs as two column halves
+// whose workgroups are co-scheduled on one XCD (blocks b and b + 8), so the second read of a slab is an L2 hit.
+// Requires K == 128, N % 128 == 0, R % 64 == 0, contiguous rows.
+constexpr int PC_K = 128, PC_KB = 256, PC_ROWS = 64;
+template <int CM, bool POOL>
+__global__ __launch_bounds__(512, 1) void mlp_fwd_pc_kernel(MlpArgs p) {
+  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int K = PC_K, KB = PC_KB, KS = K / 16, SR = PC_ROWS, NL = SR / 8;
+  constexpr int PF = 3;                                      // slabs in flight per producer (3 x 8 float4)
+  extern __shared__ __attribute__((aligned(16))) char pc_smem[];
+  char* s_a = pc_smem;                                       // [2 stages][P][64 rows x KB]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const bool producer = wave < 4;
+  int bx = (int)blockIdx.x, gx = (int)gridDim.x, h = 0;
+  if (p.N == 256) {                                          // two column halves, interleaved in runs of 8 blocks
+    h = (bx >> 3) & 1;
+    bx = (bx & 7) | ((bx >> 4) << 3);
+    gx >>= 1;
+  }
+  const int nslab = p.R / SR;
+  const int N = p.N;
+  // ---- producer state: lane's patch = channels 4*k4 .. +3 of rows prow + 8 i ---------------------------
+  const int k4 = tid & 31, prow = (tid >> 5) & 7;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rq[PF][NL];
+  auto fetch = [&](int slab, float4 (&r)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      r[i] = *reinterpret_cast<const float4*>(p.X + (size_t)(slab * SR + prow + 8 * i) * p.ldx + 4 * k4);
+  };
+  auto commit = [&](int stage, const float4 (&r)[NL]) {
+    char* base = s_a + (size_t)stage * P * SR * KB;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float4 x = r[i];
+      x.x = fmaxf(0.f, __builtin_fmaf(x.x, sc.x, sh.x));
+      x.y = fmaxf(0.f, __builtin_fmaf(x.y, sc.y, sh.y));
+      x.z = fmaxf(0.f, __builtin_fmaf(x.z, sc.z, sh.z));
+      x.w = fmaxf(0.f, __builtin_fmaf(x.w, sc.w, sh.w));
+      unsigned p0[P], p1[P];
+      fr_split_pair<P>(x.x, x.y, p0);
+      fr_split_pair<P>(x.z, x.w, p1);
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+        *reinterpret_cast<uint2*>(base + q * SR * KB + fr_swz<KB>(prow + 8 * i, k4 >> 1) + 8 * (k4 & 1)) =
+            make_uint2(p0[q], p1[q]);
+    }
+  };
+  const int col = h * 128 + 32 * (wave & 3) + lr;             // consumers: this lane's output column
+  float cs1 = 0.f, cs2 = 0.f;
+  // (the two roles are two separate loops with the same barrier count, so that the register allocation is the
+  // larger of the two states, not their sum)
+  if (producer) {
+    sc = *reinterpret_cast<const float4*>(p.vec + 4 * k4);
+    sh = *reinterpret_cast<const float4*>(p.vec + K + 4 * k4);
+    // rq[d] holds slab j + 1 + d of this workgroup's sequence; slab 0 goes through rq[PF - 1] first
+    if (bx < nslab) { fetch(bx, rq[PF - 1]); }
+#pragma unroll
+    for (int d = 0; d < PF - 1; ++d)
+      if (bx + (d + 1) * gx < nslab) fetch(bx + (d + 1) * gx, rq[d]);
+    if (bx < nslab) commit(0, rq[PF - 1]);
+    if (bx + PF * gx < nslab) fetch(bx + PF * gx, rq[PF - 1]);
+    lds_barrier();
+    int j = 0;
+    for (int slab = bx; slab < nslab; slab += gx, ++j) {
+      // slab j + 1 into the other stage (its rows were requested PF slabs ago), then slab j + 1 + PF into flight
+      if (slab + gx < nslab) commit((j + 1) & 1, rq[0]);
+#pragma unroll
+      for (int d = 0; d + 1 < PF; ++d)
+#pragma unroll
+        for (int i = 0; i < NL; ++i) rq[d][i] = rq[d + 1][i];
+      if (slab + (PF + 1) * gx < nslab) fetch(slab + (PF + 1) * gx, rq[PF - 1]);
+      lds_barrier();
+    }
+  } else {
+    // ---- consumer: its weight row as MFMA B fragments, resident for the whole launch ------------------------
+    bf16x8 bfrag[KS][P];
+    unsigned flip = 0;
+    const float* wrow = p.Bt + (size_t)col * K + 8 * lh;
+#pragma unroll
+    for (int sidx = 0; sidx < KS; ++sidx) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wrow + 16 * sidx);
+      const float4 w1 = *reinterpret_cast<const float4*>(wrow + 16 * sidx + 4);
+      unsigned q0[P], q1[P], q2[P], q3[P];
+      fr_split_pair<P>(w0.x, w0.y, q0);
+      fr_split_pair<P>(w0.z, w0.w, q1);
+      fr_split_pair<P>(w1.x, w1.y, q2);
+      fr_split_pair<P>(w1.z, w1.w, q3);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const uint4 u = make_uint4(q0[q], q1[q], q2[q], q3[q]);
+        bfrag[sidx][q] = __builtin_bit_cast(bf16x8, u);
+      }
+    }
+    if constexpr (POOL) flip = p.fin.gamma[col] < 0.f ? 0x80000000u : 0u;
+    lds_barrier();
+    int j = 0;
+    for (int slab = bx; slab < nslab; slab += gx, ++j) {
+      const char* base = s_a + (size_t)(j & 1) * P * SR * KB;
+      // two row tiles = two independent accumulator chains
+      f32x16 acc[2][1];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][0][r] = 0.f;
+#pragma unroll
+      for (int sidx = 0; sidx < KS; ++sidx) {
+        bf16x8 a0[P], a1[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          a0[q] = *reinterpret_cast<const bf16x8*>(base + q * SR * KB + fr_swz<KB>(lr, 2 * sidx + lh));
+          a1[q] = *reinterpret_cast<const bf16x8*>(base + q * SR * KB + fr_swz<KB>(32 + lr, 2 * sidx + lh));
+        }
+        fr_mfma<P>(acc[0][0], a0, bfrag[sidx]);
+        fr_mfma<P>(acc[1][0], a1, bfrag[sidx]);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int row0 = slab * SR + 32 * rt;
+        float* yp = p.Y + (size_t)(row0 + 4 * lh) * p.ldy + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yp[(size_t)((r & 3) + 8 * (r >> 2)) * p.ldy] = acc[rt][0][r];
+        f32x2_t a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2_t v = {acc[rt][0][r], acc[rt][0][r + 1]};
+          a1 += v;
+          a2 = __builtin_elementwise_fma(v, v, a2);
+        }
+        cs1 += a1.x + a1.y;
+        cs2 += a2.x + a2.y;
+        if constexpr (POOL) {
+          const f32x16 (&one)[1][1] = *reinterpret_cast<const f32x16 (*)[1][1]>(&acc[rt]);
+          if (p.ns == 16) pool_epilogue_sel<1, 1, 16>(p, one, 0, row0, col, lh, flip);
+          else pool_epilogue_sel<1, 1, 32>(p, one, 0, row0, col, lh, flip);
+        }
+      }
+      lds_barrier();
+    }
+  }
+  // ---- column statistics: lanes l / l + 32 share a column; a consumer wave owns its columns alone --------
+  if (!producer) {
+    cs1 += __shfl_xor(cs1, 32);
+    cs2 += __shfl_xor(cs2, 32);
+    if (lh == 0) {
+      atomicAdd(p.stats + col, (double)cs1);
+      atomicAdd(p.stats + N + col, (double)cs2);
+    }
+  }
+  if (p.fin.ss != nullptr) {
+    // train-mode BN bookkeeping by the last workgroup (as mlp_gemm_kernel: only atomics touch the sums)
+    __syncthreads();
+    if (tid == 0) {
+      const int total = (int)gridDim.x;
+      const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
+      const int g = (int)blockIdx.x % SCHED_GROUPS;
+      const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
+      int* t = p.fin.ticket + FIN_OFF;
+      int last = 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own sum atomics acknowledged first (csrc/bn_fin.h)
+      if (atomicAdd(t + 1 + g, 1) == members - 1) {
+        atomicExch(t + 1 + g, 0);
+        if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {
+      const BnFin& f = p.fin;
+      if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
+      for (int c = tid; c < N; c += 512) {
+        const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+        const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        bn_finalize_channel(c, N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss,
+                            f.mi, f.conv_bias);
+      }
+    }
+  }
+}
+
 // ---- BN statistics -> per-channel scale/shift (+ running stats, saved mean/invstd) -----------
 __global__ void bn_finalize_kernel(int N, double count, double* __restrict__ stats,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1909,6 +2104,32 @@ static int launch_gemm(const MlpArgs& a, hipStream_t s) {
 template <int PRO, bool STATS, bool POOL, bool RED, int BF16>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
   if constexpr ((BF16 == 1 || BF16 == 2) && !RED && STATS && PRO == PRO_BNRELU) {
+    // producer / consumer forward for 128-channel inputs (mlp_fwd_pc_kernel): SA2-4 and the vote aggregation
+    static const int pc_on = env_int("DEMF_FWD_PC", 1);
+    static const int pc_min_r = env_int("DEMF_FWD_PC_MIN_R", 16384);
+    const bool pc_sel = !POOL || (a.pmin == nullptr && a.fin.gamma != nullptr && a.pmax && a.amax);
+    if (pc_on && a.st == 0 && a.K == PC_K && (a.N == 128 || a.N == 256) && a.ldx == PC_K && a.ldy == a.N &&
+        a.ldb == 0 && pc_sel && a.R >= pc_min_r && a.R % PC_ROWS == 0 && a.vec != nullptr && a.stats != nullptr &&
+        (!POOL || a.ns == 16 || a.ns == 32) && (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
+      constexpr int P = BF16 == 2 ? 3 : 1;
+      const size_t bytes = (size_t)2 * P * PC_ROWS * PC_KB;
+      static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
+      const int nslab = a.R / PC_ROWS, halves = a.N / 128;
+      int gh = cus / halves;                       // workgroups per column half
+      if (gh > nslab) gh = nslab;
+      if (halves == 2) gh = gh / 8 * 8 > 0 ? gh / 8 * 8 : 8;   // interleaved halves: runs of 8 blocks
+      static bool configured = false;
+      if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_pc_kernel<BF16, POOL>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+          set_error("mlp_fwd_pc: cannot reserve %zu bytes of LDS", bytes);
+          return DEMF_ELAUNCH;
+        }
+        configured = true;
+      }
+      hipLaunchKernelGGL((mlp_fwd_pc_kernel<BF16, POOL>), dim3(gh * halves), dim3(512), bytes, s, a);
+      return check_launch("mlp_fwd_pc");
+    }
     // weight-resident, barrier-free forward (mlp_fwd_res_kernel): 64-channel inputs, N = 64 / 128
     static const int fr_on = env_int("DEMF_FWD_RES", 1);
     const bool sel = !POOL || (a.pmin == nullptr && a.fin.gamma != nullptr);

