@@ -182,6 +182,20 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& p, int z, size_t oc, 
 }
 
 // MA / MB: staging mode of the A / B operand (stage_mode); ADD = a second addend on either operand
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  With
+// (x = column tile, y = row tile) and a column count that is a multiple of 8 tiles, XCD i would own COLUMN
+// tiles i, i + 8, ... of every row block: each of the 8 L2s pulls the whole A operand (measured: 25-28 MB
+// fetched per 2 048 x 256 x 256 launch for 4.5 MB of operands).  Re-deal: linear id L -> row block
+// (L mod 8) + 8 * (L / (8 gx)), column tile (L / 8) mod gx, so that all column tiles of a row block run on ONE
+// XCD back to back (A rows fetched once in total, the small B operand once per XCD).
+__device__ __forceinline__ void xcd_rows(int& bx, int& by, int gx, int gy) {
+  if ((gy & 7) == 0) {
+    const int L = bx + gx * by;
+    by = (L & 7) + 8 * (L / (8 * gx));
+    bx = (L >> 3) % gx;
+  }
+}
+
 template <int MA, int MB, bool ADD, bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float s_a[G_BM * G_LD];
@@ -189,7 +203,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int wm = wave & 1, wn = wave >> 1;
-  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_rows(bx, by, gridDim.x, gridDim.y);
+  const int m0 = by * G_BM, n0 = bx * G_BN;
   const int z = blockIdx.z / p.splitk, sp = blockIdx.z - z * p.splitk;
   // split-K: contiguous K ranges, multiples of the K step
   const int kchunk = ((p.K + p.splitk - 1) / p.splitk + G_BK - 1) / G_BK * G_BK;
@@ -488,7 +504,9 @@ __global__ __launch_bounds__(256, ADD ? 2 : 4) void gemm_ks_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float s_a[32 * G_LD];
   __shared__ __attribute__((aligned(16))) float s_b[32 * G_LD];
   __shared__ float s_red[4][16][64];
-  gemm_ks_body<MA, MB, ADD, BF16>(p, blockIdx.x, blockIdx.y, blockIdx.z, s_a, s_b, s_red);
+  int bx = blockIdx.x, by = blockIdx.y;
+  xcd_rows(bx, by, gridDim.x, gridDim.y);
+  gemm_ks_body<MA, MB, ADD, BF16>(p, bx, by, blockIdx.z, s_a, s_b, s_red);
 }
 
 // Several small GEMMs of the SAME operand form in ONE launch (the weight gradients of a decoder layer:
@@ -499,6 +517,7 @@ struct GemmGroup {
   GemmArgs p[GEMM_GROUP_MAX];
   int start[GEMM_GROUP_MAX + 1];
   int n;
+  int dbg;
 };
 template <int MA, int MB, bool ADD, bool BF16>
 __global__ __launch_bounds__(256, ADD ? 2 : 4) void gemm_ks_group_kernel(GemmGroup g) {
@@ -511,8 +530,174 @@ __global__ __launch_bounds__(256, ADD ? 2 : 4) void gemm_ks_group_kernel(GemmGro
   const GemmArgs& p = g.p[i];
   const int local = b - g.start[i];
   const int gx = (p.N + 31) / 32, gy = (p.M + 31) / 32;
-  const int bx = local % gx, by = (local / gx) % gy, bz = local / (gx * gy);
+  // the K slice is the fastest index: with 8 slices (and tile counts that are multiples of 8) XCD i runs
+  // slice i of every tile, so each reduction range of both operands lands in exactly one L2
+  const int sp = local % p.splitk, rest = local / p.splitk;
+  const int bx = rest % gx, by = (rest / gx) % gy, bz = (rest / (gx * gy)) * p.splitk + sp;
   gemm_ks_body<MA, MB, ADD, BF16>(p, bx, by, bz, s_a, s_b, s_red);
+}
+
+// ---- weight-gradient group on the bf16 matrix cores: 64 x 64 output tiles, fp32 operands as P bf16 planes ------
+// C[m][n] += sum_k A[k * sak + m] * (B[k * sbk + n] (+ B2)), both operands contiguous ACROSS the reduction
+// (dW = dY^T.X of a linear layer: m = output channel, n = input channel, k = row).  The 32 x 32-tile kernel above
+// spends a launch of 7 552 workgroups on the ten weight gradients of a decoder layer (118 us, 268 MB fetched for
+// 30 MB of operands: every tile re-reads 32-column strips, the fp32 MFMA issues 64 cycles per 32 x 32 x 2).
+// Here a workgroup owns a 64 x 64 tile of one K slice; per 32-row step the two 32 x 64 fp32 strips go
+// global -> registers (one step ahead), are split ONCE into P bf16 terms (P = 3: x = h + m + l exactly, the six
+// products of weight >= 2^-16, as csrc/mlp.hip's fp32-grade mode; P = 1: rounded, the bf16 compute mode) and land as
+// [column][step] planes in a double-buffered LDS tile (ONE barrier per step); a wave (2 x 2 over the tile) reads
+// its fragments as ds_read_b128 and issues v_mfma_f32_32x32x16_bf16.  (A first version kept the fp32 strips in
+// LDS and split per use: every value split by two waves, ~400 VALU cycles per 192 MFMA cycles - 65 us.)  Row sums of A (the bias gradient) ride on the staged registers of the n-tile-0
+// workgroups.  The K slice is the fastest workgroup index (XCD i = slice i when splitk == 8).
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+// two fp32 values -> P packed bf16 pairs (low half = a): one v_cvt_pk_bf16_f32 per plane, the residuals
+// on both elements at once (x = h + m + l exactly for P = 3)
+template <int P>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[P]) {
+  const f32x2 x = {a, b};
+  const bf16x2 h = __builtin_convertvector(x, bf16x2);
+  o[0] = __builtin_bit_cast(unsigned, h);
+  if constexpr (P == 3) {
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r, bf16x2);
+    o[1] = __builtin_bit_cast(unsigned, m);
+    const f32x2 l = r - __builtin_convertvector(m, f32x2);
+    o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+  }
+}
+// byte offset of 16-byte chunk `chunk` (8 reduction steps) of the 64-byte row of column `col`; chunks are
+// XOR-swizzled by bits 2-3 of the column so that a fragment read (lane = column) touches every bank once
+__device__ __forceinline__ int tn_swz(int col, int chunk) { return col * 64 + ((chunk ^ ((col >> 2) & 3)) << 4); }
+
+template <int P>
+__global__ __launch_bounds__(256, 3) void gemm_tn_group_kernel(GemmGroup g) {
+  // [buffer][operand][plane][64 columns x 32 reduction steps] bf16
+  __shared__ __attribute__((aligned(16))) char s_pl[2][2][P][4096];
+  __shared__ float4 s_rs[128];
+  const int b = blockIdx.x;
+  // which problem: lane i compares against start[i + 1] (one load + a ballot instead of a chain of dependent loads)
+  const int li = threadIdx.x & 63;
+  const int gi = __builtin_amdgcn_readfirstlane(
+      __popcll(__ballot(li + 1 < g.n && b >= g.start[li + 1 < GEMM_GROUP_MAX ? li + 1 : GEMM_GROUP_MAX])));
+  const GemmArgs& p = g.p[gi];
+  const int local = b - g.start[gi];
+  const int gx = (p.N + 63) / 64, gy = (p.M + 63) / 64;
+  const int sp = local % p.splitk, rest = local / p.splitk;
+  const int bx = rest % gx, by = (rest / gx) % gy, z = rest / (gx * gy);
+  const int m0 = by * 64, n0 = bx * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lc = lane & 31, lh = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  const int kchunk = ((p.K + p.splitk - 1) / p.splitk + 31) / 32 * 32;
+  const int kbeg = sp * kchunk, kend = min(p.K, kbeg + kchunk);
+  const int zo = z / p.zdiv, zi = z - zo * p.zdiv;
+  const size_t ob = (size_t)zo * p.sbb + (size_t)zi * p.sbb2;
+  // staging: waves 0-1 move the A strip, waves 2-3 the B strip; thread u = t & 127 takes reduction steps
+  // 4 (u >> 4) .. + 3 of columns 4 (u & 15) .. + 3, splits them ONCE and leaves [column][step] planes in LDS
+  const int opd = t >> 7, u = t & 127, rg = u >> 4, sc = (u & 15) * 4;
+  const float* src = opd == 0 ? p.A + (size_t)zo * p.sab + (size_t)zi * p.sab2 + m0 + sc : p.B + ob + n0 + sc;
+  const float* src2 = (opd == 1 && p.B2 != nullptr && m0 < p.b2_rows) ? p.B2 + ob + n0 + sc : nullptr;
+  const long long sk = opd == 0 ? p.sak : p.sbk;
+  const bool col_ok = opd == 0 ? m0 + sc < p.M : n0 + sc < p.N;        // M, N % 4 == 0 in this form
+  const bool do_asum = p.asum != nullptr && bx == 0 && opd == 0;
+  // two register stages: the loads of steps s + 1 and s + 2 are in flight while step s is contracted (a step's
+  // MFMA phase is ~0.3 us, a load from another XCD's rows well over that); the second addend is added at commit
+  // time, not at fetch time (an add right behind the loads would park the wave on them)
+  float4 rv[2][4], rw[2][4], rs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](auto stage, int k0) {
+    constexpr int S = decltype(stage)::value;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + 4 * rg + j;
+      rv[S][j] = rw[S][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col_ok && k < kend && !(g.dbg & 8)) {
+        rv[S][j] = *reinterpret_cast<const float4*>(src + (size_t)k * sk);
+        if (src2 != nullptr) rw[S][j] = *reinterpret_cast<const float4*>(src2 + (size_t)k * sk);
+      }
+    }
+  };
+  auto commit = [&](auto stage, int buf) {
+    constexpr int S = decltype(stage)::value;
+    if (src2 != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rv[S][j] = add4(rv[S][j], rw[S][j]);
+    }
+    if (do_asum) rs4 = add4(rs4, add4(add4(rv[S][0], rv[S][1]), add4(rv[S][2], rv[S][3])));
+    const float* f = reinterpret_cast<const float*>(rv[S]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned lo[P], hi[P];
+      split_pair<P>(f[c], f[4 + c], lo);
+      split_pair<P>(f[8 + c], f[12 + c], hi);
+      const int off = tn_swz(sc + c, rg >> 1) + 8 * (rg & 1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(&s_pl[buf][opd][q][off]) = make_uint2(lo[q], hi[q]);
+    }
+  };
+  f32x16 acc, acc1;       // two accumulator chains (one per 16-step chunk): dependent MFMAs wait on each other
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = acc1[r] = 0.f;
+  auto step = [&](auto stage, int k0, int buf) {
+    if (!(g.dbg & 4)) commit(stage, buf);
+    lds_barrier();
+    if (k0 + 64 < kend) fetch(stage, k0 + 64);
+    if (g.dbg & 2) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 pa[P], pb[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        pa[q] = *reinterpret_cast<const bf16x8*>(&s_pl[buf][0][q][tn_swz(32 * wm + lc, 2 * c + lh)]);
+        pb[q] = *reinterpret_cast<const bf16x8*>(&s_pl[buf][1][q][tn_swz(32 * wn + lc, 2 * c + lh)]);
+      }
+      f32x16& ac = c == 0 ? acc : acc1;
+      if constexpr (P == 3) {   // smallest products first
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[2], pb[0], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[2], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], pb[1], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1], pb[0], ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[1], ac, 0, 0, 0);
+      }
+      ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0], pb[0], ac, 0, 0, 0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  if (kbeg < kend) fetch(S0{}, kbeg);
+  if (kbeg + 32 < kend) fetch(S1{}, kbeg + 32);
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    step(S0{}, k0, 0);
+    if (k0 + 32 < kend) step(S1{}, k0 + 32, 1);
+  }
+  // accumulator register r = row (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32 x 32 tile, column lc
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+  const int n = n0 + 32 * wn + lc;
+  if (n < p.N && !(g.dbg & 16)) {
+    float* C = p.C + (size_t)zo * p.scb + (size_t)zi * p.scb2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < p.M) {
+        float* dst = C + (size_t)m * p.scm + n;
+        const float v = p.alpha * acc[r];
+        if (g.dbg & 1) *dst = v;
+        else if (p.splitk > 1) atomicAdd(dst, v);
+        else if (p.flags & GEMM_ACCUM) *dst += v;
+        else *dst = v;
+      }
+    }
+  }
+  if (p.asum != nullptr && bx == 0) {       // (workgroup-uniform)
+    if (opd == 0) s_rs[u] = rs4;
+    lds_barrier();
+    if (t < 64 && m0 + t < p.M) {
+      const float* f = reinterpret_cast<const float*>(s_rs);
+      float v = 0.f;
+      for (int j = 0; j < 8; ++j) v += f[(16 * j + (t >> 2)) * 4 + (t & 3)];
+      atomicAdd(p.asum + (size_t)z * p.M + m0 + t, v);
+    }
+  }
 }
 
 // staging mode of an operand with rows R, reduction K, strides (sr, sk).  Global dwordx4 loads only
@@ -1025,6 +1210,11 @@ extern "C" int demf_gemm_f32(const demf_gemm_desc* d, demf_stream_t stream) {
 extern "C" int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stream_t stream) {
   DEMF_REQUIRE(descs != nullptr && n >= 1, "gemm_group: no descriptors");
   const bool bf = compute_bf16();
+  // modes 1 / 2: the 64 x 64-tile kernel on the bf16 matrix cores (one / three terms per operand); mode 0
+  // (native fp32 MFMA) keeps the 32 x 32-tile kernel
+  static const bool tn_off = getenv("DEMF_GEMM_TN3") && atoi(getenv("DEMF_GEMM_TN3")) == 0;   // A/B switch
+  const bool tn3 = compute_mode() != 0 && !tn_off;
+  static const int tn_split = getenv("DEMF_GEMM_TN_SPLIT") ? atoi(getenv("DEMF_GEMM_TN_SPLIT")) : 0;   // A/B: forced K split
   int i0 = 0;
   while (i0 < n) {
     // longest run of consecutive problems that can share one launch: small-tile path, both operands
@@ -1035,11 +1225,14 @@ extern "C" int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stre
       const GemmArgs& p = descs[i0 + cnt];
       if (int e = gemm_validate(p)) return e;
       const bool ok = gemm_is_small(p) && stage_mode(p.sam, p.sak, p.M, p.K) == 2 &&
-                      stage_mode(p.sbn, p.sbk, p.N, p.K) == 2 && !(p.flags & GEMM_FP32) && p.A2 == nullptr;
+                      stage_mode(p.sbn, p.sbk, p.N, p.K) == 2 && !(p.flags & GEMM_FP32) && p.A2 == nullptr &&
+                      // the 64 x 64-tile kernel carries alpha, accumulation and the row sums, no other epilogue
+                      (!tn3 || ((p.flags & ~GEMM_ACCUM) == 0 && p.bias == nullptr && p.C2 == nullptr &&
+                                (p.B2 == nullptr || p.b2_rows % 64 == 0 || p.b2_rows >= p.M)));
       if (!ok) break;
       g.p[cnt] = p;
       g.start[cnt] = tiles;
-      tiles += cdiv(p.N, 32) * cdiv(p.M, 32) * p.batch * p.splitk;
+      tiles += (tn3 ? cdiv(p.N, 64) * cdiv(p.M, 64) : cdiv(p.N, 32) * cdiv(p.M, 32)) * p.batch * g.p[cnt].splitk;
       ++cnt;
     }
     if (cnt == 0) {                       // not groupable: its own launch
@@ -1047,8 +1240,31 @@ extern "C" int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stre
       ++i0;
       continue;
     }
+    if (tn3) {
+      // K split of the run: one resident round of workgroups (3 per CU) instead of the callers' 8 slices -
+      // every extra slice repeats the launch ramp and the atomic epilogue (measured on the ten weight
+      // gradients of a decoder layer, 252 tiles: 8 slices 60 us, 3 slices 51 us, 2 slices 56 us)
+      int base = 0;
+      for (int i = 0; i < cnt; ++i) base += cdiv(g.p[i].N, 64) * cdiv(g.p[i].M, 64) * g.p[i].batch;
+      const int want = tn_split > 0 ? tn_split : (768 + base / 2) / base;
+      tiles = 0;
+      for (int i = 0; i < cnt; ++i) {
+        GemmArgs& q = g.p[i];
+        if (q.splitk > 1) q.splitk = want < 2 ? 2 : (want < q.splitk ? want : q.splitk);   // (>= 2: C stays accumulated)
+        g.start[i] = tiles;
+        tiles += cdiv(q.N, 64) * cdiv(q.M, 64) * q.batch * q.splitk;
+      }
+    }
     g.start[cnt] = tiles;
     g.n = cnt;
+    g.dbg = getenv("DEMF_TN_DBG") ? atoi(getenv("DEMF_TN_DBG")) : 0;
+    if (tn3) {
+      if (bf) hipLaunchKernelGGL((gemm_tn_group_kernel<1>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+      else hipLaunchKernelGGL((gemm_tn_group_kernel<3>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
+      if (int e = check_launch("gemm_tn_group_kernel")) return e;
+      i0 += cnt;
+      continue;
+    }
     if (bf) hipLaunchKernelGGL((gemm_ks_group_kernel<2, 2, true, true>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL((gemm_ks_group_kernel<2, 2, true, false>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
     if (int e = check_launch("gemm_ks_group_kernel")) return e;

@@ -480,12 +480,28 @@ def test_gemm_group_and_bias_row_sums():
         if with_x2:
             want[:N // 2] += dy.double()[:, :N // 2].t() @ x2.double()
         outs.append((dw, db, want, dy.double().sum(0)))
+    # the per-head value projection's gradient: 8 batched (32 x 256) products over strided column blocks,
+    # and a ragged one (40 x 72: partial 64 x 64 tiles, reduction not a multiple of the 32-row step)
+    H, Dh, Ct = 8, 32, 256
+    dmo, zz = _r(R, H * Dh, seed=80), _r(R, H * Ct, seed=81)
+    dvp = torch.zeros(H * Dh, Ct, device="cuda")
+    fused.gemm(Dh, Ct, R, _p(dmo), (1, H * Dh), _p(zz), (1, H * Ct), _p(dvp), Ct, batch=H, sab=(Dh, 0),
+               sbb=(Ct, 0), scb=(Dh * Ct, 0), splitk=8, group=descs)
+    want_vp = torch.stack([dmo.double()[:, h * Dh:(h + 1) * Dh].t() @ zz.double()[:, h * Ct:(h + 1) * Ct]
+                           for h in range(H)]).reshape(H * Dh, Ct)
+    dyr, xr = _r(1000, 40, seed=82), _r(1000, 72, seed=83)
+    dwr, dbr = torch.zeros(40, 72, device="cuda"), torch.zeros(40, device="cuda")
+    fused.weight_grad(dyr, xr, dwr, dbr, group=descs)
+    keep += [dmo, zz, dyr, xr]
     # one more that cannot join a group (A K-contiguous): Y = X W^T
     xa, wa = _r(300, 64, seed=90), _r(96, 64, seed=91)
     ya = torch.empty(300, 96, device="cuda")
     fused.gemm(300, 96, 64, _p(xa), (64, 1), _p(wa), (64, 1), _p(ya), 96, group=descs)
-    assert len(descs) == 6
+    assert len(descs) == 8
     fused.gemm_group(descs)
+    _close(dvp, want_vp, 1e-4, "batched per-head dW")
+    _close(dwr, dyr.double().t() @ xr.double(), 1e-4, "ragged dW")
+    _close(dbr, dyr.double().sum(0), 1e-4, "ragged bias gradient")
     for dw, db, want, wb in outs:
         _close(dw, want, 1e-4, "grouped dW")
         _close(db, wb, 1e-4, "bias gradient = row sums of the A operand")
