@@ -748,10 +748,10 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_k(int R, const float* 
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + 64 * i;
-    s_out[(size_t)row * C + c] = v[i];
+    if (s_out != nullptr) s_out[(size_t)row * C + c] = v[i];
     y[(size_t)row * C + c] = __builtin_fmaf((v[i] - mean) * rstd, gamma[c], beta[c]);
   }
-  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+  if (lane == 0 && stats != nullptr) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
 // backward: ds = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma ;  dx = ds * keep/(1-p)
@@ -1300,7 +1300,8 @@ extern "C" int demf_add_dropout_ln_fwd(int R, int C, const float* x, const float
                                        const float* gamma, const float* beta, float eps, float p,
                                        const void* rng, int op_id, float* s_out, float* y,
                                        float* stats, demf_stream_t stream) {
-  DEMF_REQUIRE(R > 0 && x && gamma && beta && s_out && y && stats, "add_dropout_ln_fwd: bad arguments");
+  // (s_out / stats may be NULL: inference callers - the frozen encoder - keep neither)
+  DEMF_REQUIRE(R > 0 && x && gamma && beta && y, "add_dropout_ln_fwd: bad arguments");
   DEMF_REQUIRE(p == 0.f || rng, "add_dropout_ln_fwd: dropout needs the rng state");
 #define CALL(V) hipLaunchKernelGGL(add_dropout_ln_fwd_k<V>, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, \
                                    R, x, identity, gamma, beta, eps, p, (const unsigned long long*)rng,        \

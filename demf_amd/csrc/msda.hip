@@ -131,6 +131,63 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(
   *reinterpret_cast<float4*>(out + item * Dh + sub * 4) = acc;
 }
 
+// The encoder's self-attention form (DeformableDetrEncoder, demf/modeling/layers/deform_detr_encoder.py:68-154 ->
+// mmcv MultiScaleDeformableAttention.forward): sampling offsets and attention LOGITS arrive raw, as columns of the
+// projection GEMM's output row (csrc/rows_gemm.hip), the projected value as further columns of the same rows
+// (pitch vpitch floats).  The kernel does what upstream does in separate elementwise launches on the way in:
+//   weights = softmax over the L*P logits of a head,   loc = ref[level] + offset / (W_level, H_level)
+// (two (R, 384)-float tensors never exist).  G lanes per (query, head), 4 channels per lane, as msda_fwd_kernel.
+template <int G, int TL, int TP>
+__global__ __launch_bounds__(256) void msda_fwd_raw_kernel(
+    int S, int H, int Dh, int Q, const float* __restrict__ value, long long vpitch,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ raw, long long ldraw, int off_col0, int lgt_col0,
+    const float* __restrict__ ref, float* __restrict__ out, long long items) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long item = t / G;
+  if (item >= items) return;
+  const int sub = (int)(t - item * G);
+  const int h = (int)(item % H);
+  const long long row = item / H;                     // b * Q + q
+  const int b = (int)(row / Q);
+  constexpr int nlp = TL * TP;
+  const int vh = (int)(vpitch / Dh);                  // row pitch of the value columns, in heads
+  const float* vb = value + (size_t)b * S * vpitch + sub * 4;
+  const float* op = raw + row * ldraw + off_col0 + h * nlp * 2;
+  const float* gp = raw + row * ldraw + lgt_col0 + h * nlp;
+  const float* rp = ref + row * TL * 2;
+  float lg[nlp], mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < nlp; ++i) {
+    lg[i] = gp[i];
+    mx = fmaxf(mx, lg[i]);
+  }
+  float den = 0.f;
+#pragma unroll
+  for (int i = 0; i < nlp; ++i) {
+    lg[i] = expf(lg[i] - mx);
+    den += lg[i];
+  }
+  const float inv = 1.f / den;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < nlp; ++i) {
+    const int l = i / TP;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const int start = (int)lsi[l];
+    const float lx = rp[2 * l] + op[2 * i] / (float)Wl;
+    const float ly = rp[2 * l + 1] + op[2 * i + 1] / (float)Hl;
+    const Corner c = make_corner(lx, ly, Hl, Wl, start, vh, Dh, h);
+    const float aw = lg[i] * inv;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v = f4_fma(c.cw[k], ld4<float>(vb + c.off[k]), v);
+    acc = f4_fma(aw, v, acc);
+  }
+  *reinterpret_cast<float4*>(out + item * Dh + sub * 4) = acc;
+}
+
 template <int G, int TL, int TP, typename VT = float>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
@@ -429,4 +486,27 @@ extern "C" int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int
                                   demf_stream_t stream) {
   return msda_bwd_impl<uint16_t>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
                                  attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,
+                                     long long vpitch, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                     const float* raw, long long ldraw, int off_col0, int lgt_col0, const float* ref,
+                                     float* out, demf_stream_t stream) {
+  if (int e = msda_check(B, S, H, Dh, L, Q, P)) return e;
+  if (B == 0 || Q == 0) return DEMF_OK;
+  DEMF_REQUIRE(value && spatial_shapes && level_start_index && raw && ref && out, "msda_fwd_raw: null pointer");
+  DEMF_REQUIRE(Dh == 32 && L == 4 && (P == 4 || P == 2), "msda_fwd_raw: built for Dh = 32, L = 4, P in {2, 4}");
+  DEMF_REQUIRE(vpitch % Dh == 0 && vpitch >= (long long)H * Dh && (long long)S * vpitch < (1LL << 31) &&
+                   (uintptr_t)value % 16 == 0 && (uintptr_t)out % 16 == 0 && vpitch % 4 == 0,
+               "msda_fwd_raw: value pitch %lld", vpitch);
+  const long long items = (long long)B * Q * H;
+  const dim3 grid((unsigned)((items * 8 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 4)
+    hipLaunchKernelGGL((msda_fwd_raw_kernel<8, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, Q, value, vpitch, spatial_shapes,
+                       level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, items);
+  else
+    hipLaunchKernelGGL((msda_fwd_raw_kernel<8, 4, 2>), grid, dim3(256), 0, s, S, H, Dh, Q, value, vpitch, spatial_shapes,
+                       level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, items);
+  return check_launch("msda_fwd_raw");
 }

@@ -28,6 +28,14 @@ from ..geometry import level_masks
 from .transformer import FFN, MultiScaleDeformableAttention
 
 
+# the encoder layers on csrc/rows_gemm.hip + the raw-input MSDA kernel (embed_dims 256, 8 heads, 4 levels);
+# False / DEMF_ENC_FUSED=0: the module path (ops.linear + torch elementwise), which the golden vectors of the
+# REAL reference encoder pin - the fused path is tested against it
+FUSED_LAYERS = bool(int(__import__("os").environ.get("DEMF_ENC_FUSED", "1")))
+CHANNELS_LAST = bool(int(__import__("os").environ.get("DEMF_IMG_NHWC", "1")))        # A/B switch
+SPLIT_FFN_LN = bool(int(__import__("os").environ.get("DEMF_ENC_SPLIT_LN", "1")))     # A/B switch
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -219,6 +227,83 @@ class DeformableDetrEncoder(nn.Module):
                 keep=img_metas)
         return cache[key]
 
+    # ---- the six layers on csrc/rows_gemm.hip: 5 launches per layer, no library GEMM, no elementwise pass ----
+    def _fused_ok(self, tokens):
+        if not (FUSED_LAYERS and tokens.is_cuda and tokens.dtype == torch.float32 and self.embed_dims == 256):
+            return False
+        for layer in self.encoder.layers:
+            a, f = layer.attentions[0], layer.ffns[0]
+            if not (a.num_heads == 8 and a.num_levels == 4 and a.num_points in (2, 4)
+                    and f.layers[0][0].out_features % 128 == 0 and f.layers[0][0].out_features % 32 == 0):
+                return False
+        return tokens.shape[1] * 1024 < 2 ** 31
+
+    def _layer_pack(self, layer, planes):
+        """The layer's frozen weights as the kernels take them: [sampling_offsets; attention_weights; value_proj]
+        stacked into one (640, 256) projection, every weight pre-split into ``planes`` bf16 planes
+        (ops.split_planes).  Cached per (weight versions, planes): a load_state_dict rebuilds it."""
+        from .. import ops
+        a, f, n = layer.attentions[0], layer.ffns[0], layer.norms
+        fc0, fc1 = f.layers[0][0], f.layers[1]
+        prm = [a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight,
+               a.attention_weights.bias, a.value_proj.weight, a.value_proj.bias, a.output_proj.weight,
+               a.output_proj.bias, fc0.weight, fc0.bias, fc1.weight, fc1.bias, n[0].weight, n[0].bias,
+               n[1].weight, n[1].bias]
+        key = (planes,) + tuple((q.data_ptr(), q._version) for q in prm)
+        pk = layer.__dict__.get("_pack")
+        if pk is None or pk["key"] != key:
+            c = lambda t: t.detach().float().contiguous()
+            # the value columns start at a column-tile boundary (128): zero rows pad [offsets | logits] up to it
+            n_q = prm[0].shape[0] + prm[2].shape[0]
+            v0 = (n_q + 127) // 128 * 128
+            zw = prm[0].new_zeros(v0 - n_q, prm[0].shape[1])
+            pk = dict(key=key, lgt0=prm[0].shape[0], v0=v0,
+                      w_in=ops.split_planes(torch.cat([c(prm[0]), c(prm[2]), zw, c(prm[4])], 0), planes),
+                      b_in=torch.cat([c(prm[1]), c(prm[3]), zw[:, 0], c(prm[5])], 0),
+                      w_out=ops.split_planes(c(prm[6]), planes), b_out=c(prm[7]),
+                      w0=ops.split_planes(c(prm[8]), planes), b0=c(prm[9]),
+                      w1=ops.split_planes(c(prm[10]), planes), b1=c(prm[11]),
+                      g1=c(prm[12]), be1=c(prm[13]), g2=c(prm[14]), be2=c(prm[15]),
+                      eps1=float(n[0].eps), eps2=float(n[1].eps))
+            layer.__dict__["_pack"] = pk
+        return pk
+
+    def _fused_layers(self, tokens, pos, st):
+        from .. import ops, _ffi
+        B, S, C = tokens.shape
+        R = B * S
+        planes = 1 if ops.get_compute_dtype() == "bf16" else 3
+        x = tokens.reshape(R, C).contiguous()
+        pos = pos.expand(B, S, C).reshape(R, C).contiguous()
+        mask = st["mask_flatten"].reshape(R).contiguous()
+        ref = st["reference_points"].contiguous()                    # (B,S,L,2)
+        F = self.encoder.layers[0].ffns[0].layers[0][0].out_features
+        new = lambda n: torch.empty((R, n), dtype=torch.float32, device=x.device)
+        samp, x1, hid, xn, raw = new(C), new(C), new(F), new(C), None
+        for layer in self.encoder.layers:
+            a = layer.attentions[0]
+            pk = self._layer_pack(layer, planes)
+            v0 = pk["v0"]
+            if raw is None or raw.shape[1] != v0 + C:
+                raw = new(v0 + C)
+            # [offsets | logits] from x + pos, value from x (padding rows zeroed): one launch
+            ops.rows_gemm(x, pk["w_in"], pk["b_in"], raw, a2=pos, a2_cols=v0, row_mask=mask, mask_col0=v0)
+            ops.msda_fwd_raw(raw, v0, 0, pk["lgt0"], ref, st["spatial_shapes"], st["level_start_index"], B, S,
+                             a.num_heads, C // a.num_heads, a.num_points, samp)
+            ops.rows_gemm(samp, pk["w_out"], pk["b_out"], x1, ln=(x, pk["g1"], pk["be1"], pk["eps1"]))
+            ops.rows_gemm(x1, pk["w0"], pk["b0"], hid, relu=True)
+            # K = 1024 with the LayerNorm epilogue runs one 128 x 256-tile workgroup per CU (~1.0 ms); as a
+            # 128-column-tile launch (two workgroups per CU) + one residual / LayerNorm pass: 0.5 + 0.15 ms
+            if SPLIT_FFN_LN:
+                ops.rows_gemm(hid, pk["w1"], pk["b1"], samp)
+                _ffi.call("demf_add_dropout_ln_fwd", R, C, samp.data_ptr(), x1.data_ptr(), pk["g2"].data_ptr(),
+                          pk["be2"].data_ptr(), pk["eps2"], 0.0, None, 0, None, xn.data_ptr(), None,
+                          torch.cuda.current_stream().cuda_stream)
+            else:
+                ops.rows_gemm(hid, pk["w1"], pk["b1"], xn, ln=(x1, pk["g2"], pk["be2"], pk["eps2"]))
+            x, xn = xn, x
+        return x.view(B, S, C)
+
     @torch.no_grad()
     def forward_tokens(self, mlvl_feats, img_metas):
         """-> dict(tokens (B,S,C), spatial [(h,w)...], mask_flatten (B,S), valid_ratios (B,L,2))."""
@@ -226,10 +311,13 @@ class DeformableDetrEncoder(nn.Module):
         st = self._static(img_metas, spatial, mlvl_feats[0].device)
         tokens = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)       # (B,S,C)
         pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(st["pos"])], 1)
-        for layer in self.encoder.layers:
-            tokens = layer(tokens, pos, st["mask_flatten"], reference_points=st["reference_points"],
-                           spatial_shapes=st["spatial_shapes"],
-                           level_start_index=st["level_start_index"])
+        if self._fused_ok(tokens):
+            tokens = self._fused_layers(tokens, pos, st)
+        else:
+            for layer in self.encoder.layers:
+                tokens = layer(tokens, pos, st["mask_flatten"], reference_points=st["reference_points"],
+                               spatial_shapes=st["spatial_shapes"],
+                               level_start_index=st["level_start_index"])
         return dict(tokens=tokens, spatial=spatial, mask_flatten=st["mask_flatten"],
                     valid_ratios=st["valid_ratios"])
 
@@ -265,10 +353,30 @@ class ImageStream(nn.Module):
     def train(self, mode=True):
         return super().train(False)                                 # always eval (norm_eval, no_grad)
 
+    def _pyramid(self, img):
+        """ResNet-50 + ChannelMapper (library convolutions).  On the GPU in channels-last memory format: MIOpen's
+        NHWC kernels are faster here (8 x 3 x 800 x 1120 fp32: 18.8 -> 16.5 ms) and the neck's (B,256,h,w) outputs
+        then ARE (B,h,w,256) in memory, so the encoder's token concat reads contiguous rows."""
+        if CHANNELS_LAST and img.is_cuda:
+            if self.__dict__.get("_nhwc_for") != img.device:
+                self.img_backbone.to(memory_format=torch.channels_last)
+                self.img_neck.to(memory_format=torch.channels_last)
+                self.__dict__["_nhwc_for"] = img.device
+            img = img.contiguous(memory_format=torch.channels_last)
+            # MIOpen's immediate mode picks slow NHWC kernels (22.7 ms); with its search - first call per shape -
+            # the same convolutions run in 16.5 ms.  Only this frozen stream has convolutions in the package.
+            prev = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = True
+            try:
+                return self.img_neck(self.img_backbone(img))
+            finally:
+                torch.backends.cudnn.benchmark = prev
+        return self.img_neck(self.img_backbone(img))
+
     @torch.no_grad()
     def tokens(self, img, img_metas):
-        return self.img_encoder.forward_tokens(self.img_neck(self.img_backbone(img)), img_metas)
+        return self.img_encoder.forward_tokens(self._pyramid(img), img_metas)
 
     @torch.no_grad()
     def forward(self, img, img_metas):
-        return self.img_encoder(self.img_neck(self.img_backbone(img)), img_metas)
+        return self.img_encoder(self._pyramid(img), img_metas)

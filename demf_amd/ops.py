@@ -808,6 +808,52 @@ def linear(x, weight, bias=None, row_mask=None):
     return y.view(*lead, weight.shape[0])
 
 
+def split_planes(w, planes=3):
+    """(N,K) fp32 weight -> (planes, N, K) bf16: planes = 3 is w = h + m + l EXACTLY (three 8-bit significand
+    slices, the operand form of the fp32-grade bf16-MFMA kernels), planes = 1 the rounded weight."""
+    w = w.detach().float().contiguous()
+    h = w.to(torch.bfloat16)
+    if planes == 1:
+        return h.unsqueeze(0).contiguous()
+    r = w - h.float()
+    m = r.to(torch.bfloat16)
+    low = (r - m.float()).to(torch.bfloat16)
+    return torch.stack([h, m, low]).contiguous()
+
+
+def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, row_mask=None, mask_col0=0):
+    """out (R,N) = epi((x [+ a2 on output columns < a2_cols]) . W^T + bias) on demf_rows_gemm_f32
+    (csrc/rows_gemm.hip): ``w_planes`` from ``split_planes``; ``relu``; ``ln`` = (residual (R,N), gamma, beta,
+    eps): LayerNorm(residual + .) in the epilogue (N == 256); ``row_mask`` (R) bool: rows zeroed in columns
+    >= mask_col0.  Forward only (the frozen image stream)."""
+    R, K = x.shape
+    planes, N, Kw = w_planes.shape
+    assert Kw == K and out.shape == (R, N) and x.stride(1) == 1 and out.stride(1) == 1
+    assert w_planes.dtype == torch.bfloat16 and w_planes.is_contiguous()
+    mode = 2 if ln is not None else (1 if relu else 0)
+    res, g, b, eps = ln if ln is not None else (None, None, None, 0.0)
+    if a2 is not None:
+        assert a2.shape == x.shape and a2.stride() == x.stride()
+    if row_mask is not None:
+        assert row_mask.dtype == torch.bool and row_mask.numel() == R and row_mask.is_contiguous()
+    _ffi.call("demf_rows_gemm_f32", R, N, K, _p(x), x.stride(0), _p(a2), int(a2_cols), _p(w_planes), planes,
+              _p(bias), mode, _p(row_mask), int(mask_col0), _p(res), res.stride(0) if res is not None else 0,
+              _p(g), _p(b), float(eps), _p(out), out.stride(0), _stream())
+    return out
+
+
+def msda_fwd_raw(raw, value_col0, off_col0, lgt_col0, ref, spatial_shapes, level_start_index, B, S, H, Dh, P, out):
+    """Self-attention form of the multi-scale deformable attention (the encoder: queries = the S tokens): raw
+    offsets / logits / projected value are column ranges of ``raw`` (B*S, ld); softmax and
+    loc = ref + offset / (W_l, H_l) happen inside the kernel (demf_msda_fwd_raw_f32).  -> out (B*S, H*Dh)"""
+    L = spatial_shapes.shape[0]
+    assert raw.stride(1) == 1 and ref.is_contiguous() and out.is_contiguous()
+    _ffi.call("demf_msda_fwd_raw_f32", B, S, H, Dh, L, S, P, raw.data_ptr() + 4 * value_col0, raw.stride(0),
+              _p(spatial_shapes), _p(level_start_index), _p(raw), raw.stride(0), int(off_col0), int(lgt_col0),
+              _p(ref), _p(out), _stream())
+    return out
+
+
 # --------------------------------------------------------------------------
 # Fused shared MLP: (1x1 conv -> train-mode BN -> ReLU) x L [-> max over ns]
 # --------------------------------------------------------------------------

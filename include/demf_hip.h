@@ -609,6 +609,30 @@ int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P,
                        float* grad_value, float* grad_sampling_loc,
                        float* grad_attn_weight, demf_stream_t stream);
 
+/* ---- the frozen image stream's encoder layers --------------------------------------------- *
+ * Long-row linear layer: C (R,N; ldc) = epi((A [+ A2 on output columns < a2_cols]) . W^T + bias), R ~ 150 000
+ * token rows, K % 32 == 0, N % 128 == 0.  W arrives PRE-SPLIT as bf16 planes (planes, N, K): planes = 3 is
+ * fp32-grade arithmetic (w = h + m + l exactly, six products per term pair on the bf16 matrix cores, as
+ * compute mode 2 of the demf_mlp_gemm_* kernels), planes = 1 the bf16 compute mode; the A rows are fp32 and are
+ * split inside the kernel.  mode 0: bias; rows with row_mask[r] != 0 are zeroed in columns >= mask_col0 (the
+ * padding mask of value_proj); mode 1: bias + ReLU; mode 2 (N == 256): LayerNorm(resid + A.W^T + bias) * gamma +
+ * beta.  Replaces, per encoder layer of demf/modeling/layers/deform_detr_encoder.py:68-154, six library GEMMs
+ * and the elementwise launches between them (query + pos, masked_fill, ReLU, residual adds, two LayerNorms).  */
+int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long lda, const float* A2, int a2_cols,
+                       const void* w_planes, int planes, const float* bias, int mode,
+                       const unsigned char* row_mask, int mask_col0, const float* resid, long long ldr,
+                       const float* gamma, const float* beta, float eps, float* C, long long ldc,
+                       demf_stream_t stream);
+/* Multi-scale deformable attention forward with RAW inputs: offsets (H*L*P*2 columns from off_col0) and attention
+ * logits (H*L*P columns from lgt_col0) of row b*Q+q of `raw` (row stride ldraw), reference points ref (B,Q,L,2),
+ * value rows of pitch vpitch floats (columns h*Dh.. of the same projection output).  The softmax over a head's
+ * L*P logits and loc = ref + offset / (W_l, H_l) - separate elementwise launches in mmcv's
+ * MultiScaleDeformableAttention.forward - happen on the way in.  Dh = 32, L = 4, P in {2, 4}. -> out (B,Q,H*Dh) */
+int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,
+                          long long vpitch, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                          const float* raw, long long ldraw, int off_col0, int lgt_col0, const float* ref,
+                          float* out, demf_stream_t stream);
+
 /* Per-point vote targets of DeMFVoteHead.get_targets_single (class_agnostic_vote_head.py:828-858),
  * batched: points (B,N,point_stride>=3), gt_boxes (B,G,7) = (x,y,z_bottom,dx,dy,dz,yaw) padded to
  * G <= 64 with valid (B,G) bytes, cos/sin of -yaw (B,G) -> vote_targets (B,N,9) = votes to the
@@ -808,7 +832,8 @@ int demf_attn_core_bwd(int B, int H, int Q, int Dh, const float* qkv, const floa
 
 /* s = identity + dropout(x) ; y = LayerNorm(s) over rows of C channels (C in 64..1024, power of two
  * multiples of 64).  s_out may alias x; stats (R,2) = mean, rstd.  nn.LayerNorm + the
- * `identity + dropout(out)` tails of mmcv MultiheadAttention / MultiScaleDeformableAttention / FFN. */
+ * `identity + dropout(out)` tails of mmcv MultiheadAttention / MultiScaleDeformableAttention / FFN.
+ * s_out and stats may be NULL (forward-only callers). */
 int demf_add_dropout_ln_fwd(int R, int C, const float* x, const float* identity, const float* gamma,
                             const float* beta, float eps, float p, const void* rng, int op_id,
                             float* s_out, float* y, float* stats, demf_stream_t stream);

@@ -95,3 +95,47 @@ def test_head_accepts_tokens():
     assert torch.equal(a["mask_flatten"], b["mask_flatten"])
     for x, y in zip(a["value_projected"], b["value_projected"]):
         assert torch.allclose(x, y, rtol=0, atol=1e-6)     # GEMM on differently strided inputs
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("num_points", [4, 2])
+def test_fused_encoder_layers_match_the_module_path(mode, num_points):
+    """embed_dims = 256, 8 heads, 4 levels (the reference's encoder shape, configs/demf/demf_votenet.py:28-47): the
+    layers on demf_rows_gemm_f32 + demf_msda_fwd_raw_f32 (5 launches per layer) against the module path - the one
+    the REAL-encoder goldens pin above - on padded images (masked value rows, partial 128-row tiles).  fp32-grade
+    mode within 1e-4 of the output scale; the bf16 mode against the same bound as the decoder's bf16 GEMMs."""
+    from demf_amd import ops
+    from demf_amd.modules import image_stream as ims
+    from demf_amd.modules.image_stream import DeformableDetrEncoder
+    torch.manual_seed(3)
+    enc = DeformableDetrEncoder(num_layers=2, embed_dims=256, num_heads=8, num_points=num_points,
+                                feedforward_channels=384, num_feats=128).cuda().eval()
+    enc.init_weights()
+    with torch.no_grad():                       # offsets / logits that actually depend on the query
+        for layer in enc.encoder.layers:
+            a = layer.attentions[0]
+            a.sampling_offsets.weight.normal_(0, 0.02)
+            a.attention_weights.weight.normal_(0, 0.05)
+            a.attention_weights.bias.normal_(0, 0.3)
+            for n in layer.norms:
+                n.weight.uniform_(0.5, 1.5)
+                n.bias.normal_(0, 0.1)
+    img, metas = fixtures.make_images(5, B=3, H=96, W=160)
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    feats = [torch.randn(3, 256, h, w, device="cuda") for h, w in shapes]
+    ops.set_compute_dtype(mode)
+    try:
+        ims.FUSED_LAYERS = False
+        want = enc.forward_tokens(feats, metas)["tokens"]
+        ims.FUSED_LAYERS = True
+        assert enc._fused_ok(torch.empty(3, 10, 256, device="cuda"))
+        got = enc.forward_tokens(feats, metas)["tokens"]
+    finally:
+        ims.FUSED_LAYERS = True
+        ops.set_compute_dtype("f32")
+    keep = ~enc._static(metas, shapes, feats[0].device)["mask_flatten"]          # tokens on the image
+    err = ((got - want).abs() * keep[..., None]).max().item()
+    scale = max(1.0, (want.abs() * keep[..., None]).max().item())
+    tol = 1e-4 if mode == "f32" else 3e-2
+    assert err <= tol * scale, (err, scale)
+    assert torch.isfinite(got).all()
