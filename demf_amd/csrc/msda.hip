@@ -17,6 +17,7 @@
 // not an ALU one.  Backward reduces grad_loc / grad_weight across the G lanes with
 // DPP adds (no LDS) and scatters grad_value with hardware fp32 atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace demf {
 
@@ -186,6 +187,66 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_kernel(
     acc = f4_fma(aw, v, acc);
   }
   *reinterpret_cast<float4*>(out + item * Dh + sub * 4) = acc;
+}
+
+// One WAVE per query for the shape the encoder runs (8 heads x 32 channels: lane = head * 8 + channel quad).  In
+// msda_fwd_raw_kernel each of the 8 lanes of a head redoes the head's softmax and all L*P corner set-ups (~45 VALU
+// operations per point, 16 points: two thirds of the kernel's instruction stream).  Here the 8 * L*P (head, point)
+// pairs of the query are dealt one or two per lane - coalesced reads of the logits / offsets row -, the softmax is a
+// reduction over the L*P lanes of a head, every pair's four corner offsets and four (bilinear x attention) weights
+// are computed ONCE and passed to the head's lanes through 4 KB of LDS per wave ([point][head] 16-byte slots:
+// the 8 heads' slots of a point are 128 contiguous bytes, a broadcast read without bank conflicts).
+// 540 -> 465 us at 8 x 18 609 queries, P = 4 (what is left is the gather itself: 9.8 GB of 16-byte loads; dealing
+// each XCD a contiguous eighth of the queries instead of every eighth workgroup measured no better, 483 us).
+template <int TL, int TP>
+__global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
+    int S, int Q, const float* __restrict__ value, long long vpitch,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ raw, long long ldraw, int off_col0, int lgt_col0,
+    const float* __restrict__ ref, float* __restrict__ out, long long rows) {
+  constexpr int H = 8, Dh = 32, NP = TL * TP, PPL = NP / 8;      // pairs per lane: 2 (P = 4) or 1 (P = 2)
+  __shared__ int4 s_off[4][NP * H];
+  __shared__ float4 s_w[4][NP * H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;          // b * Q + q
+  if (row >= rows) return;                                         // (wave-uniform; no workgroup barrier below)
+  const int b = (int)(row / Q);
+  const int vh = (int)(vpitch / Dh);
+  const float* rrow = raw + row * ldraw;
+#pragma unroll
+  for (int s = 0; s < PPL; ++s) {
+    const int pi = lane + 64 * s, h = pi / NP, i = pi - h * NP, l = i / TP;
+    const float lg = rrow[lgt_col0 + pi];
+    const float2 of = *reinterpret_cast<const float2*>(rrow + off_col0 + 2 * pi);
+    float mx = lg;
+#pragma unroll
+    for (int o = NP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = expf(lg - mx);
+    float den = e;
+#pragma unroll
+    for (int o = NP / 2; o > 0; o >>= 1) den += __shfl_xor(den, o);
+    const float aw = e / den;
+    const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+    const float2 rp = *reinterpret_cast<const float2*>(ref + row * (TL * 2) + 2 * l);
+    const Corner c = make_corner(rp.x + of.x / (float)Wl, rp.y + of.y / (float)Hl, Hl, Wl, (int)lsi[l], vh, Dh, h);
+    s_off[wave][i * H + h] = make_int4(c.off[0], c.off[1], c.off[2], c.off[3]);
+    s_w[wave][i * H + h] = make_float4(c.cw[0] * aw, c.cw[1] * aw, c.cw[2] * aw, c.cw[3] * aw);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's own LDS writes (in order, one wave)
+  __builtin_amdgcn_wave_barrier();
+  const int h = lane >> 3, sub = lane & 7;
+  const float* vb = value + (size_t)b * S * vpitch + sub * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int4 o = s_off[wave][i * H + h];
+    const float4 w = s_w[wave][i * H + h];
+    acc = f4_fma(w.x, ld4<float>(vb + o.x), acc);
+    acc = f4_fma(w.y, ld4<float>(vb + o.y), acc);
+    acc = f4_fma(w.z, ld4<float>(vb + o.z), acc);
+    acc = f4_fma(w.w, ld4<float>(vb + o.w), acc);
+  }
+  *reinterpret_cast<float4*>(out + row * (H * Dh) + lane * 4) = acc;
 }
 
 template <int G, int TL, int TP, typename VT = float>
@@ -502,6 +563,18 @@ extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, 
   const long long items = (long long)B * Q * H;
   const dim3 grid((unsigned)((items * 8 + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
+  static const bool lanes8 = getenv("DEMF_MSDA_RAW_LANES") && atoi(getenv("DEMF_MSDA_RAW_LANES"));   // A/B switch
+  if (H == 8 && !lanes8 && ldraw % 2 == 0 && off_col0 % 2 == 0 && (uintptr_t)raw % 8 == 0 && (uintptr_t)ref % 8 == 0) {
+    const long long rows = (long long)B * Q;
+    const dim3 g2((unsigned)((rows + 3) / 4));
+    if (P == 4)
+      hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 4>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
+                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows);
+    else
+      hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 2>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
+                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows);
+    return check_launch("msda_fwd_raw_wave");
+  }
   if (P == 4)
     hipLaunchKernelGGL((msda_fwd_raw_kernel<8, 4, 4>), grid, dim3(256), 0, s, S, H, Dh, Q, value, vpitch, spatial_shapes,
                        level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, items);
