@@ -516,6 +516,9 @@ def main():
             pyr = ist._pyramid(img)
             secondary["image_backbone_neck_ms"] = time_steps(lambda: ist._pyramid(img), 5)
             secondary["image_encoder_ms"] = time_steps(lambda: ist.img_encoder.forward_tokens(pyr, batch["img_metas"]), 5)
+            # its linear layers: 6 layers x 2 x rows x (256 x (640 + 256) + 2 x 256 x 1024) flop (csrc/rows_gemm.hip)
+            enc_flop = 6 * 2.0 * args.batch * sum(h * w for h, w in PYRAMID_SHAPES) * (256 * 896 + 2 * 256 * 1024)
+            secondary["image_encoder_gemm_tflops_incl_msda_time"] = enc_flop / secondary["image_encoder_ms"] * 1e-9
 
             def e2e():
                 ist.tokens(img, batch["img_metas"])
