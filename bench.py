@@ -524,6 +524,16 @@ def main():
                 ist.tokens(img, batch["img_metas"])
                 step_resident()
             secondary["e2e_ms_per_step"] = time_steps(e2e, 10)
+            # pipelined: the (frozen, no_grad) stream of batch k+1 on a side stream under the step of batch k
+            side = torch.cuda.Stream()
+
+            def e2e_pipe():
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ist.tokens(img, batch["img_metas"])
+                step_resident()
+                torch.cuda.current_stream().wait_stream(side)
+            secondary["e2e_pipelined_ms_per_step"] = time_steps(e2e_pipe, 10)
             del ist, img, pyr
         # (c) BASELINE configs[1]: the SA path alone (forward / forward+backward / the index pre-pass)
         for B1 in (1, 8):

@@ -139,3 +139,73 @@ def test_fused_encoder_layers_match_the_module_path(mode, num_points):
     tol = 1e-4 if mode == "f32" else 3e-2
     assert err <= tol * scale, (err, scale)
     assert torch.isfinite(got).all()
+
+
+@pytest.mark.parametrize("planes", [3, 1])
+def test_rows_gemm_epilogues_vs_fp64(planes):
+    """demf_rows_gemm_f32 (csrc/rows_gemm.hip) alone against fp64: the positional addend on a column range, bias,
+    padding-row zeroing, ReLU, residual + LayerNorm; R not a multiple of the 128-row tile, K = 256 and 1024.
+    planes = 3: the error of an fp32 GEMM (<= 2e-6 of the output scale here); planes = 1: operands rounded to bf16
+    once, checked against the same rounding in fp64."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g).cuda()
+    R = 1000
+    rb = (lambda t: t.bfloat16().double()) if planes == 1 else (lambda t: t.double())
+    tol = 2e-6 if planes == 3 else 2e-5          # (planes = 1: fp32 accumulation of exactly representable products)
+    # mode 0: [x + pos | x] . W^T + b, rows zeroed from column 256 on
+    x, pos, w, b = rnd(R, 256), rnd(R, 256), rnd(384, 256) / 16, rnd(384)
+    mask = torch.rand(R, generator=g).cuda() < 0.2
+    out = torch.empty(R, 384, device="cuda")
+    ops.rows_gemm(x, ops.split_planes(w, planes), b, out, a2=pos, a2_cols=256, row_mask=mask, mask_col0=256)
+    want = torch.cat([rb(x + pos) @ rb(w[:256]).t(), rb(x) @ rb(w[256:]).t()], 1) + b.double()
+    want[:, 256:][mask] = 0
+    err = (out.double() - want).abs().max().item()
+    assert err <= tol * want.abs().max().item(), err
+    # mode 1: ReLU, K = 1024 -> N = 128; a strided input (row pitch 1280)
+    big = rnd(R, 1280)
+    h, w1, b1 = big[:, :1024], rnd(128, 1024) / 32, rnd(128)
+    out = torch.empty(R, 128, device="cuda")
+    ops.rows_gemm(h, ops.split_planes(w1, planes), b1, out, relu=True)
+    want = torch.relu(rb(h) @ rb(w1).t() + b1.double())
+    err = (out.double() - want).abs().max().item()
+    assert err <= tol * want.abs().max().item(), err
+    # mode 2: LayerNorm(residual + x . W^T + b), K = 256 and 1024
+    for K in (256, 1024):
+        a, w2, b2, res = rnd(R, K), rnd(256, K) / K ** 0.5, rnd(256), rnd(R, 256)
+        gam, bet = torch.rand(256, generator=g).cuda() + 0.5, rnd(256)
+        out = torch.empty(R, 256, device="cuda")
+        ops.rows_gemm(a, ops.split_planes(w2, planes), b2, out, ln=(res, gam, bet, 1e-5))
+        s = rb(a) @ rb(w2).t() + b2.double() + res.double()
+        want = torch.nn.functional.layer_norm(s, (256,), gam.double(), bet.double(), 1e-5)
+        err = (out.double() - want).abs().max().item()
+        assert err <= 5e-6 * max(1.0, want.abs().max().item()), (K, err)
+
+
+def test_msda_raw_matches_the_composed_operator():
+    """demf_msda_fwd_raw_f32 (softmax + sampling locations inside, value rows with a pitch) against
+    MultiScaleDeformableAttnFunction on explicitly computed locations / weights - both its kernels (one wave per
+    query, and 8 lanes per (query, head) via DEMF_MSDA_RAW_LANES in a fresh process is covered by the encoder test)."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, Dh, L = 2, 8, 32, 4
+    shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
+    S = sum(h * w for h, w in shapes)
+    shp = torch.tensor(shapes, dtype=torch.long, device="cuda")
+    lsi = torch.tensor([0] + list(np.cumsum([h * w for h, w in shapes])[:-1]), dtype=torch.long, device="cuda")
+    for P in (4, 2):
+        n_off, n_lgt = H * L * P * 2, H * L * P
+        v0 = (n_off + n_lgt + 127) // 128 * 128
+        raw = torch.randn(B * S, v0 + H * Dh, generator=g).cuda()
+        raw[:, :n_off] *= 3.0                                    # offsets of a few pixels, some off the image
+        ref = torch.rand(B, S, L, 2, generator=g).cuda()
+        out = torch.empty(B * S, H * Dh, device="cuda")
+        ops.msda_fwd_raw(raw, v0, 0, n_off, ref, shp, lsi, B, S, H, Dh, P, out)
+        off = raw[:, :n_off].view(B, S, H, L, P, 2)
+        w = raw[:, n_off:n_off + n_lgt].view(B, S, H, L * P).softmax(-1).view(B, S, H, L, P)
+        norm = torch.stack([shp[:, 1], shp[:, 0]], -1).float()
+        loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+        value = raw[:, v0:].reshape(B, S, H, Dh).contiguous()
+        want = ops.MultiScaleDeformableAttnFunction.apply(value, shp, lsi, loc.contiguous(), w.contiguous(), 64)
+        err = (out.view(B, S, -1) - want).abs().max().item()
+        assert err <= 1e-5 * max(1.0, want.abs().max().item()), (P, err)
