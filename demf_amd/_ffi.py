@@ -54,7 +54,8 @@ SIGNATURES = {
     "demf_loss_total": [_c_int] + [_ptr] * 4,
     "demf_loss_total_bwd": [_c_int] + [_ptr] * 4,
     "demf_target_weights": [_c_int] + [_ptr] * 5,
-    "demf_rows_gemm_f32": [_c_int] * 3 + [_ptr, ctypes.c_longlong, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
+    "demf_rows_ln_pos_f32": [_c_int] * 2 + [_ptr] * 4 + [_c_float] + [_ptr] * 4,
+    "demf_rows_gemm_f32": [_c_int] * 3 + [_ptr, ctypes.c_longlong, _ptr, _c_int, _c_int, _ptr, _c_int, _ptr, _c_int, _ptr, _c_int,
                            _ptr, ctypes.c_longlong, _ptr, _ptr, _c_float, _ptr, ctypes.c_longlong, _ptr],
     "demf_msda_fwd_raw_f32": [_c_int] * 7 + [_ptr, ctypes.c_longlong, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_int, _c_int,
                               _ptr, _ptr, _ptr],

@@ -1257,7 +1257,8 @@ extern "C" int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_stre
     }
     g.start[cnt] = tiles;
     g.n = cnt;
-    g.dbg = getenv("DEMF_TN_DBG") ? atoi(getenv("DEMF_TN_DBG")) : 0;
+    static const int tn_dbg = getenv("DEMF_TN_DBG") ? atoi(getenv("DEMF_TN_DBG")) : 0;   // phase-skip timing experiments
+    g.dbg = tn_dbg;
     if (tn3) {
       if (bf) hipLaunchKernelGGL((gemm_tn_group_kernel<1>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);
       else hipLaunchKernelGGL((gemm_tn_group_kernel<3>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, g);

@@ -32,7 +32,8 @@ using u32x4 = unsigned __attribute__((ext_vector_type(4)));
 struct RowsGemmArgs {
   int R, N, K;
   const float* A; long long lda;
-  const float* A2; int a2_cols;        // A + A2 feeds output columns < a2_cols (a multiple of the column tile)
+  const float* A2; int a2_cols;        // output columns < a2_cols (a multiple of the column tile) are fed by A + A2
+  int a2_replace;                      // ... or by A2 INSTEAD of A (a second, pre-added operand: q = x + pos)
   const __bf16* W;                     // (P, N, K) bf16 planes of the (N, K) weight
   const float* bias;                   // (N) or null
   int mode;                            // 0 bias, 1 bias + ReLU, 2 bias + residual + LayerNorm (N == 256)
@@ -92,7 +93,9 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void rows_gemm_kernel(RowsGemmArg
   const int by = (L & 7) + 8 * (L / (8 * gx)), bx = (L >> 3) % gx;
   const int m0 = by * RG_BM, n0 = bx * BN;
   if (m0 >= p.R) return;
-  const bool add2 = p.A2 != nullptr && n0 < p.a2_cols;
+  const bool alt = p.A2 != nullptr && n0 < p.a2_cols;
+  const bool add2 = alt && !p.a2_replace;
+  const float* __restrict__ Ap = (alt && p.a2_replace) ? p.A2 : p.A;
   // staging roles: A - thread t moves float4 kq = t & 7 of rows (t >> 3) and (t >> 3) + 64;
   //                B - 16-byte chunk (t & 3) of column (t >> 2) [+ 128] of every plane
   const int ar = t >> 3, akq = t & 7, bc = t >> 2, bch = t & 3;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void rows_gemm_kernel(RowsGemmArg
       const int row = m0 + ar + 64 * i;
       ra[G][i] = ra2[G][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < p.R && !(p.dbg & 4)) {
-        ra[G][i] = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + k0 + 4 * akq);
+        ra[G][i] = *reinterpret_cast<const float4*>(Ap + (size_t)row * p.lda + k0 + 4 * akq);
         if (add2) ra2[G][i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda + k0 + 4 * akq);
       }
     }
@@ -282,6 +285,129 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void rows_gemm_kernel(RowsGemmArg
   }
 }
 
+// Four-wave form of the 128 x 128 tile: 2 x 2 waves of 64 x 64 (four accumulator tiles per wave), one LDS stage
+// (48 KB at P = 3), three workgroups per CU.  Per MFMA a wave reads 0.5 KB of fragments instead of 0.75 KB (the
+// 8-wave form's 64 x 32 wave tiles put LDS reads + stores of two co-resident workgroups at ~3 000 cycles per step
+// pair, level with the MFMA time), and three workgroups rotate through load / split / MFMA instead of two.
+template <int P, bool ADD2>
+__global__ __launch_bounds__(256, 3) void rows_gemm4_kernel(RowsGemmArgs p) {
+  constexpr int BN = 128;
+  constexpr int A_BYTES = RG_BM * 64, B_BYTES = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lc = lane & 31, lh = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  const int gx = p.N / BN;
+  const int L = blockIdx.x;
+  const int by = (L & 7) + 8 * (L / (8 * gx)), bx = (L >> 3) % gx;
+  const int m0 = by * RG_BM, n0 = bx * BN;
+  if (m0 >= p.R) return;
+  const bool alt = p.A2 != nullptr && n0 < p.a2_cols;
+  const bool add2 = ADD2 && alt && !p.a2_replace;
+  const float* __restrict__ Ap = (alt && p.a2_replace) ? p.A2 : p.A;
+  // staging: A - float4 kq = t & 7 of rows (t >> 3) + 32 i; B - 16-byte chunk (t & 3) of columns (t >> 2) + 64 j
+  const int ar = t >> 3, akq = t & 7, bc = t >> 2, bch = t & 3;
+  float4 ra[4], ra2[ADD2 ? 4 : 1];
+  u32x4 rb[P * 2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + ar + 32 * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (ADD2) ra2[i] = ra[i];
+      if (row < p.R) {
+        ra[i] = *reinterpret_cast<const float4*>(Ap + (size_t)row * p.lda + k0 + 4 * akq);
+        if constexpr (ADD2)
+          if (add2) ra2[i] = *reinterpret_cast<const float4*>(p.A2 + (size_t)row * p.lda + k0 + 4 * akq);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        rb[q * 2 + j] = *reinterpret_cast<const u32x4*>(p.W + ((size_t)q * p.N + n0 + bc + 64 * j) * p.K + k0 + 8 * bch);
+  };
+  auto commit = [&]() {
+    char* sa = smem;
+    char* sb = sa + P * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = ra[i];
+      if constexpr (ADD2) { v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w; }   // (zeros if !add2)
+      unsigned lo[P], hi[P];
+      rg_split_pair<P>(v.x, v.y, lo);
+      rg_split_pair<P>(v.z, v.w, hi);
+      const int off = rg_swz(ar + 32 * i, akq >> 1) + 8 * (akq & 1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(sa + q * A_BYTES + off) = make_uint2(lo[q], hi[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<u32x4*>(sb + q * B_BYTES + rg_swz(bc + 64 * j, bch)) = rb[q * 2 + j];
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    commit();
+    lds_barrier();
+    if (k0 + 32 < p.K) fetch(k0 + 32);
+    const char* sa = smem;
+    const char* sb = sa + P * A_BYTES;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 pa[2][P];
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          pa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * A_BYTES + rg_swz(64 * wm + 32 * i + lc, 2 * c + lh));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bf16x8 pb[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          pb[q] = *reinterpret_cast<const bf16x8*>(sb + q * B_BYTES + rg_swz(64 * wn + 32 * j + lc, 2 * c + lh));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rg_mfma<P>(acc[i][j], pa[i], pb);
+      }
+    }
+    lds_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + 64 * wn + 32 * j + lc;
+    const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+    const bool masked = p.row_mask != nullptr && col >= p.mask_col0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < p.R) {
+          float v = acc[i][j][r] + bias;
+          if (p.mode == 1) v = fmaxf(v, 0.f);
+          if (masked && p.row_mask[row]) v = 0.f;
+          p.C[(size_t)row * p.ldc + col] = v;
+        }
+      }
+  }
+}
+
+template <int P, bool ADD2>
+static int rows_gemm4_launch(const RowsGemmArgs& a, hipStream_t s) {
+  constexpr int lds = P * (RG_BM * 64 + 128 * 64);
+  const int gx = a.N / 128, gy = (cdiv(a.R, RG_BM) + 7) / 8 * 8;
+  hipLaunchKernelGGL((rows_gemm4_kernel<P, ADD2>), dim3(gx * gy), dim3(256), lds, s, a);
+  return check_launch("rows_gemm4_kernel");
+}
+
 template <int P, int BN, bool TWO>
 static int rows_gemm_launch(const RowsGemmArgs& a, hipStream_t s) {
   constexpr int bytes = (TWO ? 1 : 2) * P * (RG_BM * 64 + BN * 64);
@@ -306,7 +432,7 @@ static int rows_gemm_launch(const RowsGemmArgs& a, hipStream_t s) {
 using namespace demf;
 
 extern "C" int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long lda, const float* A2, int a2_cols,
-                                  const void* w_planes, int planes, const float* bias, int mode,
+                                  int a2_op, const void* w_planes, int planes, const float* bias, int mode,
                                   const unsigned char* row_mask, int mask_col0, const float* resid, long long ldr,
                                   const float* gamma, const float* beta, float eps, float* C, long long ldc,
                                   demf_stream_t stream) {
@@ -315,11 +441,13 @@ extern "C" int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long
   DEMF_REQUIRE(K % 32 == 0 && lda % 4 == 0, "rows_gemm: K %% 32 and lda %% 4 required (K = %d, lda = %lld)", K, lda);
   DEMF_REQUIRE(mode >= 0 && mode <= 2, "rows_gemm: mode %d", mode);
   RowsGemmArgs a{};
-  a.R = R; a.N = N; a.K = K; a.A = A; a.lda = lda; a.A2 = A2; a.a2_cols = a2_cols;
+  DEMF_REQUIRE(a2_op == 0 || a2_op == 1, "rows_gemm: a2_op %d", a2_op);
+  a.R = R; a.N = N; a.K = K; a.A = A; a.lda = lda; a.A2 = A2; a.a2_cols = a2_cols; a.a2_replace = a2_op;
   a.W = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.mode = mode;
   a.row_mask = row_mask; a.mask_col0 = mask_col0; a.resid = resid; a.ldr = ldr;
   a.gamma = gamma; a.beta = beta; a.eps = eps; a.C = C; a.ldc = ldc;
-  a.dbg = getenv("DEMF_RG_DBG") ? atoi(getenv("DEMF_RG_DBG")) : 0;
+  static const int rg_dbg = getenv("DEMF_RG_DBG") ? atoi(getenv("DEMF_RG_DBG")) : 0;    // phase-skip timing experiments
+  a.dbg = rg_dbg;
   hipStream_t s = (hipStream_t)stream;
   if (mode == 2) {
     DEMF_REQUIRE(N == 256 && resid != nullptr && gamma != nullptr && beta != nullptr && ldr % 4 == 0 && ldc % 4 == 0,
@@ -328,7 +456,67 @@ extern "C" int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long
   }
   DEMF_REQUIRE(N % 128 == 0, "rows_gemm: N %% 128 required (N = %d)", N);
   DEMF_REQUIRE(A2 == nullptr || a2_cols % 128 == 0 || a2_cols >= N, "rows_gemm: a2_cols must be a multiple of 128");
+  static const int w8 = getenv("DEMF_RG_WAVES8") ? atoi(getenv("DEMF_RG_WAVES8")) : 0;    // A/B: the 8-wave forms
+  if (!w8) {
+    // (the adding form needs 16 more staging registers: 116 bytes of scratch at three planes, 631 vs 400 us on the
+    // encoder's input projection - it stays on the 8-wave form; callers with a pre-added operand use a2_op = 1)
+    if (A2 == nullptr || a2_op == 1)
+      return planes == 3 ? rows_gemm4_launch<3, false>(a, s) : rows_gemm4_launch<1, false>(a, s);
+    if (planes == 1) return rows_gemm4_launch<1, true>(a, s);
+  }
   static const bool one = getenv("DEMF_RG_ONE") && atoi(getenv("DEMF_RG_ONE"));     // A/B: one workgroup per CU
   if (one) return planes == 3 ? rows_gemm_launch<3, 128, false>(a, s) : rows_gemm_launch<1, 128, false>(a, s);
   return planes == 3 ? rows_gemm_launch<3, 128, true>(a, s) : rows_gemm_launch<1, 128, true>(a, s);
+}
+
+namespace demf {
+// y = LayerNorm(resid + x) * gamma + beta over rows of 256 channels, and ypos = y + pos (the next layer's query):
+// one wave per row, 4 values per lane.  The encoder's FFN tail (identity + dropout(.) in eval, nn.LayerNorm) and
+// the `query + query_pos` of the NEXT layer's attention in one pass.
+__global__ __launch_bounds__(256) void rows_ln_pos_kernel(int R, const float* __restrict__ x, const float* __restrict__ resid,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, const float* __restrict__ pos,
+                                                          float* __restrict__ y, float* __restrict__ ypos) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const size_t o = (size_t)row * 256 + 4 * lane;
+  float4 v = *reinterpret_cast<const float4*>(x + o);
+  if (resid != nullptr) {
+    const float4 r = *reinterpret_cast<const float4*>(resid + o);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  float4 out = v;
+  if (gamma != nullptr) {
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    const float mean = s * (1.f / 256.f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) q += __shfl_xor(q, k);
+    const float rstd = 1.f / sqrtf(q * (1.f / 256.f) + eps);
+    const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    const float4 b4 = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    out.x = dx * rstd * g4.x + b4.x; out.y = dy * rstd * g4.y + b4.y;
+    out.z = dz * rstd * g4.z + b4.z; out.w = dw * rstd * g4.w + b4.w;
+  }
+  if (y != nullptr) *reinterpret_cast<float4*>(y + o) = out;
+  if (ypos != nullptr) {
+    const float4 p4 = *reinterpret_cast<const float4*>(pos + o);
+    out.x += p4.x; out.y += p4.y; out.z += p4.z; out.w += p4.w;
+    *reinterpret_cast<float4*>(ypos + o) = out;
+  }
+}
+}  // namespace demf
+
+extern "C" int demf_rows_ln_pos_f32(int R, int C, const float* x, const float* resid, const float* gamma,
+                                    const float* beta, float eps, const float* pos, float* y, float* ypos,
+                                    demf_stream_t stream) {
+  DEMF_REQUIRE(R > 0 && C == 256 && x != nullptr && (y != nullptr || ypos != nullptr) && (ypos == nullptr || pos != nullptr) &&
+                   (gamma == nullptr) == (beta == nullptr),
+               "rows_ln_pos: bad arguments (C must be 256)");
+  hipLaunchKernelGGL(demf::rows_ln_pos_kernel, dim3(demf::cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, R, x, resid,
+                     gamma, beta, eps, pos, y, ypos);
+  return demf::check_launch("rows_ln_pos_kernel");
 }

@@ -33,6 +33,7 @@ from .transformer import FFN, MultiScaleDeformableAttention
 # REAL reference encoder pin - the fused path is tested against it
 FUSED_LAYERS = bool(int(__import__("os").environ.get("DEMF_ENC_FUSED", "1")))
 CHANNELS_LAST = bool(int(__import__("os").environ.get("DEMF_IMG_NHWC", "1")))        # A/B switch
+PRE_ADD = bool(int(__import__("os").environ.get("DEMF_ENC_PRE_ADD", "0")))           # A/B switch (measured neutral: 13.4 vs 13.2 ms)
 SPLIT_FFN_LN = bool(int(__import__("os").environ.get("DEMF_ENC_SPLIT_LN", "1")))     # A/B switch
 
 
@@ -280,25 +281,38 @@ class DeformableDetrEncoder(nn.Module):
         F = self.encoder.layers[0].ffns[0].layers[0][0].out_features
         new = lambda n: torch.empty((R, n), dtype=torch.float32, device=x.device)
         samp, x1, hid, xn, raw = new(C), new(C), new(F), new(C), None
-        for layer in self.encoder.layers:
+        st_ = torch.cuda.current_stream().cuda_stream
+        # q = x + pos as its own operand (PRE_ADD): written by the pass that produces x (the previous layer's
+        # residual + LayerNorm pass; one add for layer 0) instead of re-added inside every column tile of the
+        # input projection - the projection then needs no addend registers and runs on the 4-wave kernel
+        q = new(C) if PRE_ADD and SPLIT_FFN_LN else None
+        if q is not None:
+            _ffi.call("demf_rows_ln_pos_f32", R, C, x.data_ptr(), None, None, None, 0.0, pos.data_ptr(), None,
+                      q.data_ptr(), st_)
+        nl = len(self.encoder.layers)
+        for li, layer in enumerate(self.encoder.layers):
             a = layer.attentions[0]
             pk = self._layer_pack(layer, planes)
             v0 = pk["v0"]
             if raw is None or raw.shape[1] != v0 + C:
                 raw = new(v0 + C)
             # [offsets | logits] from x + pos, value from x (padding rows zeroed): one launch
-            ops.rows_gemm(x, pk["w_in"], pk["b_in"], raw, a2=pos, a2_cols=v0, row_mask=mask, mask_col0=v0)
+            if q is not None:
+                ops.rows_gemm(x, pk["w_in"], pk["b_in"], raw, a2=q, a2_cols=v0, a2_replace=True, row_mask=mask,
+                              mask_col0=v0)
+            else:
+                ops.rows_gemm(x, pk["w_in"], pk["b_in"], raw, a2=pos, a2_cols=v0, row_mask=mask, mask_col0=v0)
             ops.msda_fwd_raw(raw, v0, 0, pk["lgt0"], ref, st["spatial_shapes"], st["level_start_index"], B, S,
                              a.num_heads, C // a.num_heads, a.num_points, samp)
             ops.rows_gemm(samp, pk["w_out"], pk["b_out"], x1, ln=(x, pk["g1"], pk["be1"], pk["eps1"]))
             ops.rows_gemm(x1, pk["w0"], pk["b0"], hid, relu=True)
             # K = 1024 with the LayerNorm epilogue runs one 128 x 256-tile workgroup per CU (~1.0 ms); as a
-            # 128-column-tile launch (two workgroups per CU) + one residual / LayerNorm pass: 0.5 + 0.15 ms
+            # 128-column-tile launch (several workgroups per CU) + one residual / LayerNorm pass: 0.43 + 0.08 ms
             if SPLIT_FFN_LN:
                 ops.rows_gemm(hid, pk["w1"], pk["b1"], samp)
-                _ffi.call("demf_add_dropout_ln_fwd", R, C, samp.data_ptr(), x1.data_ptr(), pk["g2"].data_ptr(),
-                          pk["be2"].data_ptr(), pk["eps2"], 0.0, None, 0, None, xn.data_ptr(), None,
-                          torch.cuda.current_stream().cuda_stream)
+                _ffi.call("demf_rows_ln_pos_f32", R, C, samp.data_ptr(), x1.data_ptr(), pk["g2"].data_ptr(),
+                          pk["be2"].data_ptr(), pk["eps2"], pos.data_ptr() if q is not None else None, xn.data_ptr(),
+                          q.data_ptr() if (q is not None and li + 1 < nl) else None, st_)
             else:
                 ops.rows_gemm(hid, pk["w1"], pk["b1"], xn, ln=(x1, pk["g2"], pk["be2"], pk["eps2"]))
             x, xn = xn, x

@@ -821,11 +821,13 @@ def split_planes(w, planes=3):
     return torch.stack([h, m, low]).contiguous()
 
 
-def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, row_mask=None, mask_col0=0):
+def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, row_mask=None, mask_col0=0,
+              a2_replace=False):
     """out (R,N) = epi((x [+ a2 on output columns < a2_cols]) . W^T + bias) on demf_rows_gemm_f32
     (csrc/rows_gemm.hip): ``w_planes`` from ``split_planes``; ``relu``; ``ln`` = (residual (R,N), gamma, beta,
     eps): LayerNorm(residual + .) in the epilogue (N == 256); ``row_mask`` (R) bool: rows zeroed in columns
-    >= mask_col0.  Forward only (the frozen image stream)."""
+    >= mask_col0; ``a2_replace``: ``a2`` is a second operand that feeds those columns INSTEAD of x (e.g. the
+    pre-added x + pos).  Forward only (the frozen image stream)."""
     R, K = x.shape
     planes, N, Kw = w_planes.shape
     assert Kw == K and out.shape == (R, N) and x.stride(1) == 1 and out.stride(1) == 1
@@ -836,7 +838,8 @@ def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, r
         assert a2.shape == x.shape and a2.stride() == x.stride()
     if row_mask is not None:
         assert row_mask.dtype == torch.bool and row_mask.numel() == R and row_mask.is_contiguous()
-    _ffi.call("demf_rows_gemm_f32", R, N, K, _p(x), x.stride(0), _p(a2), int(a2_cols), _p(w_planes), planes,
+    _ffi.call("demf_rows_gemm_f32", R, N, K, _p(x), x.stride(0), _p(a2), int(a2_cols), int(bool(a2_replace)),
+              _p(w_planes), planes,
               _p(bias), mode, _p(row_mask), int(mask_col0), _p(res), res.stride(0) if res is not None else 0,
               _p(g), _p(b), float(eps), _p(out), out.stride(0), _stream())
     return out

@@ -619,10 +619,16 @@ int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int P,
  * beta.  Replaces, per encoder layer of demf/modeling/layers/deform_detr_encoder.py:68-154, six library GEMMs
  * and the elementwise launches between them (query + pos, masked_fill, ReLU, residual adds, two LayerNorms).  */
 int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long lda, const float* A2, int a2_cols,
+                       int a2_op /* 0: A + A2 on those columns, 1: A2 INSTEAD of A (a pre-added operand) */,
                        const void* w_planes, int planes, const float* bias, int mode,
                        const unsigned char* row_mask, int mask_col0, const float* resid, long long ldr,
                        const float* gamma, const float* beta, float eps, float* C, long long ldc,
                        demf_stream_t stream);
+/* y = LayerNorm(resid + x) * gamma + beta over rows of C = 256 channels (gamma == beta == NULL: y = resid + x) and
+ * ypos = y + pos; y or ypos may be NULL.  The FFN tail of an encoder layer and the `query + query_pos` of the next
+ * layer's attention (mmcv MultiScaleDeformableAttention.forward) in one pass.                                    */
+int demf_rows_ln_pos_f32(int R, int C, const float* x, const float* resid, const float* gamma, const float* beta,
+                         float eps, const float* pos, float* y, float* ypos, demf_stream_t stream);
 /* Multi-scale deformable attention forward with RAW inputs: offsets (H*L*P*2 columns from off_col0) and attention
  * logits (H*L*P columns from lgt_col0) of row b*Q+q of `raw` (row stride ldraw), reference points ref (B,Q,L,2),
  * value rows of pitch vpitch floats (columns h*Dh.. of the same projection output).  The softmax over a head's
