@@ -472,12 +472,14 @@ struct __attribute__((aligned(32))) FpsCand { float v; unsigned tk; float x, y, 
 //     so the wave reduces and searches again only in the rounds that lower its own candidate.
 // One barrier per round: waves publish their candidate (double-buffered by round parity, rewritten only
 // for two rounds after a change), every wave reduces the 16.  Picks are bit-identical to the full update.
-template <int PPT>
-__global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const float* __restrict__ xyz,
+// NW waves per scene: 16 (1 024 threads, PPT <= 20 slots per lane) or 8 (512 threads, PPT <= 40: the per-round
+// skeleton - box test, candidate exchange, reduce - is issued by two waves per SIMD instead of four).
+template <int PPT, int NW = 16>
+__global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const float* __restrict__ xyz,
                                                          const int* __restrict__ perm, int* __restrict__ idx) {
-  constexpr int BS = 1024, NW = 16, PP = PPT / 2;
+  constexpr int BS = 64 * NW, PP = PPT / 2, SB = PPT > 32 ? 6 : 5;      // SB: bits of the slot number under the tie key
   static_assert(PPT % 2 == 0 && PP < 63, "pairs of slots, lane 63 is the candidate's");
-  asm volatile("" ::: "v127");                   // the CU's whole register file, as fps_reg_kernel
+  if constexpr (NW == 16) asm volatile("" ::: "v127");   // the CU's whole register file, as fps_reg_kernel
   __shared__ FpsCand s_cand[2][16];
   __shared__ int s_idx[FPS_IDX_CHUNK];
   const int b = blockIdx.x;
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const flo
       px[i][q] = x; py[i][q] = y; pz[i][q] = z;
       tmp[p] = ok ? 1e10f : -2.f;                 // pad slots can never reach the maximum
       const unsigned key = ok ? (((unsigned)k & 1023u) << 5) | ((unsigned)k >> 10) : 0x7FFFu;
-      kp[p] = (key << 5) | (unsigned)p;
+      kp[p] = (key << SB) | (unsigned)p;
       if (ok) {
         l[0] = fminf(l[0], x); h[0] = fmaxf(h[0], x);
         l[1] = fminf(l[1], y); h[1] = fmaxf(h[1], y);
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const flo
         for (int p = 0; p < PPT; ++p) bt = tmp[p] == cv ? umin(bt, kp[p]) : bt;
         const unsigned btmin = wave_min_u32(bt);
         const int wl = __builtin_ctzll(__ballot(bt == btmin));
-        ctk = btmin >> 5;
+        ctk = btmin >> SB;
         // its coordinates: a scalar branch on the (wave-uniform) slot, one v_readlane per coordinate
 #define DEMF_FPS_PICK(P)                                                                       \
   case P:                                                                                      \
@@ -567,12 +569,14 @@ __global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const flo
       cz = readlane_f(pz[(P) / 2][(P) % 2], wl);                                               \
     }                                                                                          \
     break;
-        switch ((int)(btmin & 31u)) {
+        switch ((int)(btmin & ((1u << SB) - 1u))) {
           DEMF_FPS_PICK(0) DEMF_FPS_PICK(1) DEMF_FPS_PICK(2) DEMF_FPS_PICK(3) DEMF_FPS_PICK(4) DEMF_FPS_PICK(5)
           DEMF_FPS_PICK(6) DEMF_FPS_PICK(7) DEMF_FPS_PICK(8) DEMF_FPS_PICK(9) DEMF_FPS_PICK(10) DEMF_FPS_PICK(11)
           DEMF_FPS_PICK(12) DEMF_FPS_PICK(13) DEMF_FPS_PICK(14) DEMF_FPS_PICK(15) DEMF_FPS_PICK(16)
           DEMF_FPS_PICK(17) DEMF_FPS_PICK(18) DEMF_FPS_PICK(19) DEMF_FPS_PICK(20) DEMF_FPS_PICK(21)
-          DEMF_FPS_PICK(22) DEMF_FPS_PICK(23)
+          DEMF_FPS_PICK(22) DEMF_FPS_PICK(23) DEMF_FPS_PICK(24) DEMF_FPS_PICK(25) DEMF_FPS_PICK(26) DEMF_FPS_PICK(27)
+          DEMF_FPS_PICK(28) DEMF_FPS_PICK(29) DEMF_FPS_PICK(30) DEMF_FPS_PICK(31) DEMF_FPS_PICK(32) DEMF_FPS_PICK(33)
+          DEMF_FPS_PICK(34) DEMF_FPS_PICK(35) DEMF_FPS_PICK(36) DEMF_FPS_PICK(37) DEMF_FPS_PICK(38) DEMF_FPS_PICK(39)
           default: break;
         }
 #undef DEMF_FPS_PICK
@@ -588,9 +592,9 @@ __global__ __launch_bounds__(1024) void fps_prune_kernel(int N, int M, const flo
     }
     lds_barrier();
     {
-      const FpsCand c = slot[lane & (NW - 1)];           // every 16-lane row: all 16 waves
+      const FpsCand c = slot[lane & (NW - 1)];           // every 16-lane row: all NW waves (twice over at NW = 8)
       const float gmax = readlane_f(row16_max_dpp(c.v), 0);
-      const unsigned long long held = __ballot(c.v == gmax) & 0xFFFFull;
+      const unsigned long long held = __ballot(c.v == gmax) & ((1ull << NW) - 1ull);
       int wv = __builtin_ctzll(held);
       if (held & (held - 1)) {                           // several waves hold it: lowest tie key
         const unsigned key = c.v == gmax ? c.tk : 0xFFFFFFFFu;
@@ -713,9 +717,16 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
     int* perm = (int*)temp;
     hipLaunchKernelGGL(fps_sort_k, dim3(B), dim3(1024), 0, s, N, xyz, perm);
 #define PRUNE(P) hipLaunchKernelGGL((fps_prune_kernel<P>), dim3(B), dim3(1024), 0, s, N, M, xyz, perm, idx)
-    if (ppt <= 4) PRUNE(4); else if (ppt <= 8) PRUNE(8); else if (ppt <= 12) PRUNE(12);
+#define PRUNE8(P) hipLaunchKernelGGL((fps_prune_kernel<P, 8>), dim3(B), dim3(512), 0, s, N, M, xyz, perm, idx)
+    // A/B switch, default 16: 8 waves x 40 slots is bit-identical but SLOWER (20 000 -> 2 048: 2 643 vs 2 058 us) -
+    // the round's critical path is the wave that has to update and search again, and that wave's work doubles
+    static const int waves = [] { const char* v = getenv("DEMF_FPS_WAVES"); return v ? atoi(v) : 16; }();
+    if (waves == 8 && ppt > 8) {                            // 8 waves x up to 40 slots per lane
+      if (ppt <= 12) PRUNE8(24); else if (ppt <= 16) PRUNE8(32); else PRUNE8(40);
+    } else if (ppt <= 4) PRUNE(4); else if (ppt <= 8) PRUNE(8); else if (ppt <= 12) PRUNE(12);
     else if (ppt <= 16) PRUNE(16); else PRUNE(20);          // 24 slots + their keys spill
 #undef PRUNE
+#undef PRUNE8
     return check_launch("fps_prune");
   }
   bool done = true;
