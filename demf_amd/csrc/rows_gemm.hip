@@ -408,6 +408,126 @@ static int rows_gemm4_launch(const RowsGemmArgs& a, hipStream_t s) {
   return check_launch("rows_gemm4_kernel");
 }
 
+// LayerNorm form with TWO workgroups per CU: 64 rows x 256 columns per workgroup (8 waves, each 64 rows x 32
+// columns), one LDS stage (12 + 48 KB at P = 3; the fp32 LayerNorm tile of 64 x 260 floats reuses it).  The
+// 128-row form above holds 64 accumulator registers per lane and runs alone on its CU in lockstep phases (§3.9c).
+template <int P>
+__global__ __launch_bounds__(512, 4) void rows_gemm_ln64_kernel(RowsGemmArgs p) {
+  constexpr int BM = 64, BN = 256;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lc = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= p.R) return;
+  // staging: A - float4 kq = t & 7 of row t >> 3; B - 16-byte chunk (t & 3) of columns (t >> 2) + 128 j
+  const int ar = t >> 3, akq = t & 7, bc = t >> 2, bch = t & 3;
+  float4 ra;
+  u32x4 rb[P * 2];
+  auto fetch = [&](int k0) {
+    const int row = m0 + ar;
+    ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < p.R) ra = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + k0 + 4 * akq);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        rb[q * 2 + j] = *reinterpret_cast<const u32x4*>(p.W + ((size_t)q * p.N + bc + 128 * j) * p.K + k0 + 8 * bch);
+  };
+  auto commit = [&]() {
+    char* sa = smem;
+    char* sb = sa + P * A_BYTES;
+    unsigned lo[P], hi[P];
+    rg_split_pair<P>(ra.x, ra.y, lo);
+    rg_split_pair<P>(ra.z, ra.w, hi);
+    const int off = rg_swz(ar, akq >> 1) + 8 * (akq & 1);
+#pragma unroll
+    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(sa + q * A_BYTES + off) = make_uint2(lo[q], hi[q]);
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        *reinterpret_cast<u32x4*>(sb + q * B_BYTES + rg_swz(bc + 128 * j, bch)) = rb[q * 2 + j];
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    commit();
+    lds_barrier();
+    if (k0 + 32 < p.K) fetch(k0 + 32);
+    const char* sa = smem;
+    const char* sb = sa + P * A_BYTES;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 pa[2][P], pb[P];
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          pa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * A_BYTES + rg_swz(32 * i + lc, 2 * c + lh));
+        pb[q] = *reinterpret_cast<const bf16x8*>(sb + q * B_BYTES + rg_swz(32 * wave + lc, 2 * c + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rg_mfma<P>(acc[i], pa[i], pb);
+    }
+    lds_barrier();
+  }
+  constexpr int LD = 260;
+  float* tile = reinterpret_cast<float*>(smem);
+  {
+    const int col = 32 * wave + lc;
+    const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LD + col] = acc[i][r] + bias;
+  }
+  __syncthreads();
+  const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + 4 * lane);
+  const float4 b4 = *reinterpret_cast<const float4*>(p.beta + 4 * lane);
+  for (int rr = 0; rr < 8; ++rr) {
+    const int rl = 8 * wave + rr, row = m0 + rl;
+    if (row >= p.R) break;                       // (wave-uniform)
+    float4 v = *reinterpret_cast<const float4*>(tile + rl * LD + 4 * lane);
+    const float4 x = *reinterpret_cast<const float4*>(p.resid + (size_t)row * p.ldr + 4 * lane);
+    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    float sum = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.f / 256.f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q * (1.f / 256.f) + p.eps);
+    float4 y;
+    y.x = dx * rstd * g4.x + b4.x; y.y = dy * rstd * g4.y + b4.y;
+    y.z = dz * rstd * g4.z + b4.z; y.w = dw * rstd * g4.w + b4.w;
+    *reinterpret_cast<float4*>(p.C + (size_t)row * p.ldc + 4 * lane) = y;
+  }
+}
+
+template <int P>
+static int rows_gemm_ln64_launch(const RowsGemmArgs& a, hipStream_t s) {
+  constexpr int stage = P * (64 * 64 + 256 * 64), ln = 64 * 260 * 4;
+  constexpr int lds = stage > ln ? stage : ln;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_gemm_ln64_kernel<P>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("rows_gemm: cannot reserve %d bytes of LDS", lds);
+      return DEMF_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((rows_gemm_ln64_kernel<P>), dim3(cdiv(a.R, 64)), dim3(512), lds, s, a);
+  return check_launch("rows_gemm_ln64_kernel");
+}
+
 template <int P, int BN, bool TWO>
 static int rows_gemm_launch(const RowsGemmArgs& a, hipStream_t s) {
   constexpr int bytes = (TWO ? 1 : 2) * P * (RG_BM * 64 + BN * 64);
@@ -452,6 +572,8 @@ extern "C" int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long
   if (mode == 2) {
     DEMF_REQUIRE(N == 256 && resid != nullptr && gamma != nullptr && beta != nullptr && ldr % 4 == 0 && ldc % 4 == 0,
                  "rows_gemm: the LayerNorm epilogue needs N == 256, a residual and gamma / beta");
+    static const int ln128 = getenv("DEMF_RG_LN128") ? atoi(getenv("DEMF_RG_LN128")) : 0;   // A/B: the 128-row form
+    if (!ln128 && A2 == nullptr) return planes == 3 ? rows_gemm_ln64_launch<3>(a, s) : rows_gemm_ln64_launch<1>(a, s);
     return planes == 3 ? rows_gemm_launch<3, 256, false>(a, s) : rows_gemm_launch<1, 256, false>(a, s);
   }
   DEMF_REQUIRE(N % 128 == 0, "rows_gemm: N %% 128 required (N = %d)", N);
