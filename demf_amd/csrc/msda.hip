@@ -203,12 +203,17 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
     int S, int Q, const float* __restrict__ value, long long vpitch,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ raw, long long ldraw, int off_col0, int lgt_col0,
-    const float* __restrict__ ref, float* __restrict__ out, long long rows) {
+    const float* __restrict__ ref, float* __restrict__ out, long long rows, int xcd_blocks) {
   constexpr int H = 8, Dh = 32, NP = TL * TP, PPL = NP / 8;      // pairs per lane: 2 (P = 4) or 1 (P = 2)
   __shared__ int4 s_off[4][NP * H];
   __shared__ float4 s_w[4][NP * H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long row = (long long)blockIdx.x * 4 + wave;          // b * Q + q
+  long long blk = blockIdx.x;
+  if (xcd_blocks) {       // XCD x (= workgroup id mod 8) takes the x-th contiguous eighth of the query blocks
+    const unsigned per = (gridDim.x + 7) / 8;
+    blk = (long long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  }
+  const long long row = blk * 4 + wave;                            // b * Q + q
   if (row >= rows) return;                                         // (wave-uniform; no workgroup barrier below)
   const int b = (int)(row / Q);
   const int vh = (int)(vpitch / Dh);
@@ -566,13 +571,14 @@ extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, 
   static const bool lanes8 = getenv("DEMF_MSDA_RAW_LANES") && atoi(getenv("DEMF_MSDA_RAW_LANES"));   // A/B switch
   if (H == 8 && !lanes8 && ldraw % 2 == 0 && off_col0 % 2 == 0 && (uintptr_t)raw % 8 == 0 && (uintptr_t)ref % 8 == 0) {
     const long long rows = (long long)B * Q;
-    const dim3 g2((unsigned)((rows + 3) / 4));
+    static const int xcd = getenv("DEMF_MSDA_XCD") ? atoi(getenv("DEMF_MSDA_XCD")) : 0;      // A/B switch
+    const dim3 g2((unsigned)(xcd ? ((rows + 3) / 4 + 7) / 8 * 8 : (rows + 3) / 4));
     if (P == 4)
       hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 4>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
-                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows);
+                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd);
     else
       hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 2>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
-                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows);
+                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd);
     return check_launch("msda_fwd_raw_wave");
   }
   if (P == 4)
