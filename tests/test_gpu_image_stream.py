@@ -97,9 +97,10 @@ def test_head_accepts_tokens():
         assert torch.allclose(x, y, rtol=0, atol=1e-6)     # GEMM on differently strided inputs
 
 
+@pytest.mark.parametrize("variant", ["default", "pre_add", "ln_epilogue"])
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("num_points", [4, 2])
-def test_fused_encoder_layers_match_the_module_path(mode, num_points):
+def test_fused_encoder_layers_match_the_module_path(mode, num_points, variant):
     """embed_dims = 256, 8 heads, 4 levels (the reference's encoder shape, configs/demf/demf_votenet.py:28-47): the
     layers on demf_rows_gemm_f32 + demf_msda_fwd_raw_f32 (5 launches per layer) against the module path - the one
     the REAL-encoder goldens pin above - on padded images (masked value rows, partial 128-row tiles).  fp32-grade
@@ -124,14 +125,20 @@ def test_fused_encoder_layers_match_the_module_path(mode, num_points):
     shapes = [(12, 20), (6, 10), (3, 5), (2, 3)]
     feats = [torch.randn(3, 256, h, w, device="cuda") for h, w in shapes]
     ops.set_compute_dtype(mode)
+    saved = (ims.PRE_ADD, ims.SPLIT_FFN_LN)
     try:
         ims.FUSED_LAYERS = False
         want = enc.forward_tokens(feats, metas)["tokens"]
         ims.FUSED_LAYERS = True
+        # the opt-in forms: q = x + pos written by the LayerNorm pass and fed as a second operand
+        # (demf_rows_ln_pos_f32, a2_op = 1); FFN-down with the LayerNorm epilogue instead of GEMM + pass
+        ims.PRE_ADD = variant == "pre_add"
+        ims.SPLIT_FFN_LN = variant != "ln_epilogue"
         assert enc._fused_ok(torch.empty(3, 10, 256, device="cuda"))
         got = enc.forward_tokens(feats, metas)["tokens"]
     finally:
         ims.FUSED_LAYERS = True
+        ims.PRE_ADD, ims.SPLIT_FFN_LN = saved
         ops.set_compute_dtype("f32")
     keep = ~enc._static(metas, shapes, feats[0].device)["mask_flatten"]          # tokens on the image
     err = ((got - want).abs() * keep[..., None]).max().item()
