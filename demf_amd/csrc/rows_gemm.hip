@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, TWO ? 4 : 2) void rows_gemm_kernel(RowsGemmArg
 // 8-wave form's 64 x 32 wave tiles put LDS reads + stores of two co-resident workgroups at ~3 000 cycles per step
 // pair, level with the MFMA time), and three workgroups rotate through load / split / MFMA instead of two.
 template <int P, bool ADD2>
-__global__ __launch_bounds__(256, 3) void rows_gemm4_kernel(RowsGemmArgs p) {
+__global__ __launch_bounds__(256, (ADD2 && P == 3) ? 2 : 3) void rows_gemm4_kernel(RowsGemmArgs p) {
   constexpr int BN = 128;
   constexpr int A_BYTES = RG_BM * 64, B_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -584,7 +584,9 @@ extern "C" int demf_rows_gemm_f32(int R, int N, int K, const float* A, long long
     // encoder's input projection - it stays on the 8-wave form; callers with a pre-added operand use a2_op = 1)
     if (A2 == nullptr || a2_op == 1)
       return planes == 3 ? rows_gemm4_launch<3, false>(a, s) : rows_gemm4_launch<1, false>(a, s);
+    static const int add4 = getenv("DEMF_RG_ADD4") ? atoi(getenv("DEMF_RG_ADD4")) : 0;      // A/B: adding form on 4 waves
     if (planes == 1) return rows_gemm4_launch<1, true>(a, s);
+    if (add4) return rows_gemm4_launch<3, true>(a, s);
   }
   static const bool one = getenv("DEMF_RG_ONE") && atoi(getenv("DEMF_RG_ONE"));     // A/B: one workgroup per CU
   if (one) return planes == 3 ? rows_gemm_launch<3, 128, false>(a, s) : rows_gemm_launch<1, 128, false>(a, s);
