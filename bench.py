@@ -506,7 +506,7 @@ def main():
                 secondary["b16_ms_per_step"] = float("nan")
         # (d) SURVEY 8(f) rank 1 / 8(d) "secondary = e2e": the frozen image stream (ResNet-50 + ChannelMapper as
         # library convolutions, the six encoder layers on csrc/rows_gemm.hip + the MSDA kernel) in front of the step
-        if args.batch <= 8:
+        def image_stream_secondary():
             from demf_amd.modules import ImageStream
             from demf_amd.config import BATCH_INPUT_SHAPE
             ist = ImageStream().to(device)
@@ -535,6 +535,11 @@ def main():
                 torch.cuda.current_stream().wait_stream(side)
             secondary["e2e_pipelined_ms_per_step"] = time_steps(e2e_pipe, 10)
             del ist, img, pyr
+        if args.batch <= 8:
+            try:
+                image_stream_secondary()
+            except Exception as exc:      # (a secondary figure must not take the headline line down with it)
+                secondary["e2e_error"] = repr(exc)[:200]
         # (c) BASELINE configs[1]: the SA path alone (forward / forward+backward / the index pre-pass)
         for B1 in (1, 8):
             f, fb, g = sa_path_ms(model, device, B1)
