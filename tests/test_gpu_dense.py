@@ -461,51 +461,59 @@ def test_vote_combine_matches_the_torch_specification():
     assert torch.equal(votes.grad[:, :3], torch.ones(64, 3, device="cuda"))
 
 
-def test_gemm_group_and_bias_row_sums():
-    """demf_gemm_group_f32: several weight-gradient-shaped products (dW = dY^T.(X [+ X2]), split-K
+@pytest.mark.parametrize("mode", ["f32", "f32_native", "bf16"])
+def test_gemm_group_and_bias_row_sums(mode):
+    """(f32: the 64 x 64-tile three-term kernel gemm_tn_group_kernel<3>; f32_native: the 32 x 32-tile fp32-MFMA
+    kernel it replaced; bf16: one plane, looser bound.)  demf_gemm_group_f32: several weight-gradient-shaped products (dW = dY^T.(X [+ X2]), split-K
     atomics into zeroed outputs) in ONE launch, each with its bias gradient taken as the row sums of
     the A operand (``asum``), + a descriptor that is not groupable (runs as its own launch) - against
     fp64 products."""
-    from demf_amd import fused
-    from demf_amd.fused import _p
-    R = 2048
-    specs = [(256, 256, False), (768, 256, True), (64, 256, False), (1024, 256, False), (256, 1024, False)]
-    descs, outs, keep = [], [], []          # (descriptors hold raw addresses: operands must stay alive)
-    for i, (N, K, with_x2) in enumerate(specs):
-        dy, x, x2 = _r(R, N, seed=20 + i), _r(R, K, seed=40 + i), _r(R, K, seed=60 + i)
-        dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
-        keep += [dy, x, x2]
-        fused.weight_grad(dy, x, dw, db, x2=x2 if with_x2 else None, x2_rows=N // 2 if with_x2 else 0, group=descs)
-        want = dy.double().t() @ x.double()
-        if with_x2:
-            want[:N // 2] += dy.double()[:, :N // 2].t() @ x2.double()
-        outs.append((dw, db, want, dy.double().sum(0)))
-    # the per-head value projection's gradient: 8 batched (32 x 256) products over strided column blocks,
-    # and a ragged one (40 x 72: partial 64 x 64 tiles, reduction not a multiple of the 32-row step)
-    H, Dh, Ct = 8, 32, 256
-    dmo, zz = _r(R, H * Dh, seed=80), _r(R, H * Ct, seed=81)
-    dvp = torch.zeros(H * Dh, Ct, device="cuda")
-    fused.gemm(Dh, Ct, R, _p(dmo), (1, H * Dh), _p(zz), (1, H * Ct), _p(dvp), Ct, batch=H, sab=(Dh, 0),
-               sbb=(Ct, 0), scb=(Dh * Ct, 0), splitk=8, group=descs)
-    want_vp = torch.stack([dmo.double()[:, h * Dh:(h + 1) * Dh].t() @ zz.double()[:, h * Ct:(h + 1) * Ct]
-                           for h in range(H)]).reshape(H * Dh, Ct)
-    dyr, xr = _r(1000, 40, seed=82), _r(1000, 72, seed=83)
-    dwr, dbr = torch.zeros(40, 72, device="cuda"), torch.zeros(40, device="cuda")
-    fused.weight_grad(dyr, xr, dwr, dbr, group=descs)
-    keep += [dmo, zz, dyr, xr]
-    # one more that cannot join a group (A K-contiguous): Y = X W^T
-    xa, wa = _r(300, 64, seed=90), _r(96, 64, seed=91)
-    ya = torch.empty(300, 96, device="cuda")
-    fused.gemm(300, 96, 64, _p(xa), (64, 1), _p(wa), (64, 1), _p(ya), 96, group=descs)
-    assert len(descs) == 8
-    fused.gemm_group(descs)
-    _close(dvp, want_vp, 1e-4, "batched per-head dW")
-    _close(dwr, dyr.double().t() @ xr.double(), 1e-4, "ragged dW")
-    _close(dbr, dyr.double().sum(0), 1e-4, "ragged bias gradient")
-    for dw, db, want, wb in outs:
-        _close(dw, want, 1e-4, "grouped dW")
-        _close(db, wb, 1e-4, "bias gradient = row sums of the A operand")
-    _close(ya, xa.double() @ wa.double().t(), 1e-4, "ungroupable member")
+    from demf_amd import ops
+    ops.set_compute_dtype(mode)
+    tol = 1e-2 if mode == "bf16" else 1e-4
+    try:
+        from demf_amd import fused
+        from demf_amd.fused import _p
+        R = 2048
+        specs = [(256, 256, False), (768, 256, True), (64, 256, False), (1024, 256, False), (256, 1024, False)]
+        descs, outs, keep = [], [], []          # (descriptors hold raw addresses: operands must stay alive)
+        for i, (N, K, with_x2) in enumerate(specs):
+            dy, x, x2 = _r(R, N, seed=20 + i), _r(R, K, seed=40 + i), _r(R, K, seed=60 + i)
+            dw, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+            keep += [dy, x, x2]
+            fused.weight_grad(dy, x, dw, db, x2=x2 if with_x2 else None, x2_rows=N // 2 if with_x2 else 0, group=descs)
+            want = dy.double().t() @ x.double()
+            if with_x2:
+                want[:N // 2] += dy.double()[:, :N // 2].t() @ x2.double()
+            outs.append((dw, db, want, dy.double().sum(0)))
+        # the per-head value projection's gradient: 8 batched (32 x 256) products over strided column blocks,
+        # and a ragged one (40 x 72: partial 64 x 64 tiles, reduction not a multiple of the 32-row step)
+        H, Dh, Ct = 8, 32, 256
+        dmo, zz = _r(R, H * Dh, seed=80), _r(R, H * Ct, seed=81)
+        dvp = torch.zeros(H * Dh, Ct, device="cuda")
+        fused.gemm(Dh, Ct, R, _p(dmo), (1, H * Dh), _p(zz), (1, H * Ct), _p(dvp), Ct, batch=H, sab=(Dh, 0),
+                   sbb=(Ct, 0), scb=(Dh * Ct, 0), splitk=8, group=descs)
+        want_vp = torch.stack([dmo.double()[:, h * Dh:(h + 1) * Dh].t() @ zz.double()[:, h * Ct:(h + 1) * Ct]
+                               for h in range(H)]).reshape(H * Dh, Ct)
+        dyr, xr = _r(1000, 40, seed=82), _r(1000, 72, seed=83)
+        dwr, dbr = torch.zeros(40, 72, device="cuda"), torch.zeros(40, device="cuda")
+        fused.weight_grad(dyr, xr, dwr, dbr, group=descs)
+        keep += [dmo, zz, dyr, xr]
+        # one more that cannot join a group (A K-contiguous): Y = X W^T
+        xa, wa = _r(300, 64, seed=90), _r(96, 64, seed=91)
+        ya = torch.empty(300, 96, device="cuda")
+        fused.gemm(300, 96, 64, _p(xa), (64, 1), _p(wa), (64, 1), _p(ya), 96, group=descs)
+        assert len(descs) == 8
+        fused.gemm_group(descs)
+        _close(dvp, want_vp, tol, "batched per-head dW")
+        _close(dwr, dyr.double().t() @ xr.double(), tol, "ragged dW")
+        _close(dbr, dyr.double().sum(0), tol, "ragged bias gradient")
+        for dw, db, want, wb in outs:
+            _close(dw, want, tol, "grouped dW")
+            _close(db, wb, tol, "bias gradient = row sums of the A operand")
+        _close(ya, xa.double() @ wa.double().t(), tol, "ungroupable member")
+    finally:
+        ops.set_compute_dtype("f32")
 
 
 @pytest.mark.parametrize("p", [0.0, 0.3])
