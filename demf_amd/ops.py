@@ -830,6 +830,9 @@ def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, r
     pre-added x + pos).  Forward only (the frozen image stream)."""
     R, K = x.shape
     planes, N, Kw = w_planes.shape
+    if not (x.is_cuda and out.is_cuda and w_planes.is_cuda):
+        raise RuntimeError("rows_gemm: operands must be GPU (HIP) tensors: demf_amd operators have no CPU path")
+    assert x.dtype == torch.float32 and out.dtype == torch.float32, "rows_gemm: fp32 rows in, fp32 rows out"
     assert Kw == K and out.shape == (R, N) and x.stride(1) == 1 and out.stride(1) == 1
     assert w_planes.dtype == torch.bfloat16 and w_planes.is_contiguous()
     mode = 2 if ln is not None else (1 if relu else 0)
