@@ -230,12 +230,24 @@ class DeformableDetrEncoder(nn.Module):
 
     # ---- the six layers on csrc/rows_gemm.hip: 5 launches per layer, no library GEMM, no elementwise pass ----
     def _fused_ok(self, tokens):
-        if not (FUSED_LAYERS and tokens.is_cuda and tokens.dtype == torch.float32 and self.embed_dims == 256):
+        """The kernel path hard-codes the reference's encoder layer (demf_votenet.py:33-40): post-norm order
+        (self_attn, norm, ffn, norm), a 2-fc ReLU FFN with identity, LayerNorm(256), eval mode (no dropout).
+        Anything else takes the module path."""
+        if not (FUSED_LAYERS and tokens.is_cuda and tokens.dtype == torch.float32 and self.embed_dims == 256
+                and not self.training):
             return False
         for layer in self.encoder.layers:
+            if not (type(layer) is EncoderLayer and len(layer.attentions) == 1 and len(layer.ffns) == 1
+                    and len(layer.norms) == 2 and not layer.training):
+                return False
             a, f = layer.attentions[0], layer.ffns[0]
-            if not (a.num_heads == 8 and a.num_levels == 4 and a.num_points in (2, 4)
-                    and f.layers[0][0].out_features % 128 == 0 and f.layers[0][0].out_features % 32 == 0):
+            if not (type(f) is FFN and len(f.layers) == 2 and isinstance(f.layers[0][0], nn.Linear)
+                    and isinstance(f.layers[0][1], nn.ReLU) and isinstance(f.layers[1], nn.Linear)):
+                return False
+            if not all(isinstance(n, nn.LayerNorm) and tuple(n.normalized_shape) == (256,) for n in layer.norms):
+                return False
+            if not (a.num_heads == 8 and a.num_levels == 4 and a.num_points in (2, 4) and a.embed_dims == 256
+                    and f.layers[0][0].out_features % 128 == 0 and f.layers[1].out_features == 256):
                 return False
         return tokens.shape[1] * 1024 < 2 ** 31
 

@@ -35,7 +35,7 @@ class _DeferredDW:
     variant.  Outside the context a job is launched at once."""
 
     def __init__(self):
-        self.on, self.jobs, self.keep = False, [], []
+        self.on, self.jobs, self.keep, self.leaves = False, [], [], set()
 
 
 DEFER = _DeferredDW()
@@ -54,11 +54,27 @@ def _plain_parameter(w):
         return False
 
 
-def dw_job(R, N, K, ldx, G, dP, arg, ns, Y, vec6, xprev, pss, dW, lddw, dw_off=0, defer=True):
-    """One dW = dZ^T A product (arguments of demf_mlp_gemm_bwd_dw_ld; tensors, ``dw_off`` floats into dW)."""
+def _leaf_key(w):
+    """Identity of the parameter a weight operand aliases (see _plain_parameter), or None."""
+    try:
+        return id(w if w.is_leaf else w._base)
+    except Exception:          # noqa: BLE001
+        return None
+
+
+def dw_job(R, N, K, ldx, G, dP, arg, ns, Y, vec6, xprev, pss, dW, lddw, dw_off=0, defer=True, leaf=None):
+    """One dW = dZ^T A product (arguments of demf_mlp_gemm_bwd_dw_ld; tensors, ``dw_off`` floats into dW).
+    ``leaf``: _leaf_key of the parameter this gradient belongs to.  A parameter consumed by TWO nodes (a shared
+    MLP called twice, tied heads) has its two gradients summed by the autograd engine as soon as the second node
+    returns - both products must have been issued by then, so a repeated leaf flushes the queue and runs at once."""
     j = _ffi.DwJob(R, N, K, ldx, _p(G), _p(dP), _p(arg), ns, _p(Y), _p(vec6), _p(xprev), _p(pss),
                    dW.data_ptr() + 4 * dw_off, lddw)
+    if DEFER.on and _DEFER_DW and defer and leaf is not None and leaf in DEFER.leaves:
+        flush_dw()
+        defer = False
     if DEFER.on and _DEFER_DW and defer:
+        if leaf is not None:
+            DEFER.leaves.add(leaf)
         DEFER.jobs.append(j)
         DEFER.keep.extend(t for t in (G, dP, arg, Y, vec6, xprev, pss, dW) if t is not None)
         return
@@ -76,16 +92,22 @@ def flush_dw():
 
 
 class deferred_weight_grads:
+    """Re-entrant: a nested context joins the outer one's queue (flushed at the OUTERMOST exit)."""
+
     def __enter__(self):
+        self._prev = DEFER.on
         DEFER.on = True
         return self
 
     def __exit__(self, *exc):
-        DEFER.on = False
+        DEFER.on = self._prev
+        if self._prev:
+            return False
         if exc[0] is None:
             flush_dw()
         else:
             DEFER.jobs, DEFER.keep = [], []
+        DEFER.leaves.clear()
         return False
 
 
@@ -1117,6 +1139,7 @@ class _SharedMLPPool(Function):
         # parameter: a torch.cat / index op in between (padded first-layer weights) would read the still empty
         # gradient when the node returns
         ctx.defer_ok = [_plain_parameter(tensors[7 * l]) for l in range(L)]
+        ctx.leaf_keys = [_leaf_key(tensors[7 * l]) if ok else None for l, ok in enumerate(ctx.defer_ok)]
         ctx.store16 = store16
         ctx.noy = noy
         ctx.x4 = x4
@@ -1211,7 +1234,7 @@ class _SharedMLPPool(Function):
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3
                 dw_job(gB * gN, N, C0, C0, dU, None, None, 1, dU, _identity_dy_vectors(N, dev), x, None, dW0, K,
-                       dw_off=3, defer=ctx.defer_ok[0])
+                       dw_off=3, defer=ctx.defer_ok[0], leaf=ctx.leaf_keys[0])
                 grads[0] = dW0
                 grads[1], grads[2] = dgamma, dbeta
                 if ctx.bias_shapes[0] is not None:
@@ -1322,7 +1345,7 @@ class _SharedMLPPool(Function):
                 G = dX
                 continue
             dw_job(R, N, K, ldx, G, dP if sparse else None, arg if sparse else None, ns, Ys[l], vec6, xprev,
-                   sss[l - 1] if l > 0 else None, dW, K, defer=ctx.defer_ok[l])
+                   sss[l - 1] if l > 0 else None, dW, K, defer=ctx.defer_ok[l], leaf=ctx.leaf_keys[l])
             grads[7 * l], grads[7 * l + 1], grads[7 * l + 2] = dW, dgamma, dbeta
             if ctx.bias_shapes[l] is not None:
                 grads[7 * l + 5] = ws32[o32:o32 + N].view(ctx.bias_shapes[l])

@@ -122,3 +122,40 @@ def make_images(seed, B=2, H=64, W=96):
         img[b, :, :, w:] = 0
         metas.append(dict(batch_input_shape=(H, W), img_shape=(h, w, 3)))
     return img, metas
+
+
+ENC256 = dict(num_layers=2, embed_dims=256, num_heads=8, num_points=4, feedforward_channels=1024, num_feats=128)
+ENC256_SHAPES = ((10, 14), (5, 7), (3, 4), (2, 2))
+ENC256_INPUT = (80, 112)
+
+
+def make_encoder_pyramid(seed, B=2, shapes=ENC256_SHAPES, input_hw=ENC256_INPUT, C=256):
+    """Synthetic neck pyramid (what ChannelMapper hands DeformableDetrEncoder.forward,
+    deform_detr_encoder.py:68) + metas with padded images: [(B,C,h_l,w_l) float32], [meta].  Scene 0 fills
+    the padded batch shape; the others are valid on a smaller (img_h, img_w), so padding masks, valid ratios
+    and masked value rows are all exercised."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    H, W = input_hw
+    feats = [rng.standard_normal((B, C, h, w)).astype(np.float32) for h, w in shapes]
+    metas = []
+    for b in range(B):
+        h = H if b == 0 else int(rng.integers(H * 2 // 3, H))
+        w = W if b == 0 else int(rng.integers(W * 2 // 3, W))
+        metas.append(dict(batch_input_shape=(H, W), img_shape=(h, w, 3)))
+    return feats, metas
+
+
+def oracle_encoder(num_layers=6, embed_dims=256, num_heads=8, num_points=4, feedforward_channels=1024,
+                   num_feats=128):
+    """oracle/model.py's restatement of DeformableDetrEncoder, built from the keyword form the product's
+    DeformableDetrEncoder takes."""
+    from oracle.model import OracleEncoder
+    return OracleEncoder(
+        dict(type="DetrTransformerEncoder", num_layers=num_layers, transformerlayers=dict(
+            type="BaseTransformerLayer", attn_cfgs=dict(
+                type="MultiScaleDeformableAttention", embed_dims=embed_dims, num_heads=num_heads,
+                num_levels=4, num_points=num_points),
+            feedforward_channels=feedforward_channels, ffn_dropout=0.1,
+            operation_order=("self_attn", "norm", "ffn", "norm"))),
+        dict(type="SinePositionalEncoding", num_feats=num_feats, normalize=True, offset=-0.5), 4, embed_dims)

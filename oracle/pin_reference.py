@@ -198,6 +198,33 @@ def encoder_goldens(seed=4):
     return out
 
 
+def encoder256_goldens(seed=6):
+    """REAL reference DeformableDetrEncoder at the reference's own encoder shape (configs/demf/demf_votenet.py:28-47:
+    256 dims, 8 heads, 4 levels, 4 points, FFN 1024, post-norm) - two layers on a small padded pyramid
+    (fixtures.make_encoder_pyramid).  This is the shape at which demf_amd's encoder runs on its hand-written
+    kernels (rows_gemm + raw MSDA), so the golden pins THAT path to the real class."""
+    ref = shim.reference()
+    t = fixtures.ENC256
+    real = ref.encoder.DeformableDetrEncoder(
+        encoder=dict(type="DetrTransformerEncoder", num_layers=t["num_layers"], transformerlayers=dict(
+            type="BaseTransformerLayer", attn_cfgs=dict(type="MultiScaleDeformableAttention",
+                                                        embed_dims=t["embed_dims"], num_heads=t["num_heads"],
+                                                        num_levels=4, num_points=t["num_points"]),
+            feedforward_channels=t["feedforward_channels"], ffn_dropout=0.1,
+            operation_order=("self_attn", "norm", "ffn", "norm"))),
+        positional_encoding=dict(type="SinePositionalEncoding", num_feats=t["num_feats"],
+                                 normalize=True, offset=-0.5),
+        num_feature_levels=4, embed_dims=t["embed_dims"])
+    fixtures.seed_weights(real, seed)
+    real.eval()
+    feats, metas = fixtures.make_encoder_pyramid(seed)
+    with torch.no_grad():
+        outs = real([torch.from_numpy(f) for f in feats], metas)
+    out = {f"enc{i}": o.numpy() for i, o in enumerate(outs)}
+    out["state_keys"] = np.array(sorted(real.state_dict()))
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     cfg = fixtures.tiny_cfg()
@@ -210,6 +237,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "ref_glue.npz"), **glue_goldens())
     np.savez_compressed(os.path.join(GOLD, "ref_bboxes.npz"), **bbox_goldens())
     np.savez_compressed(os.path.join(GOLD, "ref_encoder.npz"), **encoder_goldens())
+    np.savez_compressed(os.path.join(GOLD, "ref_encoder256.npz"), **encoder256_goldens())
     print("golden vectors written to", GOLD)
 
 

@@ -11,14 +11,31 @@ from oracle.model import OracleDeMF, OracleImageStream
 
 pytestmark = pytest.mark.gpu
 
-STREAM = dict(base=16, blocks=(1, 1, 1, 1), embed_dims=64, num_layers=2, num_heads=8,
-              feedforward_channels=128, gn_groups=16, num_feats=32)
+# the image stream at the reference's encoder shape (256 dims, 8 heads, 4 levels, P = 4, FFN a multiple of 128): the
+# encoder then runs on this package's kernel path (rows_gemm + raw MSDA; DeformableDetrEncoder._fused_ok), so the
+# detector chain below exercises THAT path against the oracle, not the module path
+STREAM = dict(base=16, blocks=(1, 1, 1, 1), embed_dims=256, num_layers=2, num_heads=8,
+              feedforward_channels=256, gn_groups=32, num_feats=128)
 H, W = 128, 192
 PYRAMID = ((16, 24), (8, 12), (4, 6), (2, 3))
 
 
+def _cfg256():
+    """fixtures.tiny_cfg widened where the 256-channel image tokens meet the head."""
+    from demf_amd.config import BackboneCfg, DeMFCfg, HeadCfg
+    t = fixtures.tiny_cfg()
+    b = t.backbone
+    return DeMFCfg(
+        backbone=BackboneCfg(in_channels=4, num_points=b.num_points, radius=b.radius, num_samples=b.num_samples,
+                             sa_channels=b.sa_channels, fp_channels=((64, 64), (64, 256))),
+        head=HeadCfg(in_channels=256, shared_conv_channels=(32, 32), embed_dims=256, num_heads=8,
+                     num_levels=4, num_points=2, attn_dropout=0.0, feedforward_channels=128,
+                     ffn_dropout=0.0, vote_conv_channels=(64, 64), num_proposal=32,
+                     agg_radius=0.6, agg_num_sample=8, agg_mlp_channels=(256, 64, 64, 256)))
+
+
 def _inputs(seed, B=3, N=4096):
-    cfg = fixtures.tiny_cfg()
+    cfg = _cfg256()
     batch = fixtures.make_scene_batch(B, N, PYRAMID, (H, W), cfg.head.embed_dims, seed=seed, n_gt=4)
     rng = np.random.default_rng(seed)
     img = rng.standard_normal((B, 3, H, W)).astype(np.float32)
@@ -70,6 +87,7 @@ def _assert_same_detections(got, want, tol=1e-3):
 def test_simple_test_vs_oracle_chain():
     cfg, batch, img = _inputs(3)
     det, ref_img, ref = _models(cfg, 3)
+    assert det.img_encoder._fused_ok(torch.empty(3, 10, 256, device="cuda")), "encoder kernel path not taken"
     det.eval()
     ref.eval()
     pts = torch.from_numpy(batch["points"])

@@ -216,3 +216,91 @@ def test_msda_raw_matches_the_composed_operator():
         want = ops.MultiScaleDeformableAttnFunction.apply(value, shp, lsi, loc.contiguous(), w.contiguous(), 64)
         err = (out.view(B, S, -1) - want).abs().max().item()
         assert err <= 1e-5 * max(1.0, want.abs().max().item()), (P, err)
+
+
+def _enc256(seed, **over):
+    from demf_amd.modules.image_stream import DeformableDetrEncoder
+    kw = dict(fixtures.ENC256)
+    kw.update(over)
+    enc = DeformableDetrEncoder(**kw)
+    fixtures.seed_weights(enc, seed)
+    return enc.cuda().eval()
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_fused_encoder_vs_real_reference_encoder_256(golden_dir, mode):
+    """The KERNEL path (demf_rows_gemm_f32 + demf_msda_fwd_raw_f32 - the default at embed_dims = 256, i.e. what
+    bench.py's image-stream leg and DeMFVoteNet run) against the REAL reference DeformableDetrEncoder at the
+    reference's own encoder shape (256 dims, 8 heads, 4 levels, P = 4, FFN 1024, two layers;
+    tests/golden/ref_encoder256.npz from oracle/pin_reference.py: encoder256_goldens): 1e-4 of the output scale on
+    image positions in the fp32-grade mode, the bf16 bound of the decoder's GEMM tests in bf16 mode."""
+    from demf_amd import ops
+    gold = np.load(os.path.join(golden_dir, "ref_encoder256.npz"))
+    enc = _enc256(6)
+    assert sorted(enc.state_dict()) == list(gold["state_keys"])
+    feats, metas = fixtures.make_encoder_pyramid(6)
+    x = [torch.from_numpy(f).cuda() for f in feats]
+    ops.set_compute_dtype(mode)
+    try:
+        assert enc._fused_ok(torch.empty(2, 10, 256, device="cuda")), "the kernel path must be the one under test"
+        calls = _count_calls(("demf_rows_gemm_f32", "demf_msda_fwd_raw_f32"))
+        with calls:
+            outs = enc(x, metas)
+        assert calls.n["demf_msda_fwd_raw_f32"] == 2 and calls.n["demf_rows_gemm_f32"] >= 8, calls.n
+    finally:
+        ops.set_compute_dtype("f32")
+    for i, o in enumerate(outs):
+        _assert_close_on_image(o.cpu(), torch.from_numpy(gold[f"enc{i}"]), metas, 1e-4 if mode == "f32" else 3e-2)
+
+
+class _count_calls:
+    """Counts _ffi.call launches by entry-point name while active (proof of which path ran)."""
+
+    def __init__(self, names):
+        self.n = {k: 0 for k in names}
+
+    def __enter__(self):
+        from demf_amd import _ffi
+        self._ffi, self._orig = _ffi, _ffi.call
+
+        def call(name, *a, **k):
+            if name in self.n:
+                self.n[name] += 1
+            return self._orig(name, *a, **k)
+        _ffi.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self._ffi.call = self._orig
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_fused_encoder_full_size_vs_oracle(mode):
+    """forward_tokens on the kernel path at the PRODUCTION shape - B = 2, 100x140 ... 13x18 (S = 18 609; 37 218 rows =
+    290 full 128-row tiles + a 98-row one), six layers, padded scene - against the CPU oracle's encoder
+    (oracle/model.py: OracleEncoder, pinned bit-exact to the REAL class by tests/test_oracle_model.py) on the same
+    neck pyramid and weights: 1e-4 of the output scale on image positions (f32 mode), the bf16 bound (bf16 mode)."""
+    from demf_amd import ops
+    from demf_amd.config import BATCH_INPUT_SHAPE, PYRAMID_SHAPES
+    kw = dict(fixtures.ENC256, num_layers=6)
+    ref = fixtures.oracle_encoder(**kw)
+    fixtures.seed_weights(ref, 8)
+    ref.eval()
+    feats, metas = fixtures.make_encoder_pyramid(8, B=2, shapes=PYRAMID_SHAPES, input_hw=BATCH_INPUT_SHAPE)
+    with torch.no_grad():
+        want = ref([torch.from_numpy(f) for f in feats], metas)
+    enc = _enc256(8, num_layers=6)
+    x = [torch.from_numpy(f).cuda() for f in feats]
+    ops.set_compute_dtype(mode)
+    try:
+        assert enc._fused_ok(torch.empty(2, 18609, 256, device="cuda"))
+        tok = enc.forward_tokens(x, metas)
+    finally:
+        ops.set_compute_dtype("f32")
+    assert tok["spatial"] == [tuple(s) for s in PYRAMID_SHAPES]
+    got, start = tok["tokens"].permute(0, 2, 1), 0
+    for w, (h, wd) in zip(want, PYRAMID_SHAPES):
+        g = got[:, :, start:start + h * wd].reshape(2, 256, h, wd)
+        start += h * wd
+        _assert_close_on_image(g.cpu(), w, metas, 1e-4 if mode == "f32" else 3e-2)
+    assert torch.isfinite(tok["tokens"]).all()

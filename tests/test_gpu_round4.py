@@ -305,3 +305,36 @@ def test_deferred_weight_gradients_reach_every_parameter():
     for n in a:
         s = a[n].abs().max().item()
         assert (a[n] - b[n]).abs().max().item() <= 1e-4 * max(s, 1e-6), n
+
+
+def test_deferred_weight_gradients_with_a_weight_used_by_two_nodes():
+    """A shared MLP called twice inside ops.deferred_weight_grads(): the autograd engine sums the two weight
+    gradients the moment the second node returns, so both products must have been ISSUED by then (a repeated
+    parameter flushes the queue and runs at once - ops.dw_job); nested contexts join the outer queue."""
+    from demf_amd import ops
+    from demf_amd.modules.layers import RowsMLP
+    torch.manual_seed(2)
+    mlp = RowsMLP([64, 64, 64], dim=1).cuda().train()
+    xa, xb = torch.randn(512, 64, device="cuda"), torch.randn(768, 64, device="cuda")
+
+    def run(defer):
+        old, ops._DEFER_DW = ops._DEFER_DW, defer
+        try:
+            for p in mlp.parameters():
+                p.grad = None
+            with ops.deferred_weight_grads():
+                with ops.deferred_weight_grads():          # re-entrant: the inner exit neither flushes nor switches off
+                    pass
+                assert ops.DEFER.on
+                loss = mlp.forward_rows(xa).square().sum() + 0.5 * mlp.forward_rows(xb).sum()
+                loss.backward()
+            assert not ops.DEFER.on and not ops.DEFER.jobs and not ops.DEFER.leaves
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in mlp.named_parameters() if p.grad is not None}
+        finally:
+            ops._DEFER_DW = old
+    a, b = run(0), run(1)
+    assert a.keys() == b.keys()
+    for n in a:
+        s = a[n].abs().max().item()
+        assert s > 0 and (a[n] - b[n]).abs().max().item() <= 1e-4 * s, n

@@ -137,3 +137,23 @@ def test_oracle_image_stream_vs_real_encoder(golden_dir):
         np.testing.assert_array_equal(p.detach().numpy(), gold[f"neck{i}"])
     for i, o in enumerate(m(torch.from_numpy(img), metas)):
         np.testing.assert_array_equal(o.numpy(), gold[f"enc{i}"])
+
+
+def test_oracle_encoder_vs_real_encoder_at_the_reference_shape(golden_dir):
+    """The same at the reference's own encoder shape (configs/demf/demf_votenet.py:28-47: 256 dims, 8 heads,
+    4 levels, 4 points, FFN 1024): tests/golden/ref_encoder256.npz is the REAL class's output on
+    fixtures.make_encoder_pyramid(6); the oracle's restatement reproduces it bit for bit."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import fixtures
+    gold = np.load(os.path.join(golden_dir, "ref_encoder256.npz"))
+    enc = fixtures.oracle_encoder(**fixtures.ENC256)
+    assert sorted(enc.state_dict()) == list(gold["state_keys"])
+    fixtures.seed_weights(enc, 6)
+    enc.eval()
+    feats, metas = fixtures.make_encoder_pyramid(6)
+    with torch.no_grad():
+        outs = enc([torch.from_numpy(f) for f in feats], metas)
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o.numpy(), gold[f"enc{i}"])
