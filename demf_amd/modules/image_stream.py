@@ -241,8 +241,9 @@ class DeformableDetrEncoder(nn.Module):
                     and len(layer.norms) == 2 and not layer.training):
                 return False
             a, f = layer.attentions[0], layer.ffns[0]
-            if not (type(f) is FFN and len(f.layers) == 2 and isinstance(f.layers[0][0], nn.Linear)
-                    and isinstance(f.layers[0][1], nn.ReLU) and isinstance(f.layers[1], nn.Linear)):
+            if not (type(f) is FFN and len(f.layers) == 3 and isinstance(f.layers[0][0], nn.Linear)
+                    and isinstance(f.layers[0][1], nn.ReLU) and isinstance(f.layers[1], nn.Linear)
+                    and isinstance(f.layers[2], nn.Dropout)):
                 return False
             if not all(isinstance(n, nn.LayerNorm) and tuple(n.normalized_shape) == (256,) for n in layer.norms):
                 return False
