@@ -401,12 +401,21 @@ class Trainer:
         else:
             G, gt, lab = None, batch["gt_bboxes_3d"], batch["gt_labels_3d"]
         feats = batch["img_features"]
+        head = getattr(self.model, "pts_bbox_head", None)
+        # A pyramid handed over as the reference's list of (B,C,H_l,W_l) maps: the captured step reads TOKENS
+        # (channels-last rows, padding zeroed) from a static buffer, and ``load`` converts every new batch
+        # straight out of the caller's maps into that buffer (one tiled-transpose launch) - instead of copying
+        # the 152 MB pyramid into static maps and transposing those inside the graph.
+        tok_static = None
+        if (not isinstance(feats, dict) and dev.type == "cuda" and hasattr(head, "pyramid_tokens")
+                and int(os.environ.get("DEMF_ZERO_COPY_TOKENS", "1"))):
+            tok_static = head.pyramid_tokens(feats, batch["img_metas"])
         static = dict(points=batch["points"].clone(),
-                      img_features=(dict(feats, tokens=feats["tokens"].clone())
+                      img_features=(tok_static if tok_static is not None else
+                                    dict(feats, tokens=feats["tokens"].clone())
                                     if isinstance(feats, dict) else [f.clone() for f in feats]),
                       img_metas=batch["img_metas"], gt_bboxes_3d=gt, gt_labels_3d=lab)
         batch = static
-        head = getattr(self.model, "pts_bbox_head", None)
         if head is not None and hasattr(head, "pin_metas"):
             head.pin_metas(static["img_metas"])     # the graph holds raw pointers into its cache entry
         side = self.side_stream if getattr(self, "side_stream", None) is not None else torch.cuda.Stream()
@@ -527,7 +536,16 @@ class Trainer:
                 geo.ensure(torch.cuda.current_stream(), new["points"], static["points"])
             static["points"].copy_(new["points"])
             nf = new["img_features"]
-            if isinstance(nf, dict):
+            metas_done = False
+            if tok_static is not None and not isinstance(nf, dict):
+                # the padding mask the conversion zeroes by is the NEW batch's: constants first
+                head.refresh_metas(static["img_metas"], new["img_metas"])
+                metas_done = True
+                head.pyramid_tokens(nf, static["img_metas"], out=tok_static)
+            elif isinstance(nf, dict):
+                if tok_static is not None and not nf.get("padding_zeroed"):
+                    raise ValueError("this step was captured on a pyramid of feature maps: load() takes maps "
+                                     "(or tokens built by DeMFVoteHead.pyramid_tokens)")
                 static["img_features"]["tokens"].copy_(nf["tokens"])
             else:
                 for d, f in zip(static["img_features"], nf):
@@ -539,7 +557,7 @@ class Trainer:
             else:
                 static["gt_bboxes_3d"].copy_(new["gt_bboxes_3d"])
                 static["gt_labels_3d"].copy_(new["gt_labels_3d"])
-            if head is not None and hasattr(head, "refresh_metas"):
+            if not metas_done and head is not None and hasattr(head, "refresh_metas"):
                 head.refresh_metas(static["img_metas"], new["img_metas"])
 
         replay.load = load

@@ -347,18 +347,48 @@ class DeMFVoteHead(nn.Module):
         return torch.clamp(uv, 0, 1)
 
     # ---- :549-594 ------------------------------------------------------------
+    def _sample_first(self, on_gpu, C0, S):
+        """The decoder samples far fewer corners than there are tokens: keep the tokens unprojected
+        (padding rows zeroed) and project after sampling (ops.msda_sample_then_project); no
+        (B,S,C) value tensor per decoder layer."""
+        att = self.decoder[0].layer.attentions[1]
+        samples = self.num_proposal * att.num_levels * att.num_points * 4
+        return bool(on_gpu and samples < S and C0 % 4 == 0 and C0 <= 256)
+
+    def pyramid_tokens(self, mlvl_feats, img_metas, out=None):
+        """The image pyramid [(B,C,H_l,W_l)] as the tokens ``prepare_image_inputs`` would build from it
+        (:570-591: flatten + concat; here one tiled-transpose launch with the padding rows zeroed, bf16 rows in
+        the bf16 compute mode) in the dict form that ``forward`` / ``prepare_image_inputs`` accept in place of
+        the pyramid - or None where that form does not apply (CPU tensors, a pyramid that needs a gradient,
+        project-then-sample).  ``out``: the dict of an earlier call - its token buffer is overwritten in place:
+        a captured step (engine.Trainer.capture) converts each new batch straight out of the caller's tensors
+        into its static token buffer instead of copying the 152 MB pyramid into static maps first and
+        converting inside the graph."""
+        feats = list(mlvl_feats)
+        on_gpu = feats[0].is_cuda and not any(f.requires_grad for f in feats) and all(f.is_contiguous() for f in feats)
+        spatial = [tuple(f.shape[-2:]) for f in feats]
+        S = sum(h * w for h, w in spatial)
+        if not self._sample_first(on_gpu, feats[0].shape[1], S) or feats[0].dtype != torch.float32:
+            return None
+        mt = self._meta_tensors(img_metas, spatial, feats[0].device, feats[0].dtype)
+        bf16 = BF16_TOKENS and ops.get_compute_dtype() == "bf16"
+        if out is not None and list(out["spatial"]) != spatial:
+            raise ValueError("pyramid_tokens: `out` holds levels %s, the pyramid has %s" % (out["spatial"], spatial))
+        tokens = ops.pyramid_to_tokens(feats, mt["mask_u8"], bf16=bf16, out=None if out is None else out["tokens"])
+        return out if out is not None else dict(tokens=tokens, spatial=spatial, padding_zeroed=True)
+
     def prepare_image_inputs(self, mlvl_feats, img_metas):
         """The part of prepare_decoder_inputs (:556-594) that depends only on the image pyramid:
         padding masks, flattened tokens, valid ratios - plus the per-layer value projection of
         the fusion attention.  Independent of the point stream, so the detector runs it on a
         side stream while furthest-point sampling occupies 8 of the 256 CUs."""
-        att = self.decoder[0].layer.attentions[1]
-        samples = self.num_proposal * att.num_levels * att.num_points * 4
+        prepared = False
         if isinstance(mlvl_feats, dict):
             # channels-last tokens (B,S,C) straight from demf_amd.modules.ImageStream.tokens():
             # no flatten + concat copy of the pyramid (:570-591)
             spatial, feat_flatten = list(mlvl_feats["spatial"]), mlvl_feats["tokens"]
             on_gpu, C0 = feat_flatten.is_cuda and not feat_flatten.requires_grad, feat_flatten.shape[2]
+            prepared = bool(mlvl_feats.get("padding_zeroed"))       # built by pyramid_tokens
         else:
             spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
             feat_flatten = None
@@ -367,13 +397,14 @@ class DeMFVoteHead(nn.Module):
             C0 = mlvl_feats[0].shape[1]
         dev = mlvl_feats["tokens"].device if isinstance(mlvl_feats, dict) else mlvl_feats[0].device
         dt = mlvl_feats["tokens"].dtype if isinstance(mlvl_feats, dict) else mlvl_feats[0].dtype
+        if dt == torch.bfloat16:                 # bf16 token rows (bf16 compute mode): the constants stay fp32
+            dt = torch.float32
         mt = self._meta_tensors(img_metas, spatial, dev, dt)
         mask_flatten, valid_ratios = mt["mask_flatten"], mt["valid_ratios"]
         S = mask_flatten.shape[1]
-        # the decoder samples far fewer corners than there are tokens: keep the tokens unprojected
-        # (padding rows zeroed) and project after sampling (ops.msda_sample_then_project); no
-        # (B,S,C) value tensor per decoder layer
-        sample_first = on_gpu and samples < S and C0 % 4 == 0 and C0 <= 256
+        sample_first = self._sample_first(on_gpu, C0, S)
+        if prepared and not sample_first:
+            raise ValueError("tokens with zeroed padding rows serve the sample-then-project attention only")
         if feat_flatten is None:
             if on_gpu:           # tiled transposes; the padding mask rides along when wanted
                 # (bf16 compute mode, sample-then-project: the tokens are an operand of nothing but the gather
@@ -383,7 +414,7 @@ class DeMFVoteHead(nn.Module):
                                                      ops.get_compute_dtype() == "bf16")
             else:
                 feat_flatten = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)
-        elif sample_first:
+        elif sample_first and not prepared:
             feat_flatten = feat_flatten.masked_fill(mask_flatten.unsqueeze(-1), 0.0)
         value_tokens = (feat_flatten, mt["keep4"]) if sample_first else None
         value_projected = None

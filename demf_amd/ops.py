@@ -1798,16 +1798,21 @@ def split_points(points):
     return xyz, feat
 
 
-def pyramid_to_tokens(mlvl_feats, zero_mask=None, bf16=False):
+def pyramid_to_tokens(mlvl_feats, zero_mask=None, bf16=False, out=None):
     """list of (B,C,H_l,W_l) -> (B, sum H_l W_l, C) channels-last tokens (no gradient: the image
     pyramid is an input of the hot path).  ``zero_mask`` (B,S) bool: tokens to write as zeros
     (image padding), fused into the transposes.  ``bf16``: bf16 token rows (the bf16 compute mode's
-    sample-then-project attention gathers them with demf_msda_*_bf16: half the bytes)."""
+    sample-then-project attention gathers them with demf_msda_*_bf16: half the bytes).  ``out``: an
+    existing token buffer of that shape / dtype to write into (the static input of a captured step)."""
     B, C = mlvl_feats[0].shape[:2]
     sizes = [f.shape[2] * f.shape[3] for f in mlvl_feats]
     S = sum(sizes)
     bf16 = bool(bf16) and C % 4 == 0 and len(sizes) <= 8
-    out = torch.empty((B, S, C), dtype=torch.bfloat16 if bf16 else torch.float32, device=mlvl_feats[0].device)
+    if out is None:
+        out = torch.empty((B, S, C), dtype=torch.bfloat16 if bf16 else torch.float32, device=mlvl_feats[0].device)
+    elif not (out.is_contiguous() and tuple(out.shape) == (B, S, C) and out.device == mlvl_feats[0].device
+              and out.dtype == (torch.bfloat16 if bf16 else torch.float32)):
+        raise ValueError("pyramid_to_tokens: `out` must be a contiguous (B,S,C) tensor of the token dtype")
     m = None if zero_mask is None else \
         (zero_mask if zero_mask.dtype == torch.uint8 else zero_mask.to(torch.uint8)).contiguous()
     for f in mlvl_feats:

@@ -157,3 +157,47 @@ def test_oracle_encoder_vs_real_encoder_at_the_reference_shape(golden_dir):
         outs = enc([torch.from_numpy(f) for f in feats], metas)
     for i, o in enumerate(outs):
         np.testing.assert_array_equal(o.numpy(), gold[f"enc{i}"])
+
+
+def test_oracle_vs_real_head_on_conditioned_weights(golden_dir):
+    """tests/golden/ref_head_cond.npz: the REAL reference head on CONDITIONED weights (200 AdamW steps of the fp64
+    oracle, oracle/pin_reference.py: conditioned_goldens) and a held-out batch.  The fp32 oracle reproduces its decode
+    outputs, losses and EVERY parameter gradient to fp32 round-off - the pin of the checker the GPU test
+    (tests/test_gpu_model.py: test_hot_path_on_conditioned_weights) then leans on."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import fixtures
+    from oracle.model import OracleDeMF
+    from oracle.pin_reference import COND as c
+    gold = np.load(os.path.join(golden_dir, "ref_head_cond.npz"))
+    cfg = fixtures.tiny_cfg()
+    batch = fixtures.make_scene_batch(c["B"], c["N"], fixtures.TINY_PYRAMID, fixtures.TINY_INPUT,
+                                      cfg.head.embed_dims, seed=c["eval_seed"], n_gt=c["n_gt"])
+    m = OracleDeMF(cfg)
+    m.load_state_dict({k[2:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("w.")})
+    m.train()
+    gtb = [torch.from_numpy(gold[f"gt_boxes.{b}"]) for b in range(c["B"])]
+    gtl = [torch.from_numpy(gold[f"gt_labels.{b}"]) for b in range(c["B"])]
+    losses, preds, _ = m.forward_train(torch.from_numpy(batch["points"]),
+                                       [torch.from_numpy(f) for f in batch["img_features"]],
+                                       batch["img_metas"], gtb, gtl)
+    for k in ("seed_indices", "aggregated_indices"):
+        np.testing.assert_array_equal(preds[k].numpy(), gold[k])
+    for i, d in enumerate(preds["decode_res_all"]):
+        for k, v in d.items():
+            if torch.is_tensor(v):
+                np.testing.assert_allclose(v.detach().numpy(), gold[f"decode{i}.{k}"], rtol=0, atol=2e-5, err_msg=k)
+    for k, v in losses.items():
+        np.testing.assert_allclose(v.item(), gold["loss." + k], rtol=1e-5, err_msg=k)
+    sum(losses.values()).backward()
+    top = max(float(np.linalg.norm(gold[k])) for k in gold.files if k.startswith("grad.pts_"))
+    n = 0
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        want = gold["grad." + name].astype(np.float64)
+        err = np.linalg.norm(p.grad.double().numpy() - want)
+        assert err <= 1e-4 * np.linalg.norm(want) + 1e-9 * top, (name, err, np.linalg.norm(want))
+        n += 1
+    assert n == len(gold["grad_names"])
