@@ -312,6 +312,12 @@ def main():
     ap.add_argument("--cu-mask", action="store_true",
                     help="pin the FPS pre-pass to its own CUs (hipExtStreamCreateWithCUMask); measured: "
                          "no effect under hipGraph replay, off by default")
+    ap.add_argument("--allreduce-stub-us", type=int, default=0,
+                    help="replace the gradient all-reduce by a spin kernel of this many microseconds "
+                         "(measures the engine's communication / compute overlap on one GPU)")
+    ap.add_argument("--allreduce-overlap", action="store_true",
+                    help="issue the collective on a communication stream and defer norm + AdamW to the start of the "
+                         "next step (default: on the step's own stream, the update right behind it)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (resident / bf16 / P=4 / clustered / B=16 step times, SA path)")
     args = ap.parse_args()
@@ -347,6 +353,9 @@ def main():
         cfg = dataclasses.replace(cfg, head=dataclasses.replace(cfg.head, num_points=args.msda_points))
     model = DeMFHotPath(cfg).to(device).train()
     trainer = engine.Trainer(model)
+    trainer.allreduce_stub_us = args.allreduce_stub_us
+    if args.allreduce_overlap:
+        trainer.allreduce_overlap = True
     # The training loop's data: NB distinct batches per rank (weak scaling: B scenes per GPU, distinct
     # seeds per rank), every one with its own per-scene GT counts - a real loader never repeats a
     # count signature, and the per-batch input path (target padding, meta refresh, static-buffer
@@ -417,13 +426,14 @@ def main():
             step()
         sync()
         repeats.append(1000.0 * (time.perf_counter() - t1) / args.steps)
+    trainer.flush()               # (overlapped collective: the last step's norm + AdamW are still owed)
     # a throughput figure over non-finite arithmetic would be meaningless: refuse to report it
     if not bool(torch.isfinite(trainer.flat.flat).all()) or \
             not all(bool(torch.isfinite(p).all()) for p in model.parameters()):
         raise RuntimeError("non-finite gradients/parameters after the timed steps")
     # the collective's own time (HIP events around the all-reduce of the flat 8.76 MB buffer)
     allreduce_us = None
-    if world > 1:
+    if world > 1 or args.allreduce_stub_us > 0:
         trainer.allreduce_events = []
         for _ in range(min(args.steps, 10)):
             step()
@@ -462,6 +472,20 @@ def main():
             secondary["ms_per_step_with_load"] = time_steps(step_loop, args.steps)
         else:
             secondary["ms_per_step_resident"] = time_steps(step_resident, args.steps)
+        # (a2) the collective's overlap, measured on ONE GPU: a 100 us spin kernel (demf_spin_us) stands in for the
+        # all-reduce (the size class RCCL needs for 8.76 MB over xGMI) - on the step's own stream
+        # with the update right behind it (serial), and on the communication stream with the update deferred behind
+        # the next batch's input path (the engine's default for world > 1)
+        if not args.resident and args.allreduce_stub_us == 0:
+            trainer.allreduce_stub_us = 100
+            trainer.allreduce_overlap = False
+            secondary["allreduce_stub100us_serial_ms_per_step"] = time_steps(step_loop, args.steps)
+            trainer.flush()
+            trainer.allreduce_overlap = True
+            secondary["allreduce_stub100us_overlapped_ms_per_step"] = time_steps(step_loop, args.steps)
+            trainer.flush()
+            trainer.allreduce_stub_us, trainer.allreduce_overlap = 0, None
+            torch.cuda.synchronize()
         # (b) the other BASELINE configurations on the same process / box, resident replay each: configs[3]
         # per GPU (bf16 compute mode), BASELINE's "8 heads x 4 points" wording (P = 4; the reference config
         # is 2), the other cloud distribution and the reference's own per-GPU batch
@@ -504,8 +528,8 @@ def main():
                 secondary["b16_scenes_per_s"] = d16["value"]
             except Exception:
                 secondary["b16_ms_per_step"] = float("nan")
-        # (d) SURVEY 8(f) rank 1 / 8(d) "secondary = e2e": the frozen image stream (ResNet-50 + ChannelMapper as
-        # library convolutions, the six encoder layers on csrc/rows_gemm.hip + the MSDA kernel) in front of the step
+        # (d) SURVEY 8(f) rank 1 / 8(d) "secondary = e2e": the frozen image stream (ResNet-50 + ChannelMapper on
+        # csrc/conv.hip, the six encoder layers on csrc/rows_gemm.hip + the MSDA kernel) in front of the step
         def image_stream_secondary():
             from demf_amd.modules import ImageStream
             from demf_amd.config import BATCH_INPUT_SHAPE
@@ -513,8 +537,14 @@ def main():
             img = torch.randn(args.batch, 3, *BATCH_INPUT_SHAPE, device=device)
             for _ in range(2):
                 ist.tokens(img, batch["img_metas"])
-            pyr = ist._pyramid(img)
-            secondary["image_backbone_neck_ms"] = time_steps(lambda: ist._pyramid(img), 5)
+            pyr = ist.pyramid(img)
+            secondary["image_backbone_neck_path"] = "csrc/conv.hip (implicit-GEMM NHWC convolutions)" \
+                if isinstance(pyr, dict) else "library convolutions (MIOpen)"
+            secondary["image_backbone_neck_ms"] = time_steps(lambda: ist.pyramid(img), 5)
+            if isinstance(pyr, dict):
+                secondary["image_backbone_neck_library_ms"] = time_steps(lambda: ist._pyramid(img), 5)
+                # ResNet-50 + ChannelMapper at 800 x 1120: 77.0 GMAC per image
+                secondary["image_backbone_neck_tflops"] = 2 * 77.0e9 * args.batch / secondary["image_backbone_neck_ms"] * 1e-9
             secondary["image_encoder_ms"] = time_steps(lambda: ist.img_encoder.forward_tokens(pyr, batch["img_metas"]), 5)
             # its linear layers: 6 layers x 2 x rows x (256 x (640 + 256) + 2 x 256 x 1024) flop (csrc/rows_gemm.hip)
             enc_flop = 6 * 2.0 * args.batch * sum(h * w for h, w in PYRAMID_SHAPES) * (256 * 896 + 2 * 256 * 1024)
@@ -598,6 +628,14 @@ def main():
         if allreduce_us is not None:
             # HIP events around the one all-reduce of the flat 8.76 MB gradient buffer (rank 0's view)
             out["allreduce_us"] = allreduce_us
+        w_, stub_, ov_ = trainer.allreduce_config()
+        out["allreduce"] = {
+            "buckets_bytes": [int(trainer.flat.flat.numel()) * 4], "collective": "one flat all-reduce (SUM), "
+            "1/world folded into AdamW", "world": w_, "stub_us": stub_, "overlap": bool(ov_),
+            "overlap_how": "issued on a communication stream behind the step's graph; norm + AdamW are enqueued at "
+                           "the start of the next step, so the collective runs underneath the next batch's input "
+                           "path (replay.load) and pre-pass launch" if ov_ else None,
+            "us": allreduce_us}
         if rank_info is not None:
             out["ranks"] = [dict(rank=r["rank"], batch_seeds=r["batch_seeds"], dropout_seed=r["dropout_seed"])
                             for r in rank_info]

@@ -59,3 +59,17 @@ extern "C" int demf_stream_create_cu_masked(const int* cus, int n, int invert, v
   *out = (void*)s;
   return DEMF_OK;
 }
+
+namespace demf {
+// wall_clock64 ticks at 100 MHz on gfx9: 100 ticks per microsecond
+__global__ __launch_bounds__(64) void spin_us_k(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace demf
+
+extern "C" int demf_spin_us(int microseconds, demf_stream_t stream) {
+  DEMF_REQUIRE(microseconds >= 0 && microseconds <= 1000000, "spin_us: %d us out of range", microseconds);
+  hipLaunchKernelGGL(demf::spin_us_k, dim3(1), dim3(64), 0, (hipStream_t)stream, 100ll * microseconds);
+  return demf::check_launch("spin_us_k");
+}

@@ -1,0 +1,379 @@
+// Convolutions of the frozen image stream on gfx950: implicit GEMM over channels-last (NHWC) activations.
+//
+// Reference: mmdet ResNet-50 (pytorch style, frozen BatchNorm, out_indices 1-3) + ChannelMapper (1x1 / 3x3 s2
+// convolutions + GroupNorm(32)) as the reference configures them in configs/deformdetr/imvotenet_image.py:3-20 and
+// runs them, under no_grad and in eval mode, at demf/modeling/detectors/demfnet.py:124-132.  Upstream these are
+// library convolutions (cuDNN there, MIOpen on ROCm: 16.5 ms at 8 x 3 x 800 x 1120 fp32, the largest block of the
+// end-to-end step since round 4).
+//
+// Here a convolution is the long-row GEMM of csrc/rows_gemm.hip with the A rows GATHERED: output pixel
+// p = (b, ho, wo) is GEMM row p, the reduction index runs over (kh, kw, c) and a 32-wide reduction step lies inside
+// ONE tap (Cin % 32 == 0), so the A tile of a step is, per row, 128 contiguous bytes of the input pixel
+// (ho*s - pad + kh, wo*s - pad + kw) - or zeros outside the image.  Nothing is unfolded in memory.  128-row x
+// (128 | 64)-column tiles, 4 waves as 2 x 2, K steps of 32 through one LDS stage, three workgroups per CU
+// rotating through load / split / MFMA; fp32-grade arithmetic is the three-term split (x = h + m + l in bf16,
+// six products on v_mfma_f32_32x32x16_bf16, fp32 accumulate - csrc/mlp.hip), the frozen weights arrive pre-split
+// as bf16 planes (P, Cout, KH*KW*Cin) with the BatchNorm scale folded in; P = 1 is the bf16 compute mode.
+// Epilogue: folded-BN bias, the bottleneck's residual add, ReLU.
+// The 7x7 stride-2 stem (Cin = 3) reads the image as NHWC4 (a zero fourth channel): one reduction step = one
+// kernel ROW = 8 pixels x 4 channels = 128 contiguous bytes starting at (ho*2 - 3 + kh, wo*2 - 3); the weight
+// has zeros at kw = 7 and c = 3, so the same tile loop serves it with K = 7 * 32.
+// Also here: the 3x3 stride-2 max-pool, NCHW -> NHWC4 of the input image, and GroupNorm over NHWC rows written
+// straight into the encoder's token buffer (B, S, 256) - the channels-last hand-over needs no transposition.
+#include "common.h"
+
+namespace demf {
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+using f32x2 = float __attribute__((ext_vector_type(2)));
+using bf16x8 = __bf16 __attribute__((ext_vector_type(8)));
+using bf16x2 = __bf16 __attribute__((ext_vector_type(2)));
+using u32x4 = unsigned __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  int B, H, W, Cin;          // input (B, H, W, Cin) fp32; STEM: (B, H, W, 4)
+  int Ho, Wo, Cout;
+  int KH, KW, stride, pad;
+  int K;                     // reduction length: KH * KW * Cin (STEM: KH * 32)
+  const float* X;
+  const __bf16* Wp;          // (P, Cout, K) bf16 planes
+  const float* bias;         // (Cout) or null
+  const float* resid;        // (B*Ho*Wo, Cout) or null: added before the ReLU
+  int relu;
+  float* Y;                  // (B*Ho*Wo, Cout)
+};
+
+template <int P>
+__device__ __forceinline__ void cv_split_pair(float a, float b, unsigned (&o)[P]) {
+  const f32x2 x = {a, b};
+  const bf16x2 h = __builtin_convertvector(x, bf16x2);
+  o[0] = __builtin_bit_cast(unsigned, h);
+  if constexpr (P == 3) {
+    const f32x2 r = x - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r, bf16x2);
+    o[1] = __builtin_bit_cast(unsigned, m);
+    const f32x2 l = r - __builtin_convertvector(m, f32x2);
+    o[2] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, bf16x2));
+  }
+}
+// 64-byte plane rows, 16-byte chunks XOR-swizzled by bits 2-3 of the row (as rg_swz in csrc/rows_gemm.hip)
+__device__ __forceinline__ int cv_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int P>
+__device__ __forceinline__ void cv_mfma(f32x16& acc, const bf16x8 (&a)[P], const bf16x8 (&b)[P]) {
+  if constexpr (P == 3) {   // smallest products first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+constexpr int CV_BM = 128;
+
+// BN = 128: waves 2 x 2 of 64 x 64; BN = 64: waves 2 x 2 of 64 x 32.
+template <int P, int BN, bool STEM>
+__global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs p) {
+  constexpr int NTW = BN / 64;                  // 32-column tiles per wave
+  constexpr int NJ = BN / 64;                   // B staging: columns (t >> 2) + 64 j
+  constexpr int A_BYTES = CV_BM * 64, B_BYTES = BN * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lc = lane & 31, lh = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  // all column tiles of a row block on ONE XCD (its gathered A rows stay in that L2)
+  const int gx = p.Cout / BN;
+  const int L = blockIdx.x;
+  const int by = (L & 7) + 8 * (L / (8 * gx)), bx = (L >> 3) % gx;
+  const int M = p.B * p.Ho * p.Wo;
+  const int m0 = by * CV_BM, n0 = bx * BN;
+  if (m0 >= M) return;
+  // staging: A - float4 kq = t & 7 of rows (t >> 3) + 32 i; B - 16-byte chunk (t & 3) of columns (t >> 2) + 64 j
+  const int ar = t >> 3, akq = t & 7, bc = t >> 2, bch = t & 3;
+  // the thread's four output pixels: top-left input coordinate and its element offset (may be negative: only
+  // dereferenced where the tap lies inside the image)
+  int hi0[4], wi0[4];
+  long long off[4];
+  const int cpp = STEM ? 4 : p.Cin;             // floats per input pixel
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + ar + 32 * i;
+    if (row < M) {
+      const int b = row / (p.Ho * p.Wo), rem = row - b * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      hi0[i] = ho * p.stride - p.pad;
+      wi0[i] = wo * p.stride - p.pad;
+      off[i] = (((long long)b * p.H + hi0[i]) * p.W + wi0[i]) * cpp;
+    } else {
+      hi0[i] = -(1 << 20); wi0[i] = -(1 << 20); off[i] = 0;      // never inside the image
+    }
+  }
+  float4 ra[4];
+  u32x4 rb[P * NJ];
+  // the tap of a reduction step (uniform): advanced incrementally, 32 channels at a time
+  int f_kh = 0, f_kw = 0, f_c0 = 0;
+  auto fetch = [&](int k0) {
+    const long long tap = STEM ? (long long)f_kh * p.W * 4 : ((long long)f_kh * p.W + f_kw) * p.Cin + f_c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hi = hi0[i] + f_kh;
+      const int wi = STEM ? wi0[i] + akq : wi0[i] + f_kw;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+        ra[i] = *reinterpret_cast<const float4*>(p.X + off[i] + tap + 4 * akq);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        rb[q * NJ + j] = *reinterpret_cast<const u32x4*>(p.Wp + ((size_t)q * p.Cout + n0 + bc + 64 * j) * p.K + k0 + 8 * bch);
+    if constexpr (STEM) {
+      ++f_kh;
+    } else {
+      f_c0 += 32;
+      if (f_c0 == p.Cin) { f_c0 = 0; if (++f_kw == p.KW) { f_kw = 0; ++f_kh; } }
+    }
+  };
+  auto commit = [&]() {
+    char* sa = smem;
+    char* sb = sa + P * A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned lo[P], hi[P];
+      cv_split_pair<P>(ra[i].x, ra[i].y, lo);
+      cv_split_pair<P>(ra[i].z, ra[i].w, hi);
+      const int o = cv_swz(ar + 32 * i, akq >> 1) + 8 * (akq & 1);
+#pragma unroll
+      for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(sa + q * A_BYTES + o) = make_uint2(lo[q], hi[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        *reinterpret_cast<u32x4*>(sb + q * B_BYTES + cv_swz(bc + 64 * j, bch)) = rb[q * NJ + j];
+  };
+  f32x16 acc[2][NTW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  fetch(0);
+  for (int k0 = 0; k0 < p.K; k0 += 32) {
+    commit();
+    lds_barrier();
+    if (k0 + 32 < p.K) fetch(k0 + 32);
+    const char* sa = smem;
+    const char* sb = sa + P * A_BYTES;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bf16x8 pa[2][P];
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          pa[i][q] = *reinterpret_cast<const bf16x8*>(sa + q * A_BYTES + cv_swz(64 * wm + 32 * i + lc, 2 * c + lh));
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        bf16x8 pb[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          pb[q] = *reinterpret_cast<const bf16x8*>(sb + q * B_BYTES + cv_swz(32 * NTW * wn + 32 * j + lc, 2 * c + lh));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) cv_mfma<P>(acc[i][j], pa[i], pb);
+      }
+    }
+    lds_barrier();
+  }
+  // accumulator register r of tile (i, j) = row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 lh, column 32 NTW wn + 32 j + lc
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int col = n0 + 32 * NTW * wn + 32 * j + lc;
+    const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+          float v = acc[i][j][r] + bias;
+          if (p.resid != nullptr) v += p.resid[(size_t)row * p.Cout + col];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.Y[(size_t)row * p.Cout + col] = v;
+        }
+      }
+  }
+}
+
+template <int P, int BN, bool STEM>
+static int conv_launch(const ConvArgs& a, hipStream_t s) {
+  constexpr int lds = P * (CV_BM * 64 + BN * 64);
+  const int M = a.B * a.Ho * a.Wo;
+  const int gx = a.Cout / BN, gy = (cdiv(M, CV_BM) + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_nhwc_kernel<P, BN, STEM>), dim3(gx * gy), dim3(256), lds, s, a);
+  return check_launch("conv_nhwc_kernel");
+}
+
+// 3x3 stride-2 pad-1 max-pool over NHWC rows, one float4 of channels per thread
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(int B, int H, int W, int C, int Ho, int Wo,
+                                                           const float* __restrict__ x, float* __restrict__ y) {
+  const long long n = (long long)B * Ho * Wo * (C / 4);
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n) return;
+  const int c4 = (int)(id % (C / 4));
+  long long r = id / (C / 4);
+  const int wo = (int)(r % Wo); r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int b = (int)(r / Ho);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * H + hi) * W + wi) * C + 4 * c4);
+      m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    }
+  }
+  *reinterpret_cast<float4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + 4 * c4) = m;
+}
+
+// (B, 3, H, W) -> (B, H, W, 4) with a zero fourth channel
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_k(long long B, long long HW, const float* __restrict__ x,
+                                                        float* __restrict__ y) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * HW) return;
+  const long long b = id / HW, q = id - b * HW;
+  const float* s = x + b * 3 * HW + q;
+  *reinterpret_cast<float4*>(y + 4 * id) = make_float4(s[0], s[HW], s[2 * HW], 0.f);
+}
+
+// GroupNorm over channels-last rows (C = 256, G groups of C / G consecutive channels), two launches:
+// sums per (image, group) in double (one atomic pair per group per workgroup), then normalise + affine, written to
+// rows [row0, row0 + HW) of a (B, S, C) token buffer.
+__global__ __launch_bounds__(256) void gn_stats_nhwc_k(int HW, int C, int G, int rows_per_wg, const float* __restrict__ x,
+                                                       double* __restrict__ sums) {
+  const int b = blockIdx.y, c = threadIdx.x;                // one thread per channel (C == blockDim.x)
+  const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+  const float* p = x + ((size_t)b * HW) * C + c;
+  float s = 0.f, ss = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float v = p[(size_t)r * C];
+    s += v;
+    ss = __builtin_fmaf(v, v, ss);
+  }
+  // fold the C / G channels of a group: consecutive lanes
+  const int cg = C / G;
+  double ds = s, dss = ss;
+  for (int m = 1; m < cg; m <<= 1) {
+    ds += __shfl_xor(ds, m);
+    dss += __shfl_xor(dss, m);
+  }
+  if ((c % cg) == 0) {
+    atomicAdd(sums + ((size_t)b * G + c / cg) * 2, ds);
+    atomicAdd(sums + ((size_t)b * G + c / cg) * 2 + 1, dss);
+  }
+}
+__global__ __launch_bounds__(256) void gn_apply_nhwc_k(int HW, int C, int G, float eps, const float* __restrict__ x,
+                                                       const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       long long y_batch_stride) {
+  const int b = blockIdx.y;
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index inside the image
+  if (id >= (long long)HW * (C / 4)) return;
+  const int c = 4 * (int)(id % (C / 4));
+  const int cg = C / G, g = c / cg;
+  const double n = (double)HW * cg;
+  const double mean = sums[((size_t)b * G + g) * 2] / n;
+  const double var = sums[((size_t)b * G + g) * 2 + 1] / n - mean * mean;
+  const float mu = (float)mean, rstd = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)b * HW * C + 4 * id);
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
+  const float4 b4 = *reinterpret_cast<const float4*>(beta + c);
+  float4 o;
+  o.x = (v.x - mu) * rstd * g4.x + b4.x; o.y = (v.y - mu) * rstd * g4.y + b4.y;
+  o.z = (v.z - mu) * rstd * g4.z + b4.z; o.w = (v.w - mu) * rstd * g4.w + b4.w;
+  *reinterpret_cast<float4*>(y + (size_t)b * y_batch_stride + 4 * id) = o;
+}
+
+}  // namespace demf
+
+using namespace demf;
+
+extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                                  const float* x, const void* w_planes, int planes, const float* bias,
+                                  const float* resid, int relu, float* y, demf_stream_t stream) {
+  DEMF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 &&
+               x != nullptr && w_planes != nullptr && y != nullptr, "conv_nhwc: bad arguments");
+  DEMF_REQUIRE(planes == 1 || planes == 3, "conv_nhwc: planes must be 1 (bf16) or 3 (fp32 as three bf16 terms)");
+  DEMF_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "conv_nhwc: Cin %% 32 and Cout %% 64 required (Cin = %d, Cout = %d)", Cin, Cout);
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.Ho = (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  DEMF_REQUIRE(a.Ho > 0 && a.Wo > 0, "conv_nhwc: empty output");
+  DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024, "conv_nhwc: too many output pixels");
+  a.K = KH * KW * Cin;
+  a.X = x; a.Wp = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.resid = resid; a.relu = relu; a.Y = y;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout % 128 == 0) return planes == 3 ? conv_launch<3, 128, false>(a, s) : conv_launch<1, 128, false>(a, s);
+  return planes == 3 ? conv_launch<3, 64, false>(a, s) : conv_launch<1, 64, false>(a, s);
+}
+
+extern "C" int demf_conv_stem7_nhwc4_f32(int B, int H, int W, int Cout, const float* x4, const void* w_planes,
+                                         int planes, const float* bias, int relu, float* y, demf_stream_t stream) {
+  DEMF_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && Cout % 64 == 0 && x4 != nullptr && w_planes != nullptr && y != nullptr,
+               "conv_stem7: bad arguments");
+  DEMF_REQUIRE(planes == 1 || planes == 3, "conv_stem7: planes must be 1 or 3");
+  ConvArgs a{};
+  a.B = B; a.H = H; a.W = W; a.Cin = 4; a.Cout = Cout; a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3;
+  a.Ho = (H + 6 - 7) / 2 + 1;
+  a.Wo = (W + 6 - 7) / 2 + 1;
+  DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024, "conv_stem7: too many output pixels");
+  a.K = 7 * 32;
+  a.X = x4; a.Wp = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.resid = nullptr; a.relu = relu; a.Y = y;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout % 128 == 0) return planes == 3 ? conv_launch<3, 128, true>(a, s) : conv_launch<1, 128, true>(a, s);
+  return planes == 3 ? conv_launch<3, 64, true>(a, s) : conv_launch<1, 64, true>(a, s);
+}
+
+extern "C" int demf_maxpool3x3s2_nhwc_f32(int B, int H, int W, int C, const float* x, float* y, demf_stream_t stream) {
+  DEMF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && x && y, "maxpool3x3s2: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long long n = (long long)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     B, H, W, C, Ho, Wo, x, y);
+  return check_launch("maxpool3x3s2_nhwc_k");
+}
+
+extern "C" int demf_nchw3_to_nhwc4_f32(int B, int H, int W, const float* x, float* y, demf_stream_t stream) {
+  DEMF_REQUIRE(B > 0 && H > 0 && W > 0 && x && y, "nchw3_to_nhwc4: bad arguments");
+  const long long n = (long long)B * H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (long long)B, (long long)H * W, x, y);
+  return check_launch("nchw3_to_nhwc4_k");
+}
+
+extern "C" int demf_groupnorm_nhwc_f32(int B, int HW, int C, int G, float eps, const float* x, const float* gamma,
+                                       const float* beta, double* sums, float* y, long long y_batch_stride,
+                                       demf_stream_t stream) {
+  DEMF_REQUIRE(B > 0 && HW > 0 && C == 256 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && ((C / G) & (C / G - 1)) == 0 &&
+               C / G <= 64 && x && gamma && beta && sums && y, "groupnorm_nhwc: bad arguments (C must be 256)");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, s) != hipSuccess) {
+    set_error("groupnorm_nhwc: memset failed");
+    return DEMF_ELAUNCH;
+  }
+  const int rows_per_wg = 64;
+  hipLaunchKernelGGL(gn_stats_nhwc_k, dim3(cdiv(HW, rows_per_wg), B), dim3(256), 0, s, HW, C, G, rows_per_wg, x, sums);
+  if (int e = check_launch("gn_stats_nhwc_k")) return e;
+  const long long n = (long long)HW * (C / 4);
+  hipLaunchKernelGGL(gn_apply_nhwc_k, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, s, HW, C, G, eps, x, sums, gamma,
+                     beta, y, y_batch_stride);
+  return check_launch("gn_apply_nhwc_k");
+}

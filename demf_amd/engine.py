@@ -247,6 +247,8 @@ class Trainer:
         """Model + optimizer state for resume (mmcv CheckpointHook, cfg:280), plus the dropout
         counter [seed, step] of the fused decoder layer so that a resumed run continues the mask
         sequence instead of replaying it from step 0."""
+        if self.fused:
+            self.flush()
         sd = dict(model=self.model.state_dict(), optimizer=self.opt.state_dict())
         if self.fused:
             from . import fused
@@ -289,26 +291,84 @@ class Trainer:
             self._arena(False)
         return total.detach()
 
-    def _update(self):
+    # ---- gradient all-reduce + clip + AdamW ------------------------------------------------------------
+    # The collective is latency-bound at 8.76 MB and nothing after it in the step can start
+    # before it ends (the clip needs the norm of the reduced gradients) - but the NEXT batch's input path can:
+    # ``replay.load`` (token conversion of the image pyramid, target padding, constants) and the launch of the
+    # coordinate pre-pass touch neither the gradients nor the parameters.  With ``overlap`` the collective is issued
+    # on a communication stream when the step's graph has been enqueued, ``replay()`` returns, and norm + AdamW
+    # are enqueued at the start of the next ``replay()`` (or by ``flush()``), behind the collective: it runs
+    # underneath whatever the caller enqueues in between.  The RCCL call itself stays an ordinary eager call on a
+    # stream - nothing is captured, so the multi-GPU path is the one the gloo / shared-GPU tests exercise.
+    def _comm(self):
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream()
+        return self._comm_stream
+
+    def allreduce_config(self):
+        """(world, stub_us, overlap): ``stub_us`` > 0 replaces the collective by a spin kernel of that length
+        (bench.py --allreduce-stub-us: the overlap measured on one GPU); overlap is opt-in (DEMF_AR_OVERLAP=1 or
+        ``trainer.allreduce_overlap = True``)."""
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        stub = int(getattr(self, "allreduce_stub_us", 0) or 0)
+        ov = getattr(self, "allreduce_overlap", None)
+        if ov is None:
+            # default OFF: measured on MI355X / ROCm 7.2 with a spin kernel in the collective's place
+            # (bench.py secondary.allreduce_stub100us_*; profiles/r05_allreduce_overlap_probe.log) the extra
+            # cross-queue dependencies of the deferred order cost 0.23 ms per step - more than a 100 us collective
+            # takes on the step's own stream
+            ov = bool(int(os.environ.get("DEMF_AR_OVERLAP", "0")))
+        return world, stub, bool(ov) and (world > 1 or stub > 0)
+
+    def _collective(self, world, stub):
+        ev = getattr(self, "allreduce_events", None)   # bench.py: HIP events around the collective
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if stub > 0:
+            from . import _ffi
+            _ffi.call("demf_spin_us", stub, torch.cuda.current_stream().cuda_stream)
+        if world > 1:
+            dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
+
+    def _finish_update(self):
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        norm = torch.linalg.vector_norm(self.flat.flat)      # of the SUM; scaled in-kernel
+        self.opt.step(norm, self.max_grad_norm, 1.0 / world)
+
+    def flush(self):
+        """Enqueue the update a deferred (overlapped) step still owes: call before reading parameters,
+        gradients or optimizer state.  ``replay()``, ``step()`` and ``state_dict()`` do it themselves."""
+        if getattr(self, "_pending_update", False):
+            self._pending_update = False
+            torch.cuda.current_stream().wait_stream(self._comm())
+            self._finish_update()
+
+    def _update(self, defer=False):
         if self.fused:
-            world = dist.get_world_size() if dist.is_initialized() else 1
-            if world > 1:
-                ev = getattr(self, "allreduce_events", None)   # bench.py: HIP events around the collective
-                if ev is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
-                if ev is not None:
-                    e1.record()
-                    ev.append((e0, e1))
-            norm = torch.linalg.vector_norm(self.flat.flat)      # of the SUM; scaled in-kernel
-            self.opt.step(norm, self.max_grad_norm, 1.0 / world)
+            self.flush()
+            world, stub, overlap = self.allreduce_config()
+            if (world > 1 or stub > 0) and overlap and defer:
+                comm = self._comm()
+                comm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(comm):
+                    self._collective(world, stub)
+                self._pending_update = True
+                return
+            if world > 1 or stub > 0:
+                self._collective(world, stub)
+            self._finish_update()
             return
         self.flat.all_reduce_mean()
         self.flat.clip_(self.max_grad_norm)
         self.opt.step()
 
     def step(self, batch):
+        if self.fused:
+            self.flush()
         total = self._fwd_bwd(batch)
         self._update()
         return total
@@ -496,11 +556,14 @@ class Trainer:
             pre-pass of the cloud last given (every step still pays for one full pre-pass)."""
             main = torch.cuda.current_stream()
             if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
+                self.flush()
                 graph.replay()
                 if graph_bwd is not None:
                     graph_bwd.replay()
                 self._update()
                 return loss
+            if graph_bwd is not None:
+                self.flush()
             if graph_bwd is not None and one_deep:
                 graph.replay()
                 geo.launch_prepass(main, next_points)
@@ -519,9 +582,13 @@ class Trainer:
             if can_prefetch:
                 # single-graph step (the default): the pre-pass goes first - enqueueing the
                 # ~900-node step graph takes the host about a millisecond
+                # (the owed update - norm + AdamW behind an overlapped collective - goes in front of the pre-pass
+                # launch: behind it the step measured 0.17 ms slower, profiles/r05_allreduce_overlap_probe.log)
+                self.flush()
                 geo.launch_prepass(main, next_points)
+            self.flush()
             graph.replay()
-            self._update()
+            self._update(defer=True)
             if can_prefetch:
                 geo.take_fresh(main)
             return loss

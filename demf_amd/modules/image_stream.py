@@ -33,6 +33,10 @@ from .transformer import FFN, MultiScaleDeformableAttention
 # REAL reference encoder pin - the fused path is tested against it
 FUSED_LAYERS = bool(int(__import__("os").environ.get("DEMF_ENC_FUSED", "1")))
 CHANNELS_LAST = bool(int(__import__("os").environ.get("DEMF_IMG_NHWC", "1")))        # A/B switch
+# ResNet-50 + ChannelMapper on csrc/conv.hip (implicit-GEMM convolutions on NHWC rows, frozen BatchNorm folded into
+# the pre-split weights, GroupNorm written straight into the token buffer); False / DEMF_IMG_CONV=0: the library
+# convolutions (MIOpen)
+CONV_KERNELS = bool(int(__import__("os").environ.get("DEMF_IMG_CONV", "1")))
 PRE_ADD = bool(int(__import__("os").environ.get("DEMF_ENC_PRE_ADD", "0")))           # A/B switch (measured neutral: 13.4 vs 13.2 ms)
 SPLIT_FFN_LN = bool(int(__import__("os").environ.get("DEMF_ENC_SPLIT_LN", "1")))     # A/B switch
 
@@ -334,9 +338,14 @@ class DeformableDetrEncoder(nn.Module):
     @torch.no_grad()
     def forward_tokens(self, mlvl_feats, img_metas):
         """-> dict(tokens (B,S,C), spatial [(h,w)...], mask_flatten (B,S), valid_ratios (B,L,2))."""
-        spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
-        st = self._static(img_metas, spatial, mlvl_feats[0].device)
-        tokens = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)       # (B,S,C)
+        if isinstance(mlvl_feats, dict):
+            # the neck's pyramid already as channels-last tokens (ImageStream on csrc/conv.hip): no concat copy
+            spatial, tokens = [tuple(sp) for sp in mlvl_feats["spatial"]], mlvl_feats["tokens"]
+            st = self._static(img_metas, spatial, tokens.device)
+        else:
+            spatial = [tuple(f.shape[-2:]) for f in mlvl_feats]
+            st = self._static(img_metas, spatial, mlvl_feats[0].device)
+            tokens = torch.cat([f.flatten(2).transpose(1, 2) for f in mlvl_feats], 1)       # (B,S,C)
         pos = torch.cat([p + self.level_embeds[l].view(1, 1, -1) for l, p in enumerate(st["pos"])], 1)
         if self._fused_ok(tokens):
             tokens = self._fused_layers(tokens, pos, st)
@@ -400,10 +409,100 @@ class ImageStream(nn.Module):
                 torch.backends.cudnn.benchmark = prev
         return self.img_neck(self.img_backbone(img))
 
+    # ---- ResNet-50 + ChannelMapper on csrc/conv.hip -------------------------------------------------------------
+    def _conv_ok(self, img):
+        """The kernel path needs channels-last friendly widths (every convolution input a multiple of 32 channels -
+        the 3-channel stem has its own form -, every output a multiple of 64), the reference's structure
+        (imvotenet_image.py:3-20: bottlenecks, 7x7 s2 stem, 256-channel neck with GroupNorm whose groups are 4 .. 64
+        consecutive channels) and frozen statistics (eval mode)."""
+        if not (CONV_KERNELS and img.is_cuda and img.dtype == torch.float32 and img.dim() == 4 and img.shape[1] == 3):
+            return False
+        bb, nk = self.img_backbone, self.img_neck
+        if bb.training or nk.training or tuple(bb.conv1.kernel_size) != (7, 7) or bb.conv1.out_channels % 64:
+            return False
+        for m in bb.modules():
+            if isinstance(m, nn.Conv2d) and m is not bb.conv1 and (m.in_channels % 32 or m.out_channels % 64):
+                return False
+        for c in list(nk.convs) + list(nk.extra_convs):
+            cg = c.conv.out_channels // c.gn.num_groups
+            if c.conv.in_channels % 32 or c.conv.out_channels != 256 or cg not in (4, 8, 16, 32, 64):
+                return False
+        return True
+
+    def _conv_pack(self, planes):
+        """Every convolution's weight as demf_conv_nhwc_f32 takes it - (Cout, KH, KW, Cin) reduction order, the frozen
+        BatchNorm scale folded in (bias = beta - mean * scale), pre-split into ``planes`` bf16 planes.  Cached per
+        (parameter / statistic versions, planes): load_state_dict rebuilds it."""
+        from .. import ops
+        bb, nk = self.img_backbone, self.img_neck
+        tensors = [t for m in (bb, nk) for t in list(m.parameters()) + list(m.buffers())]
+        key = (planes,) + tuple((t.data_ptr(), t._version) for t in tensors)
+        pk = self.__dict__.get("_conv_pack_cache")
+        if pk is not None and pk["key"] == key:
+            return pk
+
+        def fold(conv, bn, stem=False):
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().float()
+            bias = (bn.bias - bn.running_mean * scale).detach().float().contiguous()
+            w = (ops.stem_weight_planes if stem else ops.conv_weight_planes)(conv.weight, planes, scale)
+            return dict(w=w, b=bias, k=conv.kernel_size[0], s=conv.stride[0], p=conv.padding[0])
+        pk = dict(key=key, stem=fold(bb.conv1, bb.bn1, stem=True), blocks=[], neck=[])
+        for i in range(4):
+            for blk in getattr(bb, f"layer{i + 1}"):
+                pk["blocks"].append(dict(
+                    c1=fold(blk.conv1, blk.bn1), c2=fold(blk.conv2, blk.bn2), c3=fold(blk.conv3, blk.bn3),
+                    ds=None if blk.downsample is None else fold(blk.downsample[0], blk.downsample[1]), stage=i,
+                    last=blk is getattr(bb, f"layer{i + 1}")[-1]))
+        for c in list(nk.convs) + list(nk.extra_convs):
+            assert c.conv.bias is None
+            pk["neck"].append(dict(w=ops.conv_weight_planes(c.conv.weight, planes), k=c.conv.kernel_size[0],
+                                   s=c.conv.stride[0], p=c.conv.padding[0], g=c.gn.num_groups, eps=float(c.gn.eps),
+                                   gamma=c.gn.weight.detach().float().contiguous(),
+                                   beta=c.gn.bias.detach().float().contiguous()))
+        self.__dict__["_conv_pack_cache"] = pk
+        return pk
+
+    def _pyramid_tokens(self, img):
+        """ResNet-50 + ChannelMapper on this package's convolution kernels -> dict(tokens (B,S,256), spatial): the
+        neck's four levels normalised straight into the encoder's channels-last token buffer (no NCHW tensor, no
+        flatten / concat copy, no MIOpen search on the first call)."""
+        from .. import ops
+        planes = 1 if ops.get_compute_dtype() == "bf16" else 3
+        pk = self._conv_pack(planes)
+        cv = lambda x, c, resid=None, relu=False: ops.conv_nhwc(x, c["w"], c.get("b"), c["k"], c["k"], c["s"], c["p"],
+                                                                resid=resid, relu=relu)
+        x = ops.maxpool3x3s2_nhwc(ops.conv_stem7(img.contiguous(), pk["stem"]["w"], pk["stem"]["b"], relu=True))
+        outs = []
+        for blk in pk["blocks"]:
+            idn = x if blk["ds"] is None else cv(x, blk["ds"])
+            y = cv(cv(x, blk["c1"], relu=True), blk["c2"], relu=True)
+            x = cv(y, blk["c3"], resid=idn, relu=True)
+            if blk["last"] and blk["stage"] in self.img_backbone.out_indices:
+                outs.append(x)
+        nk = self.img_neck
+        raws = [cv(o, c) for o, c in zip(outs, pk["neck"][:len(nk.convs)])]
+        for j, c in enumerate(pk["neck"][len(nk.convs):]):
+            raws.append(cv(outs[-1] if j == 0 else raws[-1], c))
+        # (an extra level beyond the first reads the NORMALISED previous level upstream: ChannelMapper.forward;
+        # the reference has exactly one extra level, fed by the last backbone map)
+        assert len(nk.extra_convs) <= 1, "more than one extra level: normalised intermediate needed"
+        spatial = [tuple(r.shape[1:3]) for r in raws]
+        S = sum(h * w for h, w in spatial)
+        tokens = torch.empty((img.shape[0], S, raws[0].shape[3]), dtype=torch.float32, device=img.device)
+        row0 = 0
+        for r, c in zip(raws, pk["neck"]):
+            ops.groupnorm_nhwc_into(r, c["g"], c["gamma"], c["beta"], c["eps"], tokens, row0)
+            row0 += r.shape[1] * r.shape[2]
+        return dict(tokens=tokens, spatial=spatial)
+
+    def pyramid(self, img):
+        """The neck's output in the form the encoder takes: token dict (kernel path) or the list of NCHW maps."""
+        return self._pyramid_tokens(img) if self._conv_ok(img) else self._pyramid(img)
+
     @torch.no_grad()
     def tokens(self, img, img_metas):
-        return self.img_encoder.forward_tokens(self._pyramid(img), img_metas)
+        return self.img_encoder.forward_tokens(self.pyramid(img), img_metas)
 
     @torch.no_grad()
     def forward(self, img, img_metas):
-        return self.img_encoder(self._pyramid(img), img_metas)
+        return self.img_encoder(self.pyramid(img), img_metas)

@@ -870,6 +870,89 @@ def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, r
     return out
 
 
+def _gpu_f32(name, *ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(name + ": operands must be GPU (HIP) tensors: demf_amd operators have no CPU path")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError(name + ": contiguous fp32 tensors required")
+
+
+def conv_weight_planes(weight, planes=3, scale=None):
+    """(Cout,Cin,KH,KW) convolution weight [x per-output-channel ``scale``: a folded frozen BatchNorm] ->
+    (planes, Cout, KH*KW*Cin) bf16 planes in the reduction order (kh, kw, c) of demf_conv_nhwc_f32."""
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale.detach().float().view(-1, 1, 1, 1)
+    return split_planes(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), planes)
+
+
+def stem_weight_planes(weight, planes=3, scale=None):
+    """(Cout,3,7,7) stem weight -> (planes, Cout, 7*32): element [kh*32 + kw*4 + c], zeros at kw == 7 / c == 3
+    (demf_conv_stem7_nhwc4_f32 reads one kernel row = 8 pixels x 4 channels per reduction step)."""
+    w = weight.detach().float()
+    assert tuple(w.shape[1:]) == (3, 7, 7)
+    if scale is not None:
+        w = w * scale.detach().float().view(-1, 1, 1, 1)
+    full = w.new_zeros(w.shape[0], 7, 8, 4)
+    full[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    return split_planes(full.reshape(w.shape[0], 224), planes)
+
+
+def conv_nhwc(x, w_planes, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None):
+    """y (B,Ho,Wo,Cout) = [relu](conv(x (B,H,W,Cin)) + bias [+ resid]) on channels-last activations
+    (demf_conv_nhwc_f32, csrc/conv.hip: implicit GEMM, nothing unfolded).  ``w_planes`` from conv_weight_planes.
+    Forward only (the frozen image stream)."""
+    B, H, W, Cin = x.shape
+    planes, Cout, K = w_planes.shape
+    _gpu_f32("conv_nhwc", x, bias, resid, out)
+    assert K == KH * KW * Cin and w_planes.dtype == torch.bfloat16 and w_planes.is_contiguous() and w_planes.is_cuda
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    assert tuple(out.shape) == (B, Ho, Wo, Cout) and (bias is None or bias.numel() == Cout)
+    assert resid is None or tuple(resid.shape) == (B, Ho, Wo, Cout)
+    _ffi.call("demf_conv_nhwc_f32", B, H, W, Cin, Cout, KH, KW, stride, pad, _p(x), _p(w_planes), planes, _p(bias),
+              _p(resid), int(bool(relu)), _p(out), _stream())
+    return out
+
+
+def conv_stem7(img, w_planes, bias, relu=True):
+    """ResNet stem: (B,3,H,W) image -> relu(conv7x7 s2 p3 + bias) as (B,H/2,W/2,Cout) channels-last rows
+    (the image passes through an NHWC4 copy: demf_nchw3_to_nhwc4_f32 + demf_conv_stem7_nhwc4_f32)."""
+    B, C, H, W = img.shape
+    planes, Cout, K = w_planes.shape
+    _gpu_f32("conv_stem7", img, bias)
+    assert C == 3 and K == 224 and w_planes.dtype == torch.bfloat16 and w_planes.is_contiguous() and w_planes.is_cuda
+    x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=img.device)
+    _ffi.call("demf_nchw3_to_nhwc4_f32", B, H, W, _p(img), _p(x4), _stream())
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cout), dtype=torch.float32, device=img.device)
+    _ffi.call("demf_conv_stem7_nhwc4_f32", B, H, W, Cout, _p(x4), _p(w_planes), planes, _p(bias), int(bool(relu)),
+              _p(out), _stream())
+    return out
+
+
+def maxpool3x3s2_nhwc(x):
+    B, H, W, C = x.shape
+    _gpu_f32("maxpool3x3s2_nhwc", x)
+    out = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    _ffi.call("demf_maxpool3x3s2_nhwc_f32", B, H, W, C, _p(x), _p(out), _stream())
+    return out
+
+
+def groupnorm_nhwc_into(x, groups, gamma, beta, eps, tokens, row0):
+    """GroupNorm of x (B,h,w,256) channels-last, written to rows [row0, row0 + h*w) of ``tokens`` (B,S,256)."""
+    B, h, w, C = x.shape
+    _gpu_f32("groupnorm_nhwc", x, gamma, beta, tokens)
+    assert tokens.shape[0] == B and tokens.shape[2] == C and row0 + h * w <= tokens.shape[1]
+    sums = torch.empty(2 * B * groups, dtype=torch.float64, device=x.device)
+    _ffi.call("demf_groupnorm_nhwc_f32", B, h * w, C, groups, float(eps), _p(x), _p(gamma), _p(beta), _p(sums),
+              tokens.data_ptr() + 4 * row0 * C, tokens.shape[1] * C, _stream())
+    return tokens
+
+
 def msda_fwd_raw(raw, value_col0, off_col0, lgt_col0, ref, spatial_shapes, level_start_index, B, S, H, Dh, P, out):
     """Self-attention form of the multi-scale deformable attention (the encoder: queries = the S tokens): raw
     offsets / logits / projected value are column ranges of ``raw`` (B*S, ld); softmax and

