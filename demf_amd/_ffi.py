@@ -19,7 +19,7 @@ _ptr = ctypes.c_void_p
 SIGNATURES = {
     "demf_stream_create_cu_masked": [_ptr, _c_int, _c_int, _ptr],
     "demf_spin_us": [_c_int, _ptr],
-    "demf_conv_nhwc_f32": [_c_int] * 9 + [_ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _ptr, _ptr],
+    "demf_conv_nhwc_f32": [_c_int] * 9 + [_ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _ptr, _ptr],
     "demf_conv_stem7_nhwc4_f32": [_c_int] * 4 + [_ptr, _ptr, _c_int, _ptr, _c_int, _ptr, _ptr],
     "demf_maxpool3x3s2_nhwc_f32": [_c_int] * 4 + [_ptr, _ptr, _ptr],
     "demf_nchw3_to_nhwc4_f32": [_c_int] * 3 + [_ptr, _ptr, _ptr],

@@ -41,6 +41,8 @@ struct ConvArgs {
   const float* resid;        // (B*Ho*Wo, Cout) or null: added before the ReLU
   int relu;
   float* Y;                  // (B*Ho*Wo, Cout)
+  int ksplit;                // > 1: blockIdx.y owns reduction steps [y * ksteps, (y + 1) * ksteps) and ADDS its
+  int ksteps;                //      partial tile into a zeroed Y (no bias / residual / ReLU)
 };
 
 template <int P>
@@ -111,8 +113,21 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
   }
   float4 ra[4];
   u32x4 rb[P * NJ];
-  // the tap of a reduction step (uniform): advanced incrementally, 32 channels at a time
+  // this workgroup's reduction range (split-K: blockIdx.y) and the tap of its first step (uniform); the tap is
+  // advanced incrementally, 32 channels at a time
+  const int nsteps = p.K / 32;
+  const int s_lo = p.ksplit > 1 ? (int)blockIdx.y * p.ksteps : 0;
+  const int s_hi = p.ksplit > 1 ? min(nsteps, s_lo + p.ksteps) : nsteps;
+  if (s_lo >= s_hi) return;
   int f_kh = 0, f_kw = 0, f_c0 = 0;
+  if constexpr (STEM) {
+    f_kh = s_lo;
+  } else {
+    const int tap0 = (32 * s_lo) / p.Cin;
+    f_c0 = 32 * s_lo - tap0 * p.Cin;
+    f_kh = tap0 / p.KW;
+    f_kw = tap0 - f_kh * p.KW;
+  }
   auto fetch = [&](int k0) {
     const long long tap = STEM ? (long long)f_kh * p.W * 4 : ((long long)f_kh * p.W + f_kw) * p.Cin + f_c0;
 #pragma unroll
@@ -160,11 +175,11 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  fetch(0);
-  for (int k0 = 0; k0 < p.K; k0 += 32) {
+  fetch(32 * s_lo);
+  for (int k0 = 32 * s_lo; k0 < 32 * s_hi; k0 += 32) {
     commit();
     lds_barrier();
-    if (k0 + 32 < p.K) fetch(k0 + 32);
+    if (k0 + 32 < 32 * s_hi) fetch(k0 + 32);
     const char* sa = smem;
     const char* sb = sa + P * A_BYTES;
 #pragma unroll
@@ -187,32 +202,59 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
     }
     lds_barrier();
   }
+  // Epilogue through LDS (the stage buffers are free now): the accumulator tiles of one 64-row half at a time
+  // become an fp32 tile, then every thread moves float4 pieces of whole rows - bias, the residual (read as
+  // float4), ReLU, one 16-byte store.  (Straight from the accumulators a lane issues 64 4-byte stores and as
+  // many 4-byte residual loads: the 64 -> 256 convolution of layer1 ran at 1.4 TB/s that way.)
   // accumulator register r of tile (i, j) = row 64 wm + 32 i + (r & 3) + 8 (r >> 2) + 4 lh, column 32 NTW wn + 32 j + lc
+  constexpr int LDP = BN + 4;                     // floats per tile row
+  constexpr int TPR = BN / 4;                     // threads per row (one float4 each)
+  constexpr int RPP = 256 / TPR;                  // rows per pass
+  float* tile = reinterpret_cast<float*>(smem);
+  const int e_cq = t % TPR, e_r0 = t / TPR;
+  const int col4 = n0 + 4 * e_cq;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr && p.ksplit <= 1) b4 = *reinterpret_cast<const float4*>(p.bias + col4);
 #pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int col = n0 + 32 * NTW * wn + 32 * j + lc;
-    const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();
+    if (wm == half) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < M) {
-          float v = acc[i][j][r] + bias;
-          if (p.resid != nullptr) v += p.resid[(size_t)row * p.Cout + col];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.Y[(size_t)row * p.Cout + col] = v;
-        }
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tile[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + 32 * NTW * wn + 32 * j + lc] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int rr = e_r0; rr < 64; rr += RPP) {
+      const int row = m0 + 64 * half + rr;
+      if (row >= M) break;
+      float4 v = *reinterpret_cast<const float4*>(tile + rr * LDP + 4 * e_cq);
+      float* dst = p.Y + (size_t)row * p.Cout + col4;
+      if (p.ksplit > 1) {
+        atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
+        continue;
       }
+      v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+      if (p.resid != nullptr) {
+        const float4 q = *reinterpret_cast<const float4*>(p.resid + (size_t)row * p.Cout + col4);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(dst) = v;
+    }
   }
 }
 
 template <int P, int BN, bool STEM>
 static int conv_launch(const ConvArgs& a, hipStream_t s) {
-  constexpr int lds = P * (CV_BM * 64 + BN * 64);
+  constexpr int stage = P * (CV_BM * 64 + BN * 64), epi = 64 * (BN + 4) * 4;
+  constexpr int lds = stage > epi ? stage : epi;
   const int M = a.B * a.Ho * a.Wo;
   const int gx = a.Cout / BN, gy = (cdiv(M, CV_BM) + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_nhwc_kernel<P, BN, STEM>), dim3(gx * gy), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_nhwc_kernel<P, BN, STEM>), dim3(gx * gy, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
   return check_launch("conv_nhwc_kernel");
 }
 
@@ -307,7 +349,7 @@ using namespace demf;
 
 extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                                   const float* x, const void* w_planes, int planes, const float* bias,
-                                  const float* resid, int relu, float* y, demf_stream_t stream) {
+                                  const float* resid, int relu, int ksplit, float* y, demf_stream_t stream) {
   DEMF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 &&
                x != nullptr && w_planes != nullptr && y != nullptr, "conv_nhwc: bad arguments");
   DEMF_REQUIRE(planes == 1 || planes == 3, "conv_nhwc: planes must be 1 (bf16) or 3 (fp32 as three bf16 terms)");
@@ -320,6 +362,11 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
   DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024, "conv_nhwc: too many output pixels");
   a.K = KH * KW * Cin;
   a.X = x; a.Wp = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.resid = resid; a.relu = relu; a.Y = y;
+  DEMF_REQUIRE(ksplit >= 1 && ksplit <= 64, "conv_nhwc: ksplit %d", ksplit);
+  DEMF_REQUIRE(ksplit == 1 || (bias == nullptr && resid == nullptr && !relu),
+               "conv_nhwc: split-K adds partial tiles into a zeroed output: no bias / residual / ReLU");
+  a.ksplit = ksplit;
+  a.ksteps = cdiv(a.K / 32, ksplit);
   hipStream_t s = (hipStream_t)stream;
   if (Cout % 128 == 0) return planes == 3 ? conv_launch<3, 128, false>(a, s) : conv_launch<1, 128, false>(a, s);
   return planes == 3 ? conv_launch<3, 64, false>(a, s) : conv_launch<1, 64, false>(a, s);
@@ -336,6 +383,7 @@ extern "C" int demf_conv_stem7_nhwc4_f32(int B, int H, int W, int Cout, const fl
   a.Wo = (W + 6 - 7) / 2 + 1;
   DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024, "conv_stem7: too many output pixels");
   a.K = 7 * 32;
+  a.ksplit = 1; a.ksteps = 7;
   a.X = x4; a.Wp = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.resid = nullptr; a.relu = relu; a.Y = y;
   hipStream_t s = (hipStream_t)stream;
   if (Cout % 128 == 0) return planes == 3 ? conv_launch<3, 128, true>(a, s) : conv_launch<1, 128, true>(a, s);

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_kernel(
 // the 8 heads' slots of a point are 128 contiguous bytes, a broadcast read without bank conflicts).
 // 540 -> 465 us at 8 x 18 609 queries, P = 4 (what is left is the gather itself: 9.8 GB of 16-byte loads; dealing
 // each XCD a contiguous eighth of the queries instead of every eighth workgroup measured no better, 483 us).
-template <int TL, int TP>
+template <int TL, int TP, bool MSDA_NT = false>
 __global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
     int S, int Q, const float* __restrict__ value, long long vpitch,
     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -221,8 +221,15 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
 #pragma unroll
   for (int s = 0; s < PPL; ++s) {
     const int pi = lane + 64 * s, h = pi / NP, i = pi - h * NP, l = i / TP;
-    const float lg = rrow[lgt_col0 + pi];
-    const float2 of = *reinterpret_cast<const float2*>(rrow + off_col0 + 2 * pi);
+    // (read-once rows: non-temporal, so that they do not push the value rows - the data with reuse - out of L2)
+    const float lg = MSDA_NT ? __builtin_nontemporal_load(rrow + lgt_col0 + pi) : rrow[lgt_col0 + pi];
+    float2 of;
+    if (MSDA_NT) {
+      of.x = __builtin_nontemporal_load(rrow + off_col0 + 2 * pi);
+      of.y = __builtin_nontemporal_load(rrow + off_col0 + 2 * pi + 1);
+    } else {
+      of = *reinterpret_cast<const float2*>(rrow + off_col0 + 2 * pi);
+    }
     float mx = lg;
 #pragma unroll
     for (int o = NP / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -251,7 +258,13 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
     acc = f4_fma(w.z, ld4<float>(vb + o.z), acc);
     acc = f4_fma(w.w, ld4<float>(vb + o.w), acc);
   }
-  *reinterpret_cast<float4*>(out + row * (H * Dh) + lane * 4) = acc;
+  if (MSDA_NT) {
+    float* o = out + row * (H * Dh) + lane * 4;
+    __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
+    __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
+  } else {
+    *reinterpret_cast<float4*>(out + row * (H * Dh) + lane * 4) = acc;
+  }
 }
 
 template <int G, int TL, int TP, typename VT = float>
@@ -573,12 +586,13 @@ extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, 
     const long long rows = (long long)B * Q;
     static const int xcd = getenv("DEMF_MSDA_XCD") ? atoi(getenv("DEMF_MSDA_XCD")) : 0;      // A/B switch
     const dim3 g2((unsigned)(xcd ? ((rows + 3) / 4 + 7) / 8 * 8 : (rows + 3) / 4));
-    if (P == 4)
-      hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 4>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
-                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd);
-    else
-      hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, 2>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes,
-                         level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd);
+    static const int nt = getenv("DEMF_MSDA_NT") ? atoi(getenv("DEMF_MSDA_NT")) : 0;         // A/B switch
+#define RAW_GO(PV, NTV)                                                                                              \
+    hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, PV, NTV>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes, \
+                       level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd)
+    if (P == 4) { if (nt) RAW_GO(4, true); else RAW_GO(4, false); }
+    else { if (nt) RAW_GO(2, true); else RAW_GO(2, false); }
+#undef RAW_GO
     return check_launch("msda_fwd_raw_wave");
   }
   if (P == 4)

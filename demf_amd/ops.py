@@ -901,9 +901,11 @@ def stem_weight_planes(weight, planes=3, scale=None):
     return split_planes(full.reshape(w.shape[0], 224), planes)
 
 
-def conv_nhwc(x, w_planes, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None):
+def conv_nhwc(x, w_planes, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None, ksplit=None):
     """y (B,Ho,Wo,Cout) = [relu](conv(x (B,H,W,Cin)) + bias [+ resid]) on channels-last activations
     (demf_conv_nhwc_f32, csrc/conv.hip: implicit GEMM, nothing unfolded).  ``w_planes`` from conv_weight_planes.
+    ``ksplit`` (default: chosen here): a plain convolution (no bias / residual / ReLU) with few output pixels and
+    a long reduction is split over the reduction, partial tiles added into a zeroed output.
     Forward only (the frozen image stream)."""
     B, H, W, Cin = x.shape
     planes, Cout, K = w_planes.shape
@@ -914,8 +916,18 @@ def conv_nhwc(x, w_planes, bias, KH, KW, stride=1, pad=0, resid=None, relu=False
         out = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     assert tuple(out.shape) == (B, Ho, Wo, Cout) and (bias is None or bias.numel() == Cout)
     assert resid is None or tuple(resid.shape) == (B, Ho, Wo, Cout)
+    plain = bias is None and resid is None and not relu
+    if ksplit is None:
+        # few tiles and a long reduction (the neck's 3x3 level: 30 tiles x 576 steps): slices until ~768 workgroups,
+        # at least 8 reduction steps each.  (With more tiles the atomic adds cost more than the idle CUs: the
+        # 2048 -> 256 1x1 level, 110 tiles, measured 0.165 ms split six ways against 0.114 ms whole.)
+        tiles = -(-(B * Ho * Wo) // 128) * (Cout // (128 if Cout % 128 == 0 else 64))
+        ksplit = max(1, min(768 // max(tiles, 1), (K // 32) // 8, 64)) if plain and tiles <= 64 else 1
+    if ksplit > 1:
+        assert plain, "conv_nhwc: split-K needs a plain convolution"
+        out.zero_()
     _ffi.call("demf_conv_nhwc_f32", B, H, W, Cin, Cout, KH, KW, stride, pad, _p(x), _p(w_planes), planes, _p(bias),
-              _p(resid), int(bool(relu)), _p(out), _stream())
+              _p(resid), int(bool(relu)), int(ksplit), _p(out), _stream())
     return out
 
 

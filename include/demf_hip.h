@@ -902,10 +902,12 @@ int demf_multi_copy(int n, const void* table, int blocks_per_segment, demf_strea
 /* y (B,Ho,Wo,Cout) = [relu]( conv(x (B,H,W,Cin), w) + bias [+ resid (B,Ho,Wo,Cout)] ), implicit GEMM.
  * w_planes: (planes, Cout, KH*KW*Cin) bf16 - the (Cout,Cin,KH,KW) weight permuted to (Cout,KH,KW,Cin) (a frozen
  * BatchNorm folded in by the caller) and split into `planes` bf16 terms (1: bf16 arithmetic; 3: fp32-grade, see
- * demf_split_planes).  Cin % 32 == 0, Cout % 64 == 0.                                              */
+ * demf_split_planes).  Cin % 32 == 0, Cout % 64 == 0.
+ * ksplit > 1: the reduction is split over ksplit workgroup rows that ADD their partial tiles into y, which
+ * must arrive zeroed (few output pixels x a long reduction: the neck's 3x3 level); bias, resid, relu unused. */
 int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                        const float* x, const void* w_planes, int planes, const float* bias,
-                       const float* resid, int relu, float* y, demf_stream_t stream);
+                       const float* resid, int relu, int ksplit, float* y, demf_stream_t stream);
 /* ResNet's 7x7 stride-2 pad-3 stem on an image stored (B,H,W,4) (zero fourth channel; demf_nchw3_to_nhwc4_f32).
  * w_planes: (planes, Cout, 7*32) with element [kh*32 + kw*4 + c] = w[cout][c][kh][kw] (zeros at kw == 7, c == 3). */
 int demf_conv_stem7_nhwc4_f32(int B, int H, int W, int Cout, const float* x4, const void* w_planes, int planes,

@@ -25,18 +25,23 @@ def _rb(t, planes):
     dict(B=2, H=25, W=35, Cin=128, Cout=128, k=3, s=2, p=1, relu=True),           # odd sizes, stride 2: 13 x 18
     dict(B=1, H=13, W=18, Cin=512, Cout=256, k=3, s=2, p=1),                      # the neck's extra level: 7 x 9
     dict(B=1, H=9, W=7, Cin=32, Cout=192, k=3, s=1, p=1, resid=True),             # Cout = 3 x 64
+    dict(B=2, H=13, W=18, Cin=512, Cout=256, k=3, s=2, p=1, plain=True),          # split-K: 126 rows x K = 4 608
+    dict(B=1, H=20, W=20, Cin=1024, Cout=256, k=1, s=1, p=0, plain=True),         # split-K on a 1x1 (8 tiles)
 ])
 def test_conv_nhwc_vs_fp64(case, planes):
     from demf_amd import ops
     g = torch.Generator().manual_seed(7)
-    c = dict(resid=False, relu=False)
+    c = dict(resid=False, relu=False, plain=False)
     c.update(case)
     x = torch.randn(c["B"], c["Cin"], c["H"], c["W"], generator=g)
     w = torch.randn(c["Cout"], c["Cin"], c["k"], c["k"], generator=g) / (c["Cin"] * c["k"] ** 2) ** 0.5
     scale = torch.rand(c["Cout"], generator=g) + 0.5
     bias = torch.randn(c["Cout"], generator=g)
     ws = w * scale.view(-1, 1, 1, 1)
-    want = F.conv2d(_rb(x, planes), _rb(ws, planes), bias.double(), stride=c["s"], padding=c["p"])
+    if c["plain"]:
+        bias = None
+    want = F.conv2d(_rb(x, planes), _rb(ws, planes), None if bias is None else bias.double(), stride=c["s"],
+                    padding=c["p"])
     res = None
     if c["resid"]:
         res = torch.randn(want.shape, generator=g)
@@ -44,9 +49,18 @@ def test_conv_nhwc_vs_fp64(case, planes):
     if c["relu"]:
         want = want.relu()
     xc = x.permute(0, 2, 3, 1).contiguous().cuda()
-    got = ops.conv_nhwc(xc, ops.conv_weight_planes(w.cuda(), planes, scale.cuda()), bias.cuda(), c["k"], c["k"],
+    if c["plain"]:
+        from demf_amd import _ffi
+        seen = []
+        orig = _ffi.call
+        _ffi.call = lambda name, *a: (seen.append(a[15]) if name == "demf_conv_nhwc_f32" else None, orig(name, *a))[1]
+    got = ops.conv_nhwc(xc, ops.conv_weight_planes(w.cuda(), planes, scale.cuda()),
+                        None if bias is None else bias.cuda(), c["k"], c["k"],
                         c["s"], c["p"], resid=None if res is None else res.permute(0, 2, 3, 1).contiguous().cuda(),
                         relu=c["relu"])
+    if c["plain"]:
+        _ffi.call = orig
+        assert seen and seen[0] > 1, "the split-K form must be the one under test"
     assert tuple(got.shape) == (want.shape[0], want.shape[2], want.shape[3], want.shape[1])
     err = (got.cpu().double().permute(0, 3, 1, 2) - want).abs().max().item()
     tol = 3e-6 if planes == 3 else 2e-5            # fp32 accumulation of exact products

@@ -31,7 +31,7 @@ def timed(fn, n=5):
     return s.elapsed_time(e) / n
 
 
-def conv(x, wp, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None):
+def conv(x, wp, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None, ksplit=None):
     y = real(x, wp, bias, KH, KW, stride, pad, resid=resid, relu=relu)
     ms = timed(lambda: real(x, wp, bias, KH, KW, stride, pad, resid=resid, relu=relu, out=y))
     M = y.shape[0] * y.shape[1] * y.shape[2]
