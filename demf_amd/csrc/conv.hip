@@ -21,6 +21,7 @@
 // Also here: the 3x3 stride-2 max-pool, NCHW -> NHWC4 of the input image, and GroupNorm over NHWC rows written
 // straight into the encoder's token buffer (B, S, 256) - the channels-last hand-over needs no transposition.
 #include "common.h"
+#include <stdlib.h>
 
 namespace demf {
 
@@ -76,8 +77,9 @@ __device__ __forceinline__ void cv_mfma(f32x16& acc, const bf16x8 (&a)[P], const
 constexpr int CV_BM = 128;
 
 // BN = 128: waves 2 x 2 of 64 x 64; BN = 64: waves 2 x 2 of 64 x 32.
-template <int P, int BN, bool STEM>
-__global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs p) {
+// WG3: three workgroups per CU also at three planes (168 registers: a few spills)
+template <int P, int BN, bool STEM, bool WG3 = false>
+__global__ __launch_bounds__(256, (P == 3 && !WG3) ? 2 : 3) void conv_nhwc_kernel(ConvArgs p) {
   constexpr int NTW = BN / 64;                  // 32-column tiles per wave
   constexpr int NJ = BN / 64;                   // B staging: columns (t >> 2) + 64 j
   constexpr int A_BYTES = CV_BM * 64, B_BYTES = BN * 64;
@@ -93,10 +95,9 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
   if (m0 >= M) return;
   // staging: A - float4 kq = t & 7 of rows (t >> 3) + 32 i; B - 16-byte chunk (t & 3) of columns (t >> 2) + 64 j
   const int ar = t >> 3, akq = t & 7, bc = t >> 2, bch = t & 3;
-  // the thread's four output pixels: top-left input coordinate and its element offset (may be negative: only
-  // dereferenced where the tap lies inside the image)
-  int hi0[4], wi0[4];
-  long long off[4];
+  // the thread's four output pixels: top-left input coordinate (two 16-bit halves of one register) and its element
+  // offset (32-bit, may be negative: only dereferenced where the tap lies inside the image)
+  int hw0[4], off[4];
   const int cpp = STEM ? 4 : p.Cin;             // floats per input pixel
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -104,11 +105,11 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
     if (row < M) {
       const int b = row / (p.Ho * p.Wo), rem = row - b * (p.Ho * p.Wo);
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      hi0[i] = ho * p.stride - p.pad;
-      wi0[i] = wo * p.stride - p.pad;
-      off[i] = (((long long)b * p.H + hi0[i]) * p.W + wi0[i]) * cpp;
+      const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+      hw0[i] = (h0 << 16) | (w0 & 0xffff);
+      off[i] = ((b * p.H + h0) * p.W + w0) * cpp;
     } else {
-      hi0[i] = -(1 << 20); wi0[i] = -(1 << 20); off[i] = 0;      // never inside the image
+      hw0[i] = (int)0xc000c000u; off[i] = 0;               // never inside the image
     }
   }
   float4 ra[4];
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
     f_kw = tap0 - f_kh * p.KW;
   }
   auto fetch = [&](int k0) {
-    const long long tap = STEM ? (long long)f_kh * p.W * 4 : ((long long)f_kh * p.W + f_kw) * p.Cin + f_c0;
+    const int tap = STEM ? f_kh * p.W * 4 : (f_kh * p.W + f_kw) * p.Cin + f_c0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int hi = hi0[i] + f_kh;
-      const int wi = STEM ? wi0[i] + akq : wi0[i] + f_kw;
+      const int hi = (hw0[i] >> 16) + f_kh;
+      const int wi = (int)(short)(hw0[i] & 0xffff) + (STEM ? akq : f_kw);
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
         ra[i] = *reinterpret_cast<const float4*>(p.X + off[i] + tap + 4 * akq);
@@ -248,13 +249,13 @@ __global__ __launch_bounds__(256, P == 3 ? 2 : 3) void conv_nhwc_kernel(ConvArgs
   }
 }
 
-template <int P, int BN, bool STEM>
+template <int P, int BN, bool STEM, bool WG3 = false>
 static int conv_launch(const ConvArgs& a, hipStream_t s) {
   constexpr int stage = P * (CV_BM * 64 + BN * 64), epi = 64 * (BN + 4) * 4;
   constexpr int lds = stage > epi ? stage : epi;
   const int M = a.B * a.Ho * a.Wo;
   const int gx = a.Cout / BN, gy = (cdiv(M, CV_BM) + 7) / 8 * 8;
-  hipLaunchKernelGGL((conv_nhwc_kernel<P, BN, STEM>), dim3(gx * gy, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_nhwc_kernel<P, BN, STEM, WG3>), dim3(gx * gy, a.ksplit > 1 ? a.ksplit : 1), dim3(256), lds, s, a);
   return check_launch("conv_nhwc_kernel");
 }
 
@@ -367,8 +368,13 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
                "conv_nhwc: split-K adds partial tiles into a zeroed output: no bias / residual / ReLU");
   a.ksplit = ksplit;
   a.ksteps = cdiv(a.K / 32, ksplit);
+  DEMF_REQUIRE((long long)B * H * W * Cin < (1ll << 31) && H < 16384 && W < 16384, "conv_nhwc: input too large for 32-bit offsets");
   hipStream_t s = (hipStream_t)stream;
-  if (Cout % 128 == 0) return planes == 3 ? conv_launch<3, 128, false>(a, s) : conv_launch<1, 128, false>(a, s);
+  static const int wg3 = getenv("DEMF_CONV_WG3") ? atoi(getenv("DEMF_CONV_WG3")) : 0;       // A/B switch
+  if (Cout % 128 == 0) {
+    if (planes == 3) return wg3 ? conv_launch<3, 128, false, true>(a, s) : conv_launch<3, 128, false>(a, s);
+    return conv_launch<1, 128, false>(a, s);
+  }
   return planes == 3 ? conv_launch<3, 64, false>(a, s) : conv_launch<1, 64, false>(a, s);
 }
 
@@ -381,7 +387,8 @@ extern "C" int demf_conv_stem7_nhwc4_f32(int B, int H, int W, int Cout, const fl
   a.B = B; a.H = H; a.W = W; a.Cin = 4; a.Cout = Cout; a.KH = 7; a.KW = 7; a.stride = 2; a.pad = 3;
   a.Ho = (H + 6 - 7) / 2 + 1;
   a.Wo = (W + 6 - 7) / 2 + 1;
-  DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024, "conv_stem7: too many output pixels");
+  DEMF_REQUIRE((long long)B * a.Ho * a.Wo < (1ll << 31) - 1024 && (long long)B * H * W * 4 < (1ll << 31) && H < 16384 &&
+               W < 16384, "conv_stem7: too many pixels");
   a.K = 7 * 32;
   a.ksplit = 1; a.ksteps = 7;
   a.X = x4; a.Wp = reinterpret_cast<const __bf16*>(w_planes); a.bias = bias; a.resid = nullptr; a.relu = relu; a.Y = y;

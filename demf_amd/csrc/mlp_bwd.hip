@@ -994,7 +994,11 @@ static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   // pre-pass of the next batch (8 FPS workgroups that each own a CU) is resident underneath the step;
   // a grid sized for all 256 CUs leaves 8 workgroups waiting for a CU and the launch ends with them
   // (measured on the step: 256 -> 6.41 ms, 248 -> 6.35, 240 -> 6.32, 232 -> 6.31, 224 -> 6.33; alone 5.86 either way)
-  static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
+  static const int cus = [] {
+    const char* b = getenv("DEMF_PERSIST_CUS_BWD");       // the backward kernels alone (A/B)
+    const char* v = b ? b : getenv("DEMF_PERSIST_CUS");
+    return v ? atoi(v) : 240;
+  }();
   const int cap = cus * (8 / NW);
   const int gx = nslab < cap ? nslab : cap;
   hipLaunchKernelGGL((mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI, ST>), dim3(gx), dim3(64 * NW), bytes, s, a);
@@ -1097,7 +1101,11 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
 }
 
 static int pool_bwd_grid(int R) {
-  static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
+  static const int cus = [] {
+    const char* b = getenv("DEMF_PERSIST_CUS_BWD");
+    const char* v = b ? b : getenv("DEMF_PERSIST_CUS");
+    return v ? atoi(v) : 240;
+  }();
   const int nslab = R / PB_RS;
   return nslab < cus ? (nslab > 0 ? nslab : 1) : cus;
 }

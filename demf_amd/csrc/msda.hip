@@ -586,7 +586,7 @@ extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, 
     const long long rows = (long long)B * Q;
     static const int xcd = getenv("DEMF_MSDA_XCD") ? atoi(getenv("DEMF_MSDA_XCD")) : 0;      // A/B switch
     const dim3 g2((unsigned)(xcd ? ((rows + 3) / 4 + 7) / 8 * 8 : (rows + 3) / 4));
-    static const int nt = getenv("DEMF_MSDA_NT") ? atoi(getenv("DEMF_MSDA_NT")) : 0;         // A/B switch
+    static const int nt = getenv("DEMF_MSDA_NT") ? atoi(getenv("DEMF_MSDA_NT")) : 1;         // A/B switch (12.94 -> 12.65 ms per 6 layers)
 #define RAW_GO(PV, NTV)                                                                                              \
     hipLaunchKernelGGL((msda_fwd_raw_wave_kernel<4, PV, NTV>), g2, dim3(256), 0, s, S, Q, value, vpitch, spatial_shapes, \
                        level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, rows, xcd)

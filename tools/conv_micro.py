@@ -56,3 +56,17 @@ for ms, line in rows:
 print(f"sum of {len(rows)} convolutions: {tot:.2f} ms")
 with torch.no_grad():
     print(f"whole pyramid(): {timed(lambda: ist.pyramid(img)):.2f} ms")
+
+# the encoder's linear layers as 1x1 "convolutions" over (1, 1, R, K) rows: the same kernel, coalesced epilogue
+R = B * 18609
+print(f"--- encoder linears through demf_conv_nhwc_f32, R = {R}")
+for K, N, relu in ((256, 1024, True), (1024, 256, False), (256, 640, False), (256, 256, False)):
+    x = torch.randn(1, 24, R // 24, K, device="cuda")
+    w = ops.split_planes(torch.randn(N, K, device="cuda") / K ** 0.5, planes)
+    b = torch.randn(N, device="cuda")
+    y = torch.empty(1, 24, R // 24, N, device="cuda")
+    ms = timed(lambda: real(x, w, b, 1, 1, 1, 0, relu=relu, out=y))
+    y2 = torch.empty(R, N, device="cuda")
+    ms2 = timed(lambda: ops.rows_gemm(x.view(R, K), w, b, y2, relu=relu))
+    print(f"K {K:5d} -> N {N:5d}: conv kernel {ms:.3f} ms {2.0 * R * K * N / ms * 1e-9:6.1f} TF/s   rows_gemm {ms2:.3f} ms {2.0 * R * K * N / ms2 * 1e-9:6.1f} TF/s"
+          f"   max diff {(y.view(R, N) - y2).abs().max().item():.2e}")
