@@ -781,8 +781,13 @@ class StepCache:
             while len(self.graphs) >= self.max_graphs:
                 old, dead = self.graphs.popitem(last=False)
                 self.stats["evicted"] += 1
-                if not any(k[0] == old[0] for k in self.graphs):
+                # (the pipe - static index buffers + the pre-pass hipGraph - of a cloud shape survives while any
+                # graph of that shape does, INCLUDING the one about to be captured)
+                if old[0] != key[0] and not any(k[0] == old[0] for k in self.graphs):
                     self.pipes.pop(old[0], None)
+                head = getattr(self.trainer.model, "pts_bbox_head", None)
+                if head is not None and hasattr(head, "unpin_metas"):
+                    head.unpin_metas(dead.static["img_metas"])
                 del dead
             pipe = self.pipes.get(key[0]) if self.prefetch else None
             r = self.trainer.capture(batch, warmup=self.warmup, prefetch_geometry=self.prefetch,

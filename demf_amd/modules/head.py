@@ -253,6 +253,12 @@ class DeMFVoteHead(nn.Module):
             raise RuntimeError("refresh_metas: no cached device constants for this metas object "
                                "(it was never used in a forward, or its entry was evicted)")
 
+    def unpin_metas(self, img_metas):
+        """Undo ``pin_metas`` (the captured graph that read this entry has been dropped: engine.StepCache)."""
+        self.__dict__.get("_meta_pinned", set()).discard(id(img_metas))
+        keep = self.__dict__.get("_meta_pinned_keep", [])
+        self.__dict__["_meta_pinned_keep"] = [m for m in keep if m is not img_metas]
+
     def pin_metas(self, img_metas):
         """Entries of ``img_metas`` are never evicted from the cache: a captured hipGraph holds raw
         pointers to their tensors (Trainer.capture calls this for its static metas)."""

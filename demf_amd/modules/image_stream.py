@@ -37,6 +37,7 @@ CHANNELS_LAST = bool(int(__import__("os").environ.get("DEMF_IMG_NHWC", "1")))   
 # the pre-split weights, GroupNorm written straight into the token buffer); False / DEMF_IMG_CONV=0: the library
 # convolutions (MIOpen)
 CONV_KERNELS = bool(int(__import__("os").environ.get("DEMF_IMG_CONV", "1")))
+MIOPEN_SEARCH = bool(int(__import__("os").environ.get("DEMF_MIOPEN_SEARCH", "0")))   # library path only
 PRE_ADD = bool(int(__import__("os").environ.get("DEMF_ENC_PRE_ADD", "0")))           # A/B switch (measured neutral: 13.4 vs 13.2 ms)
 SPLIT_FFN_LN = bool(int(__import__("os").environ.get("DEMF_ENC_SPLIT_LN", "1")))     # A/B switch
 
@@ -400,7 +401,11 @@ class ImageStream(nn.Module):
                 self.__dict__["_nhwc_for"] = img.device
             img = img.contiguous(memory_format=torch.channels_last)
             # MIOpen's immediate mode picks slow NHWC kernels (22.7 ms); with its search - first call per shape -
-            # the same convolutions run in 16.5 ms.  Only this frozen stream has convolutions in the package.
+            # the same convolutions run in 16.5 ms.  The search flag is process-global (it races with any other
+            # thread that runs convolutions), so it is opt-in: DEMF_MIOPEN_SEARCH=1.  (This library path is the
+            # fall-back for widths the kernels of csrc/conv.hip do not take, and the A/B reference of bench.py.)
+            if not MIOPEN_SEARCH:
+                return self.img_neck(self.img_backbone(img))
             prev = torch.backends.cudnn.benchmark
             torch.backends.cudnn.benchmark = True
             try:

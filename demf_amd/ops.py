@@ -742,29 +742,38 @@ def _identity_dy_vectors(n, device):
 
 
 class _LinearRows(Function):
-    """y = x W^T + b on rows [, rows selected by ``row_mask`` zeroed].  GEMMs through hipBLASLt
-    (the slab-split dW kernel for long reductions); the bias gradient through demf_colsum_f32
-    instead of at::sum (see include/demf_hip.h).  The row mask is applied in place on the fresh
-    output / on the incoming gradient: one pass each, no autograd view+in-place machinery."""
+    """y = x W^T + b on rows [, rows selected by ``row_mask`` zeroed].  No library GEMM: few rows (heads, vote
+    module, position embedding) run on the strided GEMM of csrc/dense.hip (``fused.gemm``); long row sets with
+    GEMM-friendly widths (the value projection of project-then-sample, the image encoder's module path: K % 32 == 0,
+    N % 128 == 0) on the long-row kernel of csrc/rows_gemm.hip with the mask fused; the weight gradient of a long
+    reduction on the slab-split dW kernel of the shared-MLP path, the bias gradient through demf_colsum_f32 / the
+    GEMM's row sums.  The row mask is applied in place on the incoming gradient: no autograd view+in-place
+    machinery."""
+
+    @staticmethod
+    def _rows_ok(R, K, N, x):
+        return R > _OWN_GEMM_ROWS and K % 32 == 0 and N % 128 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0
 
     @staticmethod
     def forward(ctx, x, weight, bias, row_mask):
+        from . import fused
         ctx.has_bias = bias is not None
-        ctx.own = row_mask is None and x.shape[0] <= _OWN_GEMM_ROWS and x.stride(1) == 1 and \
-            (bias is None or bias.is_contiguous())
-        if ctx.own:
-            # few rows (heads, vote module, position embedding): the strided GEMM of csrc/dense.hip
-            from . import fused
-            R, K = x.shape
-            N = weight.shape[0]
-            y = torch.empty((R, N), dtype=torch.float32, device=x.device)
-            fused.gemm(R, N, K, _p(x), (x.stride(0), 1), _p(weight), weight.stride(), _p(y), N,
-                       bias=_p(bias))
-            ctx.save_for_backward(x, weight)
-            return y
-        y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+        R, K = x.shape
+        N = weight.shape[0]
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        if bias is not None and not bias.is_contiguous():
+            bias = bias.contiguous()
+        y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        planes = 1 if get_compute_dtype() == "bf16" else 3
+        if _LinearRows._rows_ok(R, K, N, x):
+            rows_gemm(x, split_planes(weight, planes), bias.detach() if bias is not None else None, y,
+                      row_mask=row_mask, mask_col0=0)
+        else:
+            fused.gemm(R, N, K, _p(x), (x.stride(0), 1), _p(weight), weight.stride(), _p(y), N, bias=_p(bias))
+            if row_mask is not None:
+                y.masked_fill_(row_mask.unsqueeze(-1), 0.0)
         if row_mask is not None:
-            y.masked_fill_(row_mask.unsqueeze(-1), 0.0)
             ctx.save_for_backward(x, weight, row_mask)
         else:
             ctx.save_for_backward(x, weight)
@@ -773,49 +782,42 @@ class _LinearRows(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
+        from . import fused
         x, weight = ctx.saved_tensors[:2]
         g = g.contiguous()
-        if ctx.own:
-            from . import fused
-            R, K = x.shape
-            N = weight.shape[0]
-            gx = gw = gb = None
-            if ctx.needs_input_grad[0]:
-                gx = torch.empty((R, K), dtype=torch.float32, device=g.device)
-                fused.gemm(R, K, N, _p(g), (N, 1), _p(weight), (weight.stride(1), weight.stride(0)),
-                           _p(gx), K)
-            if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-                # one zero-filled workspace for dW | db (split-K atomics, column sums)
-                ws = zeros(N * K + N, g.device)
-                gw = ws[:N * K].view(N, K)
-                # (+ the bias gradient = row sums of the A operand, taken by the same launch)
-                gb = ws[N * K:] if ctx.has_bias else None
-                in_gemm = gb is not None and N % 4 == 0 and N >= 4
-                fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, x.stride(0)), _p(gw), K,
-                           splitk=fused._splitk(R), asum=_p(gb) if in_gemm else None)
-                if gb is not None and not in_gemm:
-                    _ffi.call("demf_colsum_f32", R, N, N, _p(g), _p(gb), _stream())
-            return gx, gw, gb, None
+        R, K = x.shape
+        N = weight.shape[0]
         if len(ctx.saved_tensors) == 3:
             # the incoming gradient is a temporary of the producer (the MSDA backward's
             # grad_value); it is masked in place rather than cloned (152 MB at the bench size)
             g.masked_fill_(ctx.saved_tensors[2].unsqueeze(-1), 0.0)
-        gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = None
-        if ctx.needs_input_grad[1]:
-            R, N, K = g.shape[0], g.shape[1], x.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((R, K), dtype=torch.float32, device=g.device)
+            if _LinearRows._rows_ok(R, N, K, g):
+                planes = 1 if get_compute_dtype() == "bf16" else 3
+                rows_gemm(g, split_planes(weight.detach().t().contiguous(), planes), None, gx)
+            else:
+                fused.gemm(R, K, N, _p(g), (N, 1), _p(weight), (weight.stride(1), weight.stride(0)), _p(gx), K)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] or want_b:
+            # one zero-filled workspace for dW | db (split-K atomics, column sums)
+            ws = zeros(N * K + N, g.device)
+            gw = ws[:N * K].view(N, K)
+            gb = ws[N * K:] if ctx.has_bias else None
+            in_gemm = False
             if R >= 32768 and N % 4 == 0 and K % 4 == 0 and x.is_contiguous():
                 # long reduction (the value projection: 149 k tokens -> 256x256): the slab-split
                 # dW kernel of the shared-MLP path, run with an identity dY prologue
-                gw = torch.zeros(N, K, dtype=g.dtype, device=g.device)
                 _ffi.call("demf_mlp_gemm_bwd_dw", R, N, K, K, _p(g), None, None, 1, _p(g),
                           _p(_identity_dy_vectors(N, g.device)), _p(x), None, _p(gw), _stream())
             else:
-                gw = g.t() @ x
-        gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(g.shape[1], dtype=g.dtype, device=g.device)
-            _ffi.call("demf_colsum_f32", g.shape[0], g.shape[1], g.shape[1], _p(g), _p(gb), _stream())
+                # (+ the bias gradient = row sums of the A operand, taken by the same launch)
+                in_gemm = gb is not None and N % 4 == 0 and N >= 4
+                fused.gemm(N, K, R, _p(g), (1, N), _p(x), (1, x.stride(0)), _p(gw), K,
+                           splitk=fused._splitk(R), asum=_p(gb) if in_gemm else None)
+            if gb is not None and not in_gemm:
+                _ffi.call("demf_colsum_f32", R, N, N, _p(g), _p(gb), _stream())
         return gx, gw, gb, None
 
 
@@ -860,9 +862,15 @@ def rows_gemm(x, w_planes, bias, out, a2=None, a2_cols=0, relu=False, ln=None, r
     mode = 2 if ln is not None else (1 if relu else 0)
     res, g, b, eps = ln if ln is not None else (None, None, None, 0.0)
     if a2 is not None:
-        assert a2.shape == x.shape and a2.stride() == x.stride()
+        assert a2.shape == x.shape and a2.stride() == x.stride() and a2.is_cuda and a2.dtype == torch.float32
     if row_mask is not None:
-        assert row_mask.dtype == torch.bool and row_mask.numel() == R and row_mask.is_contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == R and row_mask.is_contiguous() and row_mask.is_cuda
+    for name, v, n in (("bias", bias, N), ("gamma", g, N), ("beta", b, N)):
+        assert v is None or (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.numel() == n), \
+            "rows_gemm: %s must be a contiguous fp32 GPU vector of %d elements" % (name, n)
+    if res is not None:
+        assert res.is_cuda and res.dtype == torch.float32 and tuple(res.shape) == (R, N) and res.stride(1) == 1 and \
+            res.stride(0) % 4 == 0 and out.stride(0) % 4 == 0, "rows_gemm: residual must be fp32 (R,N) rows"
     _ffi.call("demf_rows_gemm_f32", R, N, K, _p(x), x.stride(0), _p(a2), int(a2_cols), int(bool(a2_replace)),
               _p(w_planes), planes,
               _p(bias), mode, _p(row_mask), int(mask_col0), _p(res), res.stride(0) if res is not None else 0,
@@ -1030,8 +1038,14 @@ _POOL_NOY = bool(int(os.environ.get("DEMF_POOL_NOY", "1")))
 _SA1_X4 = bool(int(os.environ.get("DEMF_SA1_X4", "1")))
 
 
+def _x3_forward_on():
+    """The no-store forwards exist in the bf16 / three-term kernels only: in mode 2 the A/B switch DEMF_X3_MASK
+    without bit 0 sends forward launches to the native-fp32 kernel (csrc/mlp.hip launch_gemm), which stores."""
+    return _COMPUTE_MODE == 1 or (_COMPUTE_MODE == 2 and (int(os.environ.get("DEMF_X3_MASK", "7") or 0) & 1))
+
+
 def _sa1_x4_ok(R, ld, shapes, training, x_grad, ns):
-    return (_SA1_X4 and training and not x_grad and _COMPUTE_MODE in (1, 2) and ld == 4 and len(shapes) >= 3
+    return (_SA1_X4 and training and not x_grad and _x3_forward_on() and ld == 4 and len(shapes) >= 3
             and shapes[0] == (64, 4) and shapes[1] == (64, 64) and R >= 16384 and not _NO_BWD_FUSE
             and not _NO_FIRST_FUSE and int(os.environ.get("DEMF_FWD_RES", "1") or 0) and
             not int(os.environ.get("DEMF_STATIC_TILES", "0") or 0))
@@ -1040,7 +1054,7 @@ def _sa1_x4_ok(R, ld, shapes, training, x_grad, ns):
 def _pool_noy_ok(R, ns, shapes, training, fuse_pool):
     """Shapes / modes of the no-store pooled last layer (N = 128 <- K = 64, 64-row groups, enough rows for
     the weight-resident forward)."""
-    return (_POOL_NOY and training and fuse_pool and _COMPUTE_MODE in (1, 2) and ns == 64 and R >= 16384
+    return (_POOL_NOY and training and fuse_pool and _x3_forward_on() and ns == 64 and R >= 16384
             and R % 64 == 0 and len(shapes) >= 2 and shapes[-1] == (128, 64) and shapes[-2][0] == 64
             and not _NO_BWD_FUSE and (_VEC_FIN & 1))
 
@@ -1238,6 +1252,7 @@ class _SharedMLPPool(Function):
         ctx.store16 = store16
         ctx.noy = noy
         ctx.x4 = x4
+        ctx.mode = _COMPUTE_MODE          # the no-store forms keep no Y to fall back on: the backward needs this mode
         ctx.geo = None
         if geo is not None:
             ctx.geo = (g_xyz, g_center, g_off, g_rows, float(g_radius), int(bool(g_norm)))
@@ -1250,6 +1265,10 @@ class _SharedMLPPool(Function):
         R, ld, ns, L, training = ctx.meta
         if not training:
             raise RuntimeError("shared_mlp_pool backward is only defined in training mode")
+        if (ctx.noy or ctx.x4) and _COMPUTE_MODE != ctx.mode:
+            raise RuntimeError("shared_mlp_pool: the forward ran in compute mode %d and did not store the rows the "
+                               "backward of mode %d reads (no-store forms); keep ops.set_compute_dtype unchanged "
+                               "between a forward and its backward" % (ctx.mode, _COMPUTE_MODE))
         saved = ctx.saved_tensors
         x, arg = saved[0], saved[1]
         Ys, sss, mis = saved[2:2 + L], saved[2 + L:2 + 2 * L], saved[2 + 2 * L:2 + 3 * L]

@@ -153,13 +153,17 @@ def ball_margin(xyz, center, r):
     return np.abs(d2 - r * r).min() / (r * r)
 
 
-def oracle_run(cfg, batch, gtb, gtl, seed, dtype, truth_taps=None, tap=True, emulate_bf16=False):
+def oracle_run(cfg, batch, gtb, gtl, seed, dtype, truth_taps=None, tap=True, emulate_bf16=False, state=None):
     """``emulate_bf16``: the oracle rounds where the product's bf16 compute mode rounds
-    (oracle/emulate.py); float64 = the emulated truth, float32 = the accumulation noise around it."""
+    (oracle/emulate.py); float64 = the emulated truth, float32 = the accumulation noise around it.
+    ``state``: a state dict to load instead of the seeded weights."""
     import contextlib
     from oracle import emulate
     ref = OracleDeMF(cfg)
-    fixtures.seed_weights(ref, seed)
+    if state is None:
+        fixtures.seed_weights(ref, seed)
+    else:
+        ref.load_state_dict(state)
     ref.train().to(dtype)
     taps = Taps(ref, truth_taps) if tap and not emulate_bf16 else None
     pts = torch.from_numpy(batch["points"]).to(dtype)
