@@ -476,7 +476,7 @@ def main():
         # all-reduce (the size class RCCL needs for 8.76 MB over xGMI) - on the step's own stream
         # with the update right behind it (serial), and on the communication stream with the update deferred behind
         # the next batch's input path (the engine's default for world > 1)
-        if not args.resident and args.allreduce_stub_us == 0:
+        if not args.resident and args.allreduce_stub_us == 0 and not os.environ.get("DEMF_BENCH_SKIP_AR_STUB"):
             trainer.allreduce_stub_us = 100
             trainer.allreduce_overlap = False
             secondary["allreduce_stub100us_serial_ms_per_step"] = time_steps(step_loop, args.steps)

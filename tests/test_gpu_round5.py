@@ -163,3 +163,23 @@ def test_linear_on_long_row_sets_has_no_library_gemm(mask):
         for got, ref in ((x.grad, gd @ wd), (w.grad, gd.t() @ xd), (b.grad, gd.sum(0))):
             err = (got.double() - ref).abs().max().item()
             assert err <= 5e-5 * ref.abs().max().item(), (R, N, err, ref.abs().max().item())
+
+
+def test_side_stream_is_probed_for_real_concurrency():
+    """engine.concurrent_stream: the stream the pipelined pre-pass (and the overlapped collective) runs on must not
+    share the main stream's hardware queue - two 400 us spin kernels, one per stream, finish in about one length."""
+    from demf_amd import _ffi, engine
+    main = torch.cuda.current_stream()
+    for _ in range(6):                                   # whatever torch's stream pool hands out next
+        side = engine.concurrent_stream()
+        side.wait_stream(main)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ffi.call("demf_spin_us", 400, main.cuda_stream)
+        with torch.cuda.stream(side):
+            _ffi.call("demf_spin_us", 400, side.cuda_stream)
+        main.wait_stream(side)
+        e1.record()
+        torch.cuda.synchronize()
+        assert e0.elapsed_time(e1) < 0.65, e0.elapsed_time(e1)
