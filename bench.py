@@ -570,6 +570,22 @@ def main():
                 step_resident()
                 torch.cuda.current_stream().wait_stream(side)
             secondary["e2e_pipelined_ms_per_step"] = time_steps(e2e_pipe, 10)
+            if args.dtype != "bf16":
+                # the frozen, no_grad stream alone in the bf16 compute mode (operands rounded to bf16, fp32
+                # accumulate; tests/test_gpu_conv.py + test_gpu_image_stream.py hold that mode to its own bars)
+                # in front of the SAME fp32-grade step: what mixed precision buys end to end
+                def stream_bf16():
+                    ops.set_compute_dtype("bf16")
+                    try:
+                        ist.tokens(img, batch["img_metas"])
+                    finally:
+                        ops.set_compute_dtype(args.dtype)
+                secondary["image_stream_bf16_ms"] = time_steps(stream_bf16, 5)
+
+                def e2e_mixed():
+                    stream_bf16()
+                    step_resident()
+                secondary["e2e_bf16_stream_ms_per_step"] = time_steps(e2e_mixed, 10)
             del ist, img, pyr
         if args.batch <= 8:
             try:
