@@ -318,6 +318,10 @@ def main():
     ap.add_argument("--allreduce-overlap", action="store_true",
                     help="issue the collective on a communication stream and defer norm + AdamW to the start of the "
                          "next step (default: on the step's own stream, the update right behind it)")
+    ap.add_argument("--double-buffer", action="store_true",
+                    help="load each batch into the idle one of TWO sets of static input buffers on an input stream "
+                         "while the previous step runs (engine.DoubleBufferedStep; measured SLOWER on MI355X / ROCm "
+                         "7.2: 5.15 vs 5.01 ms - a third active hardware queue costs more than the 0.1 ms it hides)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (resident / bf16 / P=4 / clustered / B=16 step times, SA path)")
     args = ap.parse_args()
@@ -393,6 +397,12 @@ def main():
         torch.cuda.set_stream(main_s)
     replay = None if args.no_graph else \
         trainer.capture(batch, prefetch_geometry=not args.no_prefetch, max_gt=MAX_GT)
+    # --double-buffer: the loading loop on double-buffered static inputs (engine.DoubleBufferedStep): batch k+1 is
+    # loaded on an input stream while step k runs.  The pre-pass pipeline is shared with the single-set replay above.
+    replay2 = None
+    if replay is not None and not args.resident and args.double_buffer and not args.no_prefetch:
+        replay2 = trainer.capture_double(batches[1], batches[2], prefetch_geometry=True, max_gt=MAX_GT,
+                                         geo_pipe=replay.geo, dry=True)
     k = [0]
 
     def step_resident():
@@ -406,8 +416,9 @@ def main():
         cur, nxt = batches[k[0] % NB], batches[(k[0] + 1) % NB]
         if replay is None:
             return trainer.step(cur)
-        replay.load(cur)
-        return replay(next_points=nxt["points"])
+        r = replay2 if replay2 is not None else replay
+        r.load(cur)
+        return r(next_points=nxt["points"])
 
     step = step_resident if args.resident else step_loop
     for _ in range(args.warmup):
@@ -641,7 +652,9 @@ def main():
                        "timed_loop": ("one resident batch replayed" if args.resident else
                                       "%d distinct HBM-resident batches cycled through replay.load(): target "
                                       "padding, meta refresh, static-buffer copies and the next cloud's "
-                                      "pre-pass are inside the timed step" % NB),
+                                      "pre-pass are inside the timed step" % NB) +
+                                     ("; double-buffered static inputs: batch k+1 is loaded on an input stream "
+                                      "while step k runs" if (not args.resident and replay2 is not None) else ""),
                        "launch": launch},
             # two more passes of the same K steps right after the timed region (stability check;
             # `value` is the first, contract-shaped region only)

@@ -628,13 +628,14 @@ class Trainer:
                 geo.take_fresh(main)
             return loss
 
-        def load(new):
+        def load(new, skip_geo=False):
             """Copy another batch into the static input buffers of the captured step.  The captured
             forward reads its FPS / ball-query / 3-NN indices from the static geometry buffers; if
             they do not hold THIS cloud's geometry, it is fetched from the finished / in-flight
             pre-pass (waiting for it) or recomputed here, so geometry and targets can never belong
-            to different batches."""
-            if can_prefetch:
+            to different batches.  ``skip_geo``: the caller has done that already (DoubleBufferedStep:
+            on the main stream, while this call runs on its input stream)."""
+            if can_prefetch and not skip_geo:
                 geo.ensure(torch.cuda.current_stream(), new["points"], static["points"])
             static["points"].copy_(new["points"])
             nf = new["img_features"]
@@ -668,6 +669,11 @@ class Trainer:
         replay.max_gt = G
         self._graph = graph
         return replay
+
+    def capture_double(self, batch_a, batch_b, **kw):
+        """Two captured steps over two sets of static input buffers (``DoubleBufferedStep``): the next batch is
+        loaded into the idle set on an input stream WHILE the current step runs."""
+        return DoubleBufferedStep(self, batch_a, batch_b, **kw)
 
     def bucketed(self, **kw):
         """A step that keeps one captured graph per input SHAPE (``StepCache``)."""
@@ -755,6 +761,78 @@ class _GeoPipe:
             # (an unrelated pre-pass in flight is left to finish; its result is dropped)
             self.launch_prepass(main, points)
             self.take_fresh(main)
+
+
+class DoubleBufferedStep:
+    """The captured step with DOUBLE-BUFFERED static inputs: two hipGraphs of the same step (same model, optimizer,
+    pre-pass pipeline) reading two sets of static input buffers.  ``load(batch)`` fills the set the NEXT call will
+    read, on an input stream, so the per-batch input path - the pyramid's conversion to tokens (63 us of HBM traffic),
+    the copies of points / padded targets / constants - runs underneath the step in flight instead of between two
+    steps (the host runs about one step ahead of the GPU, so ``load(k+1)`` is enqueued while step k executes).
+    Same calling convention as ``Trainer.capture``'s replay:
+
+        step = trainer.capture_double(batch_0, batch_1)
+        for k in range(steps):
+            if k: step.load(batch_k)            # k = 0: batch_0 is in place
+            loss = step(next_points=batch_{k+1}["points"])
+
+    Ordering: a set is overwritten only after the last step that read it has finished (event), and a step waits for
+    its set's load (event).  The reference's loader does the same thing with pinned-memory prefetch threads
+    (mmcv's DataLoader workers feeding MMDistributedDataParallel, /root/reference/train.py:140-147)."""
+
+    def __init__(self, trainer, batch_a, batch_b, **kw):
+        if batch_a["img_metas"] is batch_b["img_metas"]:
+            raise ValueError("capture_double: the two batches must carry their own img_metas objects (each set of "
+                             "static buffers owns the device constants cached for its metas)")
+        self.trainer = trainer
+        first = trainer.capture(batch_a, **kw)
+        kw2 = dict(kw)
+        kw2.update(dry=True, geo_pipe=first.geo)
+        second = trainer.capture(batch_b, **kw2)
+        self.slots = [first, second]
+        self.geo, self.max_gt = first.geo, first.max_gt
+        self.input_stream = concurrent_stream()
+        self.loaded = [None, None]           # event: the set's load has finished
+        self.done = [None, None]             # event: the last step that read the set has finished
+        self.nxt = 0                         # the set the next call replays (set 0 holds batch_a)
+        # the shared pre-pass pipeline must describe batch_a's cloud for the first call
+        if self.geo is not None:
+            self.geo.ensure(torch.cuda.current_stream(), batch_a["points"])
+
+    @property
+    def static(self):
+        return self.slots[self.nxt].static
+
+    def load(self, new):
+        s = self.nxt
+        main = torch.cuda.current_stream()
+        if self.slots[s].geo is not None:
+            # geometry bookkeeping (normally a no-op: the pre-pass of this cloud was launched under the previous step
+            # and moved into the static index buffers at its end) belongs to the main stream
+            self.slots[s].geo.ensure(main, new["points"])
+        ins = self.input_stream
+        if self.done[s] is not None:
+            ins.wait_event(self.done[s])
+        else:
+            ins.wait_stream(main)            # first use of the set: behind its capture
+        with torch.cuda.stream(ins):
+            self.slots[s].load(new, skip_geo=True)
+            ev = torch.cuda.Event()
+            ev.record(ins)
+        self.loaded[s] = ev
+
+    def __call__(self, next_points=None):
+        s = self.nxt
+        main = torch.cuda.current_stream()
+        if self.loaded[s] is not None:
+            main.wait_event(self.loaded[s])
+            self.loaded[s] = None
+        out = self.slots[s](next_points=next_points)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.done[s] = ev
+        self.nxt = 1 - s
+        return out
 
 
 class StepCache:
