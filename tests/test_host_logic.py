@@ -166,3 +166,69 @@ def test_compute_dtype_names_and_native_override(monkeypatch):
     finally:
         monkeypatch.delenv("DEMF_F32_NATIVE", raising=False)
         ops.set_compute_dtype("f32")
+
+
+def test_image_stream_conv_path_host_logic_vs_oracle(monkeypatch):
+    """The HOST side of the convolution kernel path (demf_amd/modules/image_stream.py: ImageStream._pyramid_tokens) with
+    the four device operators replaced by torch restatements of their C-ABI contract: frozen-BatchNorm folding, the
+    (Cout, KH, KW, Cin) reduction order of ops.conv_weight_planes, the stem's 7 x (8 pixels x 4 channels) packing, the
+    bottleneck wiring (downsample branch, residual, strides), the neck incl. its 3x3 stride-2 level and GroupNorm
+    written into token rows - against the CPU oracle's NCHW pyramid (oracle/model.py) at the reference's channel widths
+    (configs/deformdetr/imvotenet_image.py:3-20).  The kernels themselves: tests/test_gpu_conv.py."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import fixtures
+    from oracle.model import OracleImageStream
+    from demf_amd import ops
+    from demf_amd.modules import ImageStream
+
+    def w_of(wp, shape):                                 # planes -> the fp32 weight they sum to
+        return wp.float().sum(0).view(*shape)
+
+    def conv_nhwc(x, wp, bias, KH, KW, stride=1, pad=0, resid=None, relu=False, out=None, ksplit=None):
+        w = w_of(wp, (wp.shape[1], KH, KW, x.shape[3])).permute(0, 3, 1, 2)
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+        y = y if resid is None else y + resid
+        return (y.relu() if relu else y).contiguous()
+
+    def conv_stem7(img, wp, bias, relu=True):
+        w = w_of(wp, (wp.shape[1], 7, 8, 4))
+        assert (w[:, :, 7] == 0).all() and (w[..., 3] == 0).all()          # the padding taps of the packing
+        y = F.conv2d(img, w[:, :, :7, :3].permute(0, 3, 1, 2), bias, stride=2, padding=3).permute(0, 2, 3, 1)
+        return y.relu().contiguous()
+
+    def maxpool(x):
+        return F.max_pool2d(x.permute(0, 3, 1, 2), 3, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
+
+    def groupnorm_into(x, groups, gamma, beta, eps, tokens, row0):
+        B, h, w, C = x.shape
+        tokens[:, row0:row0 + h * w] = F.group_norm(x.permute(0, 3, 1, 2), groups, gamma, beta, eps) \
+            .permute(0, 2, 3, 1).reshape(B, h * w, C)
+
+    monkeypatch.setattr(ops, "conv_nhwc", conv_nhwc)
+    monkeypatch.setattr(ops, "conv_stem7", conv_stem7)
+    monkeypatch.setattr(ops, "maxpool3x3s2_nhwc", maxpool)
+    monkeypatch.setattr(ops, "groupnorm_nhwc_into", groupnorm_into)
+    cfg = dict(base=64, blocks=(2, 1, 2, 1), embed_dims=256, num_layers=1, num_heads=8, feedforward_channels=256,
+               gn_groups=32, num_feats=128)
+    img, _ = fixtures.make_images(12, B=2, H=96, W=160)
+    ref = OracleImageStream(**cfg)
+    fixtures.seed_weights(ref, 12)
+    with torch.no_grad():
+        want = ref.img_neck(ref.img_backbone(torch.from_numpy(img)))
+    m = ImageStream(**cfg)
+    fixtures.seed_weights(m, 12)
+    with torch.no_grad():
+        got = m._pyramid_tokens(torch.from_numpy(img))
+    assert got["spatial"] == [tuple(p.shape[-2:]) for p in want]
+    start = 0
+    for p in want:
+        h, w = p.shape[-2:]
+        g = got["tokens"][:, start:start + h * w].view(2, h, w, 256).permute(0, 3, 1, 2)
+        start += h * w
+        assert (g - p).abs().max().item() <= 5e-5 * max(1.0, p.abs().max().item())
+    # the pack is cached per (parameter versions, planes) and rebuilt by load_state_dict
+    pk = m._conv_pack(3)
+    assert m._conv_pack(3) is pk
+    m.load_state_dict(m.state_dict())
+    assert m._conv_pack(3) is not pk
