@@ -314,7 +314,11 @@ def test_shape_bucketed_capture_matches_eager_steps(dropout):
     for i, (x, y) in enumerate(zip(la, lb)):
         assert abs(x - y) <= 2e-3 * (1 + i / 4) * abs(x), (i, x, y)
     assert ((pa - pb).norm() / pa.norm()).item() < 2e-4
-    assert ((ba - bb).norm() / ba.norm()).item() < 1e-4       # BatchNorm statistics: no extra warm-up passes
+    # BatchNorm statistics: no extra warm-up passes (one leaked pass moves them by ~1e-1).  The run is bimodal: in
+    # about one run of four a near-tie (max-pool / ReLU) resolves differently between the two engines at step 7
+    # (loss 15.920 vs 15.863, the same two values every time, also at the round-4 commit) and the statistics then
+    # differ by 1.2e-3 instead of < 1e-4
+    assert ((ba - bb).norm() / ba.norm()).item() < 3e-3
 
 
 def test_step_cache_evicts_least_recently_used():
