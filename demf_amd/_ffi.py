@@ -25,6 +25,7 @@ SIGNATURES = {
     "demf_nchw3_to_nhwc4_f32": [_c_int] * 3 + [_ptr, _ptr, _ptr],
     "demf_groupnorm_nhwc_f32": [_c_int] * 4 + [_c_float, _ptr, _ptr, _ptr, _ptr, _ptr, ctypes.c_longlong, _ptr],
     "demf_fps_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, _ptr, _ptr],
+    "demf_fps_ws_f32": [_c_int, _c_int, _c_int, _ptr, _ptr, ctypes.c_longlong, _ptr, _ptr],
     "demf_ball_query_f32": [_c_int, _c_int, _c_int, _c_float, _c_float, _c_int, _ptr, _ptr,
                             _ptr, _ptr],
     "demf_ball_query_grid_ws": [_c_int, _c_int, _ptr, _ptr],

@@ -684,6 +684,92 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int N, int M, int BSR
   }
 }
 
+// The same verification spread over the chip (round 5).  fps_ordered_check_k squeezes its N*M pair evaluations
+// through ONE compute unit per scene: 162 us at 2 048 -> 1 024, 288 us for the four checks of a step - all of it on
+// the serial pre-pass chain (and at B = 1 the chip is otherwise idle).  Here
+//   fps_check_e_k    : E[k] = min_{i<k} d(q_i, q_k); a workgroup takes 64 consecutive k, its 4 waves split the i range;
+//   fps_check_test_k : one thread per j walks k < min(j, M) with the running minimum r and tests E[k] > r; a workgroup
+//                      per 256 points; the verdict of a scene is ONE packed atomic (arrivals | violations << 16), the
+//                      last workgroup to arrive writes flag[b] and idx = 0..M-1 - no fence, no second variable.
+// Same predicate, same dist2(), same comparisons as above: the outcome is identical.
+// Scratch (ints, in the caller's (B,N) temp): flag[B] | ticket[B] | E[B*M] (floats); needs 2 + M <= N.
+__global__ __launch_bounds__(256) void fps_check_e_k(int N, int M, const float* __restrict__ xyz, int* __restrict__ flag,
+                                                     int* __restrict__ ticket, float* __restrict__ E) {
+  __shared__ float s_min[4][64];
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  xyz += (size_t)b * N * 3;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { flag[b] = 0; ticket[b] = 0; }
+  const int k = blockIdx.x * 64 + lane;
+  const int kk = k < M ? k : M - 1;
+  const float qx = xyz[3 * kk], qy = xyz[3 * kk + 1], qz = xyz[3 * kk + 2];
+  // i ranges over [0, 64 * blockIdx.x + 63): the wave's quarter, every lane masks i >= its own k
+  const int hi = blockIdx.x * 64 + 64;
+  const int per = (hi + 3) / 4;
+  const int i0 = wave * per, i1 = min(hi, i0 + per);
+  float e = 1e10f;
+  for (int i = i0; i < i1; ++i) {                 // (i is wave-uniform: scalar loads)
+    const float d = dist2(xyz[3 * i] - qx, xyz[3 * i + 1] - qy, xyz[3 * i + 2] - qz);
+    e = i < k ? fminf(e, d) : e;
+  }
+  s_min[wave][lane] = e;
+  __syncthreads();
+  if (wave == 0 && k < M)
+    E[(size_t)b * M + k] = fminf(fminf(s_min[0][lane], s_min[1][lane]), fminf(s_min[2][lane], s_min[3][lane]));
+}
+
+__global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const float* __restrict__ xyz,
+                                                        const float* __restrict__ E, int* __restrict__ idx,
+                                                        int* __restrict__ flag, int* __restrict__ ticket) {
+  __shared__ float4 s_q[FPS_PREFIX_MAX];       // {x, y, z, E[k]}
+  __shared__ int s_bad, s_last;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  xyz += (size_t)b * N * 3;
+  idx += (size_t)b * M;
+  E += (size_t)b * M;
+  for (int t = tid; t < M; t += 256) s_q[t] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], E[t]);
+  if (tid == 0) s_bad = 0;
+  __syncthreads();
+  const int j = blockIdx.x * 256 + tid;
+  bool bad = false;
+  if (j < N) {
+    const float qx = xyz[3 * j], qy = xyz[3 * j + 1], qz = xyz[3 * j + 2];
+    float r = 1e10f;
+    const int kmax = j < M ? j : M;
+    int k = 0;
+    for (; k + 8 <= kmax && !bad; k += 8) {
+      float d[8], e[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float4 o = s_q[k + v];
+        d[v] = dist2(o.x - qx, o.y - qy, o.z - qz);
+        e[v] = o.w;
+      }
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        bad |= (k + v >= 1) && !(e[v] > r);
+        r = fminf(r, d[v]);
+      }
+    }
+    for (; k < kmax; ++k) {
+      const float4 o = s_q[k];
+      bad |= (k >= 1) && !(o.w > r);
+      r = fminf(r, dist2(o.x - qx, o.y - qy, o.z - qz));
+    }
+  }
+  if (bad) s_bad = 1;
+  __syncthreads();
+  if (tid == 0) {
+    const int old = atomicAdd(ticket + b, 1 + (s_bad ? 0x10000 : 0));
+    const int now = old + 1 + (s_bad ? 0x10000 : 0);
+    s_last = ((now & 0xffff) == (int)gridDim.x) ? (now >> 16 ? 1 : 2) : 0;      // 2: last, no violation anywhere
+  }
+  __syncthreads();
+  if (s_last == 2) {
+    for (int t = tid; t < M; t += 256) idx[t] = t;
+    if (tid == 0) flag[b] = 1;
+  }
+}
+
 template <int BS, int PPT>
 static void launch_reg(int B, int N, int M, const float* xyz, int* idx, const int* skip,
                        hipStream_t s) {
@@ -694,8 +780,24 @@ static void launch_reg(int B, int N, int M, const float* xyz, int* idx, const in
 
 using namespace demf;
 
+static int fps_impl(int B, int N, int M, const float* xyz, float* temp, long long temp_floats, int* idx,
+                    demf_stream_t stream);
+
 extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, int* idx,
                             demf_stream_t stream) {
+  // (the scratch size is implied by the shape class: see include/demf_hip.h; the ordered-input check gets the
+  // B words the contract promises, i.e. its one-CU form)
+  return fps_impl(B, N, M, xyz, temp, temp != nullptr ? (long long)B : 0, idx, stream);
+}
+
+extern "C" int demf_fps_ws_f32(int B, int N, int M, const float* xyz, float* temp, long long temp_floats, int* idx,
+                               demf_stream_t stream) {
+  DEMF_REQUIRE(temp == nullptr || temp_floats >= B, "fps_ws: scratch of %lld floats for %d scenes", temp_floats, B);
+  return fps_impl(B, N, M, xyz, temp, temp != nullptr ? temp_floats : 0, idx, stream);
+}
+
+static int fps_impl(int B, int N, int M, const float* xyz, float* temp, long long temp_floats, int* idx,
+                    demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0, "fps: bad sizes B=%d N=%d M=%d", B, N, M);
   if (B == 0 || M == 0) return DEMF_OK;
   DEMF_REQUIRE(xyz && idx, "fps: null pointer");
@@ -707,7 +809,16 @@ extern "C" int demf_fps_f32(int B, int N, int M, const float* xyz, float* temp, 
   // first (needs B ints of scratch in `temp`); scenes it verifies are skipped by the main kernel
   const int* skip = nullptr;
   if (temp != nullptr && M >= 2 && M <= FPS_PREFIX_MAX && N <= 4 * M && bs >= 64 && ppt <= 24) {
-    hipLaunchKernelGGL(fps_ordered_check_k, dim3(B), dim3(1024), 0, s, N, M, xyz, idx, (int*)temp);
+    static const int split = [] { const char* v = getenv("DEMF_FPS_CHECK_SPLIT"); return v ? atoi(v) : 1; }();   // A/B
+    if (split && temp_floats >= (long long)B * (M + 2) && cdiv(N, 256) < 0x8000) {
+      int* flag = (int*)temp;
+      int* ticket = flag + B;
+      float* E = temp + 2 * (size_t)B;
+      hipLaunchKernelGGL(fps_check_e_k, dim3(cdiv(M, 64), B), dim3(256), 0, s, N, M, xyz, flag, ticket, E);
+      hipLaunchKernelGGL(fps_check_test_k, dim3(cdiv(N, 256), B), dim3(256), 0, s, N, M, xyz, E, idx, flag, ticket);
+    } else {
+      hipLaunchKernelGGL(fps_ordered_check_k, dim3(B), dim3(1024), 0, s, N, M, xyz, idx, (int*)temp);
+    }
     skip = (const int*)temp;
   }
   // large clouds with the (B, N) scratch at hand: Hilbert-cell order + the exact box-pruned kernel

@@ -268,11 +268,12 @@ class _FurthestPointSampling(Function):
             # (large clouds: the scratch holds the Hilbert-cell order of the exact box-pruned kernel)
             temp = torch.empty((B, N), dtype=torch.float32, device=points_xyz.device)
         elif 2 <= num_points <= 1024 and N <= 4 * num_points and not _NO_FPS_CHECK:
-            # B flags for the ordered-input check (every SA level after the first samples a cloud
-            # that already is in FPS order)
-            temp = torch.empty((B,), dtype=torch.float32, device=points_xyz.device)
-        _ffi.call("demf_fps_f32", B, N, num_points, _p(points_xyz), _p(temp), _p(idx),
-                  _stream())
+            # scratch of the ordered-input check (every SA level after the first samples a cloud that already
+            # is in FPS order): B flags + B tickets + the B x M nearest-earlier-sample distances of its
+            # chip-wide form (demf_fps_ws_f32)
+            temp = torch.empty((B, num_points + 2), dtype=torch.float32, device=points_xyz.device)
+        _ffi.call("demf_fps_ws_f32", B, N, num_points, _p(points_xyz), _p(temp),
+                  0 if temp is None else temp.numel(), _p(idx), _stream())
         ctx.mark_non_differentiable(idx)
         return idx
 
