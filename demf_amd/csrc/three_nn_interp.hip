@@ -9,6 +9,7 @@
 // Strict '<' insertion keeps the upstream "earliest source wins ties" order.
 // three_interpolate: 3-tap weighted row gather; HBM/L2-bound.
 #include "common.h"
+#include <stdlib.h>
 
 namespace demf {
 
@@ -65,6 +66,82 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     } else {
       // PointFPModule.forward: dist = sqrt(dist2); r = 1 / (dist + 1e-8); weight = r / sum(r) -
       // the five element-wise launches of the reference's expression, in its operation order
+      const float d1 = sqrtf(b1), d2 = sqrtf(b2), d3 = sqrtf(b3);
+      const float r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f), r3 = 1.0f / (d3 + 1e-8f);
+      const float sum = (r1 + r2) + r3;
+      float* ww = weight_out + ((size_t)b * n + t) * 3;
+      dd[0] = d1; dd[1] = d2; dd[2] = d3;
+      ww[0] = r1 / sum; ww[1] = r2 / sum; ww[2] = r3 / sum;
+    }
+  }
+}
+
+// The same search with EIGHT lanes per target (round 5).  three_nn_kernel walks the m sources with one thread per
+// target - 1 024 x 512 pairs per scene on four waves, a branchy dependent top-3 insertion per pair: 40-67 us per call
+// on the serial pre-pass chain.  Here lane c of a group takes the sources k = c, c + 8, ... (consecutive LDS words
+// across the group, the 8 groups of a wave broadcast), keeps its own three smallest, and the group selects the three
+// smallest of its 24 candidates by the key (distance bits << 32 | index): squared distances are >= +0, so their
+// bit patterns order like the values, and the index in the low word reproduces the sequential scan's tie rule
+// (strict <: the earlier source wins).  Bit-identical results; needs m >= 64.
+__global__ __launch_bounds__(256) void three_nn_split_kernel(int n, int m,
+                                                             const float* __restrict__ target,
+                                                             const float* __restrict__ source,
+                                                             float* __restrict__ dist2_out,
+                                                             int* __restrict__ idx_out,
+                                                             float* __restrict__ weight_out) {
+  __shared__ float sx[NN_TILE], sy[NN_TILE], sz[NN_TILE];
+  const int b = blockIdx.y;
+  target += (size_t)b * n * 3;
+  source += (size_t)b * m * 3;
+  const int c = threadIdx.x & 7;
+  const int t = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const bool ok = t < n;
+  const int tt = ok ? t : n - 1;
+  const float ux = target[3 * tt + 0], uy = target[3 * tt + 1], uz = target[3 * tt + 2];
+  const unsigned long long KINF = ((unsigned long long)0x7f800000u << 32);     // +inf, index 0: the scan's initial state
+  unsigned long long k1 = KINF, k2 = KINF, k3 = KINF;
+  for (int k0 = 0; k0 < m; k0 += NN_TILE) {
+    const int cnt = min(NN_TILE, m - k0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt; k += blockDim.x) {
+      sx[k] = source[3 * (k0 + k) + 0];
+      sy[k] = source[3 * (k0 + k) + 1];
+      sz[k] = source[3 * (k0 + k) + 2];
+    }
+    __syncthreads();
+    for (int k = c; k < cnt; k += 8) {
+      const float d = dist2(ux - sx[k], uy - sy[k], uz - sz[k]);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(k0 + k);
+      // (d < b) on values == (key < kb) on keys for finite d >= 0 with increasing indices; NaN (sign clear) sorts last
+      if (d == d) {
+        if (key < k1) { k3 = k2; k2 = k1; k1 = key; }
+        else if (key < k2) { k3 = k2; k2 = key; }
+        else if (key < k3) { k3 = key; }
+      }
+    }
+  }
+  // the group's three smallest keys: three rounds of (minimum over the 8 heads, the owner pops)
+  unsigned long long out[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    unsigned long long mn = k1;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const unsigned long long other = __shfl_xor(mn, o);
+      mn = other < mn ? other : mn;
+    }
+    out[r] = mn;
+    if (k1 == mn && mn != KINF) { k1 = k2; k2 = k3; k3 = KINF; }
+  }
+  if (ok && c == 0) {
+    const float b1 = __uint_as_float((unsigned)(out[0] >> 32)), b2 = __uint_as_float((unsigned)(out[1] >> 32)),
+                b3 = __uint_as_float((unsigned)(out[2] >> 32));
+    float* dd = dist2_out + ((size_t)b * n + t) * 3;
+    int* ii = idx_out + ((size_t)b * n + t) * 3;
+    ii[0] = (int)(unsigned)out[0]; ii[1] = (int)(unsigned)out[1]; ii[2] = (int)(unsigned)out[2];
+    if (weight_out == nullptr) {
+      dd[0] = b1; dd[1] = b2; dd[2] = b3;
+    } else {
       const float d1 = sqrtf(b1), d2 = sqrtf(b2), d3 = sqrtf(b3);
       const float r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f), r3 = 1.0f / (d3 + 1e-8f);
       const float sum = (r1 + r2) + r3;
@@ -199,14 +276,23 @@ static inline int grid_rows(long long rows) {
 
 using namespace demf;
 
+static bool three_nn_split(int m) {
+  static const int on = [] { const char* v = getenv("DEMF_THREE_NN_SPLIT"); return v ? atoi(v) : 1; }();   // A/B switch
+  return on && m >= 64;
+}
+
 extern "C" int demf_three_nn_f32(int B, int n, int m, const float* target,
                                  const float* source, float* dist2, int* idx,
                                  demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && n >= 0 && m >= 1, "three_nn: bad sizes B=%d n=%d m=%d", B, n, m);
   if (B == 0 || n == 0) return DEMF_OK;
   DEMF_REQUIRE(target && source && dist2 && idx, "three_nn: null pointer");
-  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
-                     (hipStream_t)stream, n, m, target, source, dist2, idx, (float*)nullptr);
+  if (three_nn_split(m))
+    hipLaunchKernelGGL(three_nn_split_kernel, dim3(cdiv(n, 32), B), dim3(256), 0,
+                       (hipStream_t)stream, n, m, target, source, dist2, idx, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
+                       (hipStream_t)stream, n, m, target, source, dist2, idx, (float*)nullptr);
   return check_launch("three_nn");
 }
 
@@ -215,8 +301,12 @@ extern "C" int demf_three_nn_weights_f32(int B, int n, int m, const float* targe
   DEMF_REQUIRE(B >= 0 && n >= 0 && m >= 1, "three_nn_weights: bad sizes B=%d n=%d m=%d", B, n, m);
   if (B == 0 || n == 0) return DEMF_OK;
   DEMF_REQUIRE(target && source && dist && idx && weight, "three_nn_weights: null pointer");
-  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
-                     (hipStream_t)stream, n, m, target, source, dist, idx, weight);
+  if (three_nn_split(m))
+    hipLaunchKernelGGL(three_nn_split_kernel, dim3(cdiv(n, 32), B), dim3(256), 0,
+                       (hipStream_t)stream, n, m, target, source, dist, idx, weight);
+  else
+    hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), B), dim3(256), 0,
+                       (hipStream_t)stream, n, m, target, source, dist, idx, weight);
   return check_launch("three_nn_weights");
 }
 

@@ -135,6 +135,25 @@ def test_three_nn_bit_exact(ops, n, m):
     assert np.isfinite(want).all() or m < 3
 
 
+@pytest.mark.parametrize("n,m", [(700, 64), (1024, 512), (333, 2100)])
+def test_three_nn_ties_bit_exact(ops, n, m):
+    """Grid-snapped clouds: many sources at EQUAL distance from a target (and duplicated sources), so the result is
+    decided by the tie rule of the sequential scan - strict <, the earlier source wins - which the eight-lane kernel
+    (demf_three_nn_f32 for m >= 64: per-lane top three, group selection by (distance bits, index)) must reproduce."""
+    snap = lambda a: (np.round(a * 2.0) / 2.0).astype(np.float32)
+    tgt = snap(scene_points(2, n, seed=n + 7))
+    src = snap(scene_points(2, m, seed=m + 8))
+    src[:, m // 2:m // 2 + 5] = src[:, :5]                     # exact duplicates at distant indices
+    d2, idx = ok.three_nn(tgt, src)
+    ties = (d2[..., 0] == d2[..., 1]).mean()
+    assert ties > 0.2, "the case must be decided by ties"
+    dist, gi = ops.three_nn(dev(tgt), dev(src))
+    np.testing.assert_array_equal(gi.cpu().numpy(), idx)
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(d2))
+    wi, _ = ops.three_nn_weights(dev(tgt), dev(src))
+    np.testing.assert_array_equal(wi.cpu().numpy(), idx)
+
+
 def test_three_interpolate(ops):
     rng = np.random.default_rng(2)
     B, C, m, n = 2, 256, 256, 512
