@@ -87,6 +87,7 @@ constexpr int FPS_IDX_CHUNK = 2048;  // selected indices buffered in LDS between
 
 #ifdef DEMF_FPS_PROFILE  // tools/ubench/fps_prof.cpp: per-phase shader-cycle accounting (wave 0)
 __device__ long long g_fps_prof[8];
+__device__ long long g_prune_prof[16][8];   // tools/ubench/fps_prune_prof.cpp: per wave of scene 0
 #define FPS_T(k) const long long t##k = __builtin_readcyclecounter();
 #define FPS_ACC(i, a, b) prof[i] += (b) - (a);
 #else
@@ -528,7 +529,13 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
   float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
   if (tid == 0) s_idx[0] = 0;
 
+#ifdef DEMF_FPS_PROFILE
+  long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int j = 1; j < M; ++j) {
+#ifdef DEMF_FPS_PROFILE
+    const long long pt0 = __builtin_readcyclecounter();
+#endif
     // ---- every pair's box (and the candidate) against the new sample, one lane each
     const float ex = raw_max3(blx - x1, x1 - bhx, 0.f);
     const float ey = raw_max3(bly - y1, y1 - bhy, 0.f);
@@ -548,6 +555,10 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
           tmp[2 * i + 1] = raw_min(d[1], tmp[2 * i + 1]);
         }
       }
+#ifdef DEMF_FPS_PROFILE
+      const long long pts = __builtin_readcyclecounter();
+      pp[7] += pts - pt0;                                 // box test + update, rounds with an update
+#endif
       if (need >> 63) {                                   // the candidate's own distance fell: search again
         float best = -1.f;
 #pragma unroll
@@ -582,15 +593,29 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
 #undef DEMF_FPS_PICK
         if (lane == 63) { blx = bhx = cx; bly = bhy = cy; blz = bhz = cz; }
         dirty = 2;
+#ifdef DEMF_FPS_PROFILE
+        pp[6] += __builtin_readcyclecounter() - pts;      // the search alone
+#endif
       }
     }
     // ---- block maximum, lowest tie key among the waves that hold it
+#ifdef DEMF_FPS_PROFILE
+    const long long pt1 = __builtin_readcyclecounter();
+    pp[0] += pt1 - pt0;
+    pp[3] += need != 0;
+    pp[4] += (need >> 63) != 0;
+    pp[5] += __builtin_popcountll(need & ~(1ull << 63));
+#endif
     FpsCand* slot = s_cand[j & 1];
     if (dirty) {
       if (lane == 0) slot[wave] = FpsCand{cv, ctk, cx, cy, cz};
       --dirty;
     }
     lds_barrier();
+#ifdef DEMF_FPS_PROFILE
+    const long long pt2 = __builtin_readcyclecounter();
+    pp[1] += pt2 - pt1;
+#endif
     {
       const FpsCand c = slot[lane & (NW - 1)];           // every 16-lane row: all NW waves (twice over at NW = 8)
       const float gmax = readlane_f(row16_max_dpp(c.v), 0);
@@ -609,6 +634,9 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
         s_idx[j & (FPS_IDX_CHUNK - 1)] = (int)(((tk & 31u) << 10) | (tk >> 5));
       }
     }
+#ifdef DEMF_FPS_PROFILE
+    pp[2] += __builtin_readcyclecounter() - pt2;
+#endif
     if (((j + 1) & (FPS_IDX_CHUNK - 1)) == 0) {
       lds_barrier();
       const int base = j + 1 - FPS_IDX_CHUNK;
@@ -616,6 +644,10 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
       lds_barrier();
     }
   }
+#ifdef DEMF_FPS_PROFILE
+  if (b == 0 && lane == 0 && wave < 16)
+    for (int i = 0; i < 8; ++i) g_prune_prof[wave][i] = pp[i];
+#endif
   lds_barrier();
   const int base = M & ~(FPS_IDX_CHUNK - 1);
   for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
