@@ -65,6 +65,45 @@ def newest_profile(pattern):
     return hits[-1] if hits else None
 
 
+LIVE_PMC = {}       # --pmc-live: {"FETCH_SIZE": summary csv, "WRITE_SIZE": summary csv} measured by THIS run
+
+
+def pmc_live(args):
+    """--pmc-live: the two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only, no tracing
+    domains) of this same command at 3 + 2 steps, summarised per kernel by tools/pmc_summary.py into a scratch
+    directory - so that `roofline.traffic` and `roofline_step.traffic_step` of this line are observed by this run
+    instead of read from the committed profiles/.  Best effort: any failure leaves the committed files in charge."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not found"
+    scratch = tempfile.mkdtemp(prefix="demf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT)
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(scratch, c)
+            cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
+                   "--dtype", args.dtype, "--batch", str(args.batch), "--msda-points", str(args.msda_points),
+                   "--cloud", args.cloud, "--no-pmc-live"]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, capture_output=True, check=True)
+            hits = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not hits:
+                return "no counter_collection.csv for " + c
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), hits[0], c],
+                                 capture_output=True, text=True, timeout=120, check=True).stdout
+            path = os.path.join(scratch, "pmc_%s.csv" % c)
+            with open(path, "w") as fh:
+                fh.write(out)
+            LIVE_PMC[c] = path
+    except Exception as exc:            # noqa: BLE001 - the committed passes remain the source
+        LIVE_PMC.clear()
+        return repr(exc)[:200]
+    return None
+
+
 def pmc_per_launch(kernel_prefix, which="max", required=False):
     """HBM bytes per launch of the kernel whose name STARTS WITH ``kernel_prefix`` (after the
     ``void demf::`` decoration), from the NEWEST committed PMC summaries
@@ -77,7 +116,8 @@ def pmc_per_launch(kernel_prefix, which="max", required=False):
     not evidence.  ``required``: raise instead of returning (None, source) when that pair has no row.
     -> (bytes | None, source file | None)"""
     import csv
-    f = newest_profile("r*_pmc_FETCH_SIZE.csv")
+    live = len(LIVE_PMC) == 2
+    f = LIVE_PMC["FETCH_SIZE"] if live else newest_profile("r*_pmc_FETCH_SIZE.csv")
     if f is None or not os.path.exists(f.replace("FETCH_SIZE", "WRITE_SIZE")):
         if required:
             raise RuntimeError("no committed PMC passes under profiles/")
@@ -97,7 +137,7 @@ def pmc_per_launch(kernel_prefix, which="max", required=False):
                     hit = float(row[3] if which == "max" else row[2])
                     break
         vals.append(hit)
-    src = os.path.relpath(f, ROOT)
+    src = "live: two rocprofv3 --pmc passes of this run (bench.py --pmc-live)" if live else os.path.relpath(f, ROOT)
     if None in vals:
         if required:
             raise RuntimeError("%s has no row for kernel prefix %r" % (src, kernel_prefix))
@@ -322,6 +362,10 @@ def main():
                     help="load each batch into the idle one of TWO sets of static input buffers on an input stream "
                          "while the previous step runs (engine.DoubleBufferedStep; measured SLOWER on MI355X / ROCm "
                          "7.2: 5.15 vs 5.01 ms - a third active hardware queue costs more than the 0.1 ms it hides)")
+    ap.add_argument("--no-pmc-live", action="store_true",
+                    help="read the HBM traffic fields from the committed profiles/ instead of re-measuring them with "
+                         "two rocprofv3 --pmc passes of this command (default at one GPU, ~10 s; falls back to the "
+                         "committed files on any failure)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (resident / bf16 / P=4 / clustered / B=16 step times, SA path)")
     args = ap.parse_args()
@@ -531,7 +575,7 @@ def main():
             import subprocess
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "--batch", "16", "--steps", str(args.steps),
                                   "--warmup", str(args.warmup), "--dtype", args.dtype, "--msda-points",
-                                  str(args.msda_points), "--no-secondary", "--no-cpu-baseline"],
+                                  str(args.msda_points), "--no-secondary", "--no-cpu-baseline", "--no-pmc-live"],
                                  capture_output=True, text=True, timeout=600)
             try:
                 d16 = json.loads(out.stdout.strip().splitlines()[-1])
@@ -572,7 +616,7 @@ def main():
                 step_resident()
             secondary["e2e_ms_per_step"] = time_steps(e2e, 10)
             # pipelined: the (frozen, no_grad) stream of batch k+1 on a side stream under the step of batch k
-            side = torch.cuda.Stream()
+            side = engine.concurrent_stream()      # (a pool stream may share the main stream's hardware queue)
 
             def e2e_pipe():
                 side.wait_stream(torch.cuda.current_stream())
@@ -679,6 +723,9 @@ def main():
         # gradient once, read the pooled gradient, its argmax rows and the raw pooled values (3 x (R/64,128)
         # words); weights and the (128,64) weight gradient < 1 %.  Algorithmic FLOPs: dX = dZ W and
         # dW = dZ^T A, 2 x 2 R 128 64.
+        if not args.no_pmc_live and world == 1 and args.batch == 8 and not args.no_graph:
+            err = pmc_live(args)
+            out["pmc_live"] = "ok" if err is None else "failed (%s): committed profiles/ used" % err
         x3 = args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"]
         # MFMA budget of the mode: native fp32 -> the fp32 MFMA peak; bf16 -> the bf16 peak; the
         # three-term split issues 6 bf16 MFMAs per algorithmic product -> bf16 peak / 6

@@ -9,7 +9,7 @@ mkdir -p $out
 export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary "$@" > $out/prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o p -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-pmc-live "$@" > $out/prof.log 2>&1
 st=$(find /tmp/prof_$tag -name '*kernel_stats.csv' | head -1)
 tr=$(find /tmp/prof_$tag -name '*kernel_trace.csv' | head -1)
 [ -n "$st" ] && cp $st $out/kernel_stats.csv
@@ -19,7 +19,7 @@ tail -1 $out/prof.log | head -c 400 > $out/bench_under_profiler.txt
 if [ -n "$PMC" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_$tag_$c
-    rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${tag}_$c -o p -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary "$@" > $out/pmc_$c.log 2>&1
+    rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${tag}_$c -o p -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --no-pmc-live "$@" > $out/pmc_$c.log 2>&1
     f=$(find /tmp/pmc_${tag}_$c -name '*counter_collection.csv' | head -1)
     [ -n "$f" ] && python $R/tools/pmc_summary.py $f $c > $out/pmc_$c.csv
   done
