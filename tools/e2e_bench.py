@@ -48,7 +48,7 @@ print(f"end-to-end step          : {ee:6.2f} ms = {B / ee * 1e3:6.1f} scenes/s")
 
 # pipelined: the frozen stream of batch k+1 on a side stream while the hot-path step of batch k runs (they share
 # nothing: the stream is no_grad and frozen); the step's launch-latency gaps are filled by the stream's kernels
-side = torch.cuda.Stream()
+side = engine.concurrent_stream()
 nxt = {}
 def e2e_pipe():
     side.wait_stream(torch.cuda.current_stream())
