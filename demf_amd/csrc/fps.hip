@@ -728,6 +728,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(int N, int M, int BSR
 __global__ __launch_bounds__(256) void fps_check_e_k(int N, int M, const float* __restrict__ xyz, int* __restrict__ flag,
                                                      int* __restrict__ ticket, float* __restrict__ E) {
   __shared__ float s_min[4][64];
+  __shared__ float4 s_p[FPS_PREFIX_MAX];          // the earlier samples, one broadcast 16-byte read per i
   const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   xyz += (size_t)b * N * 3;
   if (blockIdx.x == 0 && threadIdx.x == 0) { flag[b] = 0; ticket[b] = 0; }
@@ -735,12 +736,24 @@ __global__ __launch_bounds__(256) void fps_check_e_k(int N, int M, const float* 
   const int kk = k < M ? k : M - 1;
   const float qx = xyz[3 * kk], qy = xyz[3 * kk + 1], qz = xyz[3 * kk + 2];
   // i ranges over [0, 64 * blockIdx.x + 63): the wave's quarter, every lane masks i >= its own k
-  const int hi = blockIdx.x * 64 + 64;
+  const int hi = min(M, (int)blockIdx.x * 64 + 64);
+  for (int t = threadIdx.x; t < hi; t += 256) s_p[t] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], 0.f);
+  __syncthreads();
   const int per = (hi + 3) / 4;
   const int i0 = wave * per, i1 = min(hi, i0 + per);
   float e = 1e10f;
-  for (int i = i0; i < i1; ++i) {                 // (i is wave-uniform: scalar loads)
-    const float d = dist2(xyz[3 * i] - qx, xyz[3 * i + 1] - qy, xyz[3 * i + 2] - qz);
+  int i = i0;
+  for (; i + 4 <= i1; i += 4) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const float4 o = s_p[i + v];
+      const float d = dist2(o.x - qx, o.y - qy, o.z - qz);
+      e = i + v < k ? fminf(e, d) : e;
+    }
+  }
+  for (; i < i1; ++i) {
+    const float4 o = s_p[i];
+    const float d = dist2(o.x - qx, o.y - qy, o.z - qz);
     e = i < k ? fminf(e, d) : e;
   }
   s_min[wave][lane] = e;
@@ -752,6 +765,11 @@ __global__ __launch_bounds__(256) void fps_check_e_k(int N, int M, const float* 
 __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const float* __restrict__ xyz,
                                                         const float* __restrict__ E, int* __restrict__ idx,
                                                         int* __restrict__ flag, int* __restrict__ ticket) {
+  // eight lanes per point j: lane c owns the steps k of the c-th eighth of [0, kmax).  The running minimum
+  // r_k = min_{i<k} d(q_i, q_j) of the sequential test is (minimum over the earlier lanes' whole ranges) min (the
+  // lane's own running minimum): a first sweep takes every lane's range minimum, an exclusive prefix minimum across
+  // the eight lanes gives each its starting value, a second sweep makes the comparisons.  Twice the distance
+  // evaluations, an eighth of the dependent chain; min is exact, so every comparison sees the same r_k.
   __shared__ float4 s_q[FPS_PREFIX_MAX];       // {x, y, z, E[k]}
   __shared__ int s_bad, s_last;
   const int b = blockIdx.y, tid = threadIdx.x;
@@ -761,38 +779,36 @@ __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const floa
   for (int t = tid; t < M; t += 256) s_q[t] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], E[t]);
   if (tid == 0) s_bad = 0;
   __syncthreads();
-  const int j = blockIdx.x * 256 + tid;
+  const int c = tid & 7;
+  const int j = blockIdx.x * 32 + (tid >> 3);
+  const int jj = j < N ? j : N - 1;
+  const float qx = xyz[3 * jj], qy = xyz[3 * jj + 1], qz = xyz[3 * jj + 2];
+  const int kmax = j < N ? (j < M ? j : M) : 0;
+  const int per = (kmax + 7) >> 3;
+  const int k0 = min(kmax, c * per), k1 = min(kmax, k0 + per);
+  float mine = 1e10f;
+  for (int k = k0; k < k1; ++k) {
+    const float4 o = s_q[k];
+    mine = fminf(mine, dist2(o.x - qx, o.y - qy, o.z - qz));
+  }
+  // exclusive prefix minimum over the 8 lanes of the group (lane c: ranges 0 .. c-1)
+  float r = 1e10f;
+#pragma unroll
+  for (int d = 1; d < 8; ++d) {
+    const float other = __shfl(mine, ((tid & 63) & ~7) + ((c - d) & 7), 64);
+    r = d <= c ? fminf(r, other) : r;
+  }
   bool bad = false;
-  if (j < N) {
-    const float qx = xyz[3 * j], qy = xyz[3 * j + 1], qz = xyz[3 * j + 2];
-    float r = 1e10f;
-    const int kmax = j < M ? j : M;
-    int k = 0;
-    for (; k + 8 <= kmax && !bad; k += 8) {
-      float d[8], e[8];
-#pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        const float4 o = s_q[k + v];
-        d[v] = dist2(o.x - qx, o.y - qy, o.z - qz);
-        e[v] = o.w;
-      }
-#pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        bad |= (k + v >= 1) && !(e[v] > r);
-        r = fminf(r, d[v]);
-      }
-    }
-    for (; k < kmax; ++k) {
-      const float4 o = s_q[k];
-      bad |= (k >= 1) && !(o.w > r);
-      r = fminf(r, dist2(o.x - qx, o.y - qy, o.z - qz));
-    }
+  for (int k = k0; k < k1; ++k) {
+    const float4 o = s_q[k];
+    bad |= (k >= 1) && !(o.w > r);
+    r = fminf(r, dist2(o.x - qx, o.y - qy, o.z - qz));
   }
   if (bad) s_bad = 1;
   __syncthreads();
   if (tid == 0) {
-    const int old = atomicAdd(ticket + b, 1 + (s_bad ? 0x10000 : 0));
-    const int now = old + 1 + (s_bad ? 0x10000 : 0);
+    const int add = 1 + (s_bad ? 0x10000 : 0);
+    const int now = atomicAdd(ticket + b, add) + add;
     s_last = ((now & 0xffff) == (int)gridDim.x) ? (now >> 16 ? 1 : 2) : 0;      // 2: last, no violation anywhere
   }
   __syncthreads();
@@ -842,12 +858,12 @@ static int fps_impl(int B, int N, int M, const float* xyz, float* temp, long lon
   const int* skip = nullptr;
   if (temp != nullptr && M >= 2 && M <= FPS_PREFIX_MAX && N <= 4 * M && bs >= 64 && ppt <= 24) {
     static const int split = [] { const char* v = getenv("DEMF_FPS_CHECK_SPLIT"); return v ? atoi(v) : 1; }();   // A/B
-    if (split && temp_floats >= (long long)B * (M + 2) && cdiv(N, 256) < 0x8000) {
+    if (split && temp_floats >= (long long)B * (M + 2) && cdiv(N, 32) < 0x8000) {
       int* flag = (int*)temp;
       int* ticket = flag + B;
       float* E = temp + 2 * (size_t)B;
       hipLaunchKernelGGL(fps_check_e_k, dim3(cdiv(M, 64), B), dim3(256), 0, s, N, M, xyz, flag, ticket, E);
-      hipLaunchKernelGGL(fps_check_test_k, dim3(cdiv(N, 256), B), dim3(256), 0, s, N, M, xyz, E, idx, flag, ticket);
+      hipLaunchKernelGGL(fps_check_test_k, dim3(cdiv(N, 32), B), dim3(256), 0, s, N, M, xyz, E, idx, flag, ticket);
     } else {
       hipLaunchKernelGGL(fps_ordered_check_k, dim3(B), dim3(1024), 0, s, N, M, xyz, idx, (int*)temp);
     }
