@@ -299,6 +299,10 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_k(long long B, long long H
 // GroupNorm over channels-last rows (C = 256, G groups of C / G consecutive channels), two launches:
 // sums per (image, group) in double (one atomic pair per group per workgroup), then normalise + affine, written to
 // rows [row0, row0 + HW) of a (B, S, C) token buffer.
+__global__ __launch_bounds__(256) void gn_zero_k(int n, double* __restrict__ a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = 0.0;
+}
 __global__ __launch_bounds__(256) void gn_stats_nhwc_k(int HW, int C, int G, int rows_per_wg, const float* __restrict__ x,
                                                        double* __restrict__ sums) {
   const int b = blockIdx.y, c = threadIdx.x;                // one thread per channel (C == blockDim.x)
@@ -420,10 +424,9 @@ extern "C" int demf_groupnorm_nhwc_f32(int B, int HW, int C, int G, float eps, c
   DEMF_REQUIRE(B > 0 && HW > 0 && C == 256 && G > 0 && C % G == 0 && (C / G) % 4 == 0 && ((C / G) & (C / G - 1)) == 0 &&
                C / G <= 64 && x && gamma && beta && sums && y, "groupnorm_nhwc: bad arguments (C must be 256)");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, s) != hipSuccess) {
-    set_error("groupnorm_nhwc: memset failed");
-    return DEMF_ELAUNCH;
-  }
+  // (a kernel, not hipMemsetAsync: memset nodes inside a captured hipGraph were found not to be ordered with the
+  // kernels around them - csrc/group_gather.hip, demf_invert_index_ws)
+  hipLaunchKernelGGL(gn_zero_k, dim3(cdiv(2 * B * G, 256)), dim3(256), 0, s, 2 * B * G, sums);
   const int rows_per_wg = 64;
   hipLaunchKernelGGL(gn_stats_nhwc_k, dim3(cdiv(HW, rows_per_wg), B), dim3(256), 0, s, HW, C, G, rows_per_wg, x, sums);
   if (int e = check_launch("gn_stats_nhwc_k")) return e;

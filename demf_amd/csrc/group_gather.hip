@@ -10,6 +10,7 @@
 // All of these are pure HBM/L2 byte movers: the roofline is bytes written + bytes
 // gathered over 8 TB/s.
 #include "common.h"
+#include <stdlib.h>
 
 namespace demf {
 
@@ -510,6 +511,69 @@ __global__ __launch_bounds__(256) void pyramid_to_tokens_k(int C, int S, TokLeve
   }
 }
 
+// ---- the same inverse lists spread over the chip (round 5) ------------------------------------------------------
+// invert_index_k is ONE workgroup per scene, and at SA1 (131 072 entries over 20 000 points) the lists do not fit
+// LDS next to the histogram, so it fills them through global cursors and insertion-sorts every list in global
+// memory: 102 us on the serial pre-pass chain.  With E ints of workspace per scene:
+//   inv_hist_k   counts[j] += 1                               one thread per entry, atomics into off[j + 1]
+//   inv_scan_k   off[j + 1] <- start[j] (exclusive scan, in place)   one workgroup per scene
+//   inv_fill_k   ws[atomicAdd(off[j + 1], 1)] = e             one thread per entry; afterwards off[j + 1] = start[j + 1],
+//                                                             i.e. the final offsets without a second cursor array
+//   inv_rank_k   rows[start + #{e' in list: e' < e}] = e      one thread per (unsorted) list position: ascending
+//                                                             lists whatever order the atomics filled them in
+__global__ __launch_bounds__(256) void inv_zero_k(long long n, int* __restrict__ a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = 0;
+}
+__global__ __launch_bounds__(256) void inv_hist_k(int N, int E, const int* __restrict__ idx, int* __restrict__ off) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e < E) atomicAdd(off + (size_t)b * (N + 1) + idx[(size_t)b * E + e] + 1, 1);
+}
+__global__ __launch_bounds__(1024) void inv_scan_k(int N, int* __restrict__ off) {
+  __shared__ int s_part[1024];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int* a = off + (size_t)b * (N + 1) + 1;          // counts of lists 0 .. N-1
+  const int chunk = (N + 1023) / 1024;
+  const int j0 = tid * chunk, j1 = j0 + chunk < N ? j0 + chunk : N;
+  int local = 0;
+  for (int j = j0; j < j1; ++j) local += a[j];
+  s_part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int v = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int j = j0; j < j1; ++j) {
+    const int c = a[j];
+    a[j] = run;
+    run += c;
+  }
+  if (tid == 0) a[-1] = 0;
+}
+__global__ __launch_bounds__(256) void inv_fill_k(int N, int E, const int* __restrict__ idx, int* __restrict__ off,
+                                                  int* __restrict__ ws) {
+  const int b = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int j = idx[(size_t)b * E + e];
+  ws[(size_t)b * E + atomicAdd(off + (size_t)b * (N + 1) + j + 1, 1)] = e;
+}
+__global__ __launch_bounds__(256) void inv_rank_k(int N, int E, const int* __restrict__ idx, const int* __restrict__ off,
+                                                  const int* __restrict__ ws, int* __restrict__ rows) {
+  const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= E) return;
+  ws += (size_t)b * E;
+  const int e = ws[q];
+  const int j = idx[(size_t)b * E + e];
+  const int* o = off + (size_t)b * (N + 1);
+  const int s = o[j], n = o[j + 1] - s;            // (after inv_fill_k: off[j] = start[j], off[j + 1] = its end)
+  int rank = 0;
+  for (int i = 0; i < n; ++i) rank += ws[s + i] < e ? 1 : 0;
+  rows[(size_t)b * E + s + rank] = e;
+}
+
 // sa_indices of the backbone (PointNet2SASSG.forward, mmdet3d pointnet2_sa_ssg.py: indices into the INPUT cloud
 // of every level's samples): out_0 = arange(N), out_l[b][i] = out_{l-1}[b][idx_l[b][i]].  One workgroup per
 // scene walks the levels (their sizes shrink 20 000 -> 2 048 -> ... -> 256), one launch instead of
@@ -775,6 +839,27 @@ extern "C" int demf_invert_index(int B, int N, int E, const int* idx, int* off, 
   hipLaunchKernelGGL(invert_index_k, dim3(B), dim3(1024), lds, (hipStream_t)stream, N, E, idx, off,
                      rows, lds_rows);
   return check_launch("invert_index");
+}
+
+extern "C" int demf_invert_index_ws(int B, int N, int E, const int* idx, int* off, int* rows, int* workspace,
+                                    demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && N >= 1 && E >= 0, "invert_index_ws: bad sizes");
+  if (B == 0) return DEMF_OK;
+  DEMF_REQUIRE(idx && off && rows, "invert_index_ws: null pointer");
+  static const int split = [] { const char* v = getenv("DEMF_INVERT_SPLIT"); return v ? atoi(v) : 1; }();   // A/B switch
+  // (the one-workgroup form keeps its lists in LDS up to ~28 k entries and is fast there)
+  if (!split || workspace == nullptr || E < 32768) return demf_invert_index(B, N, E, idx, off, rows, stream);
+  hipStream_t s = (hipStream_t)stream;
+  // (a kernel, not hipMemsetAsync: inside the step's hipGraph a memset node was not ordered with the kernels around
+  // it - the one-batch graph of bench.py --no-prefetch faulted on the stale counts)
+  const long long nz = (long long)B * (N + 1);
+  hipLaunchKernelGGL(inv_zero_k, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, nz, off);
+  const dim3 ge(cdiv(E, 256), B);
+  hipLaunchKernelGGL(inv_hist_k, ge, dim3(256), 0, s, N, E, idx, off);
+  hipLaunchKernelGGL(inv_scan_k, dim3(B), dim3(1024), 0, s, N, off);
+  hipLaunchKernelGGL(inv_fill_k, ge, dim3(256), 0, s, N, E, idx, off, workspace);
+  hipLaunchKernelGGL(inv_rank_k, ge, dim3(256), 0, s, N, E, idx, off, workspace, rows);
+  return check_launch("invert_index_ws");
 }
 
 extern "C" int demf_group_concat_cl_bwd_gather(int B, int N, int E, int C, int ldo, int feat_col,

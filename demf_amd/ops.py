@@ -580,7 +580,9 @@ def invert_index(idx, num_source):
     E = idx[0].numel()
     off = torch.empty((B, num_source + 1), dtype=torch.int32, device=idx.device)
     rows = torch.empty((B, E), dtype=torch.int32, device=idx.device)
-    _ffi.call("demf_invert_index", B, num_source, E, _p(idx), _p(off), _p(rows), _stream())
+    # (long entry lists - SA1 - are inverted chip-wide: that form needs B * E ints of scratch)
+    ws = torch.empty((B, E), dtype=torch.int32, device=idx.device) if E >= 32768 else None
+    _ffi.call("demf_invert_index_ws", B, num_source, E, _p(idx), _p(off), _p(rows), _p(ws), _stream())
     return off, rows
 
 

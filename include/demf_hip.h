@@ -194,6 +194,11 @@ int demf_maxpool_ns_bwd(int R, int ns, int C, const float* grad_out, const int* 
  * -> CSR by source point: off (B,N+1), rows (B,E) = entry positions e = m*ns+s, ascending within a
  * list.  N <= 16384.  Coordinate-only (QueryAndGroup's idx, class_agnostic_vote_head.py:383). */
 int demf_invert_index(int B, int N, int E, const int* idx, int* off, int* rows, demf_stream_t stream);
+/* The same with B * E ints of workspace: for E >= 32 768 entries per scene (SA1: the lists do not fit one workgroup's
+ * LDS) the inversion runs spread over the chip - histogram, scan, fill, rank (five launches) - instead of one
+ * workgroup per scene with a global insertion sort (102 -> ~35 us).  Identical output.                     */
+int demf_invert_index_ws(int B, int N, int E, const int* idx, int* off, int* rows, int* workspace,
+                         demf_stream_t stream);
 
 /* sa_indices of the backbone (mmdet3d PointNet2SASSG.forward as used by demf/modeling: every level's samples as
  * indices into the INPUT cloud): out[0] (B,N) = arange(N), out[l] (B, samples[l-1]) = out[l-1] gathered by the

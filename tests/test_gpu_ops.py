@@ -303,7 +303,8 @@ def test_colsum_matches_fp64_sum(R, N):
     assert torch.allclose(out.double(), ref, rtol=1e-5, atol=1e-4 * (R ** 0.5))
 
 
-@pytest.mark.parametrize("B,N,M,ns", [(2, 900, 70, 16), (3, 2048, 1024, 32), (1, 7, 3, 4), (2, 16384, 64, 8)])
+@pytest.mark.parametrize("B,N,M,ns", [(2, 900, 70, 16), (3, 2048, 1024, 32), (1, 7, 3, 4), (2, 16384, 64, 8),
+                                      (2, 20000, 2048, 64), (3, 5000, 1024, 32)])     # (E >= 32 768: the chip-wide form)
 def test_invert_index(ops, B, N, M, ns):
     """demf_invert_index: CSR inverse of a ball-query result - every list holds exactly the
     entry positions that reference the point, ascending (bit-exact against numpy)."""
