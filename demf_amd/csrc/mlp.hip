@@ -1843,8 +1843,14 @@ struct DwArgs {
   int nsub_k;            // sub-blocks along K
   int chunk;             // 32-row slabs per claim
   int* sched;            // dynamic slab chunks: per-blockIdx.y {next chunk}, {finished}, + total; or null
-  int dbg;               // DEMF_DW_DBG phase-skip bits (measurement only): 1 MFMAs, 2 gather + split, 4 transform + stage, 8 flush, 16 loads
+  int dbg;               // DEMF_DW_DBG phase-skip bits (builds with -DDEMF_DW_PROFILE only): 1 MFMAs, 2 gather + split,
+                         // 4 transform + stage, 8 flush, 16 loads
 };
+#ifdef DEMF_DW_PROFILE
+#define DW_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define DW_DBG(p, bit) false
+#endif
 
 // Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
 // tiles tn = wn + 2i (i < TN), tk = wk + 2j (j < TK), so per row pair it reads TN + TK LDS
@@ -1899,10 +1905,10 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
     for (int jj = 0; jj < 4; ++jj) {
       const int f = threadIdx.x + 256 * jj;
       const int r = f / qn, c = (f - r * qn) * 4;
-      oky[jj] = f < 32 * qn && row0 + r < p.R && p.n0 * 32 + c < p.N && !(p.dbg & 16);
+      oky[jj] = f < 32 * qn && row0 + r < p.R && p.n0 * 32 + c < p.N && !DW_DBG(p, 16);
       mlp_fetch<PROY>(ay, row0 + r, p.n0 * 32 + c, oky[jj], ry[jj]);
       const int r2 = f / qk, c2 = (f - r2 * qk) * 4;
-      oka[jj] = f < 32 * qk && row0 + r2 < p.R && p.k0 * 32 + c2 < p.K && !(p.dbg & 16);
+      oka[jj] = f < 32 * qk && row0 + r2 < p.R && p.k0 * 32 + c2 < p.K && !DW_DBG(p, 16);
       mlp_fetch<PRO_NONE>(ax, row0 + r2, p.k0 * 32 + c2, oka[jj], ra[jj]);
     }
   };
@@ -1923,7 +1929,7 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
       if (last) s_next = claimed;
     }
     __syncthreads();                                 // previous slab fully consumed (and s_v* ready)
-    if (!(p.dbg & 4))
+    if (!DW_DBG(p, 4))
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int f = threadIdx.x + 256 * jj;
@@ -1974,7 +1980,7 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
         // lane supplies rows 16c + 8lh .. +7 of column lr of its tiles
         bf16x8 ah[TN], am[TN], al[TN];
         auto gather = [&](const float* col, int ld, bf16x8& h, bf16x8& m, bf16x8& l) {
-          if (p.dbg & 2) { h = m = l = bf16x8{}; return; }
+          if (DW_DBG(p, 2)) { h = m = l = bf16x8{}; return; }
           const float* q = col + (16 * c + 8 * lh) * ld;
           split3(make_float4(q[0], q[ld], q[2 * ld], q[3 * ld]),
                  make_float4(q[4 * ld], q[5 * ld], q[6 * ld], q[7 * ld]), h, m, l);
@@ -1987,7 +1993,7 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
           gather(s_a + (wk + 2 * j) * 32 + lr, ldk, bh, bm, bl);
 #pragma unroll
           for (int i = 0; i < TN; ++i) {
-            if (p.dbg & 1) { acc[i][j][0] += (float)al[i][0] + (float)bh[0]; continue; }
+            if (DW_DBG(p, 1)) { acc[i][j][0] += (float)al[i][0] + (float)bh[0]; continue; }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
@@ -2033,7 +2039,7 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
         for (int r = 0; r < 16; ++r) {
           const int n = (p.n0 + tn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
           const int k = (p.k0 + tk) * 32 + lr;
-          if (n < p.N && k < p.K && (!(p.dbg & 8) || acc[i][j][r] == 12345.f)) atomicAdd(p.dW + (size_t)n * p.lddw + k, acc[i][j][r]);
+          if (n < p.N && k < p.K && (!DW_DBG(p, 8) || acc[i][j][r] == 12345.f)) atomicAdd(p.dW + (size_t)n * p.lddw + k, acc[i][j][r]);
         }
       }
     }

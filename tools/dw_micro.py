@@ -1,6 +1,6 @@
 """Times the step's weight-gradient products (the 13 few-row jobs + the vote-aggregation pair traced with
 DEMF_DW_TRACE=1) through demf_mlp_gemm_bwd_dw_group: each job alone and all of them as the deferred group.
-Knobs: DEMF_DW_GRID (row chunks x sub-blocks per job), DEMF_DW_SMALL_R (64 x 64 sub-blocks below it)."""
+Phase-skip bits DEMF_DW_DBG need a library built with -DDEMF_DW_PROFILE.  Knobs: DEMF_DW_GRID (row chunks x sub-blocks per job), DEMF_DW_SMALL_R (64 x 64 sub-blocks below it)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
