@@ -3007,7 +3007,10 @@ int dw_plan(int R, int N, int K, int ldx, const float* G, const float* dP, const
   // few rows: 64 x 64 sub-blocks (4x as many blockIdx.y columns) and correspondingly fewer row chunks -
   // every block ends by adding its whole sub-block to dW with atomics, and with 128 x 128 sub-blocks x
   // R/128 chunks that flush (R/128 x N x K atomics) is most of a small launch
-  static const int small_r = env_int("DEMF_DW_SMALL_R", 16384);
+  // (round 5: also the 32 768-row products of the vote aggregation - they then join the grouped launch of the other
+  // few-row products instead of running as two launches of their own: 292 -> 277 us for the step's 17 products,
+  // tools/dw_micro.py; 5.074 -> 5.059 ms per step in situ)
+  static const int small_r = env_int("DEMF_DW_SMALL_R", 65536);
   if (R <= small_r) tn = tk = 1;
   DwArgs a{};
   a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
