@@ -1852,6 +1852,10 @@ struct DwArgs {
 #define DW_DBG(p, bit) false
 #endif
 
+#ifndef DEMF_DW_TR
+#define DEMF_DW_TR 1      // transpose-read fragments from bf16 planes (0: the per-wave fp32 column gather - A/B builds)
+#endif
+
 // Waves form a 2 x 2 grid over the (<= 4 x 4) output tiles of the launch: wave (wn, wk) owns
 // tiles tn = wn + 2i (i < TN), tk = wk + 2j (j < TK), so per row pair it reads TN + TK LDS
 // values for TN*TK MFMAs.
@@ -1870,12 +1874,23 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
   }
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // staged widths are padded to the wave grid (2*TN, 2*TK tiles) so idle tiles read zeros
-  const int WN = 2 * TN * 32, WK = 2 * TK * 32;      // columns of dY / A staged per slab
-  const int ldn = WN + 4, ldk = WK + 4;
-  float* s_dy = smem;                                // [32][WN + 4]
-  float* s_a = s_dy + 32 * ldn;                      // [32][WK + 4]
-  float* s_vy = s_a + 32 * ldk;                      // 5 x N backward vectors of this layer
+  constexpr int WN = 2 * TN * 32, WK = 2 * TK * 32;  // columns of dY / A staged per slab
+  // TR (round 5, the bf16-MFMA modes): the slab is split ONCE by the staging threads and kept as row-major bf16
+  // planes [PL][32][W + 8]; a wave's fragment - 8 consecutive ROWS of one column - is two ds_read_b64_tr_b16 per
+  // plane (the 16 lanes of a group pass the addresses of a 4-row x 16-column block and receive one column each:
+  // tools/ubench/tr16_probe.cpp).  Before, every wave gathered its columns from an fp32 slab with 8 ds_read_b32 and
+  // split them itself - each element twice over (the two waves that share an operand), 250 of the loop's 650
+  // instructions.  Same planes, same MFMA order: bit-identical results.
+  constexpr bool TR = DEMF_DW_TR && X3 != 0;
+  constexpr int PL = X3 == 1 ? 3 : 1;
+  constexpr int ldn = TR ? WN + 8 : WN + 4, ldk = TR ? WK + 8 : WK + 4;     // row strides (bf16 / float elements)
+  constexpr int PBN = 32 * ldn * 2, PBK = 32 * ldk * 2;                     // TR: bytes per plane
+  float* s_dy = smem;                                // [32][WN + 4] fp32, or the dY planes
+  float* s_a = TR ? reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + PL * PBN) : s_dy + 32 * ldn;
+  float* s_vy = TR ? reinterpret_cast<float*>(reinterpret_cast<char*>(s_a) + PL * PBK) : s_a + 32 * ldk;   // 5 x N vectors
   float* s_vx = s_vy + 5 * p.N;                      // [scale|shift] of the previous layer (2K)
+  char* const p_dy = reinterpret_cast<char*>(s_dy);
+  char* const p_a = reinterpret_cast<char*>(s_a);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int wn = wave >> 1, wk = wave & 1;
@@ -1895,9 +1910,32 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
   ax.K = p.K; ax.ldx = p.ldx; ax.X = p.Xp;
 
   // per-thread slots of the 32-row slab: float4 index f = threadIdx.x + 256*j
-  const int qn = WN / 4, qk = WK / 4;
+  constexpr int qn = WN / 4, qk = WK / 4;
   MlpRaw<PROY> ry[4];
   MlpRaw<PRO_NONE> ra[4];
+  // TR: a float4 (4 consecutive columns of a row) -> its PL planes, one ds_write_b64 each
+  auto stage_planes = [&](char* dst, int plane_bytes, const float4& v) {
+    if constexpr (X3 == 1) {
+      bf16x4 h, m, l;
+      split3(v, h, m, l);
+      *reinterpret_cast<bf16x4*>(dst) = h;
+      *reinterpret_cast<bf16x4*>(dst + plane_bytes) = m;
+      *reinterpret_cast<bf16x4*>(dst + 2 * plane_bytes) = l;
+    } else {
+      *reinterpret_cast<bf16x4*>(dst) = to_bf16x4(v);
+    }
+  };
+  // TR: rows 16c + 8lh .. + 7 of column col0 + lr of one plane (lane t of a 16-lane group addresses row t >> 2,
+  // columns 4 (t & 3) .. + 3 of the group's 4 x 16 block)
+  const int tr_off = ((lane & 15) >> 2) * 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  auto frag = [&](const char* plane, int ld, int col0, int c) {
+    using v4s = short __attribute__((ext_vector_type(4)));
+    using lds_v4s = v4s __attribute__((address_space(3)));
+    const char* q = plane + ((16 * c + 8 * lh) * ld + col0 + tr_col) * 2 + tr_off * ld;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(q));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(q + 8 * ld));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   bool oky[4], oka[4];
   auto prefetch = [&](int slab) {
     const int row0 = slab * 32;
@@ -1935,8 +1973,9 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
       const int f = threadIdx.x + 256 * jj;
       if (f < 32 * qn) {
         const int r = f / qn, c = (f - r * qn) * 4;
-        *reinterpret_cast<float4*>(s_dy + r * ldn + c) =
-            mlp_xform<PROY>(ay, s_vy, p.n0 * 32 + c, oky[jj], ry[jj]);
+        const float4 v = mlp_xform<PROY>(ay, s_vy, p.n0 * 32 + c, oky[jj], ry[jj]);
+        if constexpr (TR) stage_planes(p_dy + (r * ldn + c) * 2, PBN, v);
+        else *reinterpret_cast<float4*>(s_dy + r * ldn + c) = v;
       }
       if (f < 32 * qk) {
         const int r = f / qk, c = (f - r * qk) * 4;
@@ -1946,14 +1985,56 @@ __device__ __forceinline__ void mlp_dw_body(DwArgs p, const int bx, const int by
           rb.x = v;
           v = mlp_xform<PRO_BNRELU>(ax, s_vx, p.k0 * 32 + c, oka[jj], rb);
         }
-        *reinterpret_cast<float4*>(s_a + r * ldk + c) = v;
+        if constexpr (TR) stage_planes(p_a + (r * ldk + c) * 2, PBK, v);
+        else *reinterpret_cast<float4*>(s_a + r * ldk + c) = v;
       }
     }
     __syncthreads();
     const int next_chunk = last ? (dyn ? s_next : chunk + gx) : chunk;
     const int next_si = last ? 0 : si + 1;
     if (next_chunk < nchunk) prefetch(next_chunk * p.chunk + next_si);
-    if constexpr (X3 == 2) {
+    if constexpr (TR && X3 == 2) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 a8[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) a8[i] = frag(p_dy, ldn, (wn + 2 * i) * 32, c);
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const bf16x8 b8 = frag(p_a, ldk, (wk + 2 * j) * 32, c);
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[i], b8, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else if constexpr (TR && X3 == 1) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 ah[TN], am[TN], al[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          ah[i] = frag(p_dy, ldn, (wn + 2 * i) * 32, c);
+          am[i] = frag(p_dy + PBN, ldn, (wn + 2 * i) * 32, c);
+          al[i] = frag(p_dy + 2 * PBN, ldn, (wn + 2 * i) * 32, c);
+        }
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const bf16x8 bh = frag(p_a, ldk, (wk + 2 * j) * 32, c);
+          const bf16x8 bm = frag(p_a + PBK, ldk, (wk + 2 * j) * 32, c);
+          const bf16x8 bl = frag(p_a + 2 * PBK, ldk, (wk + 2 * j) * 32, c);
+#pragma unroll
+          for (int i = 0; i < TN; ++i) {
+            if (DW_DBG(p, 1)) { acc[i][j][0] += (float)al[i][0] + (float)bh[0]; continue; }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    } else if constexpr (X3 == 2) {
       // compute dtype bf16: the same column gather, operands rounded to bf16, one MFMA per tile pair
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -3012,6 +3093,8 @@ int dw_plan(int R, int N, int K, int ldx, const float* G, const float* dP, const
   // tools/dw_micro.py; 5.074 -> 5.059 ms per step in situ)
   static const int small_r = env_int("DEMF_DW_SMALL_R", 65536);
   if (R <= small_r) tn = tk = 1;
+  static const int tile_ab = env_int("DEMF_DW_TILE", 0);       // A/B: 12 -> 64 x 128 sub-blocks, 21 -> 128 x 64, 22, 11
+  if (tile_ab) { tn = TNt > 2 ? tile_ab / 10 : 1; tk = TKt > 2 ? tile_ab % 10 : 1; }
   DwArgs a{};
   a.R = R; a.N = N; a.K = K; a.ldx = ldx; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.ns = ns;
   a.vec = vec6; a.Xp = Xprev; a.pvec = prev_scale_shift; a.dW = dW; a.lddw = lddw;
@@ -3019,7 +3102,12 @@ int dw_plan(int R, int N, int K, int ldx, const float* G, const float* dP, const
   const int nsub_n = cdiv(TNt, 2 * tn);
   a.nsub_k = cdiv(TKt, 2 * tk);
   const int nsub = nsub_n * a.nsub_k;
-  pl.lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
+  static const int x3mask_lds = env_int("DEMF_X3_MASK", 7);
+  const int x3_lds = (compute_bf16() && !env_int("DEMF_DW_F32", 0)) ? 2 : ((compute_mode() == 2 && (x3mask_lds & 4)) ? 1 : 0);
+  if (DEMF_DW_TR && x3_lds != 0)      // bf16 planes [PL][32][W + 8] of both operands (mlp_dw_body)
+    pl.lds = (size_t)(x3_lds == 1 ? 3 : 1) * 32 * ((2 * tn * 32 + 8) + (2 * tk * 32 + 8)) * 2 + sizeof(float) * (5 * N + 2 * K);
+  else
+    pl.lds = sizeof(float) * (32 * ((2 * tn * 32 + 4) + (2 * tk * 32 + 4)) + 5 * N + 2 * K);
   int gx = cdiv(R, 32 * 4);
   const int tot = env_int("DEMF_DW_GRID", 512);
   const int cap = tot / nsub > 16 ? tot / nsub : 16;
