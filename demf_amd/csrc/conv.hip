@@ -259,6 +259,118 @@ static int conv_launch(const ConvArgs& a, hipStream_t s) {
   return check_launch("conv_nhwc_kernel");
 }
 
+// ---- 1 x 1, stride 1, Cin = 64 (ResNet-50's first stage: 64 -> 256 with the residual, 64 -> 64) --------------------------
+// These layers are HBM byte movers (1.03 GB per launch at 8 x 200 x 280 pixels for 14.7 GFLOP) and the tile kernel ran
+// them at 2.7 TB/s: two reduction steps per tile, then an epilogue whose residual loads start when the MFMAs are done.
+// Here the whole (Cout x 64) weight is staged ONCE per workgroup as bf16 planes (Cout = 256, three planes: 96 KB) and
+// every wave walks its own 32-pixel tiles without a barrier: the pixel rows go global -> registers -> fragments (a lane
+// holds exactly the 8 consecutive channels of its pixel an MFMA step wants - no LDS for A), the next tile's rows and
+// the next column tile's residual are requested before the current MFMAs are issued, and a column tile (K = 64 is the
+// whole reduction) is finished and stored 32 columns = one 128-byte line per row at a time.
+__device__ __forceinline__ int cv_sw128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int P, int NT>
+__global__ __launch_bounds__(512, 1) void conv1x1_c64_stream_kernel(ConvArgs p) {
+  constexpr int COUT = 32 * NT, PLANE = COUT * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [P][COUT][64 bf16]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lc = lane & 31, lh = lane >> 5;
+  for (int c = t; c < P * COUT * 8; c += 512) {
+    const int q = c / (COUT * 8), rem = c - q * COUT * 8, row = rem >> 3, ch = rem & 7;
+    *reinterpret_cast<u32x4*>(smem + q * PLANE + cv_sw128(row, ch)) =
+        *reinterpret_cast<const u32x4*>(p.Wp + ((size_t)q * COUT + row) * 64 + 8 * ch);
+  }
+  __syncthreads();
+  float* const epi = reinterpret_cast<float*>(smem + P * PLANE) + wave * (32 * 36);     // this wave's 32 x 32 (+4) fp32 tile
+  const int M = p.B * p.Ho * p.Wo;
+  const int ntile = (M + 31) / 32, nw = (int)gridDim.x * 8;
+  int tile = (int)blockIdx.x * 8 + wave;
+  float4 ra[8];
+  auto fetch = [&](int tl) {
+    const int row = min(tl * 32 + lc, M - 1);                      // (rows beyond M: a valid address, never stored)
+    const float* src = p.X + (size_t)row * 64 + 8 * lh;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      ra[2 * s4] = *reinterpret_cast<const float4*>(src + 16 * s4);
+      ra[2 * s4 + 1] = *reinterpret_cast<const float4*>(src + 16 * s4 + 4);
+    }
+  };
+  if (tile < ntile) fetch(tile);
+  for (; tile < ntile; tile += nw) {
+    bf16x8 pa[4][P];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      unsigned o0[P], o1[P], o2[P], o3[P];
+      cv_split_pair<P>(ra[2 * s4].x, ra[2 * s4].y, o0);
+      cv_split_pair<P>(ra[2 * s4].z, ra[2 * s4].w, o1);
+      cv_split_pair<P>(ra[2 * s4 + 1].x, ra[2 * s4 + 1].y, o2);
+      cv_split_pair<P>(ra[2 * s4 + 1].z, ra[2 * s4 + 1].w, o3);
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        const u32x4 v = {o0[q], o1[q], o2[q], o3[q]};
+        pa[s4][q] = __builtin_bit_cast(bf16x8, v);
+      }
+    }
+    if (tile + nw < ntile) fetch(tile + nw);
+    const int row0 = tile * 32;
+    const bool full = row0 + 32 <= M;
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+      const int col = 32 * j + lc;
+      // the finished 32 x 32 tile leaves through the wave's private LDS tile as float4 rows: lane -> row (lane >> 3) + 8 i,
+      // columns 4 (lane & 7) .. + 3 - four 16-byte stores per column tile instead of sixteen 4-byte ones, and the residual
+      // arrives the same way (requested before the MFMAs are issued)
+      const int er = lane >> 3, ec = 32 * j + 4 * (lane & 7);
+      float4 rs[4];
+      if (p.resid != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          rs[i] = *reinterpret_cast<const float4*>(p.resid + (size_t)min(row0 + er + 8 * i, M - 1) * COUT + ec);
+      }
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bf16x8 pb[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+          pb[q] = *reinterpret_cast<const bf16x8*>(smem + q * PLANE + cv_sw128(col, 2 * s4 + lh));
+        cv_mfma<P>(acc, pa[s4], pb);
+      }
+      const float bias = p.bias != nullptr ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) epi[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lc] = acc[r] + bias;
+      // (one wave: its own ds_writes are complete before its ds_reads are issued - program order on the LDS queue)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + er + 8 * i;
+        float4 v = *reinterpret_cast<const float4*>(epi + (er + 8 * i) * 36 + 4 * (lane & 7));
+        if (p.resid != nullptr) { v.x += rs[i].x; v.y += rs[i].y; v.z += rs[i].z; v.w += rs[i].w; }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (full || row < M) *reinterpret_cast<float4*>(p.Y + (size_t)row * COUT + ec) = v;
+      }
+    }
+  }
+}
+
+template <int P, int NT>
+static int conv1x1_c64_launch(const ConvArgs& a, hipStream_t s) {
+  constexpr int lds = P * 32 * NT * 128 + 8 * 32 * 36 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_c64_stream_kernel<P, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("conv_nhwc: cannot reserve %d bytes of LDS", lds);
+      return DEMF_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  const int M = a.B * a.Ho * a.Wo;
+  const int wgs = min(256, cdiv(cdiv(M, 32), 8));
+  hipLaunchKernelGGL((conv1x1_c64_stream_kernel<P, NT>), dim3(wgs), dim3(512), lds, s, a);
+  return check_launch("conv1x1_c64_stream_kernel");
+}
+
 // 3x3 stride-2 pad-1 max-pool over NHWC rows, one float4 of channels per thread
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(int B, int H, int W, int C, int Ho, int Wo,
                                                            const float* __restrict__ x, float* __restrict__ y) {
@@ -374,6 +486,12 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
   a.ksteps = cdiv(a.K / 32, ksplit);
   DEMF_REQUIRE((long long)B * H * W * Cin < (1ll << 31) && H < 16384 && W < 16384, "conv_nhwc: input too large for 32-bit offsets");
   hipStream_t s = (hipStream_t)stream;
+  static const int stream64 = getenv("DEMF_CONV_STREAM64") ? atoi(getenv("DEMF_CONV_STREAM64")) : 1;   // A/B switch
+  if (stream64 && Cin == 64 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && ksplit == 1 && (Cout == 256 || Cout == 64) &&
+      (long long)B * H * W >= 16384) {
+    if (Cout == 256) return planes == 3 ? conv1x1_c64_launch<3, 8>(a, s) : conv1x1_c64_launch<1, 8>(a, s);
+    return planes == 3 ? conv1x1_c64_launch<3, 2>(a, s) : conv1x1_c64_launch<1, 2>(a, s);
+  }
   static const int wg3 = getenv("DEMF_CONV_WG3") ? atoi(getenv("DEMF_CONV_WG3")) : 0;       // A/B switch
   if (Cout % 128 == 0) {
     if (planes == 3) return wg3 ? conv_launch<3, 128, false, true>(a, s) : conv_launch<3, 128, false>(a, s);
