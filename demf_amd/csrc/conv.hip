@@ -371,6 +371,127 @@ static int conv1x1_c64_launch(const ConvArgs& a, hipStream_t s) {
   return check_launch("conv1x1_c64_stream_kernel");
 }
 
+// The same form for 1 x 1, stride 1 layers with 128 / 256 input channels (ResNet-50's 128 -> 512 and 256 -> 1024 expansions
+// with the residual, 256 -> 64 / 128 reductions): a workgroup keeps the weight rows of ONE group of 32 NT output channels
+// (blockIdx.y; 96 KB of planes at NT x KC = 8), the reduction is streamed in chunks of 64 channels with the next chunk's
+// rows in flight, the NT accumulator tiles stay in registers until the last chunk.
+template <int KB>
+__device__ __forceinline__ int cv_swk(int row, int chunk) { return row * KB + ((chunk ^ (row & (KB / 16 - 1))) << 4); }
+
+template <int P, int NT, int KC>
+__global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvArgs p) {
+  constexpr int COLS = 32 * NT, K = 64 * KC, KB = 2 * K, PLANE = COLS * KB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [P][COLS][K bf16], then 8 fp32 tiles of 32 x 36
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lc = lane & 31, lh = lane >> 5;
+  const int n0 = (int)blockIdx.y * COLS;
+  for (int c = t; c < P * COLS * (KB / 16); c += 512) {
+    const int q = c / (COLS * (KB / 16)), rem = c - q * COLS * (KB / 16), row = rem / (KB / 16), ch = rem % (KB / 16);
+    *reinterpret_cast<u32x4*>(smem + q * PLANE + cv_swk<KB>(row, ch)) =
+        *reinterpret_cast<const u32x4*>(p.Wp + ((size_t)q * p.Cout + n0 + row) * K + 8 * ch);
+  }
+  __syncthreads();
+  float* const epi = reinterpret_cast<float*>(smem + P * PLANE) + wave * (32 * 36);
+  const int M = p.B * p.Ho * p.Wo;
+  const int ntile = (M + 31) / 32, nw = (int)gridDim.x * 8;
+  int tile = (int)blockIdx.x * 8 + wave;
+  float4 ra[8];
+  auto fetch = [&](int tl, int kc) {
+    const int row = min(tl * 32 + lc, M - 1);
+    const float* src = p.X + (size_t)row * K + 64 * kc + 8 * lh;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      ra[2 * s4] = *reinterpret_cast<const float4*>(src + 16 * s4);
+      ra[2 * s4 + 1] = *reinterpret_cast<const float4*>(src + 16 * s4 + 4);
+    }
+  };
+  if (tile < ntile) fetch(tile, 0);
+  for (; tile < ntile; tile += nw) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 1
+    for (int kc = 0; kc < KC; ++kc) {
+      bf16x8 pa[4][P];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        unsigned o0[P], o1[P], o2[P], o3[P];
+        cv_split_pair<P>(ra[2 * s4].x, ra[2 * s4].y, o0);
+        cv_split_pair<P>(ra[2 * s4].z, ra[2 * s4].w, o1);
+        cv_split_pair<P>(ra[2 * s4 + 1].x, ra[2 * s4 + 1].y, o2);
+        cv_split_pair<P>(ra[2 * s4 + 1].z, ra[2 * s4 + 1].w, o3);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const u32x4 v = {o0[q], o1[q], o2[q], o3[q]};
+          pa[s4][q] = __builtin_bit_cast(bf16x8, v);
+        }
+      }
+      if (kc + 1 < KC) fetch(tile, kc + 1);
+      else if (tile + nw < ntile) fetch(tile + nw, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          bf16x8 pb[P];
+#pragma unroll
+          for (int q = 0; q < P; ++q)
+            pb[q] = *reinterpret_cast<const bf16x8*>(smem + q * PLANE + cv_swk<KB>(32 * j + lc, 8 * kc + 2 * s4 + lh));
+          cv_mfma<P>(acc[j], pa[s4], pb);
+        }
+    }
+    const int row0 = tile * 32;
+    const bool full = row0 + 32 <= M;
+    const int er = lane >> 3;
+    float4 rs[4];
+    auto fetch_resid = [&](int j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        rs[i] = *reinterpret_cast<const float4*>(p.resid + (size_t)min(row0 + er + 8 * i, M - 1) * p.Cout + n0 + 32 * j + 4 * (lane & 7));
+    };
+    if (p.resid != nullptr) fetch_resid(0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float bias = p.bias != nullptr ? p.bias[n0 + 32 * j + lc] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) epi[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + lc] = acc[j][r] + bias;
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(epi + (er + 8 * i) * 36 + 4 * (lane & 7));
+        if (p.resid != nullptr) { v[i].x += rs[i].x; v[i].y += rs[i].y; v[i].z += rs[i].z; v[i].w += rs[i].w; }
+        if (p.relu) { v[i].x = fmaxf(v[i].x, 0.f); v[i].y = fmaxf(v[i].y, 0.f); v[i].z = fmaxf(v[i].z, 0.f); v[i].w = fmaxf(v[i].w, 0.f); }
+      }
+      if (p.resid != nullptr && j + 1 < NT) fetch_resid(j + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = row0 + er + 8 * i;
+        if (full || row < M) *reinterpret_cast<float4*>(p.Y + (size_t)row * p.Cout + n0 + 32 * j + 4 * (lane & 7)) = v[i];
+      }
+    }
+  }
+}
+
+template <int P, int NT, int KC>
+static int conv1x1_stream_launch(const ConvArgs& a, hipStream_t s) {
+  constexpr int lds = P * 32 * NT * 128 * KC + 8 * 32 * 36 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<P, NT, KC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      set_error("conv_nhwc: cannot reserve %d bytes of LDS", lds);
+      return DEMF_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  const int M = a.B * a.Ho * a.Wo;
+  const int groups = a.Cout / (32 * NT);
+  int wgs = 256 / groups;
+  wgs = min(wgs < 1 ? 1 : wgs, cdiv(cdiv(M, 32), 8));
+  hipLaunchKernelGGL((conv1x1_stream_kernel<P, NT, KC>), dim3(wgs, groups), dim3(512), lds, s, a);
+  return check_launch("conv1x1_stream_kernel");
+}
+
 // 3x3 stride-2 pad-1 max-pool over NHWC rows, one float4 of channels per thread
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_k(int B, int H, int W, int C, int Ho, int Wo,
                                                            const float* __restrict__ x, float* __restrict__ y) {
@@ -491,6 +612,13 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
       (long long)B * H * W >= 16384) {
     if (Cout == 256) return planes == 3 ? conv1x1_c64_launch<3, 8>(a, s) : conv1x1_c64_launch<1, 8>(a, s);
     return planes == 3 ? conv1x1_c64_launch<3, 2>(a, s) : conv1x1_c64_launch<1, 2>(a, s);
+  }
+  static const int streamk = getenv("DEMF_CONV_STREAMK") ? atoi(getenv("DEMF_CONV_STREAMK")) : 1;   // A/B switch (bits: 1 K = 128, 2 K = 256)
+  if (streamk && KH == 1 && KW == 1 && stride == 1 && pad == 0 && ksplit == 1 && (long long)B * H * W >= 16384) {
+    if ((streamk & 1) && Cin == 128 && Cout % 128 == 0)
+      return planes == 3 ? conv1x1_stream_launch<3, 4, 2>(a, s) : conv1x1_stream_launch<1, 4, 2>(a, s);
+    if ((streamk & 2) && Cin == 256 && Cout % 64 == 0)
+      return planes == 3 ? conv1x1_stream_launch<3, 2, 4>(a, s) : conv1x1_stream_launch<1, 2, 4>(a, s);
   }
   static const int wg3 = getenv("DEMF_CONV_WG3") ? atoi(getenv("DEMF_CONV_WG3")) : 0;       // A/B switch
   if (Cout % 128 == 0) {
