@@ -27,6 +27,15 @@ def _rb(t, planes):
     dict(B=1, H=9, W=7, Cin=32, Cout=192, k=3, s=1, p=1, resid=True),             # Cout = 3 x 64
     dict(B=2, H=13, W=18, Cin=512, Cout=256, k=3, s=2, p=1, plain=True),          # split-K: 126 rows x K = 4 608
     dict(B=1, H=20, W=20, Cin=1024, Cout=256, k=1, s=1, p=0, plain=True),         # split-K on a 1x1 (8 tiles)
+    # >= 16 384 pixels, 1 x 1 stride 1, 64 / 128 / 256 input channels: the weight-resident streaming kernels
+    # (csrc/conv.hip conv1x1_c64_stream_kernel / conv1x1_stream_kernel); 129 x 131 = 16 899 pixels: a ragged last tile
+    dict(B=1, H=129, W=131, Cin=64, Cout=256, k=1, s=1, p=0, resid=True, relu=True),
+    dict(B=1, H=129, W=131, Cin=64, Cout=256, k=1, s=1, p=0),
+    dict(B=1, H=129, W=131, Cin=64, Cout=64, k=1, s=1, p=0, relu=True),
+    dict(B=1, H=129, W=131, Cin=128, Cout=512, k=1, s=1, p=0, resid=True, relu=True),
+    dict(B=1, H=129, W=131, Cin=256, Cout=1024, k=1, s=1, p=0, resid=True, relu=True),
+    dict(B=1, H=129, W=131, Cin=256, Cout=64, k=1, s=1, p=0, relu=True),
+    dict(B=2, H=128, W=64, Cin=256, Cout=128, k=1, s=1, p=0),
 ])
 def test_conv_nhwc_vs_fp64(case, planes):
     from demf_amd import ops
