@@ -613,7 +613,7 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
     if (Cout == 256) return planes == 3 ? conv1x1_c64_launch<3, 8>(a, s) : conv1x1_c64_launch<1, 8>(a, s);
     return planes == 3 ? conv1x1_c64_launch<3, 2>(a, s) : conv1x1_c64_launch<1, 2>(a, s);
   }
-  static const int streamk = getenv("DEMF_CONV_STREAMK") ? atoi(getenv("DEMF_CONV_STREAMK")) : 1;   // A/B switch (bits: 1 K = 128, 2 K = 256)
+  static const int streamk = getenv("DEMF_CONV_STREAMK") ? atoi(getenv("DEMF_CONV_STREAMK")) : 3;   // A/B switch (bits: 1 K = 128, 2 K = 256)
   static const int stream_min = getenv("DEMF_CONV_STREAM_MIN") ? atoi(getenv("DEMF_CONV_STREAM_MIN")) : 16384;   // rows
   if (streamk && KH == 1 && KW == 1 && stride == 1 && pad == 0 && ksplit == 1 && (long long)B * H * W >= stream_min) {
     if ((streamk & 1) && Cin == 128 && Cout % 128 == 0)
