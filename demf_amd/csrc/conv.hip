@@ -538,25 +538,41 @@ __global__ __launch_bounds__(256) void gn_zero_k(int n, double* __restrict__ a) 
 }
 __global__ __launch_bounds__(256) void gn_stats_nhwc_k(int HW, int C, int G, int rows_per_wg, const float* __restrict__ x,
                                                        double* __restrict__ sums) {
-  const int b = blockIdx.y, c = threadIdx.x;                // one thread per channel (C == blockDim.x)
+  // a wave per row (64 lanes x float4 = the 256 channels), four rows per step and workgroup, four steps in flight
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
-  const float* p = x + ((size_t)b * HW) * C + c;
+  const float* p = x + ((size_t)b * HW) * C + 4 * lane;
   float s = 0.f, ss = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const float v = p[(size_t)r * C];
-    s += v;
-    ss = __builtin_fmaf(v, v, ss);
+  for (int r = r0 + wave; r < r1; r += 16) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r + 4 * u < r1) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(r + 4 * u) * C);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      ss = __builtin_fmaf(v[u].x, v[u].x, __builtin_fmaf(v[u].y, v[u].y, __builtin_fmaf(v[u].z, v[u].z, __builtin_fmaf(v[u].w, v[u].w, ss))));
+    }
   }
-  // fold the C / G channels of a group: consecutive lanes
-  const int cg = C / G;
+  // fold the C / G channels of a group: (C / G) / 4 consecutive lanes
+  const int lpg = C / G / 4;
   double ds = s, dss = ss;
-  for (int m = 1; m < cg; m <<= 1) {
+  for (int m = 1; m < lpg; m <<= 1) {
     ds += __shfl_xor(ds, m);
     dss += __shfl_xor(dss, m);
   }
-  if ((c % cg) == 0) {
-    atomicAdd(sums + ((size_t)b * G + c / cg) * 2, ds);
-    atomicAdd(sums + ((size_t)b * G + c / cg) * 2 + 1, dss);
+  // the four waves through LDS, then one atomic pair per group and workgroup
+  __shared__ double s_gn[4][64][2];
+  s_gn[wave][lane][0] = ds;
+  s_gn[wave][lane][1] = dss;
+  __syncthreads();
+  if (wave == 0 && (lane % lpg) == 0) {
+    ds = (s_gn[0][lane][0] + s_gn[1][lane][0]) + (s_gn[2][lane][0] + s_gn[3][lane][0]);
+    dss = (s_gn[0][lane][1] + s_gn[1][lane][1]) + (s_gn[2][lane][1] + s_gn[3][lane][1]);
+    atomicAdd(sums + ((size_t)b * G + lane / lpg) * 2, ds);
+    atomicAdd(sums + ((size_t)b * G + lane / lpg) * 2 + 1, dss);
   }
 }
 __global__ __launch_bounds__(256) void gn_apply_nhwc_k(int HW, int C, int G, float eps, const float* __restrict__ x,
@@ -674,7 +690,9 @@ extern "C" int demf_groupnorm_nhwc_f32(int B, int HW, int C, int G, float eps, c
   // (a kernel, not hipMemsetAsync: memset nodes inside a captured hipGraph were found not to be ordered with the
   // kernels around them - csrc/group_gather.hip, demf_invert_index_ws)
   hipLaunchKernelGGL(gn_zero_k, dim3(cdiv(2 * B * G, 256)), dim3(256), 0, s, 2 * B * G, sums);
-  const int rows_per_wg = 64;
+  // ~1 024 workgroups at most: a workgroup ends with 2 G atomics onto the image's 2 G sums
+  int rows_per_wg = cdiv((int)(((long long)HW * B + 1023) / 1024), 16) * 16;
+  if (rows_per_wg < 64) rows_per_wg = 64;
   hipLaunchKernelGGL(gn_stats_nhwc_k, dim3(cdiv(HW, rows_per_wg), B), dim3(256), 0, s, HW, C, G, rows_per_wg, x, sums);
   if (int e = check_launch("gn_stats_nhwc_k")) return e;
   const long long n = (long long)HW * (C / 4);
