@@ -66,6 +66,8 @@ SIGNATURES = {
                            _ptr, ctypes.c_longlong, _ptr, _ptr, _c_float, _ptr, ctypes.c_longlong, _ptr],
     "demf_msda_fwd_raw_f32": [_c_int] * 7 + [_ptr, ctypes.c_longlong, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_int, _c_int,
                               _ptr, _ptr, _ptr],
+    "demf_msda_fwd_raw_head_f32": [_c_int] * 4 + [_ptr, ctypes.c_longlong, _ptr, _ptr, _ptr, ctypes.c_longlong, _c_int, _c_int,
+                                   _ptr, _ptr, _c_int, _c_int, _ptr],
     "demf_invert_index": [_c_int] * 3 + [_ptr] * 4,
     "demf_invert_index_ws": [_c_int] * 3 + [_ptr] * 5,
     "demf_mlp_gemm_bwd_dw_group": [_c_int, _ptr, _ptr],

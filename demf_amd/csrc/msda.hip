@@ -267,6 +267,137 @@ __global__ __launch_bounds__(256) void msda_fwd_raw_wave_kernel(
   }
 }
 
+// (scene, head)-major form of the above with the COARSE levels' value rows resident in LDS (round 5).  The gather is
+// bound by the vector memory path: 64 KB of 16-byte loads per query, ~1 000 TA cycles, 250 us per encoder layer at the
+// very best and 400-415 measured.  A head's slice of levels LS .. 3 - 875 + 234 tokens x 128 bytes = 139 KB at the
+// reference's pyramid - fits a CU's 160 KB: a workgroup takes one (scene, head) and a share of the queries, stages that
+// slice once, and serves half of every query's samples from LDS (128 B/clk beside the 64 B/clk of the vector cache).
+// One wave per SIMD (the slice leaves room for four waves' exchange buffers only): the memory parallelism comes from
+// inside the wave - all global corner loads of eight queries' fine-level samples are requested before the LDS half is
+// summed.  Lane = (query of the wave's eight, channel quad); a lane sets up one or two (level, point) pairs of its
+// query's head, the group's softmax is three shuffles, offsets / weights go round through 4 KB of LDS per wave.
+constexpr int MSDA_HW = 8;          // waves per workgroup of msda_fwd_raw_head_kernel (20 bytes of exchange slot per sample)
+template <int TP, int LS>
+__global__ __launch_bounds__(64 * MSDA_HW, 1) void msda_fwd_raw_head_kernel(
+    int S, int Q, const float* __restrict__ value, long long vpitch,
+    const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ raw, long long ldraw, int off_col0, int lgt_col0,
+    const float* __restrict__ ref, float* __restrict__ out, int qpc) {
+  constexpr int TL = 4, Dh = 32, H = 8, NP = TL * TP, PPL = NP / 8, NG = LS * TP;   // NG: samples served from memory
+  extern __shared__ __attribute__((aligned(16))) char hsm[];
+  // exchange slots [wave][query of 8][sample]: the four (bilinear x attention) weights and ONE word - the offset of the
+  // (low, low) corner, a multiple of four, with "the high column / row is a different token" in its two low bits
+  float4* s_w = reinterpret_cast<float4*>(hsm);
+  int* s_off = reinterpret_cast<int*>(hsm + MSDA_HW * 8 * NP * 16);
+  float4* s_val = reinterpret_cast<float4*>(hsm + MSDA_HW * 8 * NP * 20);   // [S - t0][8] float4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int t0 = (int)lsi[LS], nst = S - t0;
+  const int vh = (int)(vpitch / Dh);
+  const float* vscene = value + (size_t)b * S * vpitch;
+  for (int i = tid; i < nst * 8; i += 64 * MSDA_HW)
+    s_val[i] = *reinterpret_cast<const float4*>(vscene + (size_t)(t0 + (i >> 3)) * vpitch + h * Dh + 4 * (i & 7));
+  __syncthreads();
+  const int grp = lane >> 3, sub = lane & 7;
+  const float* vb = vscene + sub * 4;
+  int* my_off = s_off + (wave * 8 + grp) * NP;
+  float4* my_w = s_w + (wave * 8 + grp) * NP;
+  const int qbeg = blockIdx.x * qpc, qend = min(Q, qbeg + qpc);
+  // a pass's raw logits / offsets / reference points are requested one pass ahead (under the previous pass's gather)
+  float lg[PPL], lgn[PPL];
+  float2 of[PPL], ofn[PPL], rp[PPL], rpn[PPL];
+  auto load_raw = [&](int q0, float (&g)[PPL], float2 (&o)[PPL], float2 (&r)[PPL]) {
+    const int q = min(q0 + grp, qend - 1);                        // (a padded group repeats the last query, never stored)
+    const long long row = (long long)b * Q + q;
+    const float* rrow = raw + row * ldraw;
+#pragma unroll
+    for (int s2 = 0; s2 < PPL; ++s2) {
+      const int i = sub + 8 * s2;
+      g[s2] = __builtin_nontemporal_load(rrow + lgt_col0 + h * NP + i);
+      o[s2].x = __builtin_nontemporal_load(rrow + off_col0 + 2 * (h * NP + i));
+      o[s2].y = __builtin_nontemporal_load(rrow + off_col0 + 2 * (h * NP + i) + 1);
+      r[s2] = *reinterpret_cast<const float2*>(ref + row * (TL * 2) + 2 * (i / TP));
+    }
+  };
+  if (qbeg + 8 * wave < qend) load_raw(qbeg + 8 * wave, lg, of, rp);
+  for (int q0 = qbeg + 8 * wave; q0 < qend; q0 += 8 * MSDA_HW) {
+    const int q = min(q0 + grp, qend - 1);
+    const long long row = (long long)b * Q + q;
+    float e[PPL];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int s2 = 0; s2 < PPL; ++s2) mx = fmaxf(mx, lg[s2]);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float den = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < PPL; ++s2) { e[s2] = expf(lg[s2] - mx); den += e[s2]; }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) den += __shfl_xor(den, o);
+#pragma unroll
+    for (int s2 = 0; s2 < PPL; ++s2) {
+      const int i = sub + 8 * s2, l = i / TP;
+      const float aw = e[s2] / den;
+      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
+      const float lx = rp[s2].x + of[s2].x / (float)Wl, ly = rp[s2].y + of[s2].y / (float)Hl;
+      // fine levels: float offsets into the scene's value rows; staged levels: float4 index into the LDS slice
+      const Corner c = l < LS ? make_corner(lx, ly, Hl, Wl, (int)lsi[l], vh, Dh, h)
+                              : make_corner(lx, ly, Hl, Wl, (int)lsi[l] - t0, 1, 8, 0);
+      my_off[i] = c.off[0] | (c.off[1] != c.off[0] ? 1 : 0) | (c.off[2] != c.off[0] ? 2 : 0);
+      my_w[i] = make_float4(c.cw[0] * aw, c.cw[1] * aw, c.cw[2] * aw, c.cw[3] * aw);
+    }
+    if (q0 + 8 * MSDA_HW < qend) load_raw(q0 + 8 * MSDA_HW, lgn, ofn, rpn);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's own LDS writes (in order, one wave)
+    __builtin_amdgcn_wave_barrier();
+    // two batches: the fine-level corners of half the samples are requested, half the LDS samples are summed under them
+    constexpr int NB = NG / 2, NLH = (NP - NG) / 2;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int bt = 0; bt < 2; ++bt) {
+      float4 gv[NB][4];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int i = bt * NB + j;
+        const int o = my_off[i];
+        const int sx = (o & 1) ? (int)vpitch : 0, sy = (o & 2) ? (int)shapes[2 * (i / TP) + 1] * (int)vpitch : 0;
+        const float* v0 = vb + (o & ~3);
+        gv[j][0] = ld4<float>(v0); gv[j][1] = ld4<float>(v0 + sx);
+        gv[j][2] = ld4<float>(v0 + sy); gv[j][3] = ld4<float>(v0 + sx + sy);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // all of the batch requested before the LDS samples are summed
+#pragma unroll
+      for (int j = 0; j < NLH; ++j) {
+        const int i = NG + bt * NLH + j;
+        const int o = my_off[i];
+        const int sx = (o & 1) ? 8 : 0, sy = (o & 2) ? (int)shapes[2 * (i / TP) + 1] * 8 : 0;
+        const float4 w = my_w[i];
+        const float4* v0 = s_val + (o & ~3) + sub;
+        acc = f4_fma(w.x, v0[0], acc);
+        acc = f4_fma(w.y, v0[sx], acc);
+        acc = f4_fma(w.z, v0[sy], acc);
+        acc = f4_fma(w.w, v0[sx + sy], acc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const float4 w = my_w[bt * NB + j];
+        acc = f4_fma(w.x, gv[j][0], acc);
+        acc = f4_fma(w.y, gv[j][1], acc);
+        acc = f4_fma(w.z, gv[j][2], acc);
+        acc = f4_fma(w.w, gv[j][3], acc);
+      }
+    }
+    if (q0 + grp < qend) {
+      float* o = out + row * (H * Dh) + h * Dh + sub * 4;
+      __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
+      __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
+    }
+    __builtin_amdgcn_wave_barrier();                              // the exchange slots are rewritten by the next pass
+#pragma unroll
+    for (int s2 = 0; s2 < PPL; ++s2) { lg[s2] = lgn[s2]; of[s2] = ofn[s2]; rp[s2] = rpn[s2]; }
+  }
+}
+
 template <int G, int TL, int TP, typename VT = float>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(
     int S, int H, int Dh, int L, int Q, int P, const VT* __restrict__ value,
@@ -565,6 +696,53 @@ extern "C" int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int
                                   demf_stream_t stream) {
   return msda_bwd_impl<uint16_t>(B, S, H, Dh, L, Q, P, value, spatial_shapes, level_start_index, sampling_loc,
                                  attn_weight, grad_out, grad_value, grad_sampling_loc, grad_attn_weight, stream);
+}
+
+// demf_msda_fwd_raw_f32 for H = 8, Dh = 32, L = 4 with the value rows of levels first_staged_level .. 3 (staged_tokens =
+// S - level_start_index[first_staged_level] of them - the CALLER knows the pyramid's shapes on the host, the library
+// never reads a device array back) resident in LDS per (scene, head): msda_fwd_raw_head_kernel.  Same results up to the
+// summation order of a query's samples.
+extern "C" int demf_msda_fwd_raw_head_f32(int B, int S, int Q, int P, const float* value, long long vpitch,
+                                          const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                          const float* raw, long long ldraw, int off_col0, int lgt_col0,
+                                          const float* ref, float* out, int first_staged_level, int staged_tokens,
+                                          demf_stream_t stream) {
+  DEMF_REQUIRE(B >= 0 && S >= 1 && Q >= 0 && (P == 2 || P == 4), "msda_fwd_raw_head: bad sizes B=%d S=%d Q=%d P=%d", B, S, Q, P);
+  if (B == 0 || Q == 0) return DEMF_OK;
+  DEMF_REQUIRE(value && spatial_shapes && level_start_index && raw && ref && out, "msda_fwd_raw_head: null pointer");
+  DEMF_REQUIRE(vpitch % 32 == 0 && vpitch >= 256 && (long long)S * vpitch < (1LL << 31) && (uintptr_t)value % 16 == 0 &&
+                   (uintptr_t)out % 16 == 0 && ldraw % 2 == 0 && off_col0 % 2 == 0 && (uintptr_t)raw % 8 == 0 &&
+                   (uintptr_t)ref % 8 == 0, "msda_fwd_raw_head: alignment / pitch");
+  const int NP = 4 * P;
+  const size_t lds = (size_t)MSDA_HW * 8 * NP * 20 + (size_t)staged_tokens * 128;
+  DEMF_REQUIRE((first_staged_level == 2 || first_staged_level == 3) && staged_tokens >= 1 && staged_tokens < S &&
+                   lds <= 160 * 1024, "msda_fwd_raw_head: levels %d .. 3 = %d tokens do not fit LDS", first_staged_level,
+               staged_tokens);
+  hipStream_t s = (hipStream_t)stream;
+  static const int target_wgs = getenv("DEMF_MSDA_HEAD_WGS") ? atoi(getenv("DEMF_MSDA_HEAD_WGS")) : 256;   // A/B knob
+  int chunks = (target_wgs + B * 8 - 1) / (B * 8);
+  if (chunks < 1) chunks = 1;
+  int qpc = ((Q + chunks - 1) / chunks + 8 * MSDA_HW - 1) / (8 * MSDA_HW) * (8 * MSDA_HW);
+  chunks = (Q + qpc - 1) / qpc;
+  const dim3 grid(chunks, 8, B);
+#define HEAD_GO(PV, LSV)                                                                                             \
+  {                                                                                                                  \
+    static size_t reserved = 0;                                                                                      \
+    if (lds > reserved) {                                                                                            \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_fwd_raw_head_kernel<PV, LSV>),                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {              \
+        set_error("msda_fwd_raw_head: cannot reserve LDS");                                                          \
+        return DEMF_ELAUNCH;                                                                                         \
+      }                                                                                                              \
+      reserved = 160 * 1024;                                                                                         \
+    }                                                                                                                \
+    hipLaunchKernelGGL((msda_fwd_raw_head_kernel<PV, LSV>), grid, dim3(64 * MSDA_HW), lds, s, S, Q, value, vpitch, spatial_shapes, \
+                       level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, qpc);                            \
+  }
+  if (P == 4) { if (first_staged_level == 2) HEAD_GO(4, 2) else HEAD_GO(4, 3) }
+  else { if (first_staged_level == 2) HEAD_GO(2, 2) else HEAD_GO(2, 3) }
+#undef HEAD_GO
+  return check_launch("msda_fwd_raw_head");
 }
 
 extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,

@@ -230,6 +230,7 @@ class DeformableDetrEncoder(nn.Module):
                 spatial_shapes=torch.as_tensor(list(spatial), dtype=torch.long, device=device),
                 level_start_index=torch.as_tensor([0] + list(np.cumsum(sizes)[:-1]),
                                                   dtype=torch.long, device=device),
+                level_sizes=tuple(int(v) for v in sizes),          # host copy: the MSDA kernel's LDS-resident levels
                 keep=img_metas)
         return cache[key]
 
@@ -321,7 +322,7 @@ class DeformableDetrEncoder(nn.Module):
             else:
                 ops.rows_gemm(x, pk["w_in"], pk["b_in"], raw, a2=pos, a2_cols=v0, row_mask=mask, mask_col0=v0)
             ops.msda_fwd_raw(raw, v0, 0, pk["lgt0"], ref, st["spatial_shapes"], st["level_start_index"], B, S,
-                             a.num_heads, C // a.num_heads, a.num_points, samp)
+                             a.num_heads, C // a.num_heads, a.num_points, samp, level_sizes=st.get("level_sizes"))
             ops.rows_gemm(samp, pk["w_out"], pk["b_out"], x1, ln=(x, pk["g1"], pk["be1"], pk["eps1"]))
             ops.rows_gemm(x1, pk["w0"], pk["b0"], hid, relu=True)
             # K = 1024 with the LayerNorm epilogue runs one 128 x 256-tile workgroup per CU (~1.0 ms); as a

@@ -976,12 +976,28 @@ def groupnorm_nhwc_into(x, groups, gamma, beta, eps, tokens, row0):
     return tokens
 
 
-def msda_fwd_raw(raw, value_col0, off_col0, lgt_col0, ref, spatial_shapes, level_start_index, B, S, H, Dh, P, out):
+_MSDA_HEAD = int(os.environ.get("DEMF_MSDA_HEAD", "1") or 0)        # A/B switch: the (scene, head)-major form
+
+
+def msda_fwd_raw(raw, value_col0, off_col0, lgt_col0, ref, spatial_shapes, level_start_index, B, S, H, Dh, P, out,
+                 level_sizes=None):
     """Self-attention form of the multi-scale deformable attention (the encoder: queries = the S tokens): raw
     offsets / logits / projected value are column ranges of ``raw`` (B*S, ld); softmax and
-    loc = ref + offset / (W_l, H_l) happen inside the kernel (demf_msda_fwd_raw_f32).  -> out (B*S, H*Dh)"""
+    loc = ref + offset / (W_l, H_l) happen inside the kernel (demf_msda_fwd_raw_f32).  -> out (B*S, H*Dh)
+    ``level_sizes`` (host ints, tokens per level): with 8 heads x 32 channels x 4 levels and enough queries the
+    coarse levels' value rows of one (scene, head) that fit LDS are kept there (demf_msda_fwd_raw_head_f32)."""
     L = spatial_shapes.shape[0]
     assert raw.stride(1) == 1 and ref.is_contiguous() and out.is_contiguous()
+    if (_MSDA_HEAD and level_sizes is not None and H == 8 and Dh == 32 and L == 4 and len(level_sizes) == 4
+            and P in (2, 4) and S >= 2048 and sum(level_sizes) == S):
+        budget = 160 * 1024 - 8 * 8 * (4 * P) * 20          # (csrc/msda.hip: MSDA_HW waves x 8 queries x samples x 20 B)
+        for first in (2, 3):
+            staged = int(sum(level_sizes[first:]))
+            if 1 <= staged < S and staged * 128 <= budget:
+                _ffi.call("demf_msda_fwd_raw_head_f32", B, S, S, P, raw.data_ptr() + 4 * value_col0, raw.stride(0),
+                          _p(spatial_shapes), _p(level_start_index), _p(raw), raw.stride(0), int(off_col0),
+                          int(lgt_col0), _p(ref), _p(out), first, staged, _stream())
+                return out
     _ffi.call("demf_msda_fwd_raw_f32", B, S, H, Dh, L, S, P, raw.data_ptr() + 4 * value_col0, raw.stride(0),
               _p(spatial_shapes), _p(level_start_index), _p(raw), raw.stride(0), int(off_col0), int(lgt_col0),
               _p(ref), _p(out), _stream())

@@ -654,6 +654,14 @@ int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, int P, cons
                           long long vpitch, const int64_t* spatial_shapes, const int64_t* level_start_index,
                           const float* raw, long long ldraw, int off_col0, int lgt_col0, const float* ref,
                           float* out, demf_stream_t stream);
+/* The same for H = 8, Dh = 32, L = 4 with the value rows of levels first_staged_level (2 or 3) .. 3 of one (scene, head)
+ * resident in LDS: staged_tokens = S - level_start_index[first_staged_level], known to the caller on the host (the
+ * library never reads a device array back); staged_tokens * 128 B + 8 KB * P / 2 ... must fit 160 KB or the call is
+ * refused.  Results equal demf_msda_fwd_raw_f32's up to the summation order of a query's samples (Q = S rows). */
+int demf_msda_fwd_raw_head_f32(int B, int S, int Q, int P, const float* value, long long vpitch,
+                               const int64_t* spatial_shapes, const int64_t* level_start_index, const float* raw,
+                               long long ldraw, int off_col0, int lgt_col0, const float* ref, float* out,
+                               int first_staged_level, int staged_tokens, demf_stream_t stream);
 
 /* Per-point vote targets of DeMFVoteHead.get_targets_single (class_agnostic_vote_head.py:828-858),
  * batched: points (B,N,point_stride>=3), gt_boxes (B,G,7) = (x,y,z_bottom,dx,dy,dz,yaw) padded to

@@ -218,6 +218,42 @@ def test_msda_raw_matches_the_composed_operator():
         assert err <= 1e-5 * max(1.0, want.abs().max().item()), (P, err)
 
 
+@pytest.mark.parametrize("shapes,first", [
+    ([(40, 56), (20, 28), (10, 14), (5, 7)], 2),          # levels 2-3 (175 tokens) resident
+    ([(120, 160), (60, 80), (30, 40), (15, 20)], 3),      # level 2 (1 200 tokens = 150 KB) does not fit: level 3 only
+])
+def test_msda_raw_head_form_matches_the_wave_form(shapes, first):
+    """demf_msda_fwd_raw_head_f32 ((scene, head)-major, the coarse levels' value rows in LDS - what the encoder runs
+    at >= 2 048 tokens) against demf_msda_fwd_raw_f32 on the same operands: equal up to the summation order."""
+    from demf_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, H, Dh, L = 2, 8, 32, 4
+    sizes = [h * w for h, w in shapes]
+    S = sum(sizes)
+    shp = torch.tensor(shapes, dtype=torch.long, device="cuda")
+    lsi = torch.tensor([0] + list(np.cumsum(sizes)[:-1]), dtype=torch.long, device="cuda")
+    for P in (4, 2):
+        n_off, n_lgt = H * L * P * 2, H * L * P
+        v0 = (n_off + n_lgt + 127) // 128 * 128
+        raw = torch.randn(B * S, v0 + H * Dh, generator=g).cuda()
+        raw[:, :n_off] *= 3.0                                    # offsets of a few pixels, some off the image
+        ref = torch.rand(B, S, L, 2, generator=g).cuda()
+        want = torch.empty(B * S, H * Dh, device="cuda")
+        got = torch.full((B * S, H * Dh), float("nan"), device="cuda")
+        ops.msda_fwd_raw(raw, v0, 0, n_off, ref, shp, lsi, B, S, H, Dh, P, want)
+        seen = []
+        from demf_amd import _ffi
+        orig = _ffi.call
+        _ffi.call = lambda name, *a: (seen.append(a[14]) if name == "demf_msda_fwd_raw_head_f32" else None, orig(name, *a))[1]
+        try:
+            ops.msda_fwd_raw(raw, v0, 0, n_off, ref, shp, lsi, B, S, H, Dh, P, got, level_sizes=tuple(sizes))
+        finally:
+            _ffi.call = orig
+        assert seen == [first], (seen, "the head form with this first resident level must be the one under test")
+        err = (got - want).abs().max().item()
+        assert err <= 1e-5 * max(1.0, want.abs().max().item()), (P, err)
+
+
 def _enc256(seed, **over):
     from demf_amd.modules.image_stream import DeformableDetrEncoder
     kw = dict(fixtures.ENC256)
