@@ -319,6 +319,20 @@ __global__ __launch_bounds__(64 * MSDA_HW, 1) void msda_fwd_raw_head_kernel(
       r[s2] = *reinterpret_cast<const float2*>(ref + row * (TL * 2) + 2 * (i / TP));
     }
   };
+  // the lane's (level, point) pairs are the same in every pass: their level constants once
+  int cHl[PPL], cWl[PPL], cst[PPL];
+  float fHl[PPL], fWl[PPL];
+#pragma unroll
+  for (int s2 = 0; s2 < PPL; ++s2) {
+    const int l = (sub + 8 * s2) / TP;
+    cHl[s2] = (int)shapes[2 * l]; cWl[s2] = (int)shapes[2 * l + 1];
+    fHl[s2] = (float)cHl[s2]; fWl[s2] = (float)cWl[s2];
+    cst[s2] = l < LS ? (int)lsi[l] : (int)lsi[l] - t0;
+  }
+  // row strides of the four levels, in the units of the packed offsets (floats in memory, float4 slots in LDS)
+  int rowstride[TL];
+#pragma unroll
+  for (int l = 0; l < TL; ++l) rowstride[l] = (int)shapes[2 * l + 1] * (l < LS ? (int)vpitch : 8);
   if (qbeg + 8 * wave < qend) load_raw(qbeg + 8 * wave, lg, of, rp);
   for (int q0 = qbeg + 8 * wave; q0 < qend; q0 += 8 * MSDA_HW) {
     const int q = min(q0 + grp, qend - 1);
@@ -338,11 +352,11 @@ __global__ __launch_bounds__(64 * MSDA_HW, 1) void msda_fwd_raw_head_kernel(
     for (int s2 = 0; s2 < PPL; ++s2) {
       const int i = sub + 8 * s2, l = i / TP;
       const float aw = e[s2] / den;
-      const int Hl = (int)shapes[2 * l], Wl = (int)shapes[2 * l + 1];
-      const float lx = rp[s2].x + of[s2].x / (float)Wl, ly = rp[s2].y + of[s2].y / (float)Hl;
+      const int Hl = cHl[s2], Wl = cWl[s2];
+      const float lx = rp[s2].x + of[s2].x / fWl[s2], ly = rp[s2].y + of[s2].y / fHl[s2];
       // fine levels: float offsets into the scene's value rows; staged levels: float4 index into the LDS slice
-      const Corner c = l < LS ? make_corner(lx, ly, Hl, Wl, (int)lsi[l], vh, Dh, h)
-                              : make_corner(lx, ly, Hl, Wl, (int)lsi[l] - t0, 1, 8, 0);
+      const Corner c = l < LS ? make_corner(lx, ly, Hl, Wl, cst[s2], vh, Dh, h)
+                              : make_corner(lx, ly, Hl, Wl, cst[s2], 1, 8, 0);
       my_off[i] = c.off[0] | (c.off[1] != c.off[0] ? 1 : 0) | (c.off[2] != c.off[0] ? 2 : 0);
       my_w[i] = make_float4(c.cw[0] * aw, c.cw[1] * aw, c.cw[2] * aw, c.cw[3] * aw);
     }
@@ -354,12 +368,14 @@ __global__ __launch_bounds__(64 * MSDA_HW, 1) void msda_fwd_raw_head_kernel(
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 1
     for (int bt = 0; bt < 2; ++bt) {
+      // (LS == 2: a batch is exactly one level)
+      const int rs_g = rowstride[bt & (TL - 1)], rs_l = rowstride[(LS + bt) & (TL - 1)];
       float4 gv[NB][4];
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int i = bt * NB + j;
         const int o = my_off[i];
-        const int sx = (o & 1) ? (int)vpitch : 0, sy = (o & 2) ? (int)shapes[2 * (i / TP) + 1] * (int)vpitch : 0;
+        const int sx = (o & 1) ? (int)vpitch : 0, sy = (o & 2) ? (NB == TP ? rs_g : rowstride[i / TP]) : 0;
         const float* v0 = vb + (o & ~3);
         gv[j][0] = ld4<float>(v0); gv[j][1] = ld4<float>(v0 + sx);
         gv[j][2] = ld4<float>(v0 + sy); gv[j][3] = ld4<float>(v0 + sx + sy);
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(64 * MSDA_HW, 1) void msda_fwd_raw_head_kernel(
       for (int j = 0; j < NLH; ++j) {
         const int i = NG + bt * NLH + j;
         const int o = my_off[i];
-        const int sx = (o & 1) ? 8 : 0, sy = (o & 2) ? (int)shapes[2 * (i / TP) + 1] * 8 : 0;
+        const int sx = (o & 1) ? 8 : 0, sy = (o & 2) ? (NLH == TP ? rs_l : rowstride[i / TP]) : 0;
         const float4 w = my_w[i];
         const float4* v0 = s_val + (o & ~3) + sub;
         acc = f4_fma(w.x, v0[0], acc);
