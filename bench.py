@@ -448,6 +448,7 @@ def main():
         replay2 = trainer.capture_double(batches[1], batches[2], prefetch_geometry=True, max_gt=MAX_GT,
                                          geo_pipe=replay.geo, dry=True)
     k = [0]
+    loop_replay = [None]        # (the all-reduce stub legs swap in a capture whose update stays eager)
 
     def step_resident():
         return trainer.step(batch) if replay is None else replay()
@@ -460,7 +461,7 @@ def main():
         cur, nxt = batches[k[0] % NB], batches[(k[0] + 1) % NB]
         if replay is None:
             return trainer.step(cur)
-        r = replay2 if replay2 is not None else replay
+        r = replay2 if replay2 is not None else (loop_replay[0] or replay)
         r.load(cur)
         return r(next_points=nxt["points"])
 
@@ -532,6 +533,11 @@ def main():
         # with the update right behind it (serial), and on the communication stream with the update deferred behind
         # the next batch's input path (the engine's default for world > 1)
         if not args.resident and args.allreduce_stub_us == 0 and not os.environ.get("DEMF_BENCH_SKIP_AR_STUB"):
+            # (the headline capture holds the optimizer update inside its graph; a collective sits between
+            # backward and update, so these legs replay a second capture whose update stays eager)
+            loop_replay[0] = trainer.capture(batch, prefetch_geometry=not args.no_prefetch, max_gt=MAX_GT,
+                                             dry=True, geo_pipe=replay.geo, update_in_graph=False)
+            secondary["ms_per_step_eager_update"] = time_steps(step_loop, args.steps)
             trainer.allreduce_stub_us = 100
             trainer.allreduce_overlap = False
             secondary["allreduce_stub100us_serial_ms_per_step"] = time_steps(step_loop, args.steps)
@@ -540,6 +546,7 @@ def main():
             secondary["allreduce_stub100us_overlapped_ms_per_step"] = time_steps(step_loop, args.steps)
             trainer.flush()
             trainer.allreduce_stub_us, trainer.allreduce_overlap = 0, None
+            loop_replay[0] = None
             torch.cuda.synchronize()
         # (b) the other BASELINE configurations on the same process / box, resident replay each: configs[3]
         # per GPU (bf16 compute mode), BASELINE's "8 heads x 4 points" wording (P = 4; the reference config

@@ -77,6 +77,9 @@ SIGNATURES = {
     "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 5 + [_c_int] + [_ptr] * 3,
     "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 9 + [_c_int, _ptr, _c_int] + [_ptr] * 3,
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
+    "demf_multi_copy_sumsq": [_c_int, _ptr, _c_int, _ptr, _ptr],
+    "demf_sumsq_f32": [ctypes.c_longlong, _ptr, _ptr, _ptr],
+    "demf_adamw_state_f32": [_c_int] + [_ptr] * 9 + [_c_float] * 5 + [_ptr],
     "demf_mlp_gemm_fwd": [_c_int] * 4 + [_ptr] * 6,
     "demf_mlp_gemm_fwd_pool": [_c_int] * 4 + [_ptr] * 5 + [_c_int] + [_ptr] * 5,
     "demf_mlp_gemm_fwd_bn": [_c_int] * 4 + [_ptr] * 7 + [_c_float, _c_float] + [_ptr] * 7,
@@ -127,6 +130,7 @@ SIGNATURES = {
     "demf_gemm_group_f32_ctx": [_ptr, _ptr, _c_int, _ptr],
     "demf_mlp_gemm_fwd_ctx": [_ptr] + [_c_int] * 4 + [_ptr] * 6,
     "demf_multi_copy": [_c_int, _ptr, _c_int, _ptr],
+    "demf_zero_f32": [ctypes.c_longlong, _ptr, _ptr],
     "demf_add_dropout_ln_fwd": [_c_int] * 2 + [_ptr] * 4 + [_c_float] * 2 + [_ptr, _c_int] + [_ptr] * 4,
     "demf_add_dropout_ln_bwd": [_c_int] * 2 + [_ptr] * 5 + [_c_float, _ptr, _c_int, _ptr, _c_int] + [_ptr] * 4,
     "demf_attn_core_fwd": [_c_int] * 4 + [_ptr, _c_float, _c_float, _ptr, _c_int] + [_ptr] * 5,

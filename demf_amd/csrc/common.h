@@ -92,6 +92,26 @@ __device__ __forceinline__ void lds_barrier() {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernels that need more than 64 KB of LDS, recorded
+// PER DEVICE (bit d of `done`: the attribute is a property of the function on one device) and safe to call from
+// several host threads (the call is idempotent; the atomic only avoids repeating it).  false: the device does not
+// offer that much LDS or the call failed - the caller falls back to a form that needs less.
+static inline bool reserve_lds(const void* fn, int bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const unsigned long long bit = 1ull << dev;
+  if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return true;
+  int max_lds = 0;
+  if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || max_lds < bytes)
+    return false;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+  return true;
+}
+
 // compute dtype switch (demf_set_compute_dtype, csrc/mlp.hip): true = bf16 MFMA, fp32 accumulate
 bool compute_bf16();
 int compute_mode();   // 0 fp32 MFMA, 1 bf16 MFMA, 2 fp32 as three bf16 terms (mlp.hip)

@@ -356,15 +356,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_c64_stream_kernel(ConvArgs p) 
 template <int P, int NT>
 static int conv1x1_c64_launch(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = P * 32 * NT * 128 + 8 * 32 * 36 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_c64_stream_kernel<P, NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      set_error("conv_nhwc: cannot reserve %d bytes of LDS", lds);
-      return DEMF_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;       // bit per device
+  if (!reserve_lds(reinterpret_cast<const void*>(&conv1x1_c64_stream_kernel<P, NT>), lds, &attr_done))
+    return -1000;                                // caller: the tile kernel
   const int M = a.B * a.Ho * a.Wo;
   const int wgs = min(256, cdiv(cdiv(M, 32), 8));
   hipLaunchKernelGGL((conv1x1_c64_stream_kernel<P, NT>), dim3(wgs), dim3(512), lds, s, a);
@@ -475,15 +469,9 @@ __global__ __launch_bounds__(512, 1) void conv1x1_stream_kernel(ConvArgs p) {
 template <int P, int NT, int KC>
 static int conv1x1_stream_launch(const ConvArgs& a, hipStream_t s) {
   constexpr int lds = P * 32 * NT * 128 * KC + 8 * 32 * 36 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_stream_kernel<P, NT, KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      set_error("conv_nhwc: cannot reserve %d bytes of LDS", lds);
-      return DEMF_ELAUNCH;
-    }
-    attr_done = true;
-  }
+  static unsigned long long attr_done = 0;       // bit per device
+  if (!reserve_lds(reinterpret_cast<const void*>(&conv1x1_stream_kernel<P, NT, KC>), lds, &attr_done))
+    return -1000;                                // caller: the tile kernel
   const int M = a.B * a.Ho * a.Wo;
   const int groups = a.Cout / (32 * NT);
   int wgs = 256 / groups;
@@ -626,16 +614,20 @@ extern "C" int demf_conv_nhwc_f32(int B, int H, int W, int Cin, int Cout, int KH
   static const int stream64 = getenv("DEMF_CONV_STREAM64") ? atoi(getenv("DEMF_CONV_STREAM64")) : 1;   // A/B switch
   if (stream64 && Cin == 64 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && ksplit == 1 && (Cout == 256 || Cout == 64) &&
       (long long)B * H * W >= 16384) {
-    if (Cout == 256) return planes == 3 ? conv1x1_c64_launch<3, 8>(a, s) : conv1x1_c64_launch<1, 8>(a, s);
-    return planes == 3 ? conv1x1_c64_launch<3, 2>(a, s) : conv1x1_c64_launch<1, 2>(a, s);
+    // (-1000: this device does not grant the kernel's LDS - the tile kernel below serves the layer)
+    const int rc = Cout == 256 ? (planes == 3 ? conv1x1_c64_launch<3, 8>(a, s) : conv1x1_c64_launch<1, 8>(a, s))
+                               : (planes == 3 ? conv1x1_c64_launch<3, 2>(a, s) : conv1x1_c64_launch<1, 2>(a, s));
+    if (rc != -1000) return rc;
   }
   static const int streamk = getenv("DEMF_CONV_STREAMK") ? atoi(getenv("DEMF_CONV_STREAMK")) : 3;   // A/B switch (bits: 1 K = 128, 2 K = 256)
   static const int stream_min = getenv("DEMF_CONV_STREAM_MIN") ? atoi(getenv("DEMF_CONV_STREAM_MIN")) : 16384;   // rows
   if (streamk && KH == 1 && KW == 1 && stride == 1 && pad == 0 && ksplit == 1 && (long long)B * H * W >= stream_min) {
+    int rc = -1000;
     if ((streamk & 1) && Cin == 128 && Cout % 128 == 0)
-      return planes == 3 ? conv1x1_stream_launch<3, 4, 2>(a, s) : conv1x1_stream_launch<1, 4, 2>(a, s);
-    if ((streamk & 2) && Cin == 256 && Cout % 64 == 0)
-      return planes == 3 ? conv1x1_stream_launch<3, 2, 4>(a, s) : conv1x1_stream_launch<1, 2, 4>(a, s);
+      rc = planes == 3 ? conv1x1_stream_launch<3, 4, 2>(a, s) : conv1x1_stream_launch<1, 4, 2>(a, s);
+    else if ((streamk & 2) && Cin == 256 && Cout % 64 == 0)
+      rc = planes == 3 ? conv1x1_stream_launch<3, 2, 4>(a, s) : conv1x1_stream_launch<1, 2, 4>(a, s);
+    if (rc != -1000) return rc;
   }
   static const int wg3 = getenv("DEMF_CONV_WG3") ? atoi(getenv("DEMF_CONV_WG3")) : 0;       // A/B switch
   if (Cout % 128 == 0) {

@@ -718,6 +718,11 @@ extern "C" int demf_msda_bwd_bf16(int B, int S, int H, int Dh, int L, int Q, int
 // S - level_start_index[first_staged_level] of them - the CALLER knows the pyramid's shapes on the host, the library
 // never reads a device array back) resident in LDS per (scene, head): msda_fwd_raw_head_kernel.  Same results up to the
 // summation order of a query's samples.
+extern "C" int demf_msda_fwd_raw_f32(int B, int S, int H, int Dh, int L, int Q, int P, const float* value,
+                                     long long vpitch, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                     const float* raw, long long ldraw, int off_col0, int lgt_col0, const float* ref,
+                                     float* out, demf_stream_t stream);
+
 extern "C" int demf_msda_fwd_raw_head_f32(int B, int S, int Q, int P, const float* value, long long vpitch,
                                           const int64_t* spatial_shapes, const int64_t* level_start_index,
                                           const float* raw, long long ldraw, int off_col0, int lgt_col0,
@@ -743,15 +748,11 @@ extern "C" int demf_msda_fwd_raw_head_f32(int B, int S, int Q, int P, const floa
   const dim3 grid(chunks, 8, B);
 #define HEAD_GO(PV, LSV)                                                                                             \
   {                                                                                                                  \
-    static size_t reserved = 0;                                                                                      \
-    if (lds > reserved) {                                                                                            \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&msda_fwd_raw_head_kernel<PV, LSV>),                     \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {              \
-        set_error("msda_fwd_raw_head: cannot reserve LDS");                                                          \
-        return DEMF_ELAUNCH;                                                                                         \
-      }                                                                                                              \
-      reserved = 160 * 1024;                                                                                         \
-    }                                                                                                                \
+    static unsigned long long reserved = 0;      /* bit per device */                                               \
+    if (!reserve_lds(reinterpret_cast<const void*>(&msda_fwd_raw_head_kernel<PV, LSV>), 160 * 1024, &reserved))      \
+      /* no 160 KB of LDS on this device: the wave-per-query form serves the same call */                            \
+      return demf_msda_fwd_raw_f32(B, S, 8, 32, 4, Q, P, value, vpitch, spatial_shapes, level_start_index, raw,      \
+                                   ldraw, off_col0, lgt_col0, ref, out, stream);                                      \
     hipLaunchKernelGGL((msda_fwd_raw_head_kernel<PV, LSV>), grid, dim3(64 * MSDA_HW), lds, s, S, Q, value, vpitch, spatial_shapes, \
                        level_start_index, raw, ldraw, off_col0, lgt_col0, ref, out, qpc);                            \
   }

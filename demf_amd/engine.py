@@ -100,6 +100,7 @@ class FlatGrads:
         self.views = []
         self._pending_tables, self._tables = [], []     # address tables of captured pack launches
         self.captured_pack = False      # set by Trainer.capture around its captures (it calls finish_capture)
+        self.sumsq_state = None         # FlatAdamW.state while a capture wants the pack to take the clip norm
         self._reserved_table = None
         off = 0
         for p in self.params:
@@ -134,8 +135,13 @@ class FlatGrads:
             # scratch that the forward graph rewrites on every replay)
             table = self._reserved_table.view(-1)[:3 * len(src)].view(3, len(src))
             blocks = max(1, min(64, max(tab[2]) // 4096))
-            _ffi.call("demf_multi_copy", len(src), table.data_ptr(), blocks,
-                      torch.cuda.current_stream().cuda_stream)
+            if self.sumsq_state is not None:
+                # + the squared norm of everything packed, for the clip of the in-graph update
+                _ffi.call("demf_multi_copy_sumsq", len(src), table.data_ptr(), blocks,
+                          self.sumsq_state.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            else:
+                _ffi.call("demf_multi_copy", len(src), table.data_ptr(), blocks,
+                          torch.cuda.current_stream().cuda_stream)
             self._pending_tables.append((table, tab))
             return
         torch._foreach_copy_(dst, src)
@@ -172,11 +178,15 @@ class FlatGrads:
 class FlatAdamW:
     """torch.optim.AdamW over parameter groups whose parameters are re-homed into ONE flat fp32
     buffer (each p.data becomes a view of it, in FlatGrads order), with flat moment buffers: a
-    step is one demf_adamw_f32 launch per group (csrc/optim.hip) with the clip coefficient and
-    the 1/world_size of the gradient mean folded in, instead of 22 multi-tensor launches + a
-    scaling pass.  Group semantics as the reference's config (demf_votenet.py:16-24)."""
+    step is ONE demf_adamw_state_f32 launch over all groups (csrc/optim.hip) with the clip coefficient
+    and the 1/world_size of the gradient mean folded in, instead of 22 multi-tensor launches + a
+    scaling pass.  Step count, learning-rate factor and the squared gradient norm live in a 64-byte
+    DEVICE state block, so the launch takes no host argument that changes from step to step and the
+    whole update can be a node of the step's hipGraph (Trainer.capture).  Group semantics as the
+    reference's config (demf_votenet.py:16-24)."""
 
     def __init__(self, groups, flat_grads, betas=(0.9, 0.999), eps=1e-8):
+        import ctypes
         params = flat_grads.params
         assert [id(p) for g in groups for p in g["params"] if p.requires_grad] == [id(p) for p in params]
         self.grads = flat_grads.flat
@@ -191,17 +201,43 @@ class FlatAdamW:
                 self.flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)
                 off += k
-            self.segments.append((start, off - start, float(g["lr"]), float(g["weight_decay"])))
+            if off > start:
+                self.segments.append((start, off - start, float(g["lr"]), float(g["weight_decay"])))
+        if not 1 <= len(self.segments) <= 4:
+            raise ValueError("FlatAdamW: %d parameter groups (demf_adamw_state_f32 takes 1..4)" % len(self.segments))
+        n = len(self.segments)
+        self._seg = ((ctypes.c_longlong * n)(*[s[0] for s in self.segments]),
+                     (ctypes.c_longlong * n)(*[s[1] for s in self.segments]),
+                     (ctypes.c_float * n)(*[s[2] for s in self.segments]),
+                     (ctypes.c_float * n)(*[s[3] for s in self.segments]))
         self.params = params
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.betas, self.eps, self.t = betas, eps, 0
-        self.lr_factor = 1.0
+        self.betas, self.eps = betas, eps
+        # { double sumsq; int64 t; uint32 ticket; float lr_factor; pad } - include/demf_hip.h
+        self.state = torch.zeros(64, dtype=torch.uint8, device=self.flat.device)
+        self._lr_factor = 1.0
+        self.state.view(torch.float32)[5] = 1.0
+
+    @property
+    def t(self):
+        """Completed optimizer steps (read from the device: synchronises)."""
+        return int(self.state.view(torch.int64)[1].item())
+
+    @t.setter
+    def t(self, value):
+        self.state.view(torch.int64)[1] = int(value)
+
+    @property
+    def lr_factor(self):
+        return self._lr_factor
 
     def set_lr_factor(self, factor):
         """Multiplies every group's base learning rate (the reference's step schedule:
-        lr_config step=[24, 32], x0.1 each - configs/_base_/schedules/schedule_3x.py:7-9)."""
-        self.lr_factor = float(factor)
+        lr_config step=[24, 32], x0.1 each - configs/_base_/schedules/schedule_3x.py:7-9).
+        Written into the device state: captured steps pick it up at their next replay."""
+        self._lr_factor = float(factor)
+        self.state.view(torch.float32)[5] = float(factor)
 
     def check_aliasing(self):
         """Every parameter must still be a view of the flat buffer: ``model.to()`` / ``.float()`` /
@@ -226,20 +262,23 @@ class FlatAdamW:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.t = int(sd["t"])
-        self.lr_factor = float(sd.get("lr_factor", 1.0))
+        self.set_lr_factor(float(sd.get("lr_factor", 1.0)))
 
-    def step(self, grad_norm=None, max_norm=0.0, grad_scale=1.0):
+    def step(self, max_norm=0.0, grad_scale=1.0, norm_taken=False):
+        """One update of every group from the flat gradient buffer.  ``norm_taken``: the squared norm
+        of the gradients is already in the device state (the captured pack took it,
+        demf_multi_copy_sumsq); otherwise one reduction launch over the flat buffer comes first."""
+        import ctypes
         from . import _ffi
         self.check_aliasing()
-        self.t += 1
         stream = torch.cuda.current_stream().cuda_stream
-        for start, n, lr, wd in self.segments:
-            lr = lr * self.lr_factor
-            o = 4 * start
-            _ffi.call("demf_adamw_f32", n, self.flat.data_ptr() + o, self.grads.data_ptr() + o,
-                      self.exp_avg.data_ptr() + o, self.exp_avg_sq.data_ptr() + o,
-                      None if grad_norm is None else grad_norm.data_ptr(), max_norm, grad_scale,
-                      lr, self.betas[0], self.betas[1], self.eps, wd, self.t, stream)
+        if max_norm > 0.0 and not norm_taken:
+            _ffi.call("demf_sumsq_f32", self.grads.numel(), self.grads.data_ptr(), self.state.data_ptr(), stream)
+        a = [ctypes.cast(x, ctypes.c_void_p) for x in self._seg]
+        _ffi.call("demf_adamw_state_f32", len(self.segments), a[0], a[1], a[2], a[3], self.flat.data_ptr(),
+                  self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                  self.state.data_ptr(), float(max_norm), float(grad_scale), self.betas[0], self.betas[1],
+                  self.eps, stream)
 
 
 class Trainer:
@@ -271,6 +310,7 @@ class Trainer:
         lr_config = dict(policy='step', step=[24, 32]), 36 epochs): lr x gamma at each milestone."""
         factor = gamma ** sum(1 for s in steps if epoch >= s)
         if self.fused:
+            self.flush()                 # (an overlapped step's owed update still uses the old rate)
             self.opt.set_lr_factor(factor)
         else:
             for g, base in zip(self.opt.param_groups, self._base_lrs):
@@ -291,6 +331,8 @@ class Trainer:
 
     def load_state_dict(self, sd):
         # copies INTO the existing (flat-buffer-resident) parameters: the views stay intact
+        if self.fused:
+            self.flush()                 # (never apply an owed update of the OLD gradients to the loaded state)
         self.model.load_state_dict(sd["model"])
         self.opt.load_state_dict(sd["optimizer"])
         if self.fused and sd.get("dropout_rng") is not None:
@@ -368,10 +410,19 @@ class Trainer:
             e1.record()
             ev.append((e0, e1))
 
-    def _finish_update(self):
+    def _finish_update(self, norm_taken=False):
         world = dist.get_world_size() if dist.is_initialized() else 1
-        norm = torch.linalg.vector_norm(self.flat.flat)      # of the SUM; scaled in-kernel
-        self.opt.step(norm, self.max_grad_norm, 1.0 / world)
+        # (the norm is that of the SUM over ranks; 1/world is applied in-kernel)
+        self.opt.step(self.max_grad_norm, 1.0 / world, norm_taken=norm_taken)
+
+    def _captured_update(self, world):
+        """The update as nodes of the step's graph (called while capturing, behind the gradient pack).  One
+        rank: the pack has taken the squared norm.  More ranks (DEMF_GRAPH_ALLREDUCE=1): the flat SUM
+        all-reduce is captured too (torch's NCCL / RCCL process group records the collective into the
+        capturing stream), then one reduction launch for the norm of the reduced gradients."""
+        if world > 1:
+            dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+        self._finish_update(norm_taken=(world == 1))
 
     def flush(self):
         """Enqueue the update a deferred (overlapped) step still owes: call before reading parameters,
@@ -452,7 +503,8 @@ class Trainer:
                 fused.set_rng_state(self.flat.flat.device, rng)
         return restore
 
-    def capture(self, batch, warmup=3, prefetch_geometry=True, max_gt=None, dry=False, geo_pipe=None):
+    def capture(self, batch, warmup=3, prefetch_geometry=True, max_gt=None, dry=False, geo_pipe=None,
+                update_in_graph=None):
         """Capture forward + loss + backward of ``batch`` (static shapes, device-resident
         inputs) into one hipGraph; returns ``replay(next_points=None)`` = graph launch + eager
         all-reduce / clip / AdamW.  The path issues no host sync or host->device copy after
@@ -485,8 +537,19 @@ class Trainer:
         in the middle of training leaves the model exactly as it found it.
         ``geo_pipe``: the pre-pass pipeline (``replay.geo``) of another capture with the same cloud
         shape (B, N, channels): both graphs then read the same index buffers and share one
-        pipelined pre-pass."""
+        pipelined pre-pass.
+        ``update_in_graph`` (default: on one rank, ``DEMF_GRAPH_UPDATE=0`` turns it off): gradient norm
+        (taken by the gradient pack on its way), clip and AdamW are nodes of the graph too - the
+        optimizer's step count / learning-rate factor / norm live on the device (FlatAdamW.state), so a
+        replay is the WHOLE step and nothing eager follows it.  With more than one rank the collective
+        sits between backward and update and stays an eager RCCL call (``DEMF_GRAPH_ALLREDUCE=1``:
+        captured as well, where the runtime allows it)."""
         dev = batch["points"].device
+        world_c, stub_c, _ = self.allreduce_config()
+        if update_in_graph is None:
+            update_in_graph = bool(int(os.environ.get("DEMF_GRAPH_UPDATE", "1")))
+        update_in_graph = bool(update_in_graph) and self.fused and stub_c == 0 and \
+            (world_c == 1 or bool(int(os.environ.get("DEMF_GRAPH_ALLREDUCE", "0"))))
         gt_list = isinstance(batch["gt_bboxes_3d"], (list, tuple))
         if gt_list and dev.type == "cuda":
             G = max_gt or max(1, max(int((b.tensor if hasattr(b, "tensor") else b).shape[0])
@@ -552,6 +615,7 @@ class Trainer:
             # goes underneath the FORWARD (~110 launches) in front of a single fwd+bwd graph:
             # 6.49 -> 6.39 ms/step.
             self.flat.captured_pack = True
+            self.flat.sumsq_state = self.opt.state if (update_in_graph and world_c == 1) else None
             try:
                 with torch.cuda.graph(graph):
                     self._arena(True)            # the arena's single fill is the graph's first node
@@ -559,17 +623,34 @@ class Trainer:
                 graph_bwd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_bwd, pool=graph.pool()):
                     self.flat.backward_into(total)
+                    if update_in_graph:
+                        self._captured_update(world_c)
             finally:
                 self._arena(False)
                 self.flat.captured_pack = False
+                self.flat.sumsq_state = None
             loss = total.detach()
         else:
             self.flat.captured_pack = True
+            self.flat.sumsq_state = self.opt.state if (update_in_graph and world_c == 1) else None
             try:
                 with torch.cuda.graph(graph):
                     loss = self._fwd_bwd(batch, static_geo)
+                    if update_in_graph:
+                        self._captured_update(world_c)
+            except Exception:
+                if update_in_graph and world_c > 1:
+                    # the runtime refused to capture the collective: fall back to the eager update
+                    # (a second capture: the failed one left nothing behind)
+                    self.flat.captured_pack = False
+                    self.flat.sumsq_state = None
+                    return self.capture(static, warmup=0, prefetch_geometry=prefetch_geometry, max_gt=max_gt,
+                                        dry=dry, geo_pipe=geo if geo is not None else geo_pipe,
+                                        update_in_graph=False)
+                raise
             finally:
                 self.flat.captured_pack = False
+                self.flat.sumsq_state = None
         self.flat.finish_capture()
         if restore is not None:
             restore()
@@ -590,12 +671,19 @@ class Trainer:
             same version) and otherwise recomputes it.  ``next_points=None`` recomputes the
             pre-pass of the cloud last given (every step still pays for one full pre-pass)."""
             main = torch.cuda.current_stream()
+            if update_in_graph:
+                w_now, stub_now, _ = self.allreduce_config()
+                if w_now != world_c or stub_now:
+                    raise RuntimeError("this step was captured with its optimizer update inside the graph "
+                                       "(world %d, no all-reduce stub); capture again with update_in_graph=False"
+                                       % world_c)
+            update = (lambda defer=False: None) if update_in_graph else self._update
             if can_prefetch and os.environ.get("DEMF_SKIP_GEO"):     # measurement only: the step alone
                 self.flush()
                 graph.replay()
                 if graph_bwd is not None:
                     graph_bwd.replay()
-                self._update()
+                update()
                 return loss
             if graph_bwd is not None:
                 self.flush()
@@ -603,7 +691,7 @@ class Trainer:
                 graph.replay()
                 geo.launch_prepass(main, next_points)
                 graph_bwd.replay()
-                self._update()
+                update()
                 geo.take_fresh(main)
                 return loss
             if graph_bwd is not None:
@@ -612,7 +700,7 @@ class Trainer:
                 if geo.state["fresh"] is not None:
                     geo.take_fresh(main)              # no stall: that pre-pass had a whole step
                 geo.launch_prepass(main, next_points)
-                self._update()
+                update()
                 return loss
             if can_prefetch:
                 # single-graph step (the default): the pre-pass goes first - enqueueing the
@@ -623,7 +711,7 @@ class Trainer:
                 geo.launch_prepass(main, next_points)
             self.flush()
             graph.replay()
-            self._update(defer=True)
+            update(defer=True)
             if can_prefetch:
                 geo.take_fresh(main)
             return loss
@@ -644,7 +732,11 @@ class Trainer:
                 # the padding mask the conversion zeroes by is the NEW batch's: constants first
                 head.refresh_metas(static["img_metas"], new["img_metas"])
                 metas_done = True
-                head.pyramid_tokens(nf, static["img_metas"], out=tok_static)
+                if head.pyramid_tokens(nf, static["img_metas"], out=tok_static) is None:
+                    # (non-contiguous / non-fp32 maps or maps that require grad: the conversion did not run and
+                    # the static token buffer would silently keep the previous batch's image features)
+                    raise ValueError("load(): the new pyramid cannot be converted in place (it must be contiguous "
+                                     "fp32 NCHW maps without requires_grad, as the captured batch's)")
             elif isinstance(nf, dict):
                 if tok_static is not None and not nf.get("padding_zeroed"):
                     raise ValueError("this step was captured on a pyramid of feature maps: load() takes maps "
@@ -654,9 +746,18 @@ class Trainer:
                 for d, f in zip(static["img_features"], nf):
                     d.copy_(f)
             if G is not None:
-                g2, l2 = self.pad_targets(new["gt_bboxes_3d"], new["gt_labels_3d"], G, dev)
-                static["gt_bboxes_3d"].copy_(g2)
-                static["gt_labels_3d"].copy_(l2)
+                nb = [b.tensor if hasattr(b, "tensor") else b for b in new["gt_bboxes_3d"]]
+                if len(nb) <= 32 and all(b.is_cuda for b in nb) and all(l.is_cuda for l in new["gt_labels_3d"]):
+                    # device lists: padded straight into the static buffers (one launch, no copies)
+                    if max(int(b.shape[0]) for b in nb) > G:
+                        raise ValueError("a scene has more ground-truth boxes than the captured step's %d slots" % G)
+                    from . import ops
+                    ops.pad_gt_lists(nb, list(new["gt_labels_3d"]), G,
+                                     out=(static["gt_bboxes_3d"], static["gt_labels_3d"]))
+                else:
+                    g2, l2 = self.pad_targets(new["gt_bboxes_3d"], new["gt_labels_3d"], G, dev)
+                    static["gt_bboxes_3d"].copy_(g2)
+                    static["gt_labels_3d"].copy_(l2)
             else:
                 static["gt_bboxes_3d"].copy_(new["gt_bboxes_3d"])
                 static["gt_labels_3d"].copy_(new["gt_labels_3d"])
@@ -664,6 +765,7 @@ class Trainer:
                 head.refresh_metas(static["img_metas"], new["img_metas"])
 
         replay.load = load
+        replay.update_in_graph = update_in_graph
         replay.static = static
         replay.geo = geo
         replay.max_gt = G
@@ -687,6 +789,26 @@ def _flat_tensors(g):
     if isinstance(g, dict):
         return [t for k in sorted(g) for t in _flat_tensors(g[k])]
     return [t for v in g for t in _flat_tensors(v)]
+
+
+def _batch_tensors(batch):
+    """Every tensor of a batch dict (points, pyramid maps / token dict, GT lists or padded GT)."""
+    out = []
+
+    def walk(v):
+        if torch.is_tensor(v):
+            out.append(v)
+        elif hasattr(v, "tensor") and torch.is_tensor(v.tensor):
+            out.append(v.tensor)
+        elif isinstance(v, dict):
+            for k, x in v.items():
+                if k != "img_metas":
+                    walk(x)
+        elif isinstance(v, (list, tuple)):
+            for x in v:
+                walk(x)
+    walk({k: v for k, v in batch.items() if k != "img_metas"})
+    return out
 
 
 class _Cloud:
@@ -815,6 +937,15 @@ class DoubleBufferedStep:
             ins.wait_event(self.done[s])
         else:
             ins.wait_stream(main)            # first use of the set: behind its capture
+        # The tensors of ``new`` (H2D copies, image-stream outputs, GT lists) are normally produced on the
+        # caller's current stream: the input stream must not read them before they are written, and the
+        # caching allocator must not hand their memory out again while the input stream still reads it.
+        ready = torch.cuda.Event()
+        ready.record(main)
+        ins.wait_event(ready)
+        for t in _batch_tensors(new):
+            if t.is_cuda:
+                t.record_stream(ins)
         with torch.cuda.stream(ins):
             self.slots[s].load(new, skip_geo=True)
             ev = torch.cuda.Event()

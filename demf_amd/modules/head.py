@@ -255,15 +255,22 @@ class DeMFVoteHead(nn.Module):
 
     def unpin_metas(self, img_metas):
         """Undo ``pin_metas`` (the captured graph that read this entry has been dropped: engine.StepCache)."""
-        self.__dict__.get("_meta_pinned", set()).discard(id(img_metas))
+        pinned = self.__dict__.get("_meta_pinned", {})
+        n = pinned.get(id(img_metas), 0)
+        if n > 1:
+            pinned[id(img_metas)] = n - 1          # another live graph still reads this entry
+            return
+        pinned.pop(id(img_metas), None)
         keep = self.__dict__.get("_meta_pinned_keep", [])
         self.__dict__["_meta_pinned_keep"] = [m for m in keep if m is not img_metas]
 
     def pin_metas(self, img_metas):
         """Entries of ``img_metas`` are never evicted from the cache: a captured hipGraph holds raw
         pointers to their tensors (Trainer.capture calls this for its static metas)."""
-        self.__dict__.setdefault("_meta_pinned", set()).add(id(img_metas))
-        self.__dict__.setdefault("_meta_pinned_keep", []).append(img_metas)
+        pinned = self.__dict__.setdefault("_meta_pinned", {})          # id -> number of graphs holding it
+        pinned[id(img_metas)] = pinned.get(id(img_metas), 0) + 1
+        if pinned[id(img_metas)] == 1:
+            self.__dict__.setdefault("_meta_pinned_keep", []).append(img_metas)
 
     def _meta_tensors(self, img_metas, mlvl_shapes, dev, dt):
         """Device-side constants derived from the (host) img_metas, cached per metas object:

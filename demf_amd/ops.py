@@ -155,9 +155,9 @@ class _ZeroArena:
         elif capturing:
             # the recorded fill covers the WHOLE buffer: a piece first taken while capturing (beyond
             # the warm-up steps' watermark) is re-zeroed on every replay too
-            self.buf.zero_()
+            _ffi.call("demf_zero_f32", self.buf.numel(), self.buf.data_ptr(), _stream())
         elif self.high:
-            self.buf[:self.high].zero_()
+            _ffi.call("demf_zero_f32", self.high, self.buf.data_ptr(), _stream())
         if capturing and not any(b is self.buf for b in self._captured):
             # the graph holds this buffer's address (its fill node, every weight-gradient workspace and
             # loss accumulator): it must outlive any later growth of the arena
@@ -1739,11 +1739,12 @@ def gt_prep(gt, labels_padded, num_dir_bins):
     return out
 
 
-def pad_gt_lists(boxes, labels, G):
+def pad_gt_lists(boxes, labels, G, out=None):
     """list of (n_b, >=7) fp32 device box rows, list of (n_b,) int64 device labels -> (gt (B,G,7),
     labels (B,G) int64 with -1 on padding slots, valid (B,G) bool): demf_pad_gt - one launch, the per-
     scene pointers and counts travel by value, nothing is uploaded.  An empty scene gets the reference's
-    all-zero fake box with label 0 (class_agnostic_vote_head.py:766-773).  B <= 32."""
+    all-zero fake box with label 0 (class_agnostic_vote_head.py:766-773).  B <= 32.
+    ``out`` = (gt, labels) of an earlier call: written in place (the static buffers of a captured step)."""
     B = len(boxes)
     dev = boxes[0].device
     keep = []
@@ -1758,8 +1759,13 @@ def pad_gt_lists(boxes, labels, G):
     dims = (ctypes.c_int * B)(*[int(b.shape[1]) if b.dim() == 2 else 7 for b, _ in keep])
     bp = (ctypes.c_void_p * B)(*[b.data_ptr() if b.numel() else None for b, _ in keep])
     lp = (ctypes.c_void_p * B)(*[l.data_ptr() if l.numel() else None for _, l in keep])
-    gt = torch.empty((B, G, 7), dtype=torch.float32, device=dev)
-    lab = torch.empty((B, G), dtype=torch.int64, device=dev)
+    if out is not None:
+        gt, lab = out
+        assert tuple(gt.shape) == (B, G, 7) and tuple(lab.shape) == (B, G) and gt.is_contiguous() and \
+            lab.is_contiguous() and gt.dtype == torch.float32 and lab.dtype == torch.int64
+    else:
+        gt = torch.empty((B, G, 7), dtype=torch.float32, device=dev)
+        lab = torch.empty((B, G), dtype=torch.int64, device=dev)
     valid = torch.empty((B, G), dtype=torch.uint8, device=dev)
     _ffi.call("demf_pad_gt", B, int(G), ctypes.addressof(counts), ctypes.addressof(dims), ctypes.addressof(bp),
               ctypes.addressof(lp), _p(gt), _p(lab), _p(valid), _stream())

@@ -757,6 +757,23 @@ int demf_adamw_f32(long long n, float* param, const float* grad, float* exp_avg,
                    const float* grad_norm, float max_norm, float grad_scale, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, demf_stream_t stream);
 
+/* The same update with its state ON THE DEVICE, so that norm + clip + AdamW are nodes of the step's
+ * hipGraph (nothing the host passes changes between replays).  `opt_state`: 64 zero-initialised bytes
+ *   { double sumsq; int64 t; uint32 ticket; float lr_factor; ... }
+ * sumsq = squared L2 norm of the gradients of ALL groups, accumulated by demf_multi_copy_sumsq (the
+ * gradient pack of a captured step) or demf_sumsq_f32 and cleared by demf_adamw_state_f32; t = completed
+ * steps (the launch uses t + 1 for the bias corrections and publishes it from its last workgroup);
+ * lr_factor multiplies every group's learning rate (the reference's step schedule,
+ * configs/_base_/schedules/schedule_3x.py:7-9).  Up to 4 parameter groups (segments [start, start + n) of
+ * the flat buffers, HOST arrays) in ONE launch; max_norm <= 0: no clipping.                            */
+int demf_multi_copy_sumsq(int n, const void* table, int blocks_per_segment, void* opt_state,
+                          demf_stream_t stream);
+int demf_sumsq_f32(long long n, const float* x, void* opt_state, demf_stream_t stream);
+int demf_adamw_state_f32(int nseg, const long long* seg_start, const long long* seg_n, const float* seg_lr,
+                         const float* seg_weight_decay, float* param, const float* grad, float* exp_avg,
+                         float* exp_avg_sq, void* opt_state, float max_norm, float grad_scale, float beta1,
+                         float beta2, float eps, demf_stream_t stream);
+
 /* ------------------------------------------------------------------ *
  * Dense blocks of the DeMF fusion decoder layer (csrc/dense.hip)
  * Reference: demf/modeling/layers/transformer.py:55-80 -> mmcv DetrTransformerDecoderLayer
@@ -909,6 +926,8 @@ int demf_dropout_mask(long long n, float p, const void* rng, int op_id, float* o
  * 4-byte words.  Replaces the per-tensor copy / memset launches of a training step: the refresh of
  * the step's static index buffers from the pipelined pre-pass, the zeroing of accumulated outputs. */
 int demf_multi_copy(int n, const void* table, int blocks_per_segment, demf_stream_t stream);
+/* x[0..n) = 0 as a kernel launch (the step's zero arena: one fill per step).                         */
+int demf_zero_f32(long long n, float* x, demf_stream_t stream);
 
 /* ------------------------------------------------------------------ *
  * Frozen image stream: convolutions on channels-last (NHWC) activations (csrc/conv.hip)

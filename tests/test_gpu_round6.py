@@ -1,0 +1,185 @@
+"""Round 6: the optimizer update as nodes of the step's hipGraph (device-resident step count / learning-rate
+factor / gradient norm), the engine fixes that came with it."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fixtures
+
+pytestmark = pytest.mark.gpu
+
+PYRAMID = ((32, 44), (16, 22), (8, 11), (4, 6))
+INPUT = (256, 352)
+
+
+def _batch(seed, n_gt, B=3):
+    from demf_amd import synthetic
+    cfg = fixtures.tiny_cfg()
+    raw = synthetic.make_scene_batch(B, 1024, PYRAMID, INPUT, cfg.head.embed_dims, seed=seed, n_gt=n_gt)
+    return dict(points=torch.from_numpy(raw["points"]).cuda(),
+                img_features=[torch.from_numpy(f).cuda() for f in raw["img_features"]],
+                img_metas=raw["img_metas"],
+                gt_bboxes_3d=[torch.from_numpy(b).cuda() for b in raw["gt_boxes"]],
+                gt_labels_3d=[torch.from_numpy(l).cuda() for l in raw["gt_labels"]])
+
+
+def _trainer(lr=2e-5, seed=3):
+    from demf_amd import engine
+    from demf_amd.modules import DeMFHotPath
+    model = DeMFHotPath(fixtures.tiny_cfg())
+    fixtures.seed_weights(model, seed)
+    model.cuda().train()
+    return engine.Trainer(model, lr=lr), model
+
+
+def test_sumsq_and_state_adamw_kernels():
+    """demf_sumsq_f32 / demf_multi_copy_sumsq accumulate the squared norm into the device state, and
+    demf_adamw_state_f32 (every group in one launch, step count and lr factor read from the device) reproduces
+    clip_grad_norm_ + torch.optim.AdamW over steps with and without active clipping and an lr-factor change."""
+    from demf_amd import _ffi, ops
+    torch.manual_seed(1)
+    n0, n1 = 5003, 777
+    n = n0 + n1
+    p = torch.randn(n, device="cuda")
+    ref_p = [p[:n0].clone().cpu().requires_grad_(), p[n0:].clone().cpu().requires_grad_()]
+    opt = torch.optim.AdamW([dict(params=[ref_p[0]], lr=0.008, weight_decay=0.01),
+                             dict(params=[ref_p[1]], lr=0.0004, weight_decay=0.02)])
+    g = torch.zeros(n, device="cuda")
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    state = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    state.view(torch.float32)[5] = 1.0
+    seg = ((ctypes.c_longlong * 2)(0, n0), (ctypes.c_longlong * 2)(n0, n1), (ctypes.c_float * 2)(0.008, 0.0004),
+           (ctypes.c_float * 2)(0.01, 0.02))
+    a = [ctypes.cast(x, ctypes.c_void_p) for x in seg]
+    st = torch.cuda.current_stream().cuda_stream
+    for it in range(6):
+        scale = 30.0 if it % 2 == 0 else 0.01
+        grads = torch.randn(n) * scale
+        if it == 4:
+            state.view(torch.float32)[5] = 0.1
+            for grp in opt.param_groups:
+                grp["lr"] *= 0.1
+        ref_p[0].grad, ref_p[1].grad = grads[:n0].clone(), grads[n0:].clone()
+        torch.nn.utils.clip_grad_norm_(ref_p, 10.0)
+        opt.step()
+        if it % 2 == 0:
+            g.copy_(grads.cuda())
+            _ffi.call("demf_sumsq_f32", n, g.data_ptr(), state.data_ptr(), st)
+        else:
+            # the pack form: two unaligned source pieces copied into g, norm taken on the way
+            src = grads.cuda()
+            k = 1001
+            pieces = [src[:k].clone(), src[k:].clone()]
+            g.zero_()
+            tab = torch.tensor([[t.data_ptr() for t in pieces], [g.data_ptr(), g.data_ptr() + 4 * k],
+                                [k, n - k]], dtype=torch.int64, device="cuda")
+            _ffi.call("demf_multi_copy_sumsq", 2, tab.data_ptr(), 4, state.data_ptr(), st)
+            assert torch.equal(g, src)
+        got = float(state.view(torch.float64)[0])
+        assert got == pytest.approx(float(grads.double().pow(2).sum()), rel=1e-6)
+        _ffi.call("demf_adamw_state_f32", 2, a[0], a[1], a[2], a[3], p.data_ptr(), g.data_ptr(), m.data_ptr(),
+                  v.data_ptr(), state.data_ptr(), 10.0, 1.0, 0.9, 0.999, 1e-8, st)
+        torch.cuda.synchronize()
+        assert int(state.view(torch.int64)[1]) == it + 1
+        assert float(state.view(torch.float64)[0]) == 0.0 and int(state.view(torch.int32)[4]) == 0
+    want = torch.cat([ref_p[0].detach(), ref_p[1].detach()])
+    assert torch.allclose(p.cpu(), want, atol=3e-6, rtol=0)
+
+
+def test_update_inside_the_graph_equals_the_eager_update():
+    """A step captured with norm + clip + AdamW as nodes of its graph (the default on one rank) walks the same
+    trajectory as the same capture with the update left eager behind the graph, batch for batch; the optimizer's
+    step count lives on the device and survives state_dict / load_state_dict; set_epoch reaches captured replays."""
+    batches = [_batch(41, 4), _batch(42, 3), _batch(43, 5)]
+    outs = []
+    for in_graph in (True, False):
+        tr, model = _trainer(lr=1e-3)
+        replay = tr.capture(batches[0], warmup=1, max_gt=8, update_in_graph=in_graph)
+        assert replay.update_in_graph == in_graph
+        losses = []
+        for k in range(6):
+            if k:
+                replay.load(batches[k % 3])
+            if k == 3:
+                tr.set_epoch(24)                       # lr x 0.1 from here on
+            losses.append(float(replay(next_points=batches[(k + 1) % 3]["points"])))
+        torch.cuda.synchronize()
+        assert tr.opt.t == 6 + 1
+        sd = tr.state_dict()
+        assert sd["optimizer"]["t"] == 7 and sd["optimizer"]["lr_factor"] == pytest.approx(0.1)
+        outs.append((losses, [p.detach().clone() for p in model.parameters()], sd))
+    (la, pa, sda), (lb, pb, sdb) = outs
+    assert la == pytest.approx(lb, rel=2e-3)
+    rel = lambda x, y: ((x.double() - y.double()).norm() / x.double().norm().clamp_min(1e-30)).item()
+    for x, y in zip(pa, pb):
+        assert rel(x, y) <= 1e-3
+    # resume: a fresh trainer loaded from the in-graph run continues with step 8's bias corrections
+    tr2, _ = _trainer(lr=1e-3)
+    tr2.load_state_dict(sda)
+    assert tr2.opt.t == 7 and tr2.opt.lr_factor == pytest.approx(0.1)
+    tr2.step(batches[0])
+    assert tr2.opt.t == 8
+
+
+def test_captured_update_refuses_a_changed_collective_setup():
+    tr, _ = _trainer()
+    b = _batch(44, 2)
+    replay = tr.capture(b, warmup=1, max_gt=8)
+    assert replay.update_in_graph
+    replay()
+    tr.allreduce_stub_us = 50
+    with pytest.raises(RuntimeError, match="update inside the graph"):
+        replay()
+
+
+def test_captured_step_is_this_librarys_kernels():
+    """The captured step is the WHOLE step (arena fill ... AdamW) and launches kernels of this library: no
+    at::native reduce / multi-tensor node and no runtime memset: the arena fill, the gradient pack with the clip
+    norm and the one-launch AdamW are kernels of the library inside the graph.  (What is left of the framework in
+    the full-size step are the autograd engine's own gradient sums of tensors with several consumers and the
+    position embedding's 6 -> 8 column weight pad: tools/op_sites.py lists them.)"""
+    from torch.profiler import ProfilerActivity, profile
+    tr, _ = _trainer()
+    b = _batch(45, 3)
+    replay = tr.capture(b, warmup=2, max_gt=8)
+    assert replay.update_in_graph
+    for _ in range(2):
+        replay()
+    torch.cuda.synchronize()
+    p0 = tr.opt.flat.clone()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        tr._graph.replay()
+        torch.cuda.synchronize()
+    assert not torch.equal(p0, tr.opt.flat), "the graph alone must have updated the parameters"
+    names = {str(e.key): int(e.count) for e in prof.key_averages()}
+    kernels = {n: c for n, c in names.items() if "(" in n or n.startswith("__amd")}
+    if not any("demf::" in n for n in kernels):
+        pytest.skip("the profiler recorded no kernels of the graph replay on this runtime")
+    joined = "\n".join(sorted(kernels))
+    for must in ("demf::zero_f32_k", "demf::multi_copy_sumsq_k", "demf::adamw_state_k"):
+        assert must in joined, (must, joined)
+    for never in ("reduce_kernel", "multi_tensor_apply", "fillBuffer", "NormTwoOps"):
+        assert never not in joined, (never, joined)
+
+
+def test_double_buffered_load_waits_for_the_producer_stream():
+    """DoubleBufferedStep.load runs on an input stream: it must see a batch that the CALLER's stream is still
+    producing.  The batch's points are written by a long chain on the current stream right before load."""
+    tr, _ = _trainer()
+    a, b2 = _batch(46, 2), _batch(47, 2)
+    step = tr.capture_double(a, b2, warmup=1, max_gt=8)
+    step(next_points=b2["points"])
+    src = _batch(48, 3)
+    want = src["points"].clone()
+    late = dict(src)
+    buf = torch.zeros_like(want)
+    from demf_amd import _ffi
+    _ffi.call("demf_spin_us", 3000, torch.cuda.current_stream().cuda_stream)      # the producer is slow...
+    buf.copy_(want)                                                               # ...and writes the cloud late
+    late["points"] = buf
+    step.load(late)
+    torch.cuda.synchronize()
+    assert torch.equal(step.static["points"], want)
