@@ -653,6 +653,194 @@ __global__ __launch_bounds__(64 * NW) void fps_prune_kernel(int N, int M, const 
   for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
 }
 
+// ---- fps_prune_kernel with the 20-slot re-search replaced by per-PAIR cached maxima (round 6) ----------------------
+// In fps_prune_kernel the wave whose candidate was consumed - one per round, always on the round's critical path - runs
+// the full search of its 20 slots: a max chain, a wave maximum, a 20-step key-select chain, a wave minimum, a slot
+// switch: ~230 dependent instructions, 1 074 cycles, after a 534-cycle update (profiles/r05_fps_exchange_variants.log).
+// Here lane i of the wave keeps, next to the bounding box of pair i, that pair's exact BEST point: (running distance,
+// (key << 5 | slot), coordinates).  A new sample can change a pair's best only by lowering that very point (every other
+// distance can only fall), which one extra vector pass over the pair lanes detects (the sample's distance to the cached
+// point, bit for bit the update's own arithmetic).  Only THOSE pairs - the consumed candidate's pair, now and then a
+// neighbour - are re-searched: 2 slots x 64 lanes each (one wave maximum, one wave minimum: ~35 instructions).  The
+// wave's candidate is the best of its <= 16 pair lanes: one row reduction.  Same exchange, same barrier, same picks.
+template <int PPT, int NW = 16>
+__global__ __launch_bounds__(64 * NW) void fps_pair_kernel(int N, int M, const float* __restrict__ xyz,
+                                                           const int* __restrict__ perm, int* __restrict__ idx) {
+  constexpr int BS = 64 * NW, PP = PPT / 2, SB = PPT > 32 ? 6 : 5;
+  static_assert(PPT % 2 == 0 && PP <= 32, "pairs of slots, pair lanes 0 .. PP-1");
+  if constexpr (NW == 16) asm volatile("" ::: "v127");   // the CU's whole register file, as fps_reg_kernel
+  __shared__ FpsCand s_cand[2][16];
+  __shared__ int s_idx[FPS_IDX_CHUNK];
+  const int b = blockIdx.x;
+  xyz += (size_t)b * N * 3;
+  perm += (size_t)b * N;
+  idx += (size_t)b * M;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f2 px[PP], py[PP], pz[PP];
+  float tmp[PPT];
+  unsigned kp[PPT];                               // (tie key << 5) | slot
+  float blx = 1e30f, bly = 1e30f, blz = 1e30f, bhx = -1e30f, bhy = -1e30f, bhz = -1e30f;
+  float pbv = -2.f, pbx = 0.f, pby = 0.f, pbz = 0.f;          // lane i < PP: pair i's best point
+  unsigned pbk = 0xFFFFFFFFu;
+  const int first = wave * 64 * PPT;
+  const int kf = perm[first < N ? first : 0];
+  const float fx = xyz[3 * kf], fy = xyz[3 * kf + 1], fz = xyz[3 * kf + 2];
+#pragma unroll
+  for (int i = 0; i < PP; ++i) {
+    float l[3] = {1e30f, 1e30f, 1e30f}, h[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int p = 2 * i + q;
+      const int pos = first + p * 64 + lane;
+      const bool ok = pos < N;
+      const int k = ok ? perm[pos] : 0;
+      const float x = ok ? xyz[3 * k] : fx, y = ok ? xyz[3 * k + 1] : fy, z = ok ? xyz[3 * k + 2] : fz;
+      px[i][q] = x; py[i][q] = y; pz[i][q] = z;
+      tmp[p] = ok ? 1e10f : -2.f;                 // pad slots can never reach the maximum
+      const unsigned key = ok ? (((unsigned)k & 1023u) << 5) | ((unsigned)k >> 10) : 0x7FFFu;
+      kp[p] = (key << SB) | (unsigned)p;
+      if (ok) {
+        l[0] = fminf(l[0], x); h[0] = fmaxf(h[0], x);
+        l[1] = fminf(l[1], y); h[1] = fmaxf(h[1], y);
+        l[2] = fminf(l[2], z); h[2] = fmaxf(h[2], z);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { l[a] = -wave_allmax(-l[a]); h[a] = wave_allmax(h[a]); }
+    if (lane == i) { blx = l[0]; bly = l[1]; blz = l[2]; bhx = h[0]; bhy = h[1]; bhz = h[2]; }
+  }
+  // pair i's exact best: maximum of its 128 running distances, lowest (key, slot) among the holders
+  auto pair_best = [&](int i) {
+    const float m = raw_max(tmp[2 * i], tmp[2 * i + 1]);
+    const float mx = wave_max_dpp(m);
+    unsigned k = tmp[2 * i] == mx ? kp[2 * i] : 0xFFFFFFFFu;
+    k = tmp[2 * i + 1] == mx ? umin(k, kp[2 * i + 1]) : k;
+    const unsigned kmin = wave_min_u32(k);
+    const int wl = __builtin_ctzll(__ballot(k == kmin));
+    const bool odd = kmin & 1u;                                  // slot 2i + 1
+    const float x = readlane_f(odd ? px[i][1] : px[i][0], wl);
+    const float y = readlane_f(odd ? py[i][1] : py[i][0], wl);
+    const float z = readlane_f(odd ? pz[i][1] : pz[i][0], wl);
+    if (lane == i) { pbv = mx; pbk = kmin; pbx = x; pby = y; pbz = z; }
+  };
+#pragma unroll
+  for (int i = 0; i < PP; ++i) pair_best(i);
+  float cv = first < N ? 1e10f : -2.f;
+  unsigned ctk = 0xFFFFFFFFu;
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  // the wave's candidate: best of the pair lanes (one row of 16)
+  auto wave_best = [&]() {
+    const float v = lane < PP ? pbv : -3.f;
+    if constexpr (PP <= 16) cv = readlane_f(row16_max_dpp(v), 0);
+    else cv = wave_max_dpp(v);
+    const unsigned k = (lane < PP && v == cv) ? pbk : 0xFFFFFFFFu;
+    unsigned kmin;
+    if constexpr (PP <= 16) kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_min_u32(k));
+    else kmin = wave_min_u32(k);
+    const int wl = __builtin_ctzll(__ballot(k == kmin));
+    ctk = kmin >> SB;
+    cx = readlane_f(pbx, wl); cy = readlane_f(pby, wl); cz = readlane_f(pbz, wl);
+  };
+  wave_best();
+  int dirty = 2;
+  float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+  if (tid == 0) s_idx[0] = 0;
+
+#ifdef DEMF_FPS_PROFILE
+  long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  for (int j = 1; j < M; ++j) {
+#ifdef DEMF_FPS_PROFILE
+    const long long pt0 = __builtin_readcyclecounter();
+#endif
+    // ---- every pair's box against the new sample, one lane each
+    const float ex = raw_max3(blx - x1, x1 - bhx, 0.f);
+    const float ey = raw_max3(bly - y1, y1 - bhy, 0.f);
+    const float ez = raw_max3(blz - z1, z1 - bhz, 0.f);
+    const float lb = dist2(ex, ey, ez);
+    const unsigned need = (unsigned)(__ballot(lane < PP && !(lb >= cv)));
+    if (need) {                                           // (wave-uniform)
+      // which of those pairs lose their cached best point to this sample?
+      const float hd = dist2(pbx - x1, pby - y1, pbz - z1);
+      const unsigned hit = (unsigned)(__ballot(lane < PP && !(hd >= pbv))) & need;
+      const f2 X1 = {x1, x1}, Y1 = {y1, y1}, Z1 = {z1, z1};
+#pragma unroll
+      for (int i = 0; i < PP; ++i) {
+        if ((need >> i) & 1u) {
+          const f2 dx = px[i] - X1, dy = py[i] - Y1, dz = pz[i] - Z1;
+          f2 d = dy * dy;                               // dist2(): fma(dz,dz,fma(dx,dx,dy*dy))
+          d = __builtin_elementwise_fma(dx, dx, d);
+          d = __builtin_elementwise_fma(dz, dz, d);
+          tmp[2 * i] = raw_min(d[0], tmp[2 * i]);
+          tmp[2 * i + 1] = raw_min(d[1], tmp[2 * i + 1]);
+          if ((hit >> i) & 1u) pair_best(i);
+        }
+      }
+      if (hit) {
+        wave_best();
+        dirty = 2;
+      }
+#ifdef DEMF_FPS_PROFILE
+      pp[7] += __builtin_readcyclecounter() - pt0;          // rounds with an update: test + update + re-search
+      pp[3] += 1;
+      pp[4] += hit != 0;
+      pp[5] += __builtin_popcount(need);
+      pp[6] += __builtin_popcount(hit);
+#endif
+    }
+#ifdef DEMF_FPS_PROFILE
+    const long long pt1 = __builtin_readcyclecounter();
+    pp[0] += pt1 - pt0;
+#endif
+    // ---- block maximum, lowest tie key among the waves that hold it
+    FpsCand* slot = s_cand[j & 1];
+    if (dirty) {
+      if (lane == 0) slot[wave] = FpsCand{cv, ctk, cx, cy, cz};
+      --dirty;
+    }
+    lds_barrier();
+#ifdef DEMF_FPS_PROFILE
+    const long long pt2 = __builtin_readcyclecounter();
+    pp[1] += pt2 - pt1;
+#endif
+    {
+      const FpsCand c = slot[lane & (NW - 1)];           // every 16-lane row: all NW waves
+      const float gmax = readlane_f(row16_max_dpp(c.v), 0);
+      const unsigned long long held = __ballot(c.v == gmax) & ((1ull << NW) - 1ull);
+      int wv = __builtin_ctzll(held);
+      if (held & (held - 1)) {                           // several waves hold it: lowest tie key
+        const unsigned key = c.v == gmax ? c.tk : 0xFFFFFFFFu;
+        const unsigned tmin = (unsigned)__builtin_amdgcn_readfirstlane((int)row16_min_u32(key));
+        wv = __builtin_ctzll(__ballot(key == tmin));
+      }
+      x1 = readlane_f(c.x, wv);
+      y1 = readlane_f(c.y, wv);
+      z1 = readlane_f(c.z, wv);
+      if (tid == 0) {
+        const unsigned tk = (unsigned)__builtin_amdgcn_readlane((int)c.tk, wv);
+        s_idx[j & (FPS_IDX_CHUNK - 1)] = (int)(((tk & 31u) << 10) | (tk >> 5));
+      }
+    }
+#ifdef DEMF_FPS_PROFILE
+    pp[2] += __builtin_readcyclecounter() - pt2;
+#endif
+    if (((j + 1) & (FPS_IDX_CHUNK - 1)) == 0) {
+      lds_barrier();
+      const int base = j + 1 - FPS_IDX_CHUNK;
+      for (int t = tid; t < FPS_IDX_CHUNK; t += BS) idx[base + t] = s_idx[t];
+      lds_barrier();
+    }
+  }
+#ifdef DEMF_FPS_PROFILE
+  if (b == 0 && lane == 0 && wave < 16)
+    for (int i = 0; i < 8; ++i) g_prune_prof[wave][i] = pp[i];
+#endif
+  lds_barrier();
+  const int base = M & ~(FPS_IDX_CHUNK - 1);
+  for (int t = tid; base + t < M; t += BS) idx[base + t] = s_idx[t];
+}
+
 struct __attribute__((aligned(32))) FpsSlot {
   float v;
   int i;
@@ -875,6 +1063,23 @@ static int fps_impl(int B, int N, int M, const float* xyz, float* temp, long lon
       M <= N) {
     int* perm = (int*)temp;
     hipLaunchKernelGGL(fps_sort_k, dim3(B), dim3(1024), 0, s, N, xyz, perm);
+    // per-pair cached maxima instead of the 20-slot re-search (round 6).  Measured on MI355X (tools/fps_micro.py):
+    // 20 000 -> 2 048: 2 364 vs 2 420 cycles per round; 16 384 -> 2 048: 2 234 vs 2 184 (fewer slots: the search it
+    // replaces is shorter) - so the default takes it above 16 slots per lane only.  DEMF_FPS_PAIR = 0 / 1 forces.
+    static const int pair_env = [] { const char* v = getenv("DEMF_FPS_PAIR"); return v ? atoi(v) : -1; }();
+    const bool pair_on = pair_env < 0 ? ppt > 16 : pair_env != 0;
+    if (pair_on) {
+#define PAIR(P) hipLaunchKernelGGL((fps_pair_kernel<P>), dim3(B), dim3(1024), 0, s, N, M, xyz, perm, idx)
+#define PAIR8(P) hipLaunchKernelGGL((fps_pair_kernel<P, 8>), dim3(B), dim3(512), 0, s, N, M, xyz, perm, idx)
+      static const int pwaves = [] { const char* v = getenv("DEMF_FPS_PAIR_WAVES"); return v ? atoi(v) : 16; }();   // A/B
+      if (pwaves == 8 && ppt > 8) {
+        if (ppt <= 12) PAIR8(24); else if (ppt <= 16) PAIR8(32); else PAIR8(40);
+      } else if (ppt <= 4) PAIR(4); else if (ppt <= 8) PAIR(8); else if (ppt <= 12) PAIR(12);
+      else if (ppt <= 16) PAIR(16); else PAIR(20);
+#undef PAIR8
+#undef PAIR
+      return check_launch("fps_pair");
+    }
 #define PRUNE(P) hipLaunchKernelGGL((fps_prune_kernel<P>), dim3(B), dim3(1024), 0, s, N, M, xyz, perm, idx)
 #define PRUNE8(P) hipLaunchKernelGGL((fps_prune_kernel<P, 8>), dim3(B), dim3(512), 0, s, N, M, xyz, perm, idx)
     // A/B switch, default 16: 8 waves x 40 slots is bit-identical but SLOWER (20 000 -> 2 048: 2 643 vs 2 058 us) -
