@@ -272,10 +272,23 @@ def test_msda_fwd_bwd(ops, B, Q, H, Dh, shapes, P):
     np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-4, atol=1e-5)
     go = np.random.default_rng(0).standard_normal(want.shape).astype(np.float32)
     out.backward(dev(go))
-    gv, gl, ga = ok.msda_bwd(value, shp, lsi, loc, attw, go)
-    np.testing.assert_allclose(v.grad.cpu().numpy(), gv, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(a.grad.cpu().numpy(), ga, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(l.grad.cpu().numpy(), gl, rtol=1e-3, atol=2e-3)
+    # (a) against the fp64 C oracle (oracle_msda_f64_bwd): every gradient within 1e-4 of its scale - the form of
+    # the north-star bar.  grad_loc at the full pyramid has |g| up to ~700 (a difference of neighbouring values
+    # times W_l = 140) and carries an fp32 cancellation error of 5e-3 ABSOLUTE in ANY fp32 evaluation of mmcv's
+    # formulas - the fp32 C oracle shows the same 5.0e-3 against fp64 - i.e. 7e-6 of scale (measured: grad_value
+    # 6.5e-6, grad_loc 7.2e-6, grad_attw 8.6e-6 of scale).
+    # (b) against the fp32 C oracle, element by element: 1e-4 relative + 1e-6 of scale (measured 0.08 of that
+    # bound: the kernel evaluates the same fp32 formulas in the same order; grad_value differs by atomics order).
+    t64 = ok.msda_bwd(value, shp, lsi, loc, attw, go, dtype=np.float64)
+    t32 = ok.msda_bwd(value, shp, lsi, loc, attw, go)
+    for name, got, w64, w32 in zip(("grad_value", "grad_loc", "grad_attw"), (v.grad, l.grad, a.grad), t64, t32):
+        got = got.cpu().numpy().astype(np.float64)
+        scale = max(1.0, float(np.abs(w64).max()))
+        err = float(np.abs(got - w64).max())
+        assert err <= 1e-4 * scale, f"{name} vs fp64: {err:.2e} (scale {scale:.3g})"
+        bound = 1e-4 * np.abs(w32) + 1e-6 * scale
+        worst = float((np.abs(got - w32) / bound).max())
+        assert worst <= 1.0, f"{name} vs the fp32 oracle: {worst:.2f} x (1e-4 |g| + 1e-6 scale)"
 
 
 def test_msda_linearity_full_size(ops):
