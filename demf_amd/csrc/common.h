@@ -90,6 +90,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Workgroup barrier in front of a "last workgroup" ticket (csrc/bn_fin.h): EVERY wave first waits for its own
+// vector-memory operations - the sum atomics it has just issued - to be acknowledged.  __syncthreads() alone does
+// not do that on this target: outside threadgroup-split mode the workgroup-scope release omits s_waitcnt vmcnt(0)
+// (checked in the ISA: global_atomic_add_f64 ... s_barrier with no wait in between), so the thread that takes the
+// ticket only knew about its OWN wave's atomics; a workgroup could finalise a layer's statistics while another
+// wave's contribution to them was still in flight - and the straggler then landed in the self-cleaning accumulator.
+__device__ __forceinline__ void sync_drained() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) for kernels that need more than 64 KB of LDS, recorded

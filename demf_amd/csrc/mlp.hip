@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   if constexpr (RED) {
     if (p.vfin.ticket != nullptr) {
       // layer l-1's backward vectors for this launch's columns, by its last workgroup (csrc/bn_fin.h)
-      __syncthreads();
+      sync_drained();
       if (threadIdx.x == 0)
         s_next = last_workgroup(p.vfin.ticket, (int)(gridDim.x * gridDim.y), (int)(blockIdx.y * gridDim.x + blockIdx.x));
       __syncthreads();
@@ -986,9 +986,9 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
   }
   if constexpr (STATS) {
     if (p.fin.ss != nullptr) {
-      // Only atomics touch the sums and the counters, and __syncthreads() waits for this block's own
+      // Only atomics touch the sums and the counters, and sync_drained() waits for every wave's own
       // to be acknowledged, so no fence is needed.  Two-level exit count as above.
-      __syncthreads();
+      sync_drained();
       if (threadIdx.x == 0) {
         const int total = (int)(gridDim.x * gridDim.y);
         const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
@@ -1337,7 +1337,7 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   }
   if (p.fin.ss != nullptr) {
     // train-mode BN bookkeeping by the last workgroup (as mlp_gemm_kernel: only atomics touch the sums)
-    __syncthreads();
+    sync_drained();
     if (tid == 0) {
       const int total = (int)gridDim.x;
       const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(512, 1) void mlp_fwd_pc_kernel(MlpArgs p) {
   }
   if (p.fin.ss != nullptr) {
     // train-mode BN bookkeeping by the last workgroup (as mlp_gemm_kernel: only atomics touch the sums)
-    __syncthreads();
+    sync_drained();
     if (tid == 0) {
       const int total = (int)gridDim.x;
       const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
@@ -1696,6 +1696,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_k(int R, int N, int ns,
     __syncthreads();
   }
   if (fin.ticket != nullptr) {     // this layer's backward vectors by the last workgroup (csrc/bn_fin.h)
+    sync_drained();
     if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
     __syncthreads();
     if (s_last) bn_vec_finalize(fin, N, 0, N, g12, threadIdx.x, 256);
@@ -1794,7 +1795,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
     atomicAdd(o2 + 2, (double)t2.z); atomicAdd(o2 + 3, (double)t2.w);
   }
   if (fin.ticket != nullptr) {     // this layer's backward vectors by the last workgroup (csrc/bn_fin.h)
-    __syncthreads();
+    sync_drained();
     if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
     __syncthreads();
     if (s_last) bn_vec_finalize(fin, N, 0, N, g12, threadIdx.x, 256);
@@ -2178,6 +2179,244 @@ static int mlp_grid(int R, int brows) {
 template <int PRO, bool STATS, bool POOL, bool RED, int CM>
 static int launch_gemm_t(const MlpArgs& a, hipStream_t s);
 
+
+// ---- few-row forward layers: 64 x 64 tiles, operands split ONCE at staging, double-buffered planes (round 6) ---------
+// The FP modules, the vote module, the vote aggregation's second layer and the prediction heads run this file's
+// forward GEMM on 2 048 ... 32 768 rows.  mlp_gemm_kernel walks a 32-column K step in ~4 200 cycles there (DESIGN_LOG
+// section 3.2: the fp32 slab goes to LDS as it is and EVERY wave splits its own fragments, two barriers per step, 24
+// MFMAs = 768 issue cycles): a 2 048 x 256 -> 128 layer is 8 dependent steps = 15 us for 0.07 GFLOP.  Here a
+// workgroup of 4 waves owns a 64 x 64 output tile; per 32-wide K step every thread takes 8 consecutive k of one A
+// row and of one W row (two float4 each, a full 128-byte line per 4 threads), applies the BN + ReLU prologue, splits
+// them into the P bf16 planes and writes ONE 16-byte chunk per plane ([row][k] planes, XOR-swizzled chunks:
+// fragment reads are conflict-free); the planes are double-buffered, so a step has ONE barrier, and the global rows
+// of step i + 2 / i + 3 are in flight in registers.  A wave contracts 32 x 32 x 32 per step: 12 MFMAs (P = 3) on
+// fragments read as ds_read_b128.  Epilogue: column statistics (fp64 atomics, one per column per workgroup), the raw
+// output, the BatchNorm bookkeeping in the last workgroup.  Column tiles of a row block run on one XCD (A read once).
+__device__ __forceinline__ int ft_swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int P>
+__device__ __forceinline__ void ft_split8(const float4& a, const float4& b, uint4 (&o)[P]) {
+  using v2f = float __attribute__((ext_vector_type(2)));
+  using v2b = __bf16 __attribute__((ext_vector_type(2)));
+  const v2f x[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+  unsigned w[4][P];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const v2b h = __builtin_convertvector(x[i], v2b);
+    w[i][0] = __builtin_bit_cast(unsigned, h);
+    if constexpr (P == 3) {
+      const v2f r = x[i] - __builtin_convertvector(h, v2f);
+      const v2b m = __builtin_convertvector(r, v2b);
+      w[i][1] = __builtin_bit_cast(unsigned, m);
+      const v2f l = r - __builtin_convertvector(m, v2f);
+      w[i][2] = __builtin_bit_cast(unsigned, __builtin_convertvector(l, v2b));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < P; ++q) o[q] = make_uint4(w[0][q], w[1][q], w[2][q], w[3][q]);
+}
+
+template <int P, bool PRO>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_tile_kernel(MlpArgs p) {
+  constexpr int PLANE = 64 * 64;                    // bytes: 64 rows x 32 k bf16
+  constexpr int BUF = 2 * P * PLANE;                // A planes | W planes of one K step
+  extern __shared__ __attribute__((aligned(16))) char ft_smem[];
+  char* s_buf = ft_smem;                            // [2][BUF]
+  float* s_vec = reinterpret_cast<float*>(ft_smem + 2 * BUF);   // [scale | shift] of the prologue (2K)
+  float* s_red = s_vec + (PRO ? 2 * p.K : 0);       // [2 waves][2 stats][64 columns]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    // all column tiles of a row block on ONE XCD, back to back (workgroups are dealt to the 8 XCDs round-robin)
+    const int gx = gridDim.x, gy = gridDim.y;
+    if ((gy & 7) == 0) {
+      const int L = bx + gx * by;
+      by = (L & 7) + 8 * (L / (8 * gx));
+      bx = (L >> 3) % gx;
+    }
+  }
+  const int m0 = by * 64, n0 = bx * 64;
+  if constexpr (PRO) {
+    for (int i = tid; i < 2 * p.K; i += 256) s_vec[i] = p.vec[i];
+  }
+  // staging map: row (tid >> 2) of the tile, k chunk (tid & 3) = 8 consecutive k
+  const int srow = tid >> 2, sch = tid & 3;
+  const int arow = min(m0 + srow, p.R - 1);         // rows beyond R: a valid address, zeroed in the transform
+  const bool arow_ok = m0 + srow < p.R;
+  const float* ga = p.X + (size_t)arow * p.ldx + 8 * sch;
+  const float* gw = p.Bt + (size_t)(n0 + srow) * p.K + 8 * sch;
+  const int nk = p.K / 32;
+  // Register ring of FOUR K steps: a row that the layer below has just written is ~2 us away (another XCD's L2
+  // or HBM), a step is ~0.5 us - with two stages every step waited for its rows.  (Stages are addressed
+  // statically - the K loop is unrolled by four - or they would live in scratch.)
+  float4 ra0[2], rw0[2], ra1[2], rw1[2], ra2[2], rw2[2], ra3[2], rw3[2];
+  auto fetch = [&](float4 (&a4)[2], float4 (&w4)[2], int ks) {
+    const float* a = ga + 32 * ks;
+    const float* w = gw + 32 * ks;
+    a4[0] = *reinterpret_cast<const float4*>(a);
+    a4[1] = *reinterpret_cast<const float4*>(a + 4);
+    w4[0] = *reinterpret_cast<const float4*>(w);
+    w4[1] = *reinterpret_cast<const float4*>(w + 4);
+  };
+  auto commit = [&](const float4 (&a4)[2], const float4 (&w4)[2], int ks, char* buf) {
+    float4 a0 = a4[0], a1 = a4[1];
+    if constexpr (PRO) {
+      const float4 c0 = *reinterpret_cast<const float4*>(s_vec + 32 * ks + 8 * sch);
+      const float4 c1 = *reinterpret_cast<const float4*>(s_vec + 32 * ks + 8 * sch + 4);
+      const float4 h0 = *reinterpret_cast<const float4*>(s_vec + p.K + 32 * ks + 8 * sch);
+      const float4 h1 = *reinterpret_cast<const float4*>(s_vec + p.K + 32 * ks + 8 * sch + 4);
+      a0.x = fmaxf(0.f, __builtin_fmaf(a0.x, c0.x, h0.x)); a0.y = fmaxf(0.f, __builtin_fmaf(a0.y, c0.y, h0.y));
+      a0.z = fmaxf(0.f, __builtin_fmaf(a0.z, c0.z, h0.z)); a0.w = fmaxf(0.f, __builtin_fmaf(a0.w, c0.w, h0.w));
+      a1.x = fmaxf(0.f, __builtin_fmaf(a1.x, c1.x, h1.x)); a1.y = fmaxf(0.f, __builtin_fmaf(a1.y, c1.y, h1.y));
+      a1.z = fmaxf(0.f, __builtin_fmaf(a1.z, c1.z, h1.z)); a1.w = fmaxf(0.f, __builtin_fmaf(a1.w, c1.w, h1.w));
+    }
+    if (!arow_ok) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
+    uint4 pa[P], pw[P];
+    ft_split8<P>(a0, a1, pa);
+    ft_split8<P>(w4[0], w4[1], pw);
+    const int off = ft_swz(srow, sch);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      *reinterpret_cast<uint4*>(buf + q * PLANE + off) = pa[q];
+      *reinterpret_cast<uint4*>(buf + (P + q) * PLANE + off) = pw[q];
+    }
+  };
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  fetch(ra0, rw0, 0);
+  if (nk > 1) fetch(ra1, rw1, 1);
+  if (nk > 2) fetch(ra2, rw2, 2);
+  if (nk > 3) fetch(ra3, rw3, 3);
+  __syncthreads();                                  // the prologue vectors
+  commit(ra0, rw0, 0, s_buf);
+  if (nk > 4) fetch(ra0, rw0, 4);
+  __syncthreads();
+  // one K step: fragments of step ks out of buffer `cur`, step ks + 1 (registers an / wn) into buffer `nxt`,
+  // the rows of step ks + 5 requested into the registers just freed
+  auto step = [&](int ks, const char* cur, char* nxt, float4 (&an)[2], float4 (&wn4)[2]) {
+    bf16x8 fa[2][P], fb[2][P];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        fa[s2][q] = *reinterpret_cast<const bf16x8*>(cur + q * PLANE + ft_swz(wm * 32 + lr, 2 * s2 + lh));
+        fb[s2][q] = *reinterpret_cast<const bf16x8*>(cur + (P + q) * PLANE + ft_swz(wn * 32 + lr, 2 * s2 + lh));
+      }
+    // two accumulators (one per 16-wide half of the step): consecutive MFMAs are independent, and the staging
+    // arithmetic of the NEXT step (issued below) runs on the vector ALU underneath them
+    if constexpr (P == 3) {   // the six products of weight >= 2^-16, smallest first (as every three-term kernel)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][2], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][2], fb[1][0], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][2], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][1], fb[0][1], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][1], fb[1][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][1], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][1], fb[1][0], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][1], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][0], acc2, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][0], acc2, 0, 0, 0);
+    }
+    if (ks + 1 < nk) {
+      commit(an, wn4, ks + 1, nxt);
+      if (ks + 5 < nk) fetch(an, wn4, ks + 5);
+    }
+    if constexpr (P == 3) {
+      // interleave: one MFMA, then a group of vector-ALU instructions of the staging code
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
+      }
+    }
+    lds_barrier();
+  };
+  for (int ks = 0; ks < nk; ks += 4) {
+    step(ks, s_buf, s_buf + BUF, ra1, rw1);                       // step 4j: stages step 4j + 1 out of ring slot 1
+    if (ks + 1 < nk) step(ks + 1, s_buf + BUF, s_buf, ra2, rw2);
+    if (ks + 2 < nk) step(ks + 2, s_buf, s_buf + BUF, ra3, rw3);
+    if (ks + 3 < nk) step(ks + 3, s_buf + BUF, s_buf, ra0, rw0);
+  }
+  // ---- epilogue: C layout of 32x32: col = lr, row = (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  const int n = n0 + wn * 32 + lr;
+  float cs1 = 0.f, cs2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m < p.R) {
+      p.Y[(size_t)m * p.ldy + n] = acc[r];
+      cs1 += acc[r];
+      cs2 = __builtin_fmaf(acc[r], acc[r], cs2);
+    }
+  }
+  cs1 += __shfl_xor(cs1, 32);
+  cs2 += __shfl_xor(cs2, 32);
+  if (lh == 0) {
+    s_red[(wm * 2 + 0) * 64 + wn * 32 + lr] = cs1;
+    s_red[(wm * 2 + 1) * 64 + wn * 32 + lr] = cs2;
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int which = tid >> 6, c = tid & 63;
+    const float v = s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c];
+    atomicAdd(p.stats + (size_t)which * p.N + n0 + c, (double)v);
+    // EVERY wave that issued sum atomics drains them before the barrier in front of the ticket: the barrier itself
+    // does not wait for another wave's vector-memory counter (workgroup-scope release omits vmcnt(0) outside
+    // threadgroup-split mode), and wave 1 carries all of this workgroup's sum of squares - taken late, the last
+    // workgroup would finalise without its own 64 rows (measured: a 1e-3 shift of every gradient below the layer in
+    // one run out of six) and the stragglers would land in the accumulator the finalize has just left zeroed.
+  }
+  // BatchNorm bookkeeping by the last workgroup (atomics only: see mlp_gemm_kernel)
+  sync_drained();
+  if (tid == 0) {
+    const int total = (int)(gridDim.x * gridDim.y);
+    const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    const int ngroups = total < SCHED_GROUPS ? total : SCHED_GROUPS;
+    const int g = lin % SCHED_GROUPS;
+    const int members = total / SCHED_GROUPS + (g < total % SCHED_GROUPS ? 1 : 0);
+    int* t = p.fin.ticket + FIN_OFF;
+    int last = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (atomicAdd(t + 1 + g, 1) == members - 1) {
+      atomicExch(t + 1 + g, 0);
+      if (atomicAdd(t, 1) == ngroups - 1) { atomicExch(t, 0); last = 1; }
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) {
+    const BnFin& f = p.fin;
+    if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
+    for (int c = tid; c < p.N; c += 256) {
+      const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+      const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + p.N + c), 0ull));
+      bn_finalize_channel(c, p.N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss, f.mi,
+                          f.conv_bias);
+    }
+  }
+}
+
+template <int P, bool PRO>
+static int launch_fwd_tile(const MlpArgs& a, hipStream_t s) {
+  const int lds = 2 * 2 * P * 64 * 64 + (PRO ? 2 * a.K * 4 : 0) + 2 * 2 * 64 * 4;
+  static unsigned long long reserved = 0;
+  if (lds > 64 * 1024 && !reserve_lds(reinterpret_cast<const void*>(&mlp_fwd_tile_kernel<P, PRO>), lds, &reserved))
+    return -1000;
+  const dim3 grid(a.N / 64, (a.R + 63) / 64);
+  hipLaunchKernelGGL((mlp_fwd_tile_kernel<P, PRO>), grid, dim3(256), lds, s, a);
+  return check_launch("mlp_fwd_tile");
+}
+
 template <int PRO, bool STATS, bool POOL = false, bool RED = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   switch (compute_mode()) {
@@ -2282,6 +2521,20 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     set_error("mlp_gemm: bf16 row storage (st=%d) is only built into the weight-resident forward (K = 64, "
               "N = 64 / 128, R >= 16384, bf16 compute mode)", a.st);
     return DEMF_EUNSUPPORTED;
+  }
+  if constexpr ((BF16 == 1 || BF16 == 2) && !RED && !POOL && STATS && (PRO == PRO_BNRELU || PRO == PRO_NONE)) {
+    // few-row forward layers on the 64 x 64 tile kernel (mlp_fwd_tile_kernel); A/B switch DEMF_FWD_TILE
+    static const int tile_on = env_int("DEMF_FWD_TILE", 1);
+    // (measured, tools/fewrow_fwd_micro.py: 4 096 x 512 -> 256 26.3 -> 17.3 us, 8 192 x 512 -> 256 33.3 -> 23.7,
+    // 2 048 x 256 -> 128 14.3 -> 10.2; at 32 768 rows mlp_gemm_kernel's 128-row tiles are level again: 43.6 vs 45.6)
+    static const int tile_max_r = env_int("DEMF_FWD_TILE_MAX_R", 16384);
+    if (tile_on && a.R <= tile_max_r && a.K % 32 == 0 && a.K >= 64 && a.K <= 1024 && a.N % 64 == 0 && a.ldx % 4 == 0 &&
+        a.ldb == 0 && a.ldy % 1 == 0 && a.stats != nullptr && a.fin.ss != nullptr && a.fin.ticket != nullptr &&
+        ((uintptr_t)a.X % 16 == 0) && ((uintptr_t)a.Bt % 16 == 0) && (PRO == PRO_NONE || a.vec != nullptr)) {
+      constexpr int P = BF16 == 2 ? 3 : 1;
+      const int rc = launch_fwd_tile<P, PRO == PRO_BNRELU>(a, s);
+      if (rc != -1000) return rc;
+    }
   }
   const dim3 block(256);
   // Two 32-row tiles per wave (256-row block tiles) while the accumulators + the raw prefetch fit
@@ -2667,7 +2920,7 @@ __global__ __launch_bounds__(256) void mlp_first_stats_k(int R, int N0, const fl
   __syncthreads();
   if (threadIdx.x < 14)
     atomicAdd(mom + threadIdx.x, (s_m[0][threadIdx.x] + s_m[1][threadIdx.x]) + (s_m[2][threadIdx.x] + s_m[3][threadIdx.x]));
-  __syncthreads();
+  sync_drained();
   if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
   __syncthreads();
   if (!s_last) return;

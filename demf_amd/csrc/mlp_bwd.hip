@@ -553,7 +553,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   if constexpr (EPI == 0) {
     if (p.vfin.ticket != nullptr) {        // layer l-1's backward vectors by the last workgroup (csrc/bn_fin.h)
       __shared__ int s_last;
-      __syncthreads();
+      sync_drained();
       if (tid == 0) s_last = last_workgroup(p.vfin.ticket, (int)gridDim.x, (int)blockIdx.x);
       __syncthreads();
       if (s_last) bn_vec_finalize(p.vfin, p.fld, p.fc0, K, p.g12, tid, NT);
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
   }
   if (p.vfin.ticket != nullptr) {          // layer L-1's backward vectors by the last workgroup (csrc/bn_fin.h)
     __shared__ int s_last;
-    __syncthreads();
+    sync_drained();
     if (tid == 0) s_last = last_workgroup(p.vfin.ticket, (int)gridDim.x, (int)blockIdx.x);
     __syncthreads();
     if (s_last) bn_vec_finalize(p.vfin, K, 0, K, p.g12, tid, NT);
