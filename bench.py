@@ -607,10 +607,12 @@ def main():
                 # the library path at its best: MIOpen's search on (first call per shape: seconds)
                 from demf_amd.modules import image_stream as _ims
                 _ims.MIOPEN_SEARCH = True
+                prev_fb, ops.LIBRARY_FALLBACK = ops.LIBRARY_FALLBACK, True     # (the A/B reference: explicitly allowed)
                 try:
                     secondary["image_backbone_neck_library_ms"] = time_steps(lambda: ist._pyramid(img), 5)
                 finally:
                     _ims.MIOPEN_SEARCH = False
+                    ops.LIBRARY_FALLBACK = prev_fb
                 # ResNet-50 + ChannelMapper at 800 x 1120: 77.0 GMAC per image
                 secondary["image_backbone_neck_tflops"] = 2 * 77.0e9 * args.batch / secondary["image_backbone_neck_ms"] * 1e-9
             secondary["image_encoder_ms"] = time_steps(lambda: ist.img_encoder.forward_tokens(pyr, batch["img_metas"]), 5)
@@ -660,6 +662,34 @@ def main():
             secondary["sa_path_b%d_fwd_ms" % B1] = f
             secondary["sa_path_b%d_fwdbwd_ms" % B1] = fb
             secondary["sa_path_b%d_prepass_ms" % B1] = g
+        # (e) the multi-rank path in software: no 8-GPU node has run this code (SCALE_r0x: skipped), so at least the
+        # launcher, the rank bookkeeping and the collective's call path are exercised by every bench run - two ranks
+        # sharing THIS GPU through gloo (DEMF_SHARE_DEVICE; RCCL refuses two ranks on one device), four scenes each.
+        # Its allreduce_us is gloo through host memory: a software-path number, not an xGMI figure.
+        if not os.environ.get("DEMF_BENCH_SKIP_WORLD2") and not os.environ.get("DEMF_SHARE_DEVICE"):
+            import socket
+            import subprocess
+            try:
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    port = str(sk.getsockname()[1])
+                env2 = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+                env2.update(DEMF_SHARE_DEVICE="1", DEMF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                            MASTER_PORT=port, OMP_NUM_THREADS="4")
+                r2 = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "2", "--steps", "5", "--warmup",
+                                     "2", "--batch", "4", "--dtype", args.dtype], env=env2, capture_output=True,
+                                    text=True, timeout=300)
+                line = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+                if r2.returncode == 0 and line:
+                    o2 = json.loads(line[-1])
+                    secondary["world2_shared_gpu"] = {
+                        "backend": "gloo, two ranks on one GPU (software path only)", "scenes_per_rank": 4,
+                        "ms_per_step": o2["ms_per_step"], "value": o2["value"], "allreduce_us": o2.get("allreduce_us"),
+                        "allreduce": o2.get("allreduce")}
+                else:
+                    secondary["world2_shared_gpu"] = {"error": (r2.stderr or r2.stdout)[-300:]}
+            except Exception as exc:      # (a secondary figure must not take the headline line down with it)
+                secondary["world2_shared_gpu"] = {"error": repr(exc)[:200]}
     rank_info = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -680,7 +710,9 @@ def main():
         else:
             launch = ("hipGraphs(fwd+loss | bwd), pre-pass of the next batch launched in between" if two_graphs
                       else "one hipGraph(fwd+loss+bwd), pre-pass of the next batch launched in front of it") + \
-                " on a side stream; eager allreduce / clip / AdamW"
+                " on a side stream; " + ("norm + clip + AdamW inside the graph"
+                                         if getattr(replay, "update_in_graph", False)
+                                         else "eager allreduce / clip / AdamW behind it")
         out = {
             "metric": "DeMF fusion fwd+bwd scenes/sec at 20k pts + 530x730 RGB",
             "value": scenes / elapsed, "unit": "scenes/s", "n_gpus": world,

@@ -113,6 +113,9 @@ class MultiheadAttention(nn.Module):
         q = q.reshape(L, B * H, Dh).transpose(0, 1)
         k = k.reshape(S, B * H, Dh).transpose(0, 1)
         v = v.reshape(S, B * H, Dh).transpose(0, 1)
+        if q.is_cuda:
+            # (the device path of the head runs the layer as one fused node - demf_amd/fused.py - and never gets here)
+            ops.library_fallback("MultiheadAttention module path (torch.bmm for QK^T and PV)")
         scores = torch.bmm(q * (1.0 / math.sqrt(Dh)), k.transpose(1, 2))        # (B*H, L, S)
         if attn_mask is not None:
             scores = scores.masked_fill(attn_mask, float("-inf")) if attn_mask.dtype == torch.bool \

@@ -26,6 +26,20 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Library (rocBLAS / MIOpen) fall-backs of the MODULE paths - torch.bmm in the seq-first MultiheadAttention module,
+# F.conv2d for image-stream widths the kernels of csrc/conv.hip do not take - are off the captured hot path (the
+# profile shows no library kernel) and must not be taken silently: they raise unless this is set
+# (DEMF_ALLOW_LIBRARY_FALLBACK=1, or ops.LIBRARY_FALLBACK = True in a test).
+LIBRARY_FALLBACK = bool(int(os.environ.get("DEMF_ALLOW_LIBRARY_FALLBACK", "0") or 0))
+
+
+def library_fallback(what):
+    """Call where a GPU module path is about to use a library GEMM / convolution instead of this package's kernels."""
+    if not LIBRARY_FALLBACK:
+        raise RuntimeError(what + ": this path would run a library (rocBLAS / MIOpen) kernel instead of the kernels of "
+                           "libdemf_hip.so; set DEMF_ALLOW_LIBRARY_FALLBACK=1 to allow it")
+
+
 class _DeferredDW:
     """Weight-gradient products of the few-row stacks, queued and issued together.  Nothing in a backward depends
     on a layer's dW (only the optimizer does), but one at a time each is a node of the step's dependency chain:

@@ -41,6 +41,22 @@ def test_ffi_table_matches_header():
     assert bound == set(decls)
 
 
+PUBLIC = {"demf_version", "demf_last_error", "demf_fps_f32", "demf_ball_query_f32", "demf_group_points_fwd",
+          "demf_group_points_bwd", "demf_gather_points_fwd", "demf_gather_points_bwd", "demf_three_nn_f32",
+          "demf_three_interpolate_fwd", "demf_three_interpolate_bwd", "demf_msda_fwd_f32", "demf_msda_bwd_f32"}
+
+
+def test_header_marks_everything_but_the_upstream_shaped_operators_internal():
+    """include/demf_hip.h: the entry points with an upstream counterpart (mmdet3d.ops / mmcv.ops) are the public ABI;
+    every other declaration carries DEMF_INTERNAL."""
+    text = open(os.path.join(ROOT, "include", "demf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    marked = set(re.findall(r"DEMF_INTERNAL[ \t]+int[ \t]+(demf_\w+)\s*\(", text))
+    every = set(_header_decls())
+    assert PUBLIC <= every
+    assert marked == every - PUBLIC, sorted((every - PUBLIC) ^ marked)
+
+
 def test_bad_arguments_are_reported_not_launched():
     # argument validation happens before any device work, so this runs without a GPU
     with pytest.raises(RuntimeError, match="bad sizes"):

@@ -27,6 +27,8 @@ t0 = time.perf_counter()
 tok = stream.tokens(img, metas); torch.cuda.synchronize()
 print(f"first image-stream call (MIOpen find etc.): {time.perf_counter() - t0:.1f} s; tokens {tuple(tok['tokens'].shape)}")
 for _ in range(2): stream.tokens(img, metas)
+from demf_amd import ops as _ops
+_ops.LIBRARY_FALLBACK = True       # the library convolutions are this line's A/B reference
 print(f"backbone+neck      : {sync_time(lambda: stream.pyramid(img), 5):7.2f} ms  (library convolutions: {sync_time(lambda: stream._pyramid(img), 5):7.2f} ms)")
 pyr = stream.pyramid(img)
 print(f"encoder (6 layers) : {sync_time(lambda: stream.img_encoder.forward_tokens(pyr, metas), 5):7.2f} ms")
