@@ -2417,6 +2417,214 @@ static int launch_fwd_tile(const MlpArgs& a, hipStream_t s) {
   return check_launch("mlp_fwd_tile");
 }
 
+
+// ---- few-row INPUT-GRADIENT launches on the same tile form -------------------------------------------------------
+// dX (R x Kout) = dY (R x N) . W (N x Kout) with dY = gi*dZ + a*y + b built in the staging of the A operand (dZ: the
+// dense upstream gradient G, or the pooled gradient dP routed by the arg-max slot; masked by the ReLU of THIS layer),
+// W read as it is: a lane takes ONE output column and 8 consecutive reduction rows of a step - 8 coalesced dword
+// loads - so its split values are exactly one 16-byte chunk of the [column][reduction] planes.  RED: the output tile
+// is also layer l-1's activation gradient - its BN-backward sums are taken on the way out (Y_{l-1} read per
+// element), the vectors by the last workgroup (csrc/bn_fin.h).  Reduction length p.K = this layer's channels N,
+// output columns p.N; p.ldb = row stride of W.
+template <int P, bool SPARSE, bool RED>
+__global__ __launch_bounds__(256, 2) void mlp_dx_tile_kernel(MlpArgs p) {
+  constexpr int PLANE = 64 * 64;
+  constexpr int BUF = 2 * P * PLANE;
+  extern __shared__ __attribute__((aligned(16))) char ft_smem[];
+  char* s_buf = ft_smem;                            // [2][BUF]
+  float* s_vec = reinterpret_cast<float*>(ft_smem + 2 * BUF);   // scale | shift | gi | a | b of THIS layer (5 x p.K)
+  float* s_red = s_vec + 5 * p.K;                   // [2 waves][2 sums][64 columns]
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm = wave & 1, wn = wave >> 1;
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if ((gy & 7) == 0) {
+      const int L = bx + gx * by;
+      by = (L & 7) + 8 * (L / (8 * gx));
+      bx = (L >> 3) % gx;
+    }
+  }
+  const int m0 = by * 64, n0 = bx * 64;
+  for (int i = tid; i < 5 * p.K; i += 256) s_vec[i] = p.vec[i];
+  // A staging: row (tid >> 2) of the tile, 8 consecutive channels of the step
+  const int srow = tid >> 2, sch = tid & 3;
+  const int arow = min(m0 + srow, p.R - 1);
+  const bool arow_ok = m0 + srow < p.R;
+  const float* gy = p.X + (size_t)arow * p.ldx + 8 * sch;                     // Y_l
+  const float* gg = SPARSE ? nullptr : p.G + (size_t)arow * p.ldx + 8 * sch;   // dense upstream gradient
+  const int rp = SPARSE ? arow / p.ns : 0;
+  const int slot = SPARSE ? arow - rp * p.ns : 0;
+  const float* gdp = SPARSE ? p.dP + (size_t)rp * p.K + 8 * sch : nullptr;
+  const int* garg = SPARSE ? p.arg + (size_t)rp * p.K + 8 * sch : nullptr;
+  // B staging: output column (tid & 63), reduction rows 8 (tid >> 6) .. + 7 of the step
+  const int bcol = tid & 63, bq = tid >> 6;
+  const float* gw = p.Bt + (size_t)(8 * bq) * p.ldb + n0 + bcol;
+  const int nk = p.K / 32;
+  struct Stage { float4 y[2], g[2]; int4 a[2]; float w[8]; };
+  Stage st0, st1;
+  auto fetch = [&](Stage& st, int ks) {
+    st.y[0] = *reinterpret_cast<const float4*>(gy + 32 * ks);
+    st.y[1] = *reinterpret_cast<const float4*>(gy + 32 * ks + 4);
+    if constexpr (SPARSE) {
+      st.g[0] = *reinterpret_cast<const float4*>(gdp + 32 * ks);
+      st.g[1] = *reinterpret_cast<const float4*>(gdp + 32 * ks + 4);
+      st.a[0] = *reinterpret_cast<const int4*>(garg + 32 * ks);
+      st.a[1] = *reinterpret_cast<const int4*>(garg + 32 * ks + 4);
+    } else {
+      st.g[0] = *reinterpret_cast<const float4*>(gg + 32 * ks);
+      st.g[1] = *reinterpret_cast<const float4*>(gg + 32 * ks + 4);
+    }
+    const float* w = gw + (size_t)(32 * ks) * p.ldb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st.w[e] = w[(size_t)e * p.ldb];
+  };
+  auto commit = [&](const Stage& st, int ks, char* buf) {
+    const int c0 = 32 * ks + 8 * sch;
+    const float y[8] = {st.y[0].x, st.y[0].y, st.y[0].z, st.y[0].w, st.y[1].x, st.y[1].y, st.y[1].z, st.y[1].w};
+    const float g[8] = {st.g[0].x, st.g[0].y, st.g[0].z, st.g[0].w, st.g[1].x, st.g[1].y, st.g[1].z, st.g[1].w};
+    const int ar[8] = {st.a[0].x, st.a[0].y, st.a[0].z, st.a[0].w, st.a[1].x, st.a[1].y, st.a[1].z, st.a[1].w};
+    float dy[8];
+    float v5[5][8];                                   // scale, shift, gi, a, b of the thread's 8 channels: float4 reads
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const float4 lo = *reinterpret_cast<const float4*>(s_vec + q * p.K + c0);
+      const float4 hi = *reinterpret_cast<const float4*>(s_vec + q * p.K + c0 + 4);
+      v5[q][0] = lo.x; v5[q][1] = lo.y; v5[q][2] = lo.z; v5[q][3] = lo.w;
+      v5[q][4] = hi.x; v5[q][5] = hi.y; v5[q][6] = hi.z; v5[q][7] = hi.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool on = __builtin_fmaf(y[e], v5[0][e], v5[1][e]) > 0.f;
+      float dz;
+      if constexpr (SPARSE) dz = (on && ar[e] == slot) ? g[e] : 0.f;
+      else dz = on ? g[e] : 0.f;
+      dy[e] = arow_ok ? __builtin_fmaf(v5[2][e], dz, __builtin_fmaf(v5[3][e], y[e], v5[4][e])) : 0.f;
+    }
+    uint4 pa[P], pw[P];
+    ft_split8<P>(make_float4(dy[0], dy[1], dy[2], dy[3]), make_float4(dy[4], dy[5], dy[6], dy[7]), pa);
+    ft_split8<P>(make_float4(st.w[0], st.w[1], st.w[2], st.w[3]), make_float4(st.w[4], st.w[5], st.w[6], st.w[7]), pw);
+    const int offa = ft_swz(srow, sch), offb = ft_swz(bcol, bq);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      *reinterpret_cast<uint4*>(buf + q * PLANE + offa) = pa[q];
+      *reinterpret_cast<uint4*>(buf + (P + q) * PLANE + offb) = pw[q];
+    }
+  };
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  fetch(st0, 0);
+  if (nk > 1) fetch(st1, 1);
+  __syncthreads();                                  // the layer's vectors
+  commit(st0, 0, s_buf);
+  if (nk > 2) fetch(st0, 2);
+  __syncthreads();
+  auto step = [&](int ks, const char* cur, char* nxt, Stage& sn) {
+    bf16x8 fa[2][P], fb[2][P];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        fa[s2][q] = *reinterpret_cast<const bf16x8*>(cur + q * PLANE + ft_swz(wm * 32 + lr, 2 * s2 + lh));
+        fb[s2][q] = *reinterpret_cast<const bf16x8*>(cur + (P + q) * PLANE + ft_swz(wn * 32 + lr, 2 * s2 + lh));
+      }
+    if constexpr (P == 3) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][2], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][2], fb[1][0], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][2], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][2], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][1], fb[0][1], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][1], fb[1][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][1], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][1], fb[1][0], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][1], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][1], acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][0], acc2, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][0], fb[0][0], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][0], fb[1][0], acc2, 0, 0, 0);
+    }
+    if (ks + 1 < nk) {
+      commit(sn, ks + 1, nxt);
+      if (ks + 3 < nk) fetch(sn, ks + 3);
+    }
+    lds_barrier();
+  };
+  // RED: this lane's 16 values of Y_{l-1} (the rows / column of its accumulator registers) are requested now and
+  // arrive underneath the K loop instead of as 16 exposed loads behind it
+  const int n = n0 + wn * 32 + lr;                  // output column of this launch
+  float yprev[16];
+  if constexpr (RED) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.R - 1);
+      yprev[r] = p.fY[(size_t)m * p.fld + p.fc0 + n];
+    }
+  }
+  for (int ks = 0; ks < nk; ks += 2) {
+    step(ks, s_buf, s_buf + BUF, st1);
+    if (ks + 1 < nk) step(ks + 1, s_buf + BUF, s_buf, st0);
+  }
+  // ---- epilogue
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  float sc0 = 0.f, sh0 = 0.f, mu0 = 0.f, is0 = 0.f;
+  if constexpr (RED) {
+    sc0 = p.fss[p.fc0 + n]; sh0 = p.fss[p.fld + p.fc0 + n];
+    mu0 = p.fmi[p.fc0 + n]; is0 = p.fmi[p.fld + p.fc0 + n];
+  }
+  float es1 = 0.f, es2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m < p.R) {
+      p.Y[(size_t)m * p.ldy + n] = acc[r];
+      if constexpr (RED) {
+        const float y = yprev[r];
+        const float dz = __builtin_fmaf(y, sc0, sh0) > 0.f ? acc[r] : 0.f;
+        es1 += dz;
+        es2 = __builtin_fmaf(dz, (y - mu0) * is0, es2);
+      }
+    }
+  }
+  if constexpr (RED) {
+    es1 += __shfl_xor(es1, 32);
+    es2 += __shfl_xor(es2, 32);
+    if (lh == 0) {
+      s_red[(wm * 2 + 0) * 64 + wn * 32 + lr] = es1;
+      s_red[(wm * 2 + 1) * 64 + wn * 32 + lr] = es2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float v = s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c];
+      atomicAdd(p.stats + (size_t)which * p.fld + p.fc0 + n0 + c, (double)v);
+    }
+    if (p.vfin.ticket != nullptr) {
+      sync_drained();
+      if (tid == 0)
+        s_last = last_workgroup(p.vfin.ticket, (int)(gridDim.x * gridDim.y), (int)(blockIdx.y * gridDim.x + blockIdx.x));
+      __syncthreads();
+      if (s_last) bn_vec_finalize(p.vfin, p.fld, p.fc0, p.N, p.stats, tid, 256);
+    }
+  }
+}
+
+template <int P, bool SPARSE, bool RED>
+static int launch_dx_tile(const MlpArgs& a, hipStream_t s) {
+  const int lds = 2 * 2 * P * 64 * 64 + 5 * a.K * 4 + 2 * 2 * 64 * 4;
+  static unsigned long long reserved = 0;
+  if (lds > 64 * 1024 && !reserve_lds(reinterpret_cast<const void*>(&mlp_dx_tile_kernel<P, SPARSE, RED>), lds, &reserved))
+    return -1000;
+  const dim3 grid(a.N / 64, (a.R + 63) / 64);
+  hipLaunchKernelGGL((mlp_dx_tile_kernel<P, SPARSE, RED>), grid, dim3(256), lds, s, a);
+  return check_launch("mlp_dx_tile");
+}
+
 template <int PRO, bool STATS, bool POOL = false, bool RED = false>
 static int launch_gemm(const MlpArgs& a, hipStream_t s) {
   switch (compute_mode()) {
@@ -2521,6 +2729,20 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     set_error("mlp_gemm: bf16 row storage (st=%d) is only built into the weight-resident forward (K = 64, "
               "N = 64 / 128, R >= 16384, bf16 compute mode)", a.st);
     return DEMF_EUNSUPPORTED;
+  }
+  if constexpr ((BF16 == 1 || BF16 == 2) && !POOL && !STATS && (PRO == PRO_DY_DENSE || PRO == PRO_DY_SPARSE)) {
+    // few-row input-gradient launches on the tile kernel (mlp_dx_tile_kernel); A/B switch DEMF_DX_TILE
+    static const int dxt_on = env_int("DEMF_DX_TILE", 1);
+    static const int dxt_max_r = env_int("DEMF_DX_TILE_MAX_R", 16384);
+    constexpr bool SP = PRO == PRO_DY_SPARSE;
+    if (dxt_on && a.R <= dxt_max_r && a.K % 32 == 0 && a.K >= 64 && a.K <= 1024 && a.N % 64 == 0 && a.ldx % 4 == 0 &&
+        a.ldb > 0 && a.vec != nullptr && ((uintptr_t)a.X % 16 == 0) && (SP ? (a.dP && a.arg && a.ns >= 1) : (a.G != nullptr)) &&
+        (SP ? ((uintptr_t)a.dP % 16 == 0 && (uintptr_t)a.arg % 16 == 0) : ((uintptr_t)a.G % 16 == 0)) &&
+        (!RED || (a.fY && a.fss && a.fmi && a.stats))) {
+      constexpr int P = BF16 == 2 ? 3 : 1;
+      const int rc = launch_dx_tile<P, SP, RED>(a, s);
+      if (rc != -1000) return rc;
+    }
   }
   if constexpr ((BF16 == 1 || BF16 == 2) && !RED && !POOL && STATS && (PRO == PRO_BNRELU || PRO == PRO_NONE)) {
     // few-row forward layers on the 64 x 64 tile kernel (mlp_fwd_tile_kernel); A/B switch DEMF_FWD_TILE
@@ -3185,6 +3407,10 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
     }
     if (e) return e;
   }
+  if (red && red->gamma != nullptr && env_int("DEMF_STATIC_TILES", 0))
+    // no counter ring, no last-workgroup ticket: the vectors of layer l-1 as a launch of their own (all K channels)
+    return demf_bn_bwd_vectors(K, (long long)R, red->g12, red->gamma, red->ss, red->mi, red->vec6, red->dgamma,
+                               red->dbeta, stream);
   return DEMF_OK;
 }
 

@@ -975,6 +975,15 @@ __global__ __launch_bounds__(256) void pool_bwd_finish_k(int nslots, const float
     dW[e] = ((s_f[0][el] + s_f[1][el]) + (s_f[2][el] + s_f[3][el])) + ((s_f[4][el] + s_f[5][el]) + (s_f[6][el] + s_f[7][el]));
 }
 
+// DEMF_STATIC_TILES=1 (no counter ring): there is no ticket for the last workgroup, so layer l-1's backward vectors
+// are formed by a launch of their own behind the pass that produced the sums - the documented contract of the
+// *_v entry points ("complete on return") holds either way.  (Found by tests/test_gpu_switches.py: the vectors were
+// simply never written in that mode.)
+static int vectors_without_ticket(const BnVecFin& vf, int K, double* g12, demf_stream_t stream) {
+  if (vf.gamma == nullptr || vf.ticket != nullptr) return DEMF_OK;
+  return demf_bn_bwd_vectors(K, (long long)vf.count, g12, vf.gamma, vf.ss, vf.mi, vf.vec, vf.dgamma, vf.dbeta, stream);
+}
+
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
 static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
   constexpr int P = CM == 2 ? 3 : 1;
@@ -1053,8 +1062,11 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
               store_flags, N, K, (int)sparse, (int)first);
     return DEMF_EUNSUPPORTED;
   }
-#define FGO(NTNv, KTv, KGv, SPv, EPv) \
-  return cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s)
+#define FGO(NTNv, KTv, KGv, SPv, EPv)                                                                                     \
+  do {                                                                                                                   \
+    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s); \
+    return rc_ ? rc_ : vectors_without_ticket(a.vfin, K, g12_prev, stream);                                              \
+  } while (0)
   if (first) { FGO(2, 2, 2, false, 1); }
   if (N == 128 && K == 64) { if (sparse) { FGO(4, 2, 1, true, 0); } else { FGO(4, 2, 1, false, 0); } }
   if (N == 128 && K == 128) { if (sparse) { FGO(4, 4, 2, true, 0); } else { FGO(4, 4, 2, false, 0); } }
@@ -1091,8 +1103,12 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
-#define FGO(NTNv, KTv, KGv, SPv) \
-  return cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, 0>(a, s)
+#define FGO(NTNv, KTv, KGv, SPv)                                                                                          \
+  do {                                                                                                                   \
+    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, 0>(a, s); \
+    if (rc_ || c0 + Kc < Ktot) return rc_;       /* (no ticket: the vectors of ALL channels behind the last chunk) */    \
+    return vectors_without_ticket(a.vfin, Ktot, g12_prev, stream);                                                       \
+  } while (0)
   if (N == 128 && Kc == 64) { if (sparse) { FGO(4, 2, 1, true); } else { FGO(4, 2, 1, false); } }
   if (N == 128 && Kc == 128) { if (sparse) { FGO(4, 4, 2, true); } else { FGO(4, 4, 2, false); } }
   if (N == 256 && Kc == 128) { if (sparse) { FGO(8, 4, 1, true); } else { FGO(8, 4, 1, false); } }
@@ -1168,7 +1184,8 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   else hipLaunchKernelGGL(mlp_bwd_pool_kernel<2>, dim3(gx), dim3(512), bytes, s, a);
   if (int e = check_launch("mlp_bwd_pool")) return e;
   hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, dW);
-  return check_launch("pool_bwd_finish");
+  if (int e = check_launch("pool_bwd_finish")) return e;
+  return vectors_without_ticket(a.vfin, K, g12_prev, stream);
 }
 
 // SA1's second layer (64 -> 64, dense upstream gradient G) with the FIRST epilogue, layer 0's raw output NOT

@@ -272,6 +272,7 @@ def _parity(cfg, B, N, pyramid, in_shape, img_shape, seeds, cap=None, risk_max=P
 MID = ((50, 70), (25, 35), (13, 18), (7, 9)), (400, 560), (400, 551)
 
 
+@pytest.mark.no_library_fallback
 def test_hot_path_vs_oracle_mid_size():
     from demf_amd.config import BackboneCfg, DeMFCfg, HeadCfg
     cfg = DeMFCfg(backbone=BackboneCfg(num_points=(1024, 512, 256, 128)),
@@ -279,6 +280,7 @@ def test_hot_path_vs_oracle_mid_size():
     _parity(cfg, 2, 6000, *MID, seeds=SEEDS["mid"], cap=GRAD_CAP["mid"])
 
 
+@pytest.mark.no_library_fallback
 def test_hot_path_vs_oracle_full_config():
     """configs/demf/demf_votenet.py sizes: 20 000 points, 800x1120 pyramid, 256 queries."""
     from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg
@@ -289,6 +291,7 @@ def test_hot_path_vs_oracle_full_config():
             cap=GRAD_CAP["full2"], risk_max=5e-2)
 
 
+@pytest.mark.no_library_fallback
 def test_hot_path_vs_oracle_full_config_four_sampling_points():
     """The whole path with P=4 sampling points per level (BASELINE.json's wording of configs[2];
     the reference config has P=2) - bench.py --msda-points 4."""
@@ -298,6 +301,7 @@ def test_hot_path_vs_oracle_full_config_four_sampling_points():
             cap=GRAD_CAP["full2p4"])
 
 
+@pytest.mark.no_library_fallback
 def test_hot_path_vs_oracle_full_config_batch_8():
     """BASELINE configs[2] as benchmarked: 8 scenes x 20 000 points x 18 609 image tokens."""
     from demf_amd.config import BATCH_INPUT_SHAPE, IMG_SHAPE, PYRAMID_SHAPES, DeMFCfg, HeadCfg

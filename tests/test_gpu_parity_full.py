@@ -27,7 +27,7 @@ import torch
 import parity_tools as P
 from oracle import fixtures
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.no_library_fallback]
 
 TARGET_NAMES = ("vote_targets", "vote_target_masks", "dir_class_targets", "dir_res_targets",
                 "mask_targets", "objectness_targets", "objectness_weights", "box_loss_weights",

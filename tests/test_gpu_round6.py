@@ -183,3 +183,21 @@ def test_double_buffered_load_waits_for_the_producer_stream():
     step.load(late)
     torch.cuda.synchronize()
     assert torch.equal(step.static["points"], want)
+
+
+def test_library_fallbacks_raise_unless_allowed():
+    """The module-path MultiheadAttention (torch.bmm) and the library convolutions of the image stream refuse to run on
+    the GPU unless DEMF_ALLOW_LIBRARY_FALLBACK=1 / ops.LIBRARY_FALLBACK is set."""
+    from demf_amd import ops
+    from demf_amd.modules.transformer import MultiheadAttention
+    mha = MultiheadAttention(64, 4).cuda()
+    q = torch.randn(5, 2, 64, device="cuda")
+    prev = ops.LIBRARY_FALLBACK
+    try:
+        ops.LIBRARY_FALLBACK = False
+        with pytest.raises(RuntimeError, match="library"):
+            mha(q)
+        ops.LIBRARY_FALLBACK = True
+        assert mha(q).shape == q.shape
+    finally:
+        ops.LIBRARY_FALLBACK = prev
