@@ -10,7 +10,7 @@ for r in csv.DictReader(open(path)):
 print("kernel,calls,mean_%s_KiB,max_%s_KiB" % (counter, counter))
 # whole-step total (every kernel, library launches included): steps = launches of the once-per-step
 # 20000 -> 2048 FPS chain (warm-up, timed, repeat and eager-timing steps of bench.py alike)
-steps = max([len(v) for k, v in agg.items() if "fps_reg_kernel<1024, 20>" in k or "fps_prune_kernel<20" in k] or [0])
+steps = max([len(v) for k, v in agg.items() if "fps_reg_kernel<1024, 20>" in k or "fps_prune_kernel<20" in k or "fps_pair_kernel<20" in k] or [0])
 if steps:
     tot = sum(sum(v) for v in agg.values())
     print('"__TOTAL_PER_STEP__",%d,%.1f,%.1f' % (steps, tot / steps, tot / steps))

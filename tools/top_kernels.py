@@ -33,7 +33,7 @@ def main():
     SKIP = nums[1] if len(nums) > 1 else 7
     rows = list(csv.DictReader(open(trace)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"] or "fps_prune_kernel<20" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"] or "fps_prune_kernel<20" in r["Kernel_Name"] or "fps_pair_kernel<20" in r["Kernel_Name"]]
     if len(marks) < K + 1 + SKIP:
         SKIP = max(0, len(marks) - K - 1)
     sel = rows[marks[-K - 1 - SKIP]:marks[-1 - SKIP]]

@@ -5,7 +5,7 @@ path, K = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 5
 SKIP = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # steps to drop at the end (eager post-pass)
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"] or "fps_prune_kernel<20" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "fps_reg_kernel<1024, 20>" in r["Kernel_Name"] or "fps_prune_kernel<20" in r["Kernel_Name"] or "fps_pair_kernel<20" in r["Kernel_Name"]]
 sel = rows[marks[-K - 1 - SKIP]:marks[-1 - SKIP]]
 span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
 busy, cur_end = 0, 0
