@@ -363,6 +363,11 @@ class Trainer:
         try:
             total = self._fwd(batch, geometry)
             self.flat.backward_into(total)
+        except BaseException:
+            if self.fused and not torch.cuda.is_current_stream_capturing():
+                from . import ops
+                ops.reset_accumulators()          # (a step that raised half-way leaves BatchNorm sums behind)
+            raise
         finally:
             self._arena(False)
         return total.detach()

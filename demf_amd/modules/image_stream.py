@@ -396,6 +396,7 @@ class ImageStream(nn.Module):
         NHWC kernels are faster here (8 x 3 x 800 x 1120 fp32: 18.8 -> 16.5 ms) and the neck's (B,256,h,w) outputs
         then ARE (B,h,w,256) in memory, so the encoder's token concat reads contiguous rows."""
         if img.is_cuda:
+            from .. import ops
             ops.library_fallback("image backbone / neck at widths csrc/conv.hip does not take (F.conv2d -> MIOpen)")
         if CHANNELS_LAST and img.is_cuda:
             if self.__dict__.get("_nhwc_for") != img.device:

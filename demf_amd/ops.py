@@ -1110,6 +1110,15 @@ def _accum64(n, device):
     return buf
 
 
+def reset_accumulators():
+    """Zero the persistent fp64 accumulators.  The kernels that consume them leave them zeroed ("self-cleaning"), which
+    holds only if every launch sequence runs to its end: an exception between a layer's statistics launch and the
+    launch that consumes them (a bad argument further down the forward, a refused fall-back) leaves sums behind that
+    the NEXT step would add to.  engine.Trainer calls this when a step raises; tests call it between cases."""
+    for buf in _ACCUM64.values():
+        buf.zero_()
+
+
 class _SharedMLPPool(Function):
     """x (R, ld) rows -> pooled (R/ns, C_L).  Per layer l the tensors are
     (W_l (N_l, K_l), gamma_l, beta_l, running_mean_l, running_var_l, conv_bias_l|None);

@@ -30,9 +30,18 @@ def _library_fallback_policy(request):
     except Exception:      # noqa: BLE001 - the library may not be built in a docs-only checkout
         yield
         return
-    prev = ops.LIBRARY_FALLBACK
+    prev, prev_env = ops.LIBRARY_FALLBACK, os.environ.get("DEMF_ALLOW_LIBRARY_FALLBACK")
     ops.LIBRARY_FALLBACK = request.node.get_closest_marker("no_library_fallback") is None
+    os.environ["DEMF_ALLOW_LIBRARY_FALLBACK"] = "1" if ops.LIBRARY_FALLBACK else "0"     # (spawned ranks / subprocesses)
     try:
         yield
     finally:
         ops.LIBRARY_FALLBACK = prev
+        try:
+            ops.reset_accumulators()     # a test that raised mid-forward must not hand BatchNorm sums to the next one
+        except Exception:                # noqa: BLE001
+            pass
+        if prev_env is None:
+            os.environ.pop("DEMF_ALLOW_LIBRARY_FALLBACK", None)
+        else:
+            os.environ["DEMF_ALLOW_LIBRARY_FALLBACK"] = prev_env
