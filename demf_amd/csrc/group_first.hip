@@ -125,16 +125,19 @@ __device__ __forceinline__ float grp_sum(float v) {
 // XG: the coordinates carry a gradient too (the vote aggregation: vote points are predicted):
 // d rel = dY . Wx^T per row -> + to the source point (summed here, written once), - to the centre
 // (3 atomics per row).
-template <int LPR, bool XG>
+// RC: y is not read back but formed again from the point's row of U and the relative coordinates, with the forward
+// kernel's own expression (same division, same fma chain: bit-identical), which halves the bytes of the launch.
+template <int LPR, bool XG, bool RC>
 __global__ __launch_bounds__(256) void group_first_bwd_k(
-    int N, int M, int ns, int ns_shift, float inv_div, const float* __restrict__ xyz,
+    int N, int M, int ns, int ns_shift, float inv_div, float div, const float* __restrict__ xyz,
     const float* __restrict__ center, const float* __restrict__ G, const float* __restrict__ Yl,
+    const float* __restrict__ U,
     const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
     float* __restrict__ dU, float* __restrict__ dWx, int dwld, long long points,
     const float* __restrict__ Wx, int wld, float* __restrict__ dxyz, float* __restrict__ dcenter) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 256 / LPR;
-  constexpr int UNR = 8;
+  constexpr int UNR = RC ? 16 : 8;
   const int sub = threadIdx.x % LPR, grp = threadIdx.x / LPR;
   const int c = sub * 4;
   const int E = M * ns;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
   const float4 vb = *reinterpret_cast<const float4*>(vec + 4 * C1 + c);
   float4 wa0 = f4_zero(), wa1 = f4_zero(), wa2 = f4_zero();  // sum (p - q)_k * dY, scaled at the end
   float4 wx0 = f4_zero(), wx1 = f4_zero(), wx2 = f4_zero();
-  if constexpr (XG) {
+  if constexpr (XG || RC) {
     wx0 = load_wx(Wx, wld, C1, c, 0);
     wx1 = load_wx(Wx, wld, C1, c, 1);
     wx2 = load_wx(Wx, wld, C1, c, 2);
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     const float px = xyz[pt * 3], py = xyz[pt * 3 + 1], pz = xyz[pt * 3 + 2];
     float4 acc = f4_zero();
     float gx = 0.f, gy = 0.f, gz = 0.f;
+    float4 u = f4_zero();
+    if constexpr (RC) {
+      if (e1 > e0) u = *reinterpret_cast<const float4*>(U + pt * C1 + c);
+    }
     for (int eb = e0; eb < e1; eb += LPR) {
       const int n = e1 - eb < LPR ? e1 - eb : LPR;
       int my_row = 0, my_m = 0;
@@ -174,6 +181,11 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
         mx = px - q[0];
         my = py - q[1];
         mz = pz - q[2];
+        if constexpr (RC) {   // the forward's relative coordinates (grouped_xyz / max_radius); dWx takes them as they are
+          mx /= div;
+          my /= div;
+          mz /= div;
+        }
       }
       for (int k0 = 0; k0 < n; k0 += UNR) {
         float4 g[UNR], y[UNR];
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
           y[k] = f4_zero();
           if (k0 + k < n) {
             g[k] = *reinterpret_cast<const float4*>(G + (rbase + row) * C1 + c);
-            y[k] = *reinterpret_cast<const float4*>(Yl + (rbase + row) * C1 + c);
+            if constexpr (!RC) y[k] = *reinterpret_cast<const float4*>(Yl + (rbase + row) * C1 + c);
           }
         }
 #pragma unroll
@@ -194,6 +206,11 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
           const int mrow = XG ? grp_bcast<LPR>(my_m, k0 + k) : 0;
           if (k0 + k < n) {
             float4 d;
+            if constexpr (RC) {
+#define GF_Y(m) y[k].m = __builtin_fmaf(rz, wx2.m, __builtin_fmaf(ry, wx1.m, __builtin_fmaf(rx, wx0.m, u.m)));
+              GF_Y(x) GF_Y(y) GF_Y(z) GF_Y(w)
+#undef GF_Y
+            }
 #define GF_DY(m)                                                                       \
             {                                                                          \
               const float dz = __builtin_fmaf(y[k].m, sc.m, sh.m) > 0.f ? g[k].m : 0.f; \
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     float tot = 0.f;
 #pragma unroll
     for (int g = 0; g < GPB; ++g) tot += base[g * C1];
-    atomicAdd(dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which, tot * inv_div);
+    atomicAdd(dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which, RC ? tot : tot * inv_div);
   }
 }
 
@@ -277,15 +294,19 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
 
 extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius,
                                     int normalize_xyz, const float* xyz, const float* center,
-                                    const float* G, const float* Y, const float* vec6,
+                                    const float* G, const float* Y, const float* U, const float* vec6,
                                     const int* inv_off, const int* inv_rows, float* dU,
                                     float* dWx, int dw_ld, const float* Wx, int w_ld, float* dxyz,
                                     float* dcenter, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_bwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0) return DEMF_OK;
-  DEMF_REQUIRE(xyz && center && G && Y && vec6 && inv_off && inv_rows && dU && dWx,
+  DEMF_REQUIRE(xyz && center && G && (Y || U) && vec6 && inv_off && inv_rows && dU && dWx,
                "group_first_bwd: null pointer");
+  DEMF_REQUIRE(U == nullptr || Wx != nullptr, "group_first_bwd: forming y again from U needs the layer's weight");
+  static const bool rc_off = getenv("DEMF_GF_RECOMPUTE") && atoi(getenv("DEMF_GF_RECOMPUTE")) == 0;   // A/B switch
+  const bool rc = U != nullptr && !(rc_off && Y != nullptr);
+  const float div = normalize_xyz ? radius : 1.0f;
   const long long points = (long long)B * N;
   const float inv_div = normalize_xyz ? 1.0f / radius : 1.0f;
   int ns_shift = -1;
@@ -298,20 +319,18 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   const dim3 grid((unsigned)blocks);
   DEMF_REQUIRE((dxyz == nullptr) == (dcenter == nullptr) && (dxyz == nullptr || Wx != nullptr),
                "group_first_bwd: dxyz, dcenter (and Wx) must be given together");
+#define GF_BWD_(L, XG_, RC_)                                                                \
+  hipLaunchKernelGGL((group_first_bwd_k<L, XG_, RC_>), grid, dim3(256), 0, s, N, M, ns, ns_shift, inv_div, div, xyz,   \
+                     center, G, Y, U, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, dxyz, dcenter)
 #define GF_BWD(L)                                                                          \
   do {                                                                                     \
-  if (dxyz)                                                                                \
-    hipLaunchKernelGGL((group_first_bwd_k<L, true>), grid, dim3(256), 0, s, N, M, ns, ns_shift,    \
-                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, \
-                       dxyz, dcenter);                                                     \
-  else                                                                                     \
-    hipLaunchKernelGGL((group_first_bwd_k<L, false>), grid, dim3(256), 0, s, N, M, ns, ns_shift,   \
-                       inv_div, xyz, center, G, Y, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, \
-                       dxyz, dcenter);                                                     \
+    if (dxyz) { if (rc) GF_BWD_(L, true, true); else GF_BWD_(L, true, false); }            \
+    else      { if (rc) GF_BWD_(L, false, true); else GF_BWD_(L, false, false); }          \
   } while (0)
   if (lpr == 64) GF_BWD(64);
   else if (lpr == 32) GF_BWD(32);
   else GF_BWD(16);
+#undef GF_BWD_
 #undef GF_BWD
   return check_launch("group_first_bwd");
 }

@@ -1186,6 +1186,7 @@ class _SharedMLPPool(Function):
                 U = torch.empty((x.shape[0], N), dtype=torch.float32, device=dev)
                 from . import fused
                 fused.gemm(x.shape[0], N, ld, _p(x), (ld, 1), W.data_ptr() + 12, (K, 1), _p(U), N)
+                ctx.geo_U = U if training else None     # the backward forms y again from it instead of reading Y_0
                 stats = None
                 if training:
                     stats = ws[woff:woff + 2 * N]
@@ -1385,7 +1386,8 @@ class _SharedMLPPool(Function):
                     dxyz = torch.empty((gB, gN, 3), dtype=torch.float32, device=dev)
                     dcenter = zeros((gB, gM, 3), dev)
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
-                          _p(g_center), _p(G), _p(Ys[0]), _p(vec6), _p(g_off), _p(g_rows), _p(dU),
+                          _p(g_center), _p(G), _p(Ys[0]), _p(getattr(ctx, "geo_U", None)), _p(vec6), _p(g_off),
+                          _p(g_rows), _p(dU),
                           _p(dW0), K, _p(W), K, _p(dxyz), _p(dcenter), st)
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3

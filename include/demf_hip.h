@@ -248,10 +248,12 @@ DEMF_INTERNAL int demf_group_first_fwd(int B, int N, int M, int ns, int C1, floa
  *   dxyz[b,j,:] = + sum over the rows of point j / radius,  dcenter[b,m,:] -= sum over s / radius */
 DEMF_INTERNAL int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius, int normalize_xyz,
                          const float* xyz, const float* center, const float* G, const float* Y,
+                         const float* U /* the forward's U (B*N, C1): y is formed again from it instead of being read
+                         (half the bytes; needs Wx), or NULL: y read from Y */,
                          const float* vec6, const int* inv_off, const int* inv_rows, float* dU,
                          float* dWx, int dw_ld /* 0: (3, C1) layout; > 0: dWx[c*dw_ld + k], i.e. columns
                          0..2 of the (C1 x dw_ld) weight gradient */,
-                         const float* Wx /* needed with dxyz */, int w_ld /* as in the forward */,
+                         const float* Wx /* needed with dxyz or U */, int w_ld /* as in the forward */,
                          float* dxyz /* (B,N,3) fully written, or NULL */,
                          float* dcenter /* (B,M,3) accumulated: arrives zeroed, or NULL */,
                          demf_stream_t stream);

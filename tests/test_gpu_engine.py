@@ -311,9 +311,14 @@ def test_shape_bucketed_capture_matches_eager_steps(dropout):
     # (two runs of the SAME path differ through the order of their fp32 atomics, and on this untrained network
     # the difference grows with every update: 2e-3 holds for the first steps, by step 7-8 single runs reach 3.5e-3 -
     # a wrong sequence of updates, e.g. a warm-up pass that was not undone, shows at its first step and is far larger)
+    # From step 6 on a near-tie (max-pool / ReLU, see below) may resolve differently between the two engines and move
+    # the loss by up to ~0.7 %: the late steps carry a 1.5e-2 ceiling, the early ones the tight bound.
     for i, (x, y) in enumerate(zip(la, lb)):
-        assert abs(x - y) <= 2e-3 * (1 + i / 4) * abs(x), (i, x, y)
-    assert ((pa - pb).norm() / pa.norm()).item() < 2e-4
+        tol = 2e-3 * (1 + i / 4) if i < 6 else 1.5e-2
+        assert abs(x - y) <= tol * abs(x), (i, x, y)
+    # parameters: one missing / extra AdamW update at this learning rate is ~3e-3 of the norm; two correct runs end
+    # within 1e-4 of each other, or within ~2.7e-4 when the step-7 near-tie described below resolved differently
+    assert ((pa - pb).norm() / pa.norm()).item() < 6e-4
     # BatchNorm statistics: no extra warm-up passes (one leaked pass moves them by ~1e-1).  The run is bimodal: in
     # about one run of four a near-tie (max-pool / ReLU) resolves differently between the two engines at step 7
     # (loss 15.920 vs 15.863, the same two values every time, also at the round-4 commit) and the statistics then
