@@ -14,6 +14,7 @@
 // weight gradient on the way.  Both are HBM/L2 byte movers: y written once (fwd), dZ and y read
 // once (bwd); the (M*ns, 3+C) grouped rows and their gradient never exist.
 #include "common.h"
+#include "bn_fin.h"
 
 namespace demf {
 
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(512) void group_first_fwd_k(
 // One group of LPR lanes per source point: sums dY over the rows that gathered the point.  The
 // list entries (and the centre of each entry's row) are fetched LPR at a time, one per lane, and
 // broadcast inside the group.
+// An atomic add costs ~20 ns at its memory channel and the adds to one cache line queue up there: W workgroups adding
+// to the same few lines end W * 20 ns after the first (tools/ubench/atomic_flush.cpp: 1024 workgroups x 384 doubles =
+// 23 us, 256 = 7 us).  The partial sums of a launch therefore go to GF_REPL copies, workgroup w to copy w % GF_REPL.
+constexpr int GF_REPL = 8;
+
 template <int LPR>
 __device__ __forceinline__ float grp_sum(float v) {
 #pragma unroll
@@ -134,7 +140,8 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     const float* __restrict__ U,
     const float* __restrict__ vec, const int* __restrict__ off, const int* __restrict__ rows_,
     float* __restrict__ dU, float* __restrict__ dWx, int dwld, long long points,
-    const float* __restrict__ Wx, int wld, float* __restrict__ dxyz, float* __restrict__ dcenter) {
+    const float* __restrict__ Wx, int wld, float* __restrict__ dxyz, float* __restrict__ dcenter,
+    double* __restrict__ wacc, int* __restrict__ ticket) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 256 / LPR;
   constexpr int UNR = RC ? 16 : 8;
@@ -258,7 +265,27 @@ __global__ __launch_bounds__(256) void group_first_bwd_k(
     float tot = 0.f;
 #pragma unroll
     for (int g = 0; g < GPB; ++g) tot += base[g * C1];
-    atomicAdd(dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which, RC ? tot : tot * inv_div);
+    tot = RC ? tot : tot * inv_div;
+    // In place in the layer's weight gradient (dwld > 0) the 3 x C1 targets lie dwld floats apart: one memory-side
+    // atomic transaction per LANE and per workgroup, ~35 us of a launch that moves 16 MB.  With an accumulator the
+    // workgroups add into 3*C1 CONTIGUOUS doubles (a few cache lines per wave) and the last one moves the totals.
+    if (wacc != nullptr) atomicAdd(wacc + (blockIdx.x % GF_REPL) * 3 * C1 + t, (double)tot);
+    else atomicAdd(dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which, tot);
+  }
+  if (wacc == nullptr) return;
+  sync_drained();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = last_workgroup(ticket, (int)gridDim.x, (int)blockIdx.x);
+  __syncthreads();
+  if (!s_last) return;
+  for (int t = threadIdx.x; t < 3 * C1; t += 256) {
+    const int which = t / C1, col = t - which * C1;
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < GF_REPL; ++r)
+      v += __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(wacc + r * 3 * C1 + t), 0ull));
+    float* dst = dwld == 0 ? dWx + which * C1 + col : dWx + (size_t)col * dwld + which;
+    *dst += (float)v;       // (this launch is the only writer of the coordinate columns)
   }
 }
 
@@ -280,7 +307,8 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
   const int lpr = C1 / 4, gpb = 512 / lpr;
   const long long chunks = (rows + lpr - 1) / lpr;
   long long blocks = (chunks + gpb - 1) / gpb;
-  if (blocks > 512) blocks = 512;  // one fp64 atomic per column per block: keep the tail short
+  static const int fcap = getenv("DEMF_GF_FWD_BLOCKS") ? atoi(getenv("DEMF_GF_FWD_BLOCKS")) : 512;
+  if (blocks > fcap) blocks = fcap;  // one fp64 atomic per column per block: keep the tail short
   const dim3 grid((unsigned)blocks);
 #define GF_FWD(L)                                                                          \
   hipLaunchKernelGGL(group_first_fwd_k<L>, grid, dim3(512), 0, s, N, M, ns, div, xyz, center, \
@@ -297,7 +325,7 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
                                     const float* G, const float* Y, const float* U, const float* vec6,
                                     const int* inv_off, const int* inv_rows, float* dU,
                                     float* dWx, int dw_ld, const float* Wx, int w_ld, float* dxyz,
-                                    float* dcenter, demf_stream_t stream) {
+                                    float* dcenter, double* wacc, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_bwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0) return DEMF_OK;
@@ -314,14 +342,20 @@ extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float r
   hipStream_t s = (hipStream_t)stream;
   const int lpr = C1 / 4, gpb = 256 / lpr;
   long long blocks = (points + gpb - 1) / gpb;
-  static const int bcap = getenv("DEMF_GF_BWD_BLOCKS") ? atoi(getenv("DEMF_GF_BWD_BLOCKS")) : 1024;
-  if (blocks > bcap) blocks = bcap;  // 3*C1 fp32 atomics per block
+  static const bool wacc_off = getenv("DEMF_GF_WACC") && atoi(getenv("DEMF_GF_WACC")) == 0;   // A/B switch
+  int* ticket = wacc && !wacc_off ? sched_slot() : nullptr;
+  if (ticket == nullptr) wacc = nullptr;          // (no counter set: every workgroup adds to dWx itself)
+  // (one group per source point and pass: more workgroups = more independent load chains in flight; the partial dWx of
+  //  a workgroup go to one of GF_REPL copies of the accumulator, so the cap no longer trades against the atomic tail)
+  static const int bcap = getenv("DEMF_GF_BWD_BLOCKS") ? atoi(getenv("DEMF_GF_BWD_BLOCKS")) : 0;
+  const int cap = bcap > 0 ? bcap : (dxyz == nullptr && wacc != nullptr ? 2048 : 1024);
+  if (blocks > cap) blocks = cap;
   const dim3 grid((unsigned)blocks);
   DEMF_REQUIRE((dxyz == nullptr) == (dcenter == nullptr) && (dxyz == nullptr || Wx != nullptr),
                "group_first_bwd: dxyz, dcenter (and Wx) must be given together");
 #define GF_BWD_(L, XG_, RC_)                                                                \
   hipLaunchKernelGGL((group_first_bwd_k<L, XG_, RC_>), grid, dim3(256), 0, s, N, M, ns, ns_shift, inv_div, div, xyz,   \
-                     center, G, Y, U, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, dxyz, dcenter)
+                     center, G, Y, U, vec6, inv_off, inv_rows, dU, dWx, dw_ld, points, Wx, w_ld, dxyz, dcenter, wacc, ticket)
 #define GF_BWD(L)                                                                          \
   do {                                                                                     \
     if (dxyz) { if (rc) GF_BWD_(L, true, true); else GF_BWD_(L, true, false); }            \

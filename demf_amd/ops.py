@@ -1329,6 +1329,8 @@ class _SharedMLPPool(Function):
         fuse_first = (ctx.geo is None and L >= 3 and not ctx.needs_input_grad[0] and ld == 4
                       and Ws[0].shape[0] <= 64 and Ws[0].shape[0] % 4 == 0 and not _NO_FIRST_FUSE)
         n64 = 2 * sum(W.shape[0] for W in Ws) + (10 * Ws[0].shape[0] + 4 if fuse_first else 0)
+        if ctx.geo is not None:
+            n64 = max(n64, 24 * Ws[0].shape[0])      # (the factored first layer's dWx totals: every sum above is consumed by then)
         ws64 = _accum64(n64, dev)
         # (+ room for the exact-zero gradients of conv biases shadowed by BatchNorm)
         nbias = sum(W.shape[0] for W, bs in zip(Ws, ctx.bias_shapes) if bs is not None)
@@ -1388,7 +1390,7 @@ class _SharedMLPPool(Function):
                 _ffi.call("demf_group_first_bwd", gB, gN, gM, ns, N, g_radius, g_norm, _p(g_xyz),
                           _p(g_center), _p(G), _p(Ys[0]), _p(getattr(ctx, "geo_U", None)), _p(vec6), _p(g_off),
                           _p(g_rows), _p(dU),
-                          _p(dW0), K, _p(W), K, _p(dxyz), _p(dcenter), st)
+                          _p(dW0), K, _p(W), K, _p(dxyz), _p(dcenter), _p(ws64[:24 * N]), st)
                 # dWf = dU^T . feat: long thin reduction -> the slab-split dW kernel, identity prologue
                 C0 = K - 3
                 dw_job(gB * gN, N, C0, C0, dU, None, None, 1, dU, _identity_dy_vectors(N, dev), x, None, dW0, K,

@@ -256,6 +256,9 @@ DEMF_INTERNAL int demf_group_first_bwd(int B, int N, int M, int ns, int C1, floa
                          const float* Wx /* needed with dxyz or U */, int w_ld /* as in the forward */,
                          float* dxyz /* (B,N,3) fully written, or NULL */,
                          float* dcenter /* (B,M,3) accumulated: arrives zeroed, or NULL */,
+                         double* wacc /* 8*3*C1 doubles, zero on entry and left zeroed: the workgroups' partial dWx are
+                         summed there (contiguous atomics) and the last workgroup adds the totals to dWx; or NULL:
+                         every workgroup adds to dWx itself */,
                          demf_stream_t stream);
 
 /* One pyramid level (B,C,HW) channel-major -> rows [row0,row0+HW) of the channels-last token buffer
