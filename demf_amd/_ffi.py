@@ -74,7 +74,7 @@ SIGNATURES = {
     "demf_sa_index_chain": [_c_int] * 3 + [_ptr] * 4,
     "demf_split_points": [ctypes.c_longlong, _c_int] + [_ptr] * 4,
     "demf_group_concat_cl_bwd_gather": [_c_int] * 6 + [_ptr] * 5,
-    "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 5 + [_c_int] + [_ptr] * 3,
+    "demf_group_first_fwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 5 + [_c_int] + [_ptr] * 4 + [_c_float] * 2 + [_ptr] * 6 + [_ptr],
     "demf_group_first_bwd": [_c_int] * 5 + [_c_float, _c_int] + [_ptr] * 10 + [_c_int, _ptr, _c_int] + [_ptr] * 4,
     "demf_adamw_f32": [ctypes.c_longlong] + [_ptr] * 5 + [_c_float] * 7 + [_c_int, _ptr],
     "demf_multi_copy_sumsq": [_c_int, _ptr, _c_int, _ptr, _ptr],

@@ -21,7 +21,34 @@ struct BnVecFin {
   float* dgamma;                // out (N)
   float* dbeta;                 // out (N)
   int* ticket;                  // counter set (sched_slot()) or null: no in-kernel finalize
+  double* racc;                 // replicated accumulator block (accum_slot()) or null: the sums go to g12 itself
 };
+
+// Replicated accumulators.  An atomic add costs ~20 ns at its memory channel and adds to one cache line queue up there,
+// so W workgroups that end by adding their partial sums to the same 2N doubles finish W * 20 ns after the first
+// (tools/ubench/atomic_flush.cpp: 1024 workgroups x 384 doubles = 23 us, 256 = 7 us).  A launch whose last workgroup
+// consumes the sums anyway (ticket != null) adds to ACC_REPL copies instead - workgroup w to copy w % ACC_REPL, i.e.
+// roughly one copy per XCD - and the last workgroup folds the copies while it clears them.
+constexpr int ACC_REPL = 8;
+constexpr int ACC_MAX_N = 1024;                          // channels per layer a block of the ring holds (2N doubles per copy)
+constexpr int ACC_SLOT_DOUBLES = ACC_REPL * 2 * ACC_MAX_N;
+double* accum_slot();   // csrc/mlp.hip: the next zeroed block of the ring (left zeroed by its consumer), or null (A/B off)
+
+// this workgroup's copy: [sum | second sum] of N doubles each
+__device__ __forceinline__ double* repl_copy(double* __restrict__ racc, int N, int lin) {
+  return racc + (size_t)(lin % ACC_REPL) * 2 * N;
+}
+// total of element i (0 .. 2N) over the copies, each left zeroed
+__device__ __forceinline__ double repl_take(double* __restrict__ racc, int N, int i) {
+  unsigned long long v[ACC_REPL];
+#pragma unroll
+  for (int r = 0; r < ACC_REPL; ++r)
+    v[r] = atomicExch(reinterpret_cast<unsigned long long*>(racc + (size_t)r * 2 * N + i), 0ull);
+  double t = 0.0;
+#pragma unroll
+  for (int r = 0; r < ACC_REPL; ++r) t += __builtin_bit_cast(double, v[r]);
+  return t;
+}
 
 // vec layout (struct of arrays, length N each): [0] scale [1] shift [2] gi = gamma*invstd
 // [3] a = -gi*invstd*mean(dZ*xhat) [4] b = -gi*mean(dZ) - a*mean   (demf_bn_bwd_vectors)
@@ -73,12 +100,57 @@ __device__ __forceinline__ void bn_vec_finalize(const BnVecFin& f, int N, int c0
                                                 int tid, int nthreads) {
   for (int i = tid; i < n; i += nthreads) {
     const int c = c0 + i;
-    const double g1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(g12 + c), 0ull));
-    const double g2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(g12 + N + c), 0ull));
+    double g1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(g12 + c), 0ull));
+    double g2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(g12 + N + c), 0ull));
+    if (f.racc != nullptr) {      // (+ the copies: a producer that knows nothing of them leaves them zero)
+      g1 += repl_take(f.racc, N, c);
+      g2 += repl_take(f.racc, N, N + c);
+    }
     bn_bwd_vectors_channel(c, N, f.count, g1, g2, f.gamma, f.ss, f.mi, f.vec, f.dgamma, f.dbeta);
   }
 }
 
 int* sched_slot();   // csrc/mlp.hip: the next self-resetting counter set of the ring
+
+// Train-mode BatchNorm bookkeeping of a forward launch (demf_bn_finalize's arguments).  With
+// ss != null the LAST workgroup of a STATS launch turns the column sums into scale / shift, saved
+// mean / invstd and the running statistics itself and leaves the sums zeroed - the separate ~5 us
+// finalize launch behind every forward GEMM disappears.
+constexpr int FIN_OFF = 40;    // ints [FIN_OFF, FIN_OFF + 17) of a counter set: exit counts of the finalize
+struct BnFin {
+  double count;
+  const float *gamma, *beta, *conv_bias;
+  float eps, momentum;
+  float *rmean, *rvar;
+  long long* nbt;
+  float *ss, *mi;
+  int* ticket;                 // counter set (sched_slot) or null
+  double* racc;                // replicated accumulator block (accum_slot, csrc/bn_fin.h) or null
+};
+
+__device__ __forceinline__ void bn_finalize_channel(int c, int N, double count, double s1, double s2,
+                                                    const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps,
+                                                    float momentum, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var,
+                                                    float* __restrict__ ss, float* __restrict__ mi,
+                                                    const float* __restrict__ conv_bias) {
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;            // biased, as BN normalises with
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  ss[c] = (float)((double)gamma[c] * invstd);                                   // scale
+  ss[N + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);      // shift
+  mi[c] = (float)mean;
+  mi[N + c] = (float)invstd;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    // a conv bias in front of a train-mode BN cancels in the output; it only shifts the batch mean
+    const double bm = mean + (conv_bias != nullptr ? (double)conv_bias[c] : 0.0);
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * bm);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
 
 }  // namespace demf

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(512) void group_first_fwd_k(
     int N, int M, int ns, float div, const float* __restrict__ xyz,
     const float* __restrict__ center, const int* __restrict__ idx, const float* __restrict__ U,
     const float* __restrict__ Wx, int wld, float* __restrict__ Y, double* __restrict__ stats,
-    long long rows) {
+    long long rows, BnFin fin) {
   constexpr int C1 = LPR * 4;
   constexpr int GPB = 512 / LPR;
   constexpr int UNR = 8;
@@ -97,19 +97,34 @@ __global__ __launch_bounds__(512) void group_first_fwd_k(
       }
     }
   }
-  if (stats == nullptr) return;
+  if (stats == nullptr && fin.ticket == nullptr) return;
   __shared__ float4 red[2][GPB][LPR];
+  __shared__ int s_last;
   red[0][grp][sub] = s;
   red[1][grp][sub] = q;
   __syncthreads();
-  // 2*C1 column totals, one thread each (fp64 from here on)
+  // 2*C1 column totals, one thread each (fp64 from here on).  With a counter set the launch's last workgroup does the
+  // BatchNorm bookkeeping itself (no finalize launch) and the partial sums go to this workgroup's copy of a replicated
+  // accumulator (csrc/bn_fin.h: 512 workgroups adding to the same 2*C1 doubles queue for ~10 us).
+  double* dst = fin.ticket != nullptr ? repl_copy(fin.racc, C1, (int)blockIdx.x) : stats;
   for (int t = threadIdx.x; t < 2 * C1; t += 512) {
     const int which = t / C1, col = t - which * C1;
     const float* base = reinterpret_cast<const float*>(&red[which][0][0]) + col;
     double tot = 0.0;
 #pragma unroll 4
     for (int g = 0; g < GPB; ++g) tot += (double)base[g * C1];
-    atomicAdd(stats + which * C1 + col, tot);
+    atomicAdd(dst + which * C1 + col, tot);
+  }
+  if (fin.ticket == nullptr) return;
+  sync_drained();
+  if (threadIdx.x == 0) s_last = last_workgroup(fin.ticket, (int)gridDim.x, (int)blockIdx.x);
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0 && fin.nbt != nullptr) *fin.nbt += 1;
+  for (int c = threadIdx.x; c < C1; c += 512) {
+    const double s1 = repl_take(fin.racc, C1, c), s2 = repl_take(fin.racc, C1, C1 + c);
+    bn_finalize_channel(c, C1, fin.count, s1, s2, fin.gamma, fin.beta, fin.eps, fin.momentum, fin.rmean, fin.rvar,
+                        fin.ss, fin.mi, fin.conv_bias);
   }
 }
 
@@ -296,7 +311,10 @@ using namespace demf;
 extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float radius,
                                     int normalize_xyz, const float* xyz, const float* center,
                                     const int* idx, const float* U, const float* Wx, int w_ld,
-                                    float* Y, double* stats, demf_stream_t stream) {
+                                    float* Y, double* stats, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* scale_shift, float* mean_invstd,
+                                    const float* conv_bias, demf_stream_t stream) {
   DEMF_REQUIRE(B >= 0 && N >= 1 && M >= 0 && ns >= 1 && (C1 == 64 || C1 == 128 || C1 == 256),
                "group_first_fwd: bad sizes B=%d N=%d M=%d ns=%d C1=%d", B, N, M, ns, C1);
   if (B == 0 || M == 0) return DEMF_OK;
@@ -310,14 +328,32 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
   static const int fcap = getenv("DEMF_GF_FWD_BLOCKS") ? atoi(getenv("DEMF_GF_FWD_BLOCKS")) : 512;
   if (blocks > fcap) blocks = fcap;  // one fp64 atomic per column per block: keep the tail short
   const dim3 grid((unsigned)blocks);
+  // train-mode BatchNorm bookkeeping (demf_bn_finalize's arguments): by the launch's last workgroup when a counter set
+  // and an accumulator block are to be had, as a launch behind this one otherwise
+  BnFin fin{};
+  const bool want_fin = scale_shift != nullptr;
+  if (want_fin) {
+    DEMF_REQUIRE(stats && gamma && beta && mean_invstd, "group_first_fwd: the BatchNorm bookkeeping needs stats, gamma, "
+                 "beta, scale_shift and mean_invstd");
+    static const bool fin_off = getenv("DEMF_GF_FIN") && atoi(getenv("DEMF_GF_FIN")) == 0;   // A/B switch
+    int* ticket = fin_off ? nullptr : sched_slot();
+    double* racc = ticket ? accum_slot() : nullptr;
+    if (ticket != nullptr && racc != nullptr)
+      fin = BnFin{(double)rows, gamma, beta, conv_bias, eps, momentum, running_mean, running_var, num_batches_tracked,
+                  scale_shift, mean_invstd, ticket, racc};
+  }
 #define GF_FWD(L)                                                                          \
   hipLaunchKernelGGL(group_first_fwd_k<L>, grid, dim3(512), 0, s, N, M, ns, div, xyz, center, \
-                     idx, U, Wx, w_ld, Y, stats, rows)
+                     idx, U, Wx, w_ld, Y, stats, rows, fin)
   if (lpr == 64) GF_FWD(64);
   else if (lpr == 32) GF_FWD(32);
   else GF_FWD(16);
 #undef GF_FWD
-  return check_launch("group_first_fwd");
+  if (int e = check_launch("group_first_fwd")) return e;
+  if (want_fin && fin.ticket == nullptr)
+    return demf_bn_finalize(C1, rows, stats, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked,
+                            scale_shift, mean_invstd, conv_bias, stream);
+  return DEMF_OK;
 }
 
 extern "C" int demf_group_first_bwd(int B, int N, int M, int ns, int C1, float radius,

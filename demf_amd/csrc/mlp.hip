@@ -118,45 +118,7 @@ enum { PRO_NONE = 0, PRO_BNRELU = 1, PRO_DY_DENSE = 2, PRO_DY_SPARSE = 3 };
 // per-channel vectors of the backward prologue ("vec5"), struct-of-arrays of length n each:
 //   [0] scale  [1] shift  (z = y*scale + shift, ReLU mask)   [2] gi = gamma*invstd
 //   [3] a = -gi*invstd*mean(dZ*xhat)   [4] b = -gi*mean(dZ) - a*mean     (dY = gi*dZ + a*y + b)
-// Train-mode BatchNorm bookkeeping of a forward launch (demf_bn_finalize's arguments).  With
-// ss != null the LAST workgroup of a STATS launch turns the column sums into scale / shift, saved
-// mean / invstd and the running statistics itself and leaves the sums zeroed - the separate ~5 us
-// finalize launch behind every forward GEMM disappears.
-constexpr int FIN_OFF = 40;    // ints [FIN_OFF, FIN_OFF + 17) of a counter set: exit counts of the finalize
-struct BnFin {
-  double count;
-  const float *gamma, *beta, *conv_bias;
-  float eps, momentum;
-  float *rmean, *rvar;
-  long long* nbt;
-  float *ss, *mi;
-  int* ticket;                 // counter set (sched_slot) or null
-};
-
-__device__ __forceinline__ void bn_finalize_channel(int c, int N, double count, double s1, double s2,
-                                                    const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, float eps,
-                                                    float momentum, float* __restrict__ running_mean,
-                                                    float* __restrict__ running_var,
-                                                    float* __restrict__ ss, float* __restrict__ mi,
-                                                    const float* __restrict__ conv_bias) {
-  const double mean = s1 / count;
-  double var = s2 / count - mean * mean;            // biased, as BN normalises with
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  ss[c] = (float)((double)gamma[c] * invstd);                                   // scale
-  ss[N + c] = (float)((double)beta[c] - mean * (double)gamma[c] * invstd);      // shift
-  mi[c] = (float)mean;
-  mi[N + c] = (float)invstd;
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    // a conv bias in front of a train-mode BN cancels in the output; it only shifts the batch mean
-    const double bm = mean + (conv_bias != nullptr ? (double)conv_bias[c] : 0.0);
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * bm);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
-}
-
+// (BnFin, bn_finalize_channel: csrc/bn_fin.h)
 struct MlpArgs {
   int R, K, N;                 // rows, reduction length, output columns
   int ldx;                     // row stride of X (floats)
@@ -967,11 +929,19 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
       }
     }
     __syncthreads();
+    // (the launch's last workgroup consumes the sums: they go to this workgroup's copy of the accumulator, bn_fin.h)
+    const int lin_s = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    double* sdst = p.stats;
+    if constexpr (RED) {
+      if (p.vfin.ticket != nullptr && p.vfin.racc != nullptr) sdst = repl_copy(p.vfin.racc, p.fld, lin_s);
+    } else {
+      if (p.fin.ss != nullptr && p.fin.racc != nullptr) sdst = repl_copy(p.fin.racc, p.N, lin_s);
+    }
     for (int i = threadIdx.x; i < NT * 64; i += 256) {
       const float v = s_red[i] + s_red[NT * 64 + i] + s_red[2 * NT * 64 + i] + s_red[3 * NT * 64 + i];
       const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
       if (cofs + nt * 32 + c < p.N)
-        atomicAdd(p.stats + which * (RED ? p.fld : p.N) + (RED ? p.fc0 : 0) + cofs + nt * 32 + c, (double)v);
+        atomicAdd(sdst + which * (RED ? p.fld : p.N) + (RED ? p.fc0 : 0) + cofs + nt * 32 + c, (double)v);
     }
   }
   if constexpr (RED) {
@@ -1011,10 +981,11 @@ __global__ __launch_bounds__(256, 2) void mlp_gemm_kernel(MlpArgs p) {
         for (int c = threadIdx.x; c < p.N; c += 256) {
           // read through the atomic unit (the sums were produced by device-scope atomics) and leave
           // the accumulator zeroed, in one exchange each
-          const double s1 = __builtin_bit_cast(
+          double s1 = __builtin_bit_cast(
               double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
-          const double s2 = __builtin_bit_cast(
+          double s2 = __builtin_bit_cast(
               double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + p.N + c), 0ull));
+          if (f.racc != nullptr) { s1 += repl_take(f.racc, p.N, c); s2 += repl_take(f.racc, p.N, p.N + c); }
           bn_finalize_channel(c, p.N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean,
                               f.rvar, f.ss, f.mi, f.conv_bias);
         }
@@ -1333,7 +1304,8 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
 #pragma unroll
     for (int w = 0; w < FR_NW; ++w) v += s_red[w * NTN * 64 + i];
     const int nt = i >> 6, which = (i >> 5) & 1, c = i & 31;
-    atomicAdd(p.stats + which * N + nt * 32 + c, (double)v);
+    double* sdst = p.fin.ss != nullptr && p.fin.racc != nullptr ? repl_copy(p.fin.racc, N, (int)blockIdx.x) : p.stats;
+    atomicAdd(sdst + which * N + nt * 32 + c, (double)v);
   }
   if (p.fin.ss != nullptr) {
     // train-mode BN bookkeeping by the last workgroup (as mlp_gemm_kernel: only atomics touch the sums)
@@ -1357,8 +1329,9 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
       const BnFin& f = p.fin;
       if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
       for (int c = tid; c < N; c += 64 * FR_NW) {
-        const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
-        const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+        double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        if (f.racc != nullptr) { s1 += repl_take(f.racc, N, c); s2 += repl_take(f.racc, N, N + c); }
         bn_finalize_channel(c, N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss,
                             f.mi, f.conv_bias);
       }
@@ -1526,8 +1499,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fwd_pc_kernel(MlpArgs p) {
     cs1 += __shfl_xor(cs1, 32);
     cs2 += __shfl_xor(cs2, 32);
     if (lh == 0) {
-      atomicAdd(p.stats + col, (double)cs1);
-      atomicAdd(p.stats + N + col, (double)cs2);
+      double* sdst = p.fin.ss != nullptr && p.fin.racc != nullptr ? repl_copy(p.fin.racc, N, (int)blockIdx.x) : p.stats;
+      atomicAdd(sdst + col, (double)cs1);
+      atomicAdd(sdst + N + col, (double)cs2);
     }
   }
   if (p.fin.ss != nullptr) {
@@ -1552,8 +1526,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fwd_pc_kernel(MlpArgs p) {
       const BnFin& f = p.fin;
       if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
       for (int c = tid; c < N; c += 512) {
-        const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
-        const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+        double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + N + c), 0ull));
+        if (f.racc != nullptr) { s1 += repl_take(f.racc, N, c); s2 += repl_take(f.racc, N, N + c); }
         bn_finalize_channel(c, N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss,
                             f.mi, f.conv_bias);
       }
@@ -1787,8 +1762,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense4_k(int R, int N,
       t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
       t2.x += v.x; t2.y += v.y; t2.z += v.z; t2.w += v.w;
     }
-    double* o1 = g12 + 4 * threadIdx.x;
-    double* o2 = g12 + N + 4 * threadIdx.x;
+    double* dst = fin.ticket != nullptr && fin.racc != nullptr ? repl_copy(fin.racc, N, (int)blockIdx.x) : g12;
+    double* o1 = dst + 4 * threadIdx.x;
+    double* o2 = dst + N + 4 * threadIdx.x;
     atomicAdd(o1, (double)t1.x); atomicAdd(o1 + 1, (double)t1.y);
     atomicAdd(o1 + 2, (double)t1.z); atomicAdd(o1 + 3, (double)t1.w);
     atomicAdd(o2, (double)t2.x); atomicAdd(o2 + 1, (double)t2.y);
@@ -2170,6 +2146,22 @@ int* sched_slot() {
   return base + SCHED_INTS * (next.fetch_add(1) % SCHED_SLOTS);
 }
 
+// Blocks of zeroed doubles for the replicated accumulators (csrc/bn_fin.h): as the counter sets, the next block of a
+// ring; the launch's last workgroup leaves it zeroed.
+constexpr int ACC_SLOTS = 128;
+__device__ double g_accum_ring[(size_t)ACC_SLOT_DOUBLES * ACC_SLOTS];
+double* accum_slot() {
+  static double* base = nullptr;
+  static std::atomic<unsigned> next{0};
+  if (base == nullptr) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_accum_ring)) != hipSuccess) return nullptr;
+    base = (double*)ptr;
+  }
+  if (!env_int("DEMF_ACC_REPL", 1)) return nullptr;     // A/B switch
+  return base + (size_t)ACC_SLOT_DOUBLES * (next.fetch_add(1) % ACC_SLOTS);
+}
+
 static int mlp_grid(int R, int brows) {
   const int tiles = (R + brows - 1) / brows;
   const int cap = env_int("DEMF_GEMM_GRID", 256 * 2);   // persistent: two 256-thread blocks per CU
@@ -2369,7 +2361,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_tile_kernel(MlpArgs p) {
   if (tid < 128) {
     const int which = tid >> 6, c = tid & 63;
     const float v = s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c];
-    atomicAdd(p.stats + (size_t)which * p.N + n0 + c, (double)v);
+    double* sdst = p.fin.racc != nullptr ? repl_copy(p.fin.racc, p.N, (int)blockIdx.y) : p.stats;
+    atomicAdd(sdst + (size_t)which * p.N + n0 + c, (double)v);
     // EVERY wave that issued sum atomics drains them before the barrier in front of the ticket: the barrier itself
     // does not wait for another wave's vector-memory counter (workgroup-scope release omits vmcnt(0) outside
     // threadgroup-split mode), and wave 1 carries all of this workgroup's sum of squares - taken late, the last
@@ -2398,8 +2391,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_tile_kernel(MlpArgs p) {
     const BnFin& f = p.fin;
     if (tid == 0 && f.nbt != nullptr) *f.nbt += 1;
     for (int c = tid; c < p.N; c += 256) {
-      const double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
-      const double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + p.N + c), 0ull));
+      double s1 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + c), 0ull));
+      double s2 = __builtin_bit_cast(double, atomicExch(reinterpret_cast<unsigned long long*>(p.stats + p.N + c), 0ull));
+      if (f.racc != nullptr) { s1 += repl_take(f.racc, p.N, c); s2 += repl_take(f.racc, p.N, p.N + c); }
       bn_finalize_channel(c, p.N, f.count, s1, s2, f.gamma, f.beta, f.eps, f.momentum, f.rmean, f.rvar, f.ss, f.mi,
                           f.conv_bias);
     }
@@ -2602,7 +2596,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dx_tile_kernel(MlpArgs p) {
     if (tid < 128) {
       const int which = tid >> 6, c = tid & 63;
       const float v = s_red[(0 * 2 + which) * 64 + c] + s_red[(1 * 2 + which) * 64 + c];
-      atomicAdd(p.stats + (size_t)which * p.fld + p.fc0 + n0 + c, (double)v);
+      double* sdst = p.vfin.ticket != nullptr && p.vfin.racc != nullptr ? repl_copy(p.vfin.racc, p.fld, (int)blockIdx.y) : p.stats;
+      atomicAdd(sdst + (size_t)which * p.fld + p.fc0 + n0 + c, (double)v);
     }
     if (p.vfin.ticket != nullptr) {
       sync_drained();
@@ -2976,6 +2971,10 @@ template <typename Launch>
 static int launch_with_finalize(MlpArgs& a, BnFin fin, Launch launch, hipStream_t s) {
   static const int off = env_int("DEMF_NO_FIN", 0);
   fin.ticket = off ? nullptr : sched_slot();
+  // (replicated accumulators: measured neutral on the forward launches - their workgroups do not end together (the
+  //  persistent SA kernels) or the 8 x 2N exchanges of the finalize cost what the shorter queue saves (the 64 x 64-tile
+  //  kernel) - so off unless DEMF_ACC_REPL_FWD=1; the row-reduction kernels of the BN backward gain 2-5 us each)
+  fin.racc = fin.ticket != nullptr && a.N <= ACC_MAX_N && env_int("DEMF_ACC_REPL_FWD", 0) ? accum_slot() : nullptr;
   a.fin = fin;
   if (fin.ticket != nullptr) return launch(a);
   a.fin.ss = nullptr;                     // (gamma stays: the pooled epilogue selects by its sign)
@@ -3288,8 +3287,11 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
     const int rp = 256 / (N / 4);
     // few blocks: every block ends with 2N same-address fp64 atomics, which serialise in L2
     // (~70 ns each), so 2048 blocks cost ~150 us in the tail alone
-    int grid = cdiv(R, rp * 16);
-    const int cap = env_int("DEMF_BNRED_GRID", 256);
+    // (with the replicated accumulators a workgroup's 2N adds queue behind an eighth of the others': one unrolled
+    //  pass of 4 row groups per workgroup, up to 1024 of them)
+    const bool repl = vf.ticket != nullptr && vf.racc != nullptr;
+    int grid = cdiv(R, rp * (repl ? env_int("DEMF_BNRED_RPB", 4) : 16));
+    const int cap = env_int("DEMF_BNRED_GRID", repl ? 1024 : 256);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(bn_bwd_reduce_dense4_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
                        Y, scale_shift, mean_invstd, g12, env_int("DEMF_BNRED_REV", 1), vf,
@@ -3301,8 +3303,9 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
   // sparse kernel's 31 us were mostly that tail)
   if (!G && yraw && N % 4 == 0 && N <= 1024 && R % ns == 0 && env_int("DEMF_BNRED_POOLED_DENSE", 1)) {
     const int Rp = R / ns, rp = 256 / (N / 4);
-    int grid = cdiv(Rp, rp * 16);
-    const int cap = env_int("DEMF_BNRED_GRID", 256);
+    const bool repl = vf.ticket != nullptr && vf.racc != nullptr;
+    int grid = cdiv(Rp, rp * (repl ? env_int("DEMF_BNRED_RPB", 4) : 16));
+    const int cap = env_int("DEMF_BNRED_GRID", repl ? 1024 : 256);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(bn_bwd_reduce_dense4_k<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, Rp, N, dP,
@@ -3342,7 +3345,8 @@ extern "C" int demf_bn_bwd_reduce_vectors(int R, int N, int ns, const float* dP,
                                           float* vec6, float* dgamma, float* dbeta, int y_bf16,
                                           demf_stream_t stream) {
   DEMF_REQUIRE(gamma && vec6 && dgamma && dbeta && dP && arg, "bn_bwd_reduce_vectors: null pointer");
-  BnVecFin vf{(double)R, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, sched_slot()};
+  BnVecFin vf{(double)R, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, sched_slot(), nullptr};
+  if (vf.ticket != nullptr && N <= ACC_MAX_N) vf.racc = accum_slot();
   if (vf.ticket == nullptr) {              // DEMF_STATIC_TILES=1: no counter sets - two launches
     if (int e = bn_bwd_reduce_impl(R, N, ns, nullptr, dP, arg, Y, yraw, scale_shift, mean_invstd, g12, BnVecFin{}, stream, y_bf16)) return e;
     return demf_bn_bwd_vectors(N, R, g12, gamma, scale_shift, mean_invstd, vec6, dgamma, dbeta, stream);
@@ -3399,7 +3403,9 @@ static int mlp_bwd_dx_impl(bool w_direct, int R, int N, int K, int ldo, const fl
     if (red) {
       a.fY = red->Yprev; a.fss = red->ss; a.fmi = red->mi; a.stats = red->g12; a.fld = K; a.fc0 = c0;
       if (red->gamma != nullptr)
-        a.vfin = BnVecFin{(double)R, red->gamma, red->ss, red->mi, red->vec6, red->dgamma, red->dbeta, sched_slot()};
+        a.vfin = BnVecFin{(double)R, red->gamma, red->ss, red->mi, red->vec6, red->dgamma, red->dbeta, sched_slot(),
+                          nullptr};
+      if (a.vfin.ticket != nullptr && K <= ACC_MAX_N && env_int("DEMF_ACC_REPL_RED", 0)) a.vfin.racc = accum_slot();
       e = G ? launch_gemm<PRO_DY_DENSE, false, false, true>(a, s)
             : launch_gemm<PRO_DY_SPARSE, false, false, true>(a, s);
     } else {

@@ -1192,13 +1192,13 @@ class _SharedMLPPool(Function):
                     stats = ws[woff:woff + 2 * N]
                     woff += 2 * N
                 # (the xyz columns of W are read in place: w_ld = K)
+                # (train mode: + the BatchNorm bookkeeping, by the launch's last workgroup)
+                fin = (_p(gamma), _p(beta), float(eps), float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi),
+                       _p(tensors[7 * l + 5])) if training else (None, None, 0.0, 0.0, None, None, None, None, None, None)
                 _ffi.call("demf_group_first_fwd", gB, gN, gM, ns, N, float(g_radius),
                           int(bool(g_norm)), _p(g_xyz), _p(g_center), _p(g_idx), _p(U), _p(W), K,
-                          _p(Y), _p(stats), st)
-                if training:
-                    _ffi.call("demf_bn_finalize", N, R, _p(stats), _p(gamma), _p(beta), float(eps),
-                              float(momentum), _p(rmean), _p(rvar), _p(nbt), _p(ss), _p(mi), _p(tensors[7 * l + 5]), st)
-                else:
+                          _p(Y), _p(stats), *fin, st)
+                if not training:
                     invstd = torch.rsqrt(rvar + eps)
                     ss[:N] = gamma * invstd
                     ss[N:] = beta - rmean * gamma * invstd

@@ -239,7 +239,13 @@ DEMF_INTERNAL int demf_group_first_fwd(int B, int N, int M, int ns, int C1, floa
                          const float* xyz, const float* center, const int* idx, const float* U,
                          const float* Wx, int w_ld /* 0: Wx is the (3, C1) copy; > 0: Wx is the layer's
                          weight (C1 x w_ld row-major) itself, columns 0..2 read in place */,
-                         float* Y, double* stats, demf_stream_t stream);
+                         float* Y, double* stats,
+                         /* train-mode BatchNorm bookkeeping of the layer (demf_bn_finalize's arguments) done by the
+                          * launch's last workgroup - or, without a counter set, by a demf_bn_finalize launch behind it;
+                          * scale_shift == NULL: none, the sums stay in stats */
+                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* scale_shift, float* mean_invstd,
+                         const float* conv_bias, demf_stream_t stream);
 /* Backward of the above through the inverse lists of demf_invert_index: with dY the BN-backward
  * transform of (G, Y) by vec6 (demf_bn_bwd_vectors; same formula as demf_mlp_gemm_bwd_dx),
  *   dU[b,j,:]  = sum of dY over the rows that gathered point j        (fully written, no atomics)
