@@ -60,6 +60,7 @@ struct FusedBwdArgs {
   // then arrive offset by fc0 with row strides ldk / ldw; pss, pmi, g12 and vfin are the WHOLE layer's.
   int ldk, ldw, fld, fc0;
   const float* W0;    // FIRST with ST bit 2: (K x 4) weight of layer 0 - Y_0 = fX.W0^T is recomputed, Xp is not read
+  int dbg;            // DEMF_BWD_DBG (timing experiments, results wrong): bit 0 = the dW flush is skipped
 };
 
 // one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   // ---- flush: dW tiles (row groups folded through LDS first), column sums ---------------------------
   __syncthreads();
   float* s_red = reinterpret_cast<float*>(smem);             // the plane regions are free now
-  {
+  if (!(p.dbg & 1)) {
 #pragma unroll
     for (int kk = 0; kk < KTW; ++kk)
 #pragma unroll
@@ -1042,6 +1043,7 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
                    (G || (dP && arg)) && (first ? (X0 != nullptr) : (dX && g12_prev)),
                "mlp_bwd_fused: null pointer");
   FusedBwdArgs a{};
+  { static const int dbg = getenv("DEMF_BWD_DBG") ? atoi(getenv("DEMF_BWD_DBG")) : 0; a.dbg = dbg; }
   a.R = R; a.N = N; a.K = K; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
   a.Xp = Yprev; a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.W = W; a.dX = dX; a.dW = dW;
   a.g12 = g12_prev; a.fX = X0; a.fsum = first_sums;
@@ -1092,6 +1094,7 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   DEMF_REQUIRE(Y && vec6 && W && Yprev && scale_shift_prev && mean_invstd_prev && dW && (G || (dP && arg)) && dX &&
                    g12_prev, "mlp_bwd_fused_cols: null pointer");
   FusedBwdArgs a{};
+  { static const int dbg = getenv("DEMF_BWD_DBG") ? atoi(getenv("DEMF_BWD_DBG")) : 0; a.dbg = dbg; }
   a.R = R; a.N = N; a.K = Kc; a.ns = ns; a.Yl = Y; a.G = G; a.dP = dP; a.arg = arg; a.vec = vec6;
   a.Xp = Yprev + c0; a.dX = dX + c0; a.W = W + c0; a.dW = dW + c0;
   a.pss = scale_shift_prev; a.pmi = mean_invstd_prev; a.g12 = g12_prev;
@@ -1201,6 +1204,7 @@ extern "C" int demf_mlp_bwd_fused_x4(int R, int N, int K, const float* G, const 
   DEMF_REQUIRE(G && Y && vec6 && W && X0 && W0 && scale_shift_prev && mean_invstd_prev && dW && first_sums,
                "mlp_bwd_fused_x4: null pointer");
   FusedBwdArgs a{};
+  { static const int dbg = getenv("DEMF_BWD_DBG") ? atoi(getenv("DEMF_BWD_DBG")) : 0; a.dbg = dbg; }
   a.R = R; a.N = N; a.K = K; a.ns = 1; a.Yl = Y; a.G = G; a.vec = vec6; a.Xp = nullptr; a.pss = scale_shift_prev;
   a.pmi = mean_invstd_prev; a.W = W; a.dW = dW; a.fX = X0; a.fsum = first_sums; a.W0 = W0;
   a.ldk = K; a.ldw = K; a.fld = K; a.fc0 = 0;
