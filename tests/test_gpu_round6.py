@@ -96,7 +96,9 @@ def test_update_inside_the_graph_equals_the_eager_update():
     batches = [_batch(41, 4), _batch(42, 3), _batch(43, 5)]
     outs = []
     for in_graph in (True, False):
-        tr, model = _trainer(lr=1e-3)
+        # (lr 3e-4: at 1e-3 this tiny untrained network hits a loss spike (14 -> 111) at the fourth batch, where the
+        #  fp32 atomics' order alone decides between two trajectories (111.57 / 118.81) in either update mode)
+        tr, model = _trainer(lr=3e-4)
         replay = tr.capture(batches[0], warmup=1, max_gt=8, update_in_graph=in_graph)
         assert replay.update_in_graph == in_graph
         losses = []
@@ -117,7 +119,7 @@ def test_update_inside_the_graph_equals_the_eager_update():
     for x, y in zip(pa, pb):
         assert rel(x, y) <= 1e-3
     # resume: a fresh trainer loaded from the in-graph run continues with step 8's bias corrections
-    tr2, _ = _trainer(lr=1e-3)
+    tr2, _ = _trainer(lr=3e-4)
     tr2.load_state_dict(sda)
     assert tr2.opt.t == 7 and tr2.opt.lr_factor == pytest.approx(0.1)
     tr2.step(batches[0])
