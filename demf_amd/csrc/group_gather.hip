@@ -847,8 +847,14 @@ extern "C" int demf_invert_index_ws(int B, int N, int E, const int* idx, int* of
   if (B == 0) return DEMF_OK;
   DEMF_REQUIRE(idx && off && rows, "invert_index_ws: null pointer");
   static const int split = [] { const char* v = getenv("DEMF_INVERT_SPLIT"); return v ? atoi(v) : 1; }();   // A/B switch
-  // (the one-workgroup form keeps its lists in LDS up to ~28 k entries and is fast there)
-  if (!split || workspace == nullptr || E < 32768) return demf_invert_index(B, N, E, idx, off, rows, stream);
+  // The one-workgroup-per-scene form keeps its lists in LDS while they fit (150 KB: SA2's 32 768 entries over 2 048
+  // points just do).  Alone on the GPU the five-launch split form is the faster one from ~28 k entries on, but the
+  // inversion belongs to the coordinate pre-pass, which the training loop runs on a side stream UNDER the previous
+  // step: there B busy CUs cost the step less than five whole-GPU launches (-0.065 ms per step at B = 8;
+  // DEMF_INVERT_SPLIT=2 restores the 32 768-entry threshold).
+  const bool fits = sizeof(int) * (2 * (size_t)N + 1 + (size_t)E) <= 150 * 1024;
+  if (!split || workspace == nullptr || (split == 2 ? E < 32768 : fits))
+    return demf_invert_index(B, N, E, idx, off, rows, stream);
   hipStream_t s = (hipStream_t)stream;
   // (a kernel, not hipMemsetAsync: inside the step's hipGraph a memset node was not ordered with the kernels around
   // it - the one-batch graph of bench.py --no-prefetch faulted on the stale counts)
