@@ -12,6 +12,7 @@ configs/_base_/schedules/schedule_3x.py:6).  MI355X-first restatement:
     and one fused clip + AdamW over the flat buffers;
   * no model sharding (the reference has none).
 """
+import contextlib
 import os
 
 import torch
@@ -279,6 +280,23 @@ class FlatAdamW:
                   self.grads.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                   self.state.data_ptr(), float(max_norm), float(grad_scale), self.betas[0], self.betas[1],
                   self.eps, stream)
+
+
+@contextlib.contextmanager
+def _gc_paused():
+    """No garbage collection inside a stream capture.  A collection that reaches an unreachable CUDAGraph (the trainer of
+    an earlier phase, kept alive by a reference cycle until now) releases that graph's memory pool, and a hipFree under
+    capture aborts the process (seen in the test suite: `Fatal Python error: Aborted`, "Garbage-collecting" on the
+    stack of a capture).  Collect once before the capture begins, then keep the collector off until it has ended."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class Trainer:
@@ -622,11 +640,11 @@ class Trainer:
             self.flat.captured_pack = True
             self.flat.sumsq_state = self.opt.state if (update_in_graph and world_c == 1) else None
             try:
-                with torch.cuda.graph(graph):
+                with _gc_paused(), torch.cuda.graph(graph):
                     self._arena(True)            # the arena's single fill is the graph's first node
                     total = self._fwd(batch, static_geo)
                 graph_bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_bwd, pool=graph.pool()):
+                with _gc_paused(), torch.cuda.graph(graph_bwd, pool=graph.pool()):
                     self.flat.backward_into(total)
                     if update_in_graph:
                         self._captured_update(world_c)
@@ -639,7 +657,7 @@ class Trainer:
             self.flat.captured_pack = True
             self.flat.sumsq_state = self.opt.state if (update_in_graph and world_c == 1) else None
             try:
-                with torch.cuda.graph(graph):
+                with _gc_paused(), torch.cuda.graph(graph):
                     loss = self._fwd_bwd(batch, static_geo)
                     if update_in_graph:
                         self._captured_update(world_c)
@@ -848,7 +866,7 @@ class _GeoPipe:
         self.static_pts = points.clone()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with _gc_paused(), torch.cuda.graph(self.graph, stream=side):
             fresh = _flat_tensors(model.index_geometry(self.static_pts))
         torch.cuda.synchronize()
         static_flat = _flat_tensors(self.static_geo)
