@@ -34,7 +34,8 @@ def test_graph_replay_matches_eager():
         tb._fwd_bwd(batch)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    from demf_amd import engine
+    with engine._gc_paused(), torch.cuda.graph(g):
         lb = tb._fwd_bwd(batch)
     tb.flat.flat.fill_(123.0)               # the replay must rewrite every gradient
     g.replay()

@@ -143,7 +143,8 @@ def test_hot_path_on_conditioned_weights(golden_dir, graph):
         torch.cuda.synchronize()
         model.load_state_dict(sd0)                  # the warm-up advanced the BatchNorm running statistics only
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        from demf_amd import engine
+        with engine._gc_paused(), torch.cuda.graph(g):
             preds, losses, grads = run()
         g.replay()
         torch.cuda.synchronize()
