@@ -123,6 +123,7 @@ SIGNATURES = {
     "demf_gemm_f32": [_ptr, _ptr],
     "demf_gemm_group_f32": [_ptr, _c_int, _ptr],
     "demf_set_compute_dtype": [_c_int],
+    "demf_set_f16_terms": [_c_int],
     "demf_get_compute_dtype": [],
     "demf_ctx_push": [_ptr],
     "demf_ctx_pop": [],

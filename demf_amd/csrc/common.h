@@ -127,4 +127,25 @@ static inline bool reserve_lds(const void* fn, int bytes, unsigned long long* do
 bool compute_bf16();
 int compute_mode();   // 0 fp32 MFMA, 1 bf16 MFMA, 2 fp32 as three bf16 terms (mlp.hip)
 
+// ---- fp32 operands as TWO fp16 terms (kernel template mode CM = 3, P = 2 planes) ------------------------------------
+// x = h + l with h = fp16(x), l = fp16(x - h): 22 significant bits when |x| lies in fp16's normal range, an absolute
+// error of 2^-25 below it.  The three products h.h', h.l', l.h' on v_mfma_f32_32x32x16_f16 (same rate as the bf16
+// instruction) leave out terms of relative weight 2^-22: half the matrix work of the six-product three-term bf16
+// split (x = h + m + l exactly, terms below 2^-24 left out), an error of the size of fp32's own accumulation noise
+// over K >= 16.  What fp16 does NOT have is range: operands must sit within [2^-1, 65504] at their LARGEST for the
+// absolute error to stay below 2^-24 of that largest value.  Activations (BatchNorm outputs) and weights do; gradient
+// operands are scaled by a power of two per slab before the split and the result is scaled back (csrc/mlp_bwd.hip).
+// Values beyond +-65504 are clamped (a finite wrong product instead of inf - inf = NaN).
+bool f16_terms();     // host: DEMF_F16_TERMS (default 1) and compute_mode() == 2
+using f16x2_v = _Float16 __attribute__((ext_vector_type(2)));
+using f16x8_v = _Float16 __attribute__((ext_vector_type(8)));
+using f32x2_v = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  f32x2_v x = {__builtin_fminf(__builtin_fmaxf(a, -65504.f), 65504.f), __builtin_fminf(__builtin_fmaxf(b, -65504.f), 65504.f)};
+  const f16x2_v h = __builtin_convertvector(x, f16x2_v);
+  hi = __builtin_bit_cast(unsigned, h);
+  const f32x2_v r = x - __builtin_convertvector(h, f32x2_v);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_v));
+}
+
 }  // namespace demf

@@ -68,6 +68,17 @@ int compute_mode() {
   return m;
 }
 bool compute_bf16() { return compute_mode() == 1; }
+// (demf_set_f16_terms; until it is called: on, or off with DEMF_F16_TERMS=0 in the environment)
+static std::atomic<int> g_f16_terms{-1};
+bool f16_terms() {
+  int on = g_f16_terms.load(std::memory_order_relaxed);
+  if (on < 0) {
+    const char* v = getenv("DEMF_F16_TERMS");
+    on = v ? (atoi(v) != 0) : 1;
+    g_f16_terms.store(on);
+  }
+  return on && compute_mode() == 2;
+}
 
 __device__ __forceinline__ bf16x4 to_bf16x4(const float4& v) {
   bf16x4 r;
@@ -1020,6 +1031,10 @@ using f32x2_t = float __attribute__((ext_vector_type(2)));
 using bf16x2_t = __bf16 __attribute__((ext_vector_type(2)));
 template <int P>
 __device__ __forceinline__ void fr_split_pair(float a, float b, unsigned (&o)[P]) {
+  if constexpr (P == 2) {       // two fp16 terms (csrc/common.h)
+    split2_f16(a, b, o[0], o[1]);
+    return;
+  }
   const f32x2_t x = {a, b};
   const bf16x2_t h = __builtin_convertvector(x, bf16x2_t);
   o[0] = __builtin_bit_cast(unsigned, h);
@@ -1033,7 +1048,11 @@ __device__ __forceinline__ void fr_split_pair(float a, float b, unsigned (&o)[P]
 }
 template <int P>
 __device__ __forceinline__ void fr_mfma(f32x16& acc, const bf16x8 (&a)[P], const bf16x8 (&b)[P]) {
-  if constexpr (P == 3) {   // six products of weight >= 2^-16, smallest first (as the CM = 2 path above)
+  if constexpr (P == 2) {   // fp16 terms: l.h', h.l', h.h'
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[1]), __builtin_bit_cast(f16x8_v, b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[0]), __builtin_bit_cast(f16x8_v, b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[0]), __builtin_bit_cast(f16x8_v, b[0]), acc, 0, 0, 0);
+  } else if constexpr (P == 3) {   // six products of weight >= 2^-16, smallest first (as the CM = 2 path above)
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
@@ -1049,7 +1068,7 @@ __device__ __forceinline__ void fr_mfma(f32x16& acc, const bf16x8 (&a)[P], const
 // input rows X, bit 1: the raw output Y (statistics and pooling still see the fp32 accumulators).  A
 // lane pair (columns 2c, 2c+1) swaps one register per row pair through DPP so that every lane stores one
 // packed dword: half the bytes AND half the store instructions of the fp32 form.
-template <int NTN, int KT, bool POOL, int CM, int ST = 0>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three-term
+template <int NTN, int KT, bool POOL, int CM, int ST = 0>   // N = 32*NTN, K = 32*KT (KT = 2); CM 1 bf16 / 2 three bf16 terms / 3 two fp16 terms
 __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   constexpr bool XB = (ST & 1) != 0, YB = (ST & 2) != 0;
   // ST bit 2 (pooled launches): the raw output is NOT stored at all - the backward of a pooled last
@@ -1065,7 +1084,7 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
   // products are taken on bf16-rounded operands, as the MFMA kernel that used to produce the rows did.
   constexpr bool XR = (ST & 8) != 0;
   static_assert(!XR || !XB, "recomputed rows have no storage type");
-  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
   constexpr int N = NTN * 32, K = KT * 32, KB = K * 2;
   constexpr int KS = K / 16;                       // MFMA K steps
   constexpr int LPR = K / 4;                       // lanes per row of the patch load (float4 each)
@@ -1357,7 +1376,7 @@ __global__ __launch_bounds__(64 * FR_NW, 1) void mlp_fwd_res_kernel(MlpArgs p) {
 constexpr int PC_K = 128, PC_KB = 256, PC_ROWS = 64;
 template <int CM, bool POOL>
 __global__ __launch_bounds__(512, 1) void mlp_fwd_pc_kernel(MlpArgs p) {
-  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
   constexpr int K = PC_K, KB = PC_KB, KS = K / 16, SR = PC_ROWS, NL = SR / 8;
   constexpr int PF = 3;                                      // slabs in flight per producer (3 x 8 float4)
   extern __shared__ __attribute__((aligned(16))) char pc_smem[];
@@ -2644,23 +2663,30 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
     if (pc_on && a.st == 0 && a.K == PC_K && (a.N == 128 || a.N == 256) && a.ldx == PC_K && a.ldy == a.N &&
         a.ldb == 0 && pc_sel && a.R >= pc_min_r && a.R % PC_ROWS == 0 && a.vec != nullptr && a.stats != nullptr &&
         (!POOL || a.ns == 16 || a.ns == 32) && (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
-      constexpr int P = BF16 == 2 ? 3 : 1;
-      const size_t bytes = (size_t)2 * P * PC_ROWS * PC_KB;
       static const int cus = [] { const char* v = getenv("DEMF_PERSIST_CUS"); return v ? atoi(v) : 240; }();
       const int nslab = a.R / PC_ROWS, halves = a.N / 128;
       int gh = cus / halves;                       // workgroups per column half
       if (gh > nslab) gh = nslab;
       if (halves == 2) gh = gh / 8 * 8 > 0 ? gh / 8 * 8 : 8;   // interleaved halves: runs of 8 blocks
-      static bool configured = false;
-      if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_pc_kernel<BF16, POOL>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-          set_error("mlp_fwd_pc: cannot reserve %zu bytes of LDS", bytes);
-          return DEMF_ELAUNCH;
-        }
-        configured = true;
-      }
-      hipLaunchKernelGGL((mlp_fwd_pc_kernel<BF16, POOL>), dim3(gh * halves), dim3(512), bytes, s, a);
+#define PCGO(CMv)                                                                                              \
+      do {                                                                                                     \
+        constexpr int P = CMv == 2 ? 3 : (CMv == 3 ? 2 : 1);                                                   \
+        const size_t bytes = (size_t)2 * P * PC_ROWS * PC_KB;                                                  \
+        static bool configured = false;                                                                        \
+        if (!configured) {                                                                                     \
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_pc_kernel<CMv, POOL>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {     \
+            set_error("mlp_fwd_pc: cannot reserve %zu bytes of LDS", bytes);                                   \
+            return DEMF_ELAUNCH;                                                                               \
+          }                                                                                                    \
+          configured = true;                                                                                   \
+        }                                                                                                      \
+        hipLaunchKernelGGL((mlp_fwd_pc_kernel<CMv, POOL>), dim3(gh * halves), dim3(512), bytes, s, a);         \
+      } while (0)
+      // (fp32 results: two fp16 terms, three products - csrc/common.h - unless DEMF_F16_TERMS=0: three bf16 terms, six)
+      if constexpr (BF16 == 2) { if (f16_terms()) PCGO(3); else PCGO(2); }
+      else PCGO(BF16);
+#undef PCGO
       return check_launch("mlp_fwd_pc");
     }
     // weight-resident, barrier-free forward (mlp_fwd_res_kernel): 64-channel inputs, N = 64 / 128
@@ -2670,7 +2696,8 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
         a.ldy == a.N && a.ldb == 0 && sel &&
         a.R >= 64 * 256 && (!POOL || ((a.ns == 16 || a.ns == 32 || a.ns == 64) && a.R % 64 == 0)) &&
         (a.fin.ss == nullptr || a.fin.ticket != nullptr)) {
-      constexpr int P = BF16 == 2 ? 3 : 1;
+      const bool h2 = BF16 == 2 && f16_terms();          // two fp16 terms instead of three bf16 ones
+      const int P = h2 ? 2 : (BF16 == 2 ? 3 : 1);
       const int ntn = a.N / 32;
       const size_t bytes = (size_t)P * a.N * 128 + (size_t)FR_NW * P * 32 * 128 + sizeof(float) * (2 * 64 + FR_NW * ntn * 64);
       const int nunit = (a.R + 63) / 64;
@@ -2679,18 +2706,23 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
       // the next batch (csrc/mlp_bwd.hip launch_fused has the measurements)
       static const int cus = env_int("DEMF_PERSIST_CUS", 240);
       if (gx > cus) gx = cus;
-#define FRGO(NTNv, STv)                                                                                     \
+#define FRGO_(NTNv, STv, CMv)                                                                               \
       do {                                                                                                  \
         static bool configured = false;                                                                     \
         if (!configured) {                                                                                  \
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_res_kernel<NTNv, 2, POOL, BF16, STv>),   \
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_res_kernel<NTNv, 2, POOL, CMv, STv>),   \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {   \
             set_error("mlp_fwd_res: cannot reserve %zu bytes of LDS", bytes);                                \
             return DEMF_ELAUNCH;                                                                             \
           }                                                                                                 \
           configured = true;                                                                                \
         }                                                                                                   \
-        hipLaunchKernelGGL((mlp_fwd_res_kernel<NTNv, 2, POOL, BF16, STv>), dim3(gx), dim3(64 * FR_NW), bytes, s, a); \
+        hipLaunchKernelGGL((mlp_fwd_res_kernel<NTNv, 2, POOL, CMv, STv>), dim3(gx), dim3(64 * FR_NW), bytes, s, a); \
+      } while (0)
+#define FRGO(NTNv, STv)                                                                                     \
+      do {                                                                                                  \
+        if constexpr (BF16 == 2) { if (h2) FRGO_(NTNv, STv, 3); else FRGO_(NTNv, STv, 2); }                \
+        else FRGO_(NTNv, STv, BF16);                                                                        \
       } while (0)
       if (a.st == 0) {
         if (ntn == 2) FRGO(2, 0); else FRGO(4, 0);
@@ -2717,6 +2749,7 @@ static int launch_gemm_t(const MlpArgs& a, hipStream_t s) {
         }
       }
 #undef FRGO
+#undef FRGO_
       return check_launch("mlp_fwd_res");
     }
   }
@@ -2872,6 +2905,11 @@ using namespace demf;
 extern "C" int demf_set_compute_dtype(int mode) {
   DEMF_REQUIRE(mode >= 0 && mode <= 2, "set_compute_dtype: 0 = fp32, 1 = bf16, 2 = fp32 as three bf16 terms");
   g_compute_mode.store(mode);
+  return DEMF_OK;
+}
+
+extern "C" int demf_set_f16_terms(int on) {
+  g_f16_terms.store(on ? 1 : 0);
   return DEMF_OK;
 }
 

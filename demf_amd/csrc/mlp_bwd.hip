@@ -66,6 +66,12 @@ struct FusedBwdArgs {
 // one fp32 value -> P bf16 planes: P = 1: rounded; P = 3: x = h + m + l exactly (csrc/mlp.hip, mode 2)
 template <int P>
 __device__ __forceinline__ void split_planes(float x, __bf16 (&o)[P]) {
+  if constexpr (P == 2) {       // two fp16 terms (csrc/common.h): the planes carry fp16 bit patterns
+    const _Float16 h = (_Float16)x;
+    o[0] = __builtin_bit_cast(__bf16, h);
+    o[1] = __builtin_bit_cast(__bf16, (_Float16)(x - (float)h));
+    return;
+  }
   o[0] = (__bf16)x;
   if constexpr (P == 3) {
     const float r = x - (float)o[0];
@@ -81,6 +87,10 @@ __device__ __forceinline__ void split_planes(float x, __bf16 (&o)[P]) {
 using f32x2 = float __attribute__((ext_vector_type(2)));
 template <int P>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&o)[P]) {
+  if constexpr (P == 2) {
+    split2_f16(a, b, o[0], o[1]);
+    return;
+  }
   const f32x2 x = {a, b};
   const bf16x2 h = __builtin_convertvector(x, bf16x2);
   o[0] = __builtin_bit_cast(unsigned, h);
@@ -105,7 +115,11 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chu
 
 template <int P>
 __device__ __forceinline__ void mfma_planes(f32x16& acc, const bf16x8 (&a)[P], const bf16x8 (&b)[P]) {
-  if constexpr (P == 3) {   // the six products of weight >= 2^-16, smallest first
+  if constexpr (P == 2) {   // fp16 terms: l.h', h.l', h.h'
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[1]), __builtin_bit_cast(f16x8_v, b[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[0]), __builtin_bit_cast(f16x8_v, b[1]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a[0]), __builtin_bit_cast(f16x8_v, b[0]), acc, 0, 0, 0);
+  } else if constexpr (P == 3) {   // the six products of weight >= 2^-16, smallest first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
@@ -115,6 +129,16 @@ __device__ __forceinline__ void mfma_planes(f32x16& acc, const bf16x8 (&a)[P], c
   } else {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
   }
+}
+
+// fp16 terms: the power of two that brings a slab's largest |dY| = m into [8, 16) - 2^11 of head-room below fp16's
+// 65504 for the slabs that follow under the same (lagging) scale, and everything down to 2^-4 of m above the
+// 2^-1 where the two-term split starts to lose bits against m itself.
+__device__ __forceinline__ float f16_scale_for(float m) {
+  int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xff) - 127;      // floor(log2 m), m > 0
+  e = 3 - e;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
 }
 
 // CW (2 or 4) consecutive elements of a row stored as fp32 or bf16 -> fp32 vector
@@ -152,7 +176,14 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   // operands, as the forward kernels compute them.
   constexpr bool XR = (ST & 4) != 0;
   static_assert(!XR || (EPI == 1 && !XB), "recomputed rows: FIRST epilogue, no storage type");
-  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
+  // CM 3: fp32 results from two fp16 terms per operand (csrc/common.h).  Activations and weights are split as they
+  // are; the gradient operand dY is first multiplied by a power of two, per workgroup and slab: the scale follows the
+  // largest |dY| this workgroup has seen in its EARLIER slabs (published by the waves in front of a barrier that is
+  // there anyway, read in the epilogue), dX is scaled back as it leaves the LDS tile, the dW accumulators when the
+  // scale changes and at the flush.  While the workgroup has seen nothing but zeros the slab's own maximum is taken
+  // first (one more barrier, normally the first slab only).
+  constexpr bool H2 = CM == 3;
   constexpr int N = NTN * 32, K = KT * 32;
   constexpr int NW = NTN * KG;              // waves per workgroup
   constexpr int NT = 64 * NW;               // threads
@@ -178,6 +209,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   float* s_vy = s_dx + RS * K;                              // 5N
   float* s_px = s_vy + 5 * N;                               // pss (2K) | pmi (2K)
   float* s_w0 = s_px + 4 * K;                               // XR: W0 (K x 4), bf16-rounded in the bf16 mode
+  float* s_mx = s_w0 + 4 * K;                               // H2: [3][8] slab maxima of |dY| per wave (2 parities + the exact pass)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
   const int lr = lane & 31, lh = lane >> 5;
@@ -287,6 +319,8 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 #pragma unroll
       for (int q = 0; q < 8; ++q) fs[c][q] = 0.f;
   }
+  float sc_cur = 1.f, run_max = 0.f;        // H2: the scale on dY, the largest |dY| of the slabs behind us
+  int par = 0;
   __syncthreads();
 
   for (; slab < nslab; slab += gridDim.x) {
@@ -296,23 +330,56 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
     {
       const bool tail = row0 + RS > p.R;                     // (uniform) rows beyond R become zeros
       unsigned pr[CW][2][P];                                 // [channel][row pair][plane]
-#pragma unroll
-      for (int e = 0; e < CW; ++e) {
+      auto dy_at = [&](int e, int j) {
         const int c = t_col + e;
         const float sc = s_vy[c], sh = s_vy[N + c], gi = s_vy[2 * N + c], va = s_vy[3 * N + c], vb = s_vy[4 * N + c];
+        const float y = ry[j][e];
+        const bool on = __builtin_fmaf(y, sc, sh) > 0.f;
+        float dz;
+        if constexpr (SPARSE) dz = (on && rarg[e] == r_slot + j) ? rdp[e] : 0.f;
+        else dz = on ? rg[j][e] : 0.f;
+        float d = __builtin_fmaf(gi, dz, __builtin_fmaf(va, y, vb));
+        if (tail && row0 + t_rl + j >= p.R) d = 0.f;
+        return d;
+      };
+      if constexpr (H2) {
+        if (run_max == 0.f) {
+          // nothing but zeros so far (normally: the first slab): this slab's own maximum first, in a pass of its own
+          float m0 = 0.f;
+#pragma unroll
+          for (int e = 0; e < CW; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m0 = __builtin_fmaxf(m0, __builtin_fabsf(dy_at(e, j)));
+          m0 = m0 == m0 ? m0 : 0.f;
+          const float wm0 = wave_allmax(m0);
+          if (lane == 0) s_mx[16 + wave] = wm0;
+          lds_barrier();
+          float mx = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[16 + w]);
+          if (mx > 0.f && mx < 3.0e38f) { run_max = mx; sc_cur = f16_scale_for(mx); }
+          lds_barrier();                                     // (the slot is rewritten by the next all-zero slab)
+        }
+      }
+      float mloc = 0.f;
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
         float dy[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float y = ry[j][e];
-          const bool on = __builtin_fmaf(y, sc, sh) > 0.f;
-          float dz;
-          if constexpr (SPARSE) dz = (on && rarg[e] == r_slot + j) ? rdp[e] : 0.f;
-          else dz = on ? rg[j][e] : 0.f;
-          dy[j] = __builtin_fmaf(gi, dz, __builtin_fmaf(va, y, vb));
-          if (tail && row0 + t_rl + j >= p.R) dy[j] = 0.f;
+          dy[j] = dy_at(e, j);
+          if constexpr (H2) {
+            mloc = __builtin_fmaxf(mloc, __builtin_fabsf(dy[j]));
+            dy[j] *= sc_cur;
+          }
         }
         split_pair<P>(dy[0], dy[1], pr[e][0]);
         split_pair<P>(dy[2], dy[3], pr[e][1]);
+      }
+      if constexpr (H2) {
+        mloc = mloc == mloc ? mloc : 0.f;                    // (a NaN gradient must not poison the scale)
+        const float wm = wave_allmax(mloc);
+        if (lane == 0) s_mx[8 * par + wave] = wm;            // read at the end of the slab, behind its barriers
       }
 #pragma unroll
       for (int q = 0; q < P; ++q) {
@@ -436,7 +503,11 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int rl = e_r0 + i * ER, row = srow0 + rl;
-        const float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
+        float4 dx = *reinterpret_cast<const float4*>(s_dx + (size_t)rl * K + 4 * e_cq);
+        if constexpr (H2) {
+          const float inv = 1.0f / sc_cur;                   // (a power of two: exact)
+          dx.x *= inv; dx.y *= inv; dx.z *= inv; dx.w *= inv;
+        }
         if (row < p.R) {
           float4 y;
           if constexpr (XR) {
@@ -493,6 +564,26 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         }
       }
     }
+    if constexpr (H2) {
+      // the scale of the NEXT slab: this slab's maximum (published in [A], in front of the barriers above) joins the
+      // running one; when the scale drops, the dW accumulators - products under the old scale - follow it
+      float mx = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[8 * par + w]);
+      par ^= 1;
+      if (mx > run_max && mx < 3.0e38f) {
+        run_max = mx;
+        const float sn = f16_scale_for(mx);
+        if (sn != sc_cur) {
+          const float f = sn / sc_cur;                       // (powers of two: exact)
+#pragma unroll
+          for (int kk = 0; kk < KTW; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dwacc[kk][r] *= f;
+          sc_cur = sn;
+        }
+      }
+    }
     // (no barrier here: the next [A] writes planes that nobody reads before the next barrier, and the dX
     // tile is only written again after it)
   }
@@ -501,13 +592,14 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   __syncthreads();
   float* s_red = reinterpret_cast<float*>(smem);             // the plane regions are free now
   if (!(p.dbg & 1)) {
+    const float inv = H2 ? 1.0f / sc_cur : 1.0f;             // (fp16 terms: the accumulators carry the dY scale)
 #pragma unroll
     for (int kk = 0; kk < KTW; ++kk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int k = 32 * (kg * KTW + kk) + lr;
-        atomicAdd(p.dW + (size_t)n * p.ldw + k, dwacc[kk][r]);
+        atomicAdd(p.dW + (size_t)n * p.ldw + k, H2 ? dwacc[kk][r] * inv : dwacc[kk][r]);
       }
   }
   // column sums: lanes with the same float4 column inside a wave first, then the 8 waves through LDS
@@ -987,9 +1079,9 @@ static int vectors_without_ticket(const BnVecFin& vf, int K, double* g12, demf_s
 
 template <int NTN, int KT, int KG, bool SPARSE, int CM, int EPI, int ST = 0>
 static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
-  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
   constexpr int N = NTN * 32, K = KT * 32, NW = NTN * KG;
-  const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K + 4 * K);
+  const size_t bytes = (size_t)NTN * P * 2 * 2048 + (size_t)P * K * 64 + sizeof(float) * (32 * K + 5 * N + 4 * K + 4 * K + 24);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_fused_kernel<NTN, KT, KG, SPARSE, CM, EPI, ST>),
@@ -1018,6 +1110,13 @@ static int launch_fused(const FusedBwdArgs& a, hipStream_t s) {
 }  // namespace demf
 
 using namespace demf;
+
+// A/B switch: DEMF_F16_TERMS_BWD=0 keeps the fused backward kernels on three bf16 terms while the forward kernels
+// take two fp16 terms
+static bool fused_h2_on() {
+  static const int on = [] { const char* v = getenv("DEMF_F16_TERMS_BWD"); return v ? atoi(v) : 1; }();
+  return on != 0;
+}
 
 static int fused_supported(int R, int N, int K, int ns, int sparse, int first) {
   const int cm = compute_mode();
@@ -1064,9 +1163,11 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
               store_flags, N, K, (int)sparse, (int)first);
     return DEMF_EUNSUPPORTED;
   }
+  const bool h2 = f16_terms() && fused_h2_on();
 #define FGO(NTNv, KTv, KGv, SPv, EPv)                                                                                     \
   do {                                                                                                                   \
-    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s); \
+    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s)                                            \
+                            : (h2 ? launch_fused<NTNv, KTv, KGv, SPv, 3, EPv>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, EPv>(a, s)); \
     return rc_ ? rc_ : vectors_without_ticket(a.vfin, K, g12_prev, stream);                                              \
   } while (0)
   if (first) { FGO(2, 2, 2, false, 1); }
@@ -1106,9 +1207,11 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
+  const bool h2 = f16_terms() && fused_h2_on();
 #define FGO(NTNv, KTv, KGv, SPv)                                                                                          \
   do {                                                                                                                   \
-    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, 0>(a, s); \
+    const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s)                                             \
+                            : (h2 ? launch_fused<NTNv, KTv, KGv, SPv, 3, 0>(a, s) : launch_fused<NTNv, KTv, KGv, SPv, 2, 0>(a, s)); \
     if (rc_ || c0 + Kc < Ktot) return rc_;       /* (no ticket: the vectors of ALL channels behind the last chunk) */    \
     return vectors_without_ticket(a.vfin, Ktot, g12_prev, stream);                                                       \
   } while (0)
@@ -1210,5 +1313,6 @@ extern "C" int demf_mlp_bwd_fused_x4(int R, int N, int K, const float* G, const 
   a.ldk = K; a.ldw = K; a.fld = K; a.fc0 = 0;
   hipStream_t s = (hipStream_t)stream;
   if (compute_mode() == 1) return launch_fused<2, 2, 2, false, 1, 1, 4>(a, s);
+  if (f16_terms() && fused_h2_on()) return launch_fused<2, 2, 2, false, 3, 1, 4>(a, s);
   return launch_fused<2, 2, 2, false, 2, 1, 4>(a, s);
 }

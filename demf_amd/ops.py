@@ -215,7 +215,7 @@ def zeros(shape, device):
 _COMPUTE_DTYPE = "f32"
 
 
-_COMPUTE_MODES = {"f32_native": 0, "bf16": 1, "f32x3": 2}
+_COMPUTE_MODES = {"f32_native": 0, "bf16": 1, "f32x3": 2, "f32h2": 2}
 # the library's mode (demf_set_compute_dtype); its initial value follows the same environment switch
 _COMPUTE_MODE = 0 if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else 2
 
@@ -230,8 +230,12 @@ def set_compute_dtype(name):
     bf16: the dense MFMA kernels - shared-MLP GEMMs forward / input-gradient / weight-gradient, the
     decoder layer's GEMMs, the linear heads - round their operands to bf16 on the way into LDS and
     run v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+    f32h2 (what "f32" selects unless DEMF_F16_TERMS=0): as f32x3, but the kernels that have the form (the SA
+    stacks' forward and fused backward kernels) take every operand as TWO fp16 terms and three products - half the
+    matrix work at ~2^-22 relative, the size of fp32's own accumulation noise (csrc/common.h); "f32x3" switches
+    that form off (pure three-term arithmetic: the mode in which two kernel forms of one layer agree bit for bit).
     Tensors in memory, BN statistics, indices, sampling and losses stay fp32 in every mode.
-    Process-wide (demf_set_compute_dtype)."""
+    Process-wide (demf_set_compute_dtype, demf_set_f16_terms)."""
     global _COMPUTE_DTYPE
     if name == "f32":
         mode = 0 if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else 2
@@ -240,6 +244,9 @@ def set_compute_dtype(name):
     else:
         raise ValueError("compute dtype must be 'f32' or one of %s" % sorted(_COMPUTE_MODES))
     _ffi.call("demf_set_compute_dtype", mode)
+    if mode == 2:
+        h2 = name == "f32h2" or (name == "f32" and int(os.environ.get("DEMF_F16_TERMS", "1") or 0) != 0)
+        _ffi.call("demf_set_f16_terms", int(h2))
     global _COMPUTE_MODE
     _COMPUTE_DTYPE, _COMPUTE_MODE = name, mode
 

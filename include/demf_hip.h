@@ -859,6 +859,11 @@ DEMF_INTERNAL int demf_gemm_group_f32(const demf_gemm_desc* descs, int n, demf_s
  * modes passes the mode with the call instead (demf_ctx below).  demf_get_compute_dtype: the mode a dense
  * call made by this thread right now would run in.                                                 */
 DEMF_INTERNAL int demf_set_compute_dtype(int mode);
+/* Mode 2 only: kernels that have the form take every fp32 operand as TWO fp16 terms (x = h + l, three products on
+ * v_mfma_f32_32x32x16_f16; gradient operands scaled by a power of two per slab) instead of three bf16 terms (six
+ * products): half the matrix work, ~2^-22 relative instead of 2^-24 - the size of fp32's own accumulation noise.
+ * Process default: on (off with DEMF_F16_TERMS=0 in the environment).  csrc/common.h. */
+DEMF_INTERNAL int demf_set_f16_terms(int on);
 DEMF_INTERNAL int demf_get_compute_dtype(void);
 
 /* The compute mode as a PARAMETER.  compute_mode: 0 / 1 / 2 as above, -1 = the process default; reserved

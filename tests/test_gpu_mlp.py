@@ -309,7 +309,16 @@ def test_pooled_forward_with_bn_bookkeeping_equals_the_separate_launches(R, K, N
     extremum that the sign of gamma selects) against demf_mlp_gemm_fwd_pool + demf_bn_finalize:
     same Y, scale / shift, mean / invstd, running statistics, counters left zeroed, and the selected
     value / row offset = the max (gamma >= 0) or min (gamma < 0) of the 4-output form."""
-    from demf_amd import _ffi
+    from demf_amd import _ffi, ops
+    # (the two forms run different kernels: bit equality needs one arithmetic - three bf16 terms everywhere)
+    ops.set_compute_dtype("f32x3")
+    try:
+        _pooled_forward_vs_separate(R, K, N, ns, _ffi)
+    finally:
+        ops.set_compute_dtype("f32")
+
+
+def _pooled_forward_vs_separate(R, K, N, ns, _ffi):
     g = torch.Generator().manual_seed(R + N)
     x = torch.randn(R, K, generator=g).cuda()
     w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()

@@ -132,6 +132,35 @@ def test_fused_backward_vs_fp64_reference(Rp, ns, ld, chans, xgrad):
         assert rel <= 5e-3, (i, rel)
 
 
+@pytest.mark.parametrize("case", [0, 2, 3, 4])
+def test_two_fp16_terms_against_three_bf16_terms(case):
+    """The default f32 mode runs the SA stacks' forward and fused backward kernels on TWO fp16 terms per operand
+    (three products, the gradient operand scaled by a power of two per slab: csrc/common.h, csrc/mlp_bwd.hip) where
+    "f32x3" runs three bf16 terms (six products).  Same inputs, both modes: outputs within 2e-6 of scale, every
+    gradient within 2e-5 relative L2 (measured 3e-7 ... 1.5e-6: the size of fp32's own accumulation noise), and
+    both equally far from fp64 autograd.  Gradient magnitudes of 1e-7 (a loss averaged over many rows) must not
+    matter: the upstream gradient is also run scaled by 2^-20."""
+    from demf_amd import ops
+    Rp, ns, ld, chans, xgrad = CASES[case]
+    x, layers, go = _make(Rp, ns, ld, chans, seed=4000 + case)
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    try:
+        for gscale in (1.0, 2.0 ** -20):
+            ops.set_compute_dtype("f32x3")
+            out3, g3 = _run(x, layers, go * gscale, ns, xgrad)
+            ops.set_compute_dtype("f32h2")
+            out2, g2 = _run(x, layers, go * gscale, ns, xgrad)
+            scale = float(out3.abs().max())
+            assert float((out2 - out3).abs().max()) <= 2e-6 * scale
+            worst = max(rel(a, b) for a, b in zip(g2, g3))
+            print("case %d, upstream gradient x %g: worst gradient rel-L2 two fp16 terms vs three bf16 terms %.2e"
+                  % (case, gscale, worst))
+            assert worst <= 2e-5, worst
+            assert all(bool(torch.isfinite(g).all()) for g in g2)
+    finally:
+        ops.set_compute_dtype("f32")
+
+
 def test_bf16_row_storage_of_the_sa1_stack():
     """bf16 compute mode (BASELINE configs[3]): an SA1-shaped stack keeps the raw outputs of layers 1 / 2
     and the gradient between their backwards as bf16 ROWS in HBM (demf_mlp_gemm_fwd_bn_st /
@@ -191,7 +220,9 @@ def test_pooled_last_layer_without_its_output(Rp, mode):
     layers[2][1][5] = -0.8
     layers[2][1][9] = 0.0
     layers[2][1][77] = 0.0
-    ops.set_compute_dtype(mode)
+    # (the forms are compared with each other: one arithmetic for all of them - in the default f32 mode the kernels that
+    #  have a two-fp16-term form and those that do not differ in the last bits, and a ReLU / max-pool near-tie may flip)
+    ops.set_compute_dtype("f32x3" if mode == "f32" else mode)
     calls = []
     orig = _ffi.call
 
