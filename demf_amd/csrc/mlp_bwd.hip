@@ -179,10 +179,8 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
   // CM 3: fp32 results from two fp16 terms per operand (csrc/common.h).  Activations and weights are split as they
   // are; the gradient operand dY is first multiplied by a power of two, per workgroup and slab: the scale follows the
-  // largest |dY| this workgroup has seen in its EARLIER slabs (published by the waves in front of a barrier that is
-  // there anyway, read in the epilogue), dX is scaled back as it leaves the LDS tile, the dW accumulators when the
-  // scale changes and at the flush.  While the workgroup has seen nothing but zeros the slab's own maximum is taken
-  // first (one more barrier, normally the first slab only).
+  // largest |dY| this workgroup has met so far, this slab included ([A] below); dX is scaled back as it leaves the
+  // LDS tile, the dW accumulators when the scale changes and at the flush.
   constexpr bool H2 = CM == 3;
   constexpr int N = NTN * 32, K = KT * 32;
   constexpr int NW = NTN * KG;              // waves per workgroup
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
   float* s_vy = s_dx + RS * K;                              // 5N
   float* s_px = s_vy + 5 * N;                               // pss (2K) | pmi (2K)
   float* s_w0 = s_px + 4 * K;                               // XR: W0 (K x 4), bf16-rounded in the bf16 mode
-  float* s_mx = s_w0 + 4 * K;                               // H2: [3][8] slab maxima of |dY| per wave (2 parities + the exact pass)
+  float* s_mx = s_w0 + 4 * K;                               // H2: [2][8] slab maxima of |dY| per wave (alternating rows)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches below
   const int lr = lane & 31, lh = lane >> 5;
@@ -343,43 +341,50 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         return d;
       };
       if constexpr (H2) {
-        if (run_max == 0.f) {
-          // nothing but zeros so far (normally: the first slab): this slab's own maximum first, in a pass of its own
-          float m0 = 0.f;
+        // The scale of this slab: the largest |dY| this workgroup has met up to and INCLUDING this slab brought into
+        // [8, 16) - taken in a pass of its own over the lane's patch (the values are formed again below; keeping them
+        // across the barrier would cost 16 registers the 256-column form does not have) and one more barrier per slab.
+        // A scale that lagged one slab behind (no barrier) was tried first and is wrong: a workgroup's first slabs may
+        // hold nothing but the BatchNorm-backward background terms, 1e5 x below the first row that carries a real
+        // gradient - beyond the 2^11 of head-room, the clamp in split2_f16 then returned 10-20 % errors in SA1's first
+        // weight gradient (tests/test_gpu_parity_full.py).  The scale never rises again: the dW accumulators hold
+        // products of the earlier slabs, and rows far below the running maximum do not need its last bits.
+        float m0 = 0.f;
 #pragma unroll
-          for (int e = 0; e < CW; ++e)
+        for (int e = 0; e < CW; ++e)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m0 = __builtin_fmaxf(m0, __builtin_fabsf(dy_at(e, j)));
-          m0 = m0 == m0 ? m0 : 0.f;
-          const float wm0 = wave_allmax(m0);
-          if (lane == 0) s_mx[16 + wave] = wm0;
-          lds_barrier();
-          float mx = 0.f;
+          for (int j = 0; j < 4; ++j) m0 = __builtin_fmaxf(m0, __builtin_fabsf(dy_at(e, j)));
+        m0 = m0 == m0 ? m0 : 0.f;                            // (a NaN gradient must not poison the scale)
+        const float wm0 = wave_allmax(m0);
+        if (lane == 0) s_mx[8 * par + wave] = wm0;
+        lds_barrier();
+        float mx = 0.f;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[16 + w]);
-          if (mx > 0.f && mx < 3.0e38f) { run_max = mx; sc_cur = f16_scale_for(mx); }
-          lds_barrier();                                     // (the slot is rewritten by the next all-zero slab)
+        for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[8 * par + w]);
+        par ^= 1;                                            // (the next slab's maxima go to the other row)
+        if (mx > run_max && mx < 3.0e38f) {
+          run_max = mx;
+          const float sn = f16_scale_for(mx);
+          if (sn != sc_cur) {
+            const float f = sn / sc_cur;                     // (powers of two: exact; f < 1)
+#pragma unroll
+            for (int kk = 0; kk < KTW; ++kk)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) dwacc[kk][r] *= f;
+            sc_cur = sn;
+          }
         }
       }
-      float mloc = 0.f;
 #pragma unroll
       for (int e = 0; e < CW; ++e) {
         float dy[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           dy[j] = dy_at(e, j);
-          if constexpr (H2) {
-            mloc = __builtin_fmaxf(mloc, __builtin_fabsf(dy[j]));
-            dy[j] *= sc_cur;
-          }
+          if constexpr (H2) dy[j] *= sc_cur;
         }
         split_pair<P>(dy[0], dy[1], pr[e][0]);
         split_pair<P>(dy[2], dy[3], pr[e][1]);
-      }
-      if constexpr (H2) {
-        mloc = mloc == mloc ? mloc : 0.f;                    // (a NaN gradient must not poison the scale)
-        const float wm = wave_allmax(mloc);
-        if (lane == 0) s_mx[8 * par + wave] = wm;            // read at the end of the slab, behind its barriers
       }
 #pragma unroll
       for (int q = 0; q < P; ++q) {
@@ -561,26 +566,6 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
             }
             if (e_cq == 0) { fcx[0] += x.x; fcx[1] += x.y; fcx[2] += x.z; fcx[3] += x.w; }
           }
-        }
-      }
-    }
-    if constexpr (H2) {
-      // the scale of the NEXT slab: this slab's maximum (published in [A], in front of the barriers above) joins the
-      // running one; when the scale drops, the dW accumulators - products under the old scale - follow it
-      float mx = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[8 * par + w]);
-      par ^= 1;
-      if (mx > run_max && mx < 3.0e38f) {
-        run_max = mx;
-        const float sn = f16_scale_for(mx);
-        if (sn != sc_cur) {
-          const float f = sn / sc_cur;                       // (powers of two: exact)
-#pragma unroll
-          for (int kk = 0; kk < KTW; ++kk)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dwacc[kk][r] *= f;
-          sc_cur = sn;
         }
       }
     }
@@ -1163,7 +1148,10 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
               store_flags, N, K, (int)sparse, (int)first);
     return DEMF_EUNSUPPORTED;
   }
-  const bool h2 = f16_terms() && fused_h2_on();
+  // two fp16 terms: the (256, 128) form only - measured 141.6 -> 115.4 us per launch there, 85.5 -> 82.8 on (128, 128)
+  // and 232 -> 229 on SA1's (64, 64) (their slabs are shorter: the extra barrier and the second pass over the patch
+  // for the scale eat the saving), which therefore stay on three bf16 terms
+  const bool h2 = f16_terms() && fused_h2_on() && N == 256 && K == 128;
 #define FGO(NTNv, KTv, KGv, SPv, EPv)                                                                                     \
   do {                                                                                                                   \
     const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s)                                            \
@@ -1207,7 +1195,7 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
-  const bool h2 = f16_terms() && fused_h2_on();
+  const bool h2 = f16_terms() && fused_h2_on() && N == 256 && Kc == 128;
 #define FGO(NTNv, KTv, KGv, SPv)                                                                                          \
   do {                                                                                                                   \
     const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s)                                             \
@@ -1313,6 +1301,5 @@ extern "C" int demf_mlp_bwd_fused_x4(int R, int N, int K, const float* G, const 
   a.ldk = K; a.ldw = K; a.fld = K; a.fc0 = 0;
   hipStream_t s = (hipStream_t)stream;
   if (compute_mode() == 1) return launch_fused<2, 2, 2, false, 1, 1, 4>(a, s);
-  if (f16_terms() && fused_h2_on()) return launch_fused<2, 2, 2, false, 3, 1, 4>(a, s);
   return launch_fused<2, 2, 2, false, 2, 1, 4>(a, s);
 }

@@ -26,6 +26,10 @@ SETTINGS = [
     {"DEMF_FPS_PAIR": "0", "DEMF_FPS_PRUNE": "0"},
     {"DEMF_GRAPH_UPDATE": "0", "_graph": "1"},     # captured step with the eager update behind it
     {"_graph": "1"},                               # captured step, update inside the graph
+    {"DEMF_F16_TERMS": "0"},                       # three bf16 terms everywhere (no two-fp16-term forms)
+    {"DEMF_F16_TERMS_BWD": "0"},                   #   ... in the fused backward kernels only
+    {"DEMF_GF_RECOMPUTE": "0", "DEMF_GF_WACC": "0", "DEMF_GF_FIN": "0", "DEMF_ACC_REPL": "0"},   # round-6 forms off
+    {"DEMF_INVERT_SPLIT": "2"},
 ]
 
 
@@ -48,7 +52,10 @@ def test_every_switch_value_gives_the_same_step():
     for extra in SETTINGS[1:]:
         got = _run(extra)
         assert got["finite"], extra
-        assert got["loss"] == pytest.approx(base["loss"], rel=2e-3), (extra, got, base)
+        # (the loss is taken AFTER an update: it inherits the gradients' sensitivity below.  2e-3 held while every form
+        #  rounded its operands alike; the two-fp16-term kernels round at 2^-22 and scale the gradient operand per
+        #  workgroup, so even the CU count moves the last bits: 3.6e-3 seen, 6e-3 allowed)
+        assert got["loss"] == pytest.approx(base["loss"], rel=6e-3), (extra, got, base)
         # (untrained weights: near-tie flips move gradient norms by per cent between ANY two kernel forms - see
         # tests/parity_tools.py; a wrong kernel form moves them by tens of per cent or makes them non-finite)
         assert got["grad_norm"] == pytest.approx(base["grad_norm"], rel=8e-2), (extra, got, base)
