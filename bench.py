@@ -336,8 +336,10 @@ def main():
                     help="compute mode of the dense MFMA kernels.  f32 = the reference's precision "
                          "(headline, BASELINE configs[2]): fp32 results; the shared-MLP GEMMs split each "
                          "fp32 operand exactly into three bf16 terms and run the six significant "
-                         "products on the bf16 MFMA (= f32x3; DEMF_F32_NATIVE=1 or f32_native: the "
-                         "fp32 MFMA itself).  bf16 = configs[3] (operands rounded to bf16, fp32 "
+                         "products on the bf16 MFMA; the SA stacks' forward kernels and their (256,128) backward "
+                         "take TWO fp16 terms and three products instead (2^-22 per operand, gradient operand "
+                         "scaled per slab; f32x3 or DEMF_F16_TERMS=0: three bf16 terms everywhere; "
+                         "DEMF_F32_NATIVE=1 or f32_native: the fp32 MFMA itself).  bf16 = configs[3] (operands rounded to bf16, fp32 "
                          "accumulate, fp32 storage / statistics / indices / losses)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -572,6 +574,9 @@ def main():
                 ops.set_compute_dtype(args.dtype)
         if args.dtype != "bf16":
             secondary["bf16_ms_per_step"] = other("bf16", args.msda_points)
+        if args.dtype == "f32":
+            # the same step with the two-fp16-term kernel forms off (three bf16 terms everywhere, round 5's arithmetic)
+            secondary["f32x3_ms_per_step"] = other("f32x3", args.msda_points)
         if args.msda_points != 4:
             secondary["p4_ms_per_step"] = other(args.dtype, 4)
         oc = "clustered" if args.cloud == "uniform" else "uniform"
