@@ -697,14 +697,21 @@ __device__ __forceinline__ int sw128(int row, int chunk) { return row * 128 + ((
 // the three-term split the transform + fold + epilogue VALU work is as long as the MFMA work).
 template <int CM>
 __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
-  constexpr int P = CM == 2 ? 3 : 1;
+  constexpr int P = CM == 2 ? 3 : (CM == 3 ? 2 : 1);
+  // CM 3: two fp16 terms per operand (csrc/common.h).  The activations (A, both orientations: A.M and the Gram matrix)
+  // and W are split as they are.  The two operands that carry the gradient's magnitude get a power-of-two scale each
+  // and an accumulator each: M = W^T diag(a) W (scale from its largest entry, once per workgroup) and the slab's sparse
+  // gi*dZ entries (scale from the slab's largest entry, taken ONE SLAB AHEAD from the prefetched words, so no barrier
+  // is added); the two partial dA tiles are scaled back and added before they meet in the LDS tile.
+  constexpr bool H2 = CM == 3;
   constexpr int N = PB_N, K = PB_K, NTN = N / 32, RS = PB_RS, NT = 512, NW = 8;
   constexpr int QK = K / 4;                 // float4 per dX row (16): thread -> (row = tid / 16 (+32), col4 = tid % 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_vy = reinterpret_cast<float*>(smem);              // 5N
   float* s_px = s_vy + 5 * N;                                // pss (2K) | pmi (2K)
   float* s_v = s_px + 4 * K;                                 // v = b^T W (K)
-  char* s_base = reinterpret_cast<char*>(s_v + K);           // everything below is also prologue / flush scratch
+  float* s_mx = s_v + K;                                     // H2: [4][8] per-wave maxima (M | gi*dZ of alternating slabs)
+  char* s_base = reinterpret_cast<char*>(s_mx + 32);         // everything below is also prologue / flush scratch
   char* s_dz = s_base;                                       // [NTN][P][64 rows x 64 B]   gi*dZ, [row][channel]
   char* s_ar = s_dz + NTN * P * 4096;                        // [2 k-halves][P][64 rows x 64 B]  A, [row][k]
   char* s_at = s_ar + 2 * P * 4096;                          // [P][64 k x 128 B]          A, [k][row]
@@ -741,15 +748,31 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) s_m[k * PB_LDM + j0 + e] = m[e];
     if ((tid & 7) == 0) s_v[k] = vk;
+    if constexpr (H2) {
+      float mm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mm = __builtin_fmaxf(mm, __builtin_fabsf(m[e]));
+      mm = mm == mm ? mm : 0.f;
+      const float wmm = wave_allmax(mm);
+      if (lane == 0) s_mx[wave] = wmm;
+    }
   }
   __syncthreads();
+  float sM = 1.f;                                            // H2: the scale on M
+  if constexpr (H2) {
+    float mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[w]);
+    if (mx > 0.f && mx < 3.0e38f) sM = f16_scale_for(mx);
+  }
   // B fragments, resident for the whole launch.  A.M: B^T[col j][red k] = M[k][j], this wave's k half (two steps)
   bf16x8 mf[2][P];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     __bf16 t[8][P];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split_planes<P>(s_m[(32 * dkh + 16 * u + 8 * lh + e) * PB_LDM + 32 * dct + lr], t[e]);
+    for (int e = 0; e < 8; ++e)
+      split_planes<P>(s_m[(32 * dkh + 16 * u + 8 * lh + e) * PB_LDM + 32 * dct + lr] * (H2 ? sM : 1.f), t[e]);
 #pragma unroll
     for (int q = 0; q < P; ++q)
 #pragma unroll
@@ -799,7 +822,25 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
   const int nslab = p.R / RS;
   int slab = blockIdx.x;
   if (slab < nslab) fetch(slab);
+  // H2: the largest |gi*dZ| entry of a slab, from the words fetch() has just requested for it
+  auto dz_max_to = [&](float* dst) {
+    float d = __builtin_fmaf(r_y, s_vy[s_c], s_vy[N + s_c]) > 0.f ? __builtin_fabsf(s_vy[2 * N + s_c] * r_dp) : 0.f;
+    d = d == d ? d : 0.f;
+    const float wm = wave_allmax(d);
+    if (lane == 0) dst[wave] = wm;
+  };
+  auto dz_scale_from = [&](const float* src) {
+    float mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, src[w]);
+    return (mx > 0.f && mx < 3.0e38f) ? f16_scale_for(mx) : 1.f;
+  };
+  float sD = 1.f;                                            // H2: the scale on this slab's gi*dZ entries
+  if constexpr (H2) {
+    if (slab < nslab) dz_max_to(s_mx + 8);
+  }
   __syncthreads();
+  if constexpr (H2) sD = dz_scale_from(s_mx + 8);
 
   for (int it = 0; slab < nslab; slab += gridDim.x, ++it) {
     const int row0 = slab * RS;
@@ -838,7 +879,7 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
     const float dzv = __builtin_fmaf(r_y, s_vy[s_c], s_vy[N + s_c]) > 0.f ? s_vy[2 * N + s_c] * r_dp : 0.f;
     if (s_part == 0) {
       __bf16 t[P];
-      split_planes<P>(dzv, t);
+      split_planes<P>(H2 ? dzv * sD : dzv, t);
 #pragma unroll
       for (int q = 0; q < P; ++q)
         *reinterpret_cast<__bf16*>(s_dz + ((s_c >> 5) * P + q) * 4096 + swz(e_row, (s_c & 31) >> 3) + 2 * (s_c & 7)) = t[q];
@@ -872,12 +913,23 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
           a[q] = *reinterpret_cast<const bf16x8*>(s_ar + (dkh * P + q) * 4096 + swz(32 * drt + lr, 2 * u + lh));
         mfma_planes<P>(pa, a, mf[u]);
       }
+      f32x16 pd;                                             // H2: the (gi*dZ).W partial, under its own scale
+      if constexpr (H2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pd[r] = 0.f;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {                          // (gi*dZ).W: channel half dkh = slices 2dkh, 2dkh + 1
 #pragma unroll
         for (int q = 0; q < P; ++q)
           a[q] = *reinterpret_cast<const bf16x8*>(s_dz + ((2 * dkh + (u >> 1)) * P + q) * 4096 + swz(32 * drt + lr, 2 * (u & 1) + lh));
-        mfma_planes<P>(pa, a, wf[u]);
+        if constexpr (H2) mfma_planes<P>(pd, a, wf[u]);
+        else mfma_planes<P>(pa, a, wf[u]);
+      }
+      if constexpr (H2) {
+        const float iM = 1.0f / sM, iD = 1.0f / sD;          // (powers of two: exact)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pa[r] = __builtin_fmaf(pd[r], iD, pa[r] * iM);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {                          // Gram tile: slab rows 32 * gs + 16u .. + 15
@@ -889,6 +941,11 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
         }
         mfma_planes<P>(gacc, ga, gb);
       }
+    }
+    const bool has_next = slab + (int)gridDim.x < nslab;
+    if constexpr (H2) {
+      // the next slab's entries have arrived underneath the MFMA phase: their maximum, in front of the fold barriers
+      if (has_next) dz_max_to(s_mx + 16 + 8 * (it & 1));
     }
     // the two partial tiles of a (row half, column half) meet in the fp32 LDS tile in two ordered rounds: in
     // round j wave (.., dkh) owns row chunk (dkh + j) % 2 = 8 accumulator registers
@@ -908,6 +965,9 @@ __global__ __launch_bounds__(512, 1) void mlp_bwd_pool_kernel(PoolBwdArgs p) {
         }
       }
       lds_barrier();
+    }
+    if constexpr (H2) {
+      if (has_next) sD = dz_scale_from(s_mx + 16 + 8 * (it & 1));
     }
     // wipe this slab's entries: the gi*dZ planes are all-zero again (nobody reads them before the next barrier)
     if (s_part == 0) {
@@ -1254,8 +1314,9 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int gx = pool_bwd_grid(R);
-  const int P = cm == 2 ? 3 : 1;
-  const size_t head = sizeof(float) * (5 * PB_N + 4 * PB_K + PB_K);                           // vectors
+  const bool h2 = cm == 2 && f16_terms() && fused_h2_on();
+  const int P = h2 ? 2 : (cm == 2 ? 3 : 1);
+  const size_t head = sizeof(float) * (5 * PB_N + 4 * PB_K + PB_K + 32);                      // vectors (+ the H2 maxima)
   const size_t main = (size_t)(PB_N / 32) * P * 4096 + 2 * P * 4096 + (size_t)P * 8192 +       // planes
                       sizeof(float) * (2 * PB_RS * PB_LDA + PB_RS * PB_K);                     // 2 x fp32 rows + dA tile
   const size_t scratch = sizeof(float) * ((size_t)PB_N * PB_K + (size_t)PB_K * PB_LDM);      // prologue: W + M
@@ -1264,17 +1325,20 @@ extern "C" int demf_mlp_bwd_pool(int R, int N, int K, int ns, const float* dP, c
   size_t body = main > scratch ? main : scratch;
   if (body < fold) body = fold;
   const size_t bytes = head + body;
-  static bool configured[3] = {false, false, false};
-  if (!configured[cm]) {
-    const void* fn = cm == 1 ? reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<1>)
-                             : reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<2>);
+  static bool configured[4] = {false, false, false, false};
+  const int var = h2 ? 3 : cm;
+  if (!configured[var]) {
+    const void* fn = var == 1 ? reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<1>)
+                   : (var == 3 ? reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<3>)
+                               : reinterpret_cast<const void*>(&mlp_bwd_pool_kernel<2>));
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
       set_error("mlp_bwd_pool: cannot reserve %zu bytes of LDS", bytes);
       return DEMF_ELAUNCH;
     }
-    configured[cm] = true;
+    configured[var] = true;
   }
-  if (cm == 1) hipLaunchKernelGGL(mlp_bwd_pool_kernel<1>, dim3(gx), dim3(512), bytes, s, a);
+  if (var == 1) hipLaunchKernelGGL(mlp_bwd_pool_kernel<1>, dim3(gx), dim3(512), bytes, s, a);
+  else if (var == 3) hipLaunchKernelGGL(mlp_bwd_pool_kernel<3>, dim3(gx), dim3(512), bytes, s, a);
   else hipLaunchKernelGGL(mlp_bwd_pool_kernel<2>, dim3(gx), dim3(512), bytes, s, a);
   if (int e = check_launch("mlp_bwd_pool")) return e;
   hipLaunchKernelGGL(pool_bwd_finish_k, dim3((PB_NACC + 31) / 32), dim3(256), 0, s, gx, workspace, dW);
