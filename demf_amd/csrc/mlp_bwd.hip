@@ -317,8 +317,38 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
 #pragma unroll
       for (int q = 0; q < 8; ++q) fs[c][q] = 0.f;
   }
-  float sc_cur = 1.f, run_max = 0.f;        // H2: the scale on dY, the largest |dY| of the slabs behind us
+  float sc_cur = 1.f, run_max = 0.f;        // H2: the scale on dY, the largest |dY| met so far
   int par = 0;
+  // dY of element (channel e, row j) of the lane's patch, from the rows fetch() holds in registers
+  auto dy_at = [&](int e, int j, int row0v, bool tailv) {
+    const int c = t_col + e;
+    const float sc = s_vy[c], sh = s_vy[N + c], gi = s_vy[2 * N + c], va = s_vy[3 * N + c], vb = s_vy[4 * N + c];
+    const float y = ry[j][e];
+    const bool on = __builtin_fmaf(y, sc, sh) > 0.f;
+    float dz;
+    if constexpr (SPARSE) dz = (on && rarg[e] == r_slot + j) ? rdp[e] : 0.f;
+    else dz = on ? rg[j][e] : 0.f;
+    float d = __builtin_fmaf(gi, dz, __builtin_fmaf(va, y, vb));
+    if (tailv && row0v + t_rl + j >= p.R) d = 0.f;
+    return d;
+  };
+  // H2: the largest |dY| of the slab whose rows are in the registers, one value per wave into row `to` of s_mx
+  auto publish_max = [&](int row0v, int to) {
+    const bool tailv = row0v + RS > p.R;
+    float m0 = 0.f;
+#pragma unroll
+    for (int e = 0; e < CW; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m0 = __builtin_fmaxf(m0, __builtin_fabsf(dy_at(e, j, row0v, tailv)));
+    m0 = m0 == m0 ? m0 : 0.f;                                // (a NaN gradient must not poison the scale)
+    const float wm0 = wave_allmax(m0);
+    if (lane == 0) s_mx[8 * to + wave] = wm0;
+  };
+  if constexpr (H2) {
+    static_assert(!H2 || PREF, "the scale is taken from the prefetched rows");
+    __syncthreads();                                         // (the vectors in s_vy)
+    if (slab < nslab) publish_max(slab * RS, 0);
+  }
   __syncthreads();
 
   for (; slab < nslab; slab += gridDim.x) {
@@ -328,36 +358,16 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
     {
       const bool tail = row0 + RS > p.R;                     // (uniform) rows beyond R become zeros
       unsigned pr[CW][2][P];                                 // [channel][row pair][plane]
-      auto dy_at = [&](int e, int j) {
-        const int c = t_col + e;
-        const float sc = s_vy[c], sh = s_vy[N + c], gi = s_vy[2 * N + c], va = s_vy[3 * N + c], vb = s_vy[4 * N + c];
-        const float y = ry[j][e];
-        const bool on = __builtin_fmaf(y, sc, sh) > 0.f;
-        float dz;
-        if constexpr (SPARSE) dz = (on && rarg[e] == r_slot + j) ? rdp[e] : 0.f;
-        else dz = on ? rg[j][e] : 0.f;
-        float d = __builtin_fmaf(gi, dz, __builtin_fmaf(va, y, vb));
-        if (tail && row0 + t_rl + j >= p.R) d = 0.f;
-        return d;
-      };
       if constexpr (H2) {
         // The scale of this slab: the largest |dY| this workgroup has met up to and INCLUDING this slab brought into
-        // [8, 16) - taken in a pass of its own over the lane's patch (the values are formed again below; keeping them
-        // across the barrier would cost 16 registers the 256-column form does not have) and one more barrier per slab.
-        // A scale that lagged one slab behind (no barrier) was tried first and is wrong: a workgroup's first slabs may
-        // hold nothing but the BatchNorm-backward background terms, 1e5 x below the first row that carries a real
-        // gradient - beyond the 2^11 of head-room, the clamp in split2_f16 then returned 10-20 % errors in SA1's first
-        // weight gradient (tests/test_gpu_parity_full.py).  The scale never rises again: the dW accumulators hold
-        // products of the earlier slabs, and rows far below the running maximum do not need its last bits.
-        float m0 = 0.f;
-#pragma unroll
-        for (int e = 0; e < CW; ++e)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) m0 = __builtin_fmaxf(m0, __builtin_fabsf(dy_at(e, j)));
-        m0 = m0 == m0 ? m0 : 0.f;                            // (a NaN gradient must not poison the scale)
-        const float wm0 = wave_allmax(m0);
-        if (lane == 0) s_mx[8 * par + wave] = wm0;
-        lds_barrier();
+        // [8, 16).  The slab's own maximum was taken ONE SLAB AHEAD - at the end of the previous slab, from the rows
+        // the prefetch had delivered by then, published in front of that slab's fold barriers (the first slab's: in
+        // front of the loop) - so neither a barrier nor a second pass over the patch stands in front of the split.
+        // (A scale that simply lagged one slab behind was tried first and is wrong: a workgroup's first slabs may hold
+        // nothing but the BatchNorm-backward background terms, 1e5 x below the first row that carries a real gradient -
+        // beyond the 2^11 of head-room; the clamp in split2_f16 then returned 10-20 % errors in SA1's first weight
+        // gradient, tests/test_gpu_parity_full.py.)  The scale never rises again: the dW accumulators hold products of
+        // the earlier slabs, and rows far below the running maximum do not need its last bits.
         float mx = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) mx = __builtin_fmaxf(mx, s_mx[8 * par + w]);
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
           run_max = mx;
           const float sn = f16_scale_for(mx);
           if (sn != sc_cur) {
-            const float f = sn / sc_cur;                     // (powers of two: exact; f < 1)
+            const float f = sn / sc_cur;                     // (powers of two: exact)
 #pragma unroll
             for (int kk = 0; kk < KTW; ++kk)
 #pragma unroll
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
         float dy[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          dy[j] = dy_at(e, j);
+          dy[j] = dy_at(e, j, row0, tail);
           if constexpr (H2) dy[j] *= sc_cur;
         }
         split_pair<P>(dy[0], dy[1], pr[e][0]);
@@ -477,6 +487,10 @@ __global__ __launch_bounds__(64 * NTN * KG, 512 / (64 * NTN * KG)) void mlp_bwd_
             a[q] = *reinterpret_cast<const bf16x8*>(s_reg + (dnh * SL + sl) * REGB + q * 2048 + swz(lr, 2 * s + lh));
           mfma_planes<P>(pa, a, wf[sl][s]);
         }
+    }
+    if constexpr (H2) {
+      // the next slab's rows have arrived underneath the MFMA phase: its maximum, in front of the fold barriers
+      if (slab + (int)gridDim.x < nslab) publish_max((slab + (int)gridDim.x) * RS, par);
     }
     // The NH partial tiles of a K tile meet in the fp32 LDS tile in NH ordered rounds: in round j wave
     // (dkt, dnh) owns row chunk (dnh + j) % NH (32/NH rows = CR accumulator registers) - the first round
@@ -1158,10 +1172,11 @@ using namespace demf;
 
 // A/B switch: DEMF_F16_TERMS_BWD=0 keeps the fused backward kernels on three bf16 terms while the forward kernels
 // take two fp16 terms
-static bool fused_h2_on() {
+static int fused_h2_mode() {
   static const int on = [] { const char* v = getenv("DEMF_F16_TERMS_BWD"); return v ? atoi(v) : 1; }();
-  return on != 0;
+  return on;
 }
+static bool fused_h2_on() { return fused_h2_mode() != 0; }
 
 static int fused_supported(int R, int N, int K, int ns, int sparse, int first) {
   const int cm = compute_mode();
@@ -1208,10 +1223,10 @@ extern "C" int demf_mlp_bwd_fused(int R, int N, int K, const float* G, const flo
               store_flags, N, K, (int)sparse, (int)first);
     return DEMF_EUNSUPPORTED;
   }
-  // two fp16 terms: the (256, 128) form only - measured 141.6 -> 115.4 us per launch there, 85.5 -> 82.8 on (128, 128)
-  // and 232 -> 229 on SA1's (64, 64) (their slabs are shorter: the extra barrier and the second pass over the patch
-  // for the scale eat the saving), which therefore stay on three bf16 terms
-  const bool h2 = f16_terms() && fused_h2_on() && N == 256 && K == 128;
+  // two fp16 terms: the (256, 128) and (128, 128) forms - measured 141.6 -> 115.4 and 86.7 -> 81.0 us per launch; SA1's
+  // (64, 64) forms gain nothing (232 -> 229: short reductions, the pass over the patch for the scale eats the saving)
+  // and stay on three bf16 terms (DEMF_F16_TERMS_BWD=2: every form, 0: none)
+  const bool h2 = f16_terms() && fused_h2_on() && (((N == 256 || N == 128) && K == 128) || fused_h2_mode() == 2);
 #define FGO(NTNv, KTv, KGv, SPv, EPv)                                                                                     \
   do {                                                                                                                   \
     const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, EPv>(a, s)                                            \
@@ -1255,7 +1270,7 @@ extern "C" int demf_mlp_bwd_fused_cols(int R, int N, int Ktot, int c0, int Kc, c
   }
   hipStream_t s = (hipStream_t)stream;
   const int cm = compute_mode();
-  const bool h2 = f16_terms() && fused_h2_on() && N == 256 && Kc == 128;
+  const bool h2 = f16_terms() && fused_h2_on() && (((N == 256 || N == 128) && Kc == 128) || fused_h2_mode() == 2);
 #define FGO(NTNv, KTv, KGv, SPv)                                                                                          \
   do {                                                                                                                   \
     const int rc_ = cm == 1 ? launch_fused<NTNv, KTv, KGv, SPv, 1, 0>(a, s)                                             \
