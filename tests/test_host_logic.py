@@ -153,9 +153,20 @@ def test_compute_dtype_names_and_native_override(monkeypatch):
     monkeypatch.setattr(_ffi, "call", lambda name, *a: seen.append((name, a)) or real(name, *a))
     try:
         monkeypatch.delenv("DEMF_F32_NATIVE", raising=False)
-        for name, mode in (("f32", 2), ("f32x3", 2), ("f32_native", 0), ("bf16", 1)):
+        monkeypatch.delenv("DEMF_F16_TERMS", raising=False)
+        # (mode 2 is followed by demf_set_f16_terms: the two-fp16-term kernel forms on for "f32" / "f32h2", off for "f32x3")
+        for name, mode, h2 in (("f32", 2, 1), ("f32x3", 2, 0), ("f32h2", 2, 1), ("f32_native", 0, None), ("bf16", 1, None)):
             ops.set_compute_dtype(name)
-            assert seen[-1] == ("demf_set_compute_dtype", (mode,)) and ops.get_compute_dtype() == name
+            calls = [c for c in seen if c[0] in ("demf_set_compute_dtype", "demf_set_f16_terms")]
+            if h2 is None:
+                assert calls[-1] == ("demf_set_compute_dtype", (mode,))
+            else:
+                assert calls[-2:] == [("demf_set_compute_dtype", (mode,)), ("demf_set_f16_terms", (h2,))]
+            assert ops.get_compute_dtype() == name
+        monkeypatch.setenv("DEMF_F16_TERMS", "0")
+        ops.set_compute_dtype("f32")
+        assert seen[-1] == ("demf_set_f16_terms", (0,))
+        monkeypatch.delenv("DEMF_F16_TERMS", raising=False)
         monkeypatch.setenv("DEMF_F32_NATIVE", "1")
         ops.set_compute_dtype("f32")
         assert seen[-1] == ("demf_set_compute_dtype", (0,))
