@@ -39,20 +39,29 @@ CLOCK_GHZ = 2.4
 # the previous layer's BN sums without the layer's (R,128) output ever stored).  `prefix`: how rocprofv3
 # prints the instantiation - matched BY PREFIX against the committed PMC / stats files.
 DOMINANT_KERNEL = {"f32_native": "mlp_bwd_pool_kernel<0>", "f32x3": "mlp_bwd_pool_kernel<2>",
-                   "bf16": "mlp_bwd_pool_kernel<1>"}
-DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[
-    "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
+                   "f32h2": "mlp_bwd_pool_kernel<3>", "bf16": "mlp_bwd_pool_kernel<1>"}
+# what "f32" means in this process: the fp32 MFMA (DEMF_F32_NATIVE=1), three bf16 terms everywhere (DEMF_F16_TERMS=0),
+# or - the default - three bf16 terms with the SA stacks' kernels on two fp16 terms (ops.set_compute_dtype)
+F32_MEANS = "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else \
+    ("f32h2" if int(os.environ.get("DEMF_F16_TERMS", "1") or 0) and int(os.environ.get("DEMF_F16_TERMS_BWD", "1") or 0)
+     else "f32x3")
+DOMINANT_KERNEL["f32"] = DOMINANT_KERNEL[F32_MEANS]
 # its forward twin (the round-3 headline): SA1 layer 3, 64 -> 128 + BN statistics + max-pool, no output store
 SA1_FWD_KERNEL = {"f32_native": "mlp_fwd_res_kernel<4, 2, true, 0", "f32x3": "mlp_fwd_res_kernel<4, 2, true, 2",
-                  "bf16": "mlp_fwd_res_kernel<4, 2, true, 1"}
+                  "f32h2": "mlp_fwd_res_kernel<4, 2, true, 3", "bf16": "mlp_fwd_res_kernel<4, 2, true, 1"}
 SA1_FWD_KERNEL["f32"] = SA1_FWD_KERNEL[
-    "f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
+    "f32_native" if F32_MEANS == "f32_native" else
+    ("f32h2" if int(os.environ.get("DEMF_F16_TERMS", "1") or 0) else "f32x3")]
 MFMA_PATH = {"f32_native": "v_mfma_f32_32x32x2_f32",
              "f32x3": "fp32 operands split exactly into 3 bf16 terms, 6 products on "
                       "v_mfma_f32_32x32x16_bf16, fp32 accumulate (error vs fp64 = the fp32 MFMA's, "
                       "tests/test_gpu_split.py)",
+             "f32h2": "fp32 operands as 2 fp16 terms, 3 products on v_mfma_f32_32x32x16_f16 in the SA stacks' forward, "
+                      "(256|128,128) backward and pooled-last-layer backward kernels (2^-22 per operand; gradient "
+                      "operands scaled by a power of two per slab: csrc/common.h); every other kernel: 3 bf16 terms, "
+                      "6 products on v_mfma_f32_32x32x16_bf16; fp32 accumulate either way",
              "bf16": "operands rounded to bf16, v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
-MFMA_PATH["f32"] = MFMA_PATH["f32_native" if int(os.environ.get("DEMF_F32_NATIVE", "0") or 0) else "f32x3"]
+MFMA_PATH["f32"] = MFMA_PATH[F32_MEANS]
 # algorithmic (compulsory) HBM bytes and FLOPs of ONE scene, fwd + bwd
 ALGO_BYTES_PER_SCENE = 190e6
 ALGO_FLOP_PER_SCENE = 46e9
@@ -727,7 +736,7 @@ def main():
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             # fp32 RESULTS; in the default mode the shared-MLP products are issued as 3-term bf16
             # splits on the bf16 MFMA (emulated fp32, error vs fp64 = the fp32 MFMA's)
-            "emulated_fp32": args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"],
+            "emulated_fp32": args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] in (MFMA_PATH["f32x3"], MFMA_PATH["f32h2"]),
             "config": {"workload": "BASELINE configs[2]: full DeMF fusion hot path fwd+loss+bwd+"
                                    "allreduce+AdamW, %d scenes/GPU x (20000 pts, 800x1120 -> "
                                    "4-level 256-ch pyramid), 256 queries, H=8 L=4 P=%d, %s"
@@ -771,10 +780,11 @@ def main():
             err = pmc_live(args)
             out["pmc_live"] = "ok" if err is None else "failed (%s): committed profiles/ used" % err
         x3 = args.dtype in ("f32", "f32x3") and MFMA_PATH[args.dtype] == MFMA_PATH["f32x3"]
+        h2 = args.dtype == "f32" and MFMA_PATH[args.dtype] == MFMA_PATH["f32h2"]      # (the dominant kernel: 3 fp16 products)
         # MFMA budget of the mode: native fp32 -> the fp32 MFMA peak; bf16 -> the bf16 peak; the
         # three-term split issues 6 bf16 MFMAs per algorithmic product -> bf16 peak / 6
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else \
-            (MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS)
+            (MFMA_BF16_PEAK_TFLOPS / 6.0 if x3 else (MFMA_BF16_PEAK_TFLOPS / 3.0 if h2 else MFMA_F32_PEAK_TFLOPS))
         mlp_ms = mlp_timer.mean_ms()
         mlp_bytes = 2 * sa1_rows * 64 * 4 + 3 * (sa1_rows // 64) * 128 * 4
         mlp_flop = 2 * 2.0 * sa1_rows * 64 * 128
@@ -782,7 +792,10 @@ def main():
         # (the committed PMC passes are B = 8 runs of the default mode; no row for this kernel in the
         # newest pair is an error there, not a silent fall-back to an older round's file)
         strict = args.batch == 8 and args.dtype == "f32" and not os.environ.get("DEMF_F32_NATIVE")
-        traffic, src = pmc_per_launch(dom, required=strict) if args.batch == 8 else (None, None)
+        try:
+            traffic, src = pmc_per_launch(dom, required=strict) if args.batch == 8 else (None, None)
+        except RuntimeError as e:      # (a stale committed pair must cost the line its `traffic`, not the line itself)
+            traffic, src = None, "unavailable: %s" % e
         tk, tk_src = top_kernels()
         out["roofline"] = {
             "kernel": "%s (SA1 layer 3 backward: dX, dW and layer 2's BN sums from the pooled gradient; the "
@@ -803,7 +816,8 @@ def main():
                     "issue (%s); the whole step: roofline_step, its five longest kernels: roofline_top5"
                     % (mlp_flop / 1e9, mfma_peak,
                        "dense bf16 MFMA peak" if args.dtype == "bf16" else
-                       ("dense bf16 MFMA peak / 6: three-term split" if x3 else "dense fp32 MFMA peak"))}
+                       ("dense bf16 MFMA peak / 6: three-term split" if x3 else
+                        ("dense fp16 MFMA peak / 3: two-term split" if h2 else "dense fp32 MFMA peak")))}
         # the forward twin (round 3's headline kernel): reads the (R,64) rows, writes only the pooled
         # (R/64,128) extremum + its row; since round 4 the (R,128) output is not stored
         fwd_ms = fwd_timer.mean_ms()
