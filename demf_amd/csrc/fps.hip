@@ -958,13 +958,18 @@ __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const floa
   // lane's own running minimum): a first sweep takes every lane's range minimum, an exclusive prefix minimum across
   // the eight lanes gives each its starting value, a second sweep makes the comparisons.  Twice the distance
   // evaluations, an eighth of the dependent chain; min is exact, so every comparison sees the same r_k.
-  __shared__ float4 s_q[FPS_PREFIX_MAX];       // {x, y, z, E[k]}
+  // {x, y, z, E[k]} at slot k + k/64: the eight lanes of a point read ranges `per` entries apart, and for the points
+  // behind the prefix per = M/8 = 128 entries = 2 KB - the same banks for all eight (an 8-way conflict on every read of
+  // both sweeps, for half of the points).  One 16-byte pad per 64 entries turns that stride into 2 080 bytes: eight
+  // different 4-bank groups.
+  __shared__ float4 s_q[FPS_PREFIX_MAX + FPS_PREFIX_MAX / 64 + 1];
+#define SQI(k_) ((k_) + ((k_) >> 6))
   __shared__ int s_bad, s_last;
   const int b = blockIdx.y, tid = threadIdx.x;
   xyz += (size_t)b * N * 3;
   idx += (size_t)b * M;
   E += (size_t)b * M;
-  for (int t = tid; t < M; t += 256) s_q[t] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], E[t]);
+  for (int t = tid; t < M; t += 256) s_q[SQI(t)] = make_float4(xyz[3 * t], xyz[3 * t + 1], xyz[3 * t + 2], E[t]);
   if (tid == 0) s_bad = 0;
   __syncthreads();
   const int c = tid & 7;
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const floa
   const int k0 = min(kmax, c * per), k1 = min(kmax, k0 + per);
   float mine = 1e10f;
   for (int k = k0; k < k1; ++k) {
-    const float4 o = s_q[k];
+    const float4 o = s_q[SQI(k)];
     mine = fminf(mine, dist2(o.x - qx, o.y - qy, o.z - qz));
   }
   // exclusive prefix minimum over the 8 lanes of the group (lane c: ranges 0 .. c-1)
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const floa
   }
   bool bad = false;
   for (int k = k0; k < k1; ++k) {
-    const float4 o = s_q[k];
+    const float4 o = s_q[SQI(k)];
     bad |= (k >= 1) && !(o.w > r);
     r = fminf(r, dist2(o.x - qx, o.y - qy, o.z - qz));
   }
@@ -1005,6 +1010,7 @@ __global__ __launch_bounds__(256) void fps_check_test_k(int N, int M, const floa
     if (tid == 0) flag[b] = 1;
   }
 }
+#undef SQI
 
 template <int BS, int PPT>
 static void launch_reg(int B, int N, int M, const float* xyz, int* idx, const int* skip,
