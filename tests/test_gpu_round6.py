@@ -203,3 +203,38 @@ def test_library_fallbacks_raise_unless_allowed():
         assert mha(q).shape == q.shape
     finally:
         ops.LIBRARY_FALLBACK = prev
+
+
+def test_replicated_accumulator_ring_wraps_cleanly():
+    """The row reductions of the BatchNorm backward add into one of 8 copies of a zeroed block taken from a ring of 128
+    (csrc/bn_fin.h accum_slot) and their last workgroup folds and clears the copies.  300 launches in a row - more than
+    two laps of the ring - must each return the sums of THEIR launch: a block that was not left zeroed, or a fold that
+    missed a copy, shows as the previous user's sums in a later result."""
+    from demf_amd import _ffi
+    torch.manual_seed(7)
+    R, N = 4096, 128
+    st = torch.cuda.current_stream().cuda_stream
+    g12 = torch.zeros(2 * N, dtype=torch.float64, device="cuda")
+    gamma = (1.0 + 0.1 * torch.randn(N)).cuda()
+    for it in range(300):
+        y = torch.randn(R, N, device="cuda")
+        dp = torch.randn(R, N, device="cuda") * (1.0 + it % 7)
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        invstd = torch.rsqrt(var + 1e-5)
+        ss = torch.cat([gamma * invstd, 0.05 - mean * gamma * invstd]).contiguous()
+        mi = torch.cat([mean, invstd]).contiguous()
+        arg = torch.zeros(R, N, dtype=torch.int32, device="cuda")
+        vec6 = torch.empty(5 * N, device="cuda")
+        dgamma, dbeta = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        _ffi.call("demf_bn_bwd_reduce_vectors", R, N, 1, dp.data_ptr(), arg.data_ptr(), y.data_ptr(), y.data_ptr(),
+                  ss.data_ptr(), mi.data_ptr(), g12.data_ptr(), gamma.data_ptr(), vec6.data_ptr(), dgamma.data_ptr(),
+                  dbeta.data_ptr(), 0, st)
+        if it % 37 == 0 or it >= 296:
+            on = (y * ss[:N] + ss[N:]) > 0
+            dz = torch.where(on, dp, torch.zeros_like(dp)).double()
+            xhat = ((y - mean) * invstd).double()
+            want_b, want_g = dz.sum(0), (dz * xhat).sum(0)
+            assert torch.allclose(dbeta.double(), want_b, rtol=1e-5, atol=1e-3), it
+            assert torch.allclose(dgamma.double(), want_g, rtol=1e-5, atol=1e-3), it
+    torch.cuda.synchronize()
+    assert float(g12.abs().max()) == 0.0
