@@ -3326,9 +3326,10 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
     // few blocks: every block ends with 2N same-address fp64 atomics, which serialise in L2
     // (~70 ns each), so 2048 blocks cost ~150 us in the tail alone
     // (with the replicated accumulators a workgroup's 2N adds queue behind an eighth of the others': one unrolled
-    //  pass of 4 row groups per workgroup, up to 1024 of them)
+    //  two unrolled passes of 4 row groups per workgroup, up to 1024 of them; measured on the resident step: 4 row groups
+    //  4.233, 8 4.208, 16 4.208-4.218 ms; without the copies (16 per workgroup, <= 256 of them) 4.248)
     const bool repl = vf.ticket != nullptr && vf.racc != nullptr;
-    int grid = cdiv(R, rp * (repl ? env_int("DEMF_BNRED_RPB", 4) : 16));
+    int grid = cdiv(R, rp * (repl ? env_int("DEMF_BNRED_RPB", 8) : 16));
     const int cap = env_int("DEMF_BNRED_GRID", repl ? 1024 : 256);
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL(bn_bwd_reduce_dense4_k<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, R, N, G,
@@ -3342,7 +3343,7 @@ static int bn_bwd_reduce_impl(int R, int N, int ns, const float* G, const float*
   if (!G && yraw && N % 4 == 0 && N <= 1024 && R % ns == 0 && env_int("DEMF_BNRED_POOLED_DENSE", 1)) {
     const int Rp = R / ns, rp = 256 / (N / 4);
     const bool repl = vf.ticket != nullptr && vf.racc != nullptr;
-    int grid = cdiv(Rp, rp * (repl ? env_int("DEMF_BNRED_RPB", 4) : 16));
+    int grid = cdiv(Rp, rp * (repl ? env_int("DEMF_BNRED_RPB", 8) : 16));
     const int cap = env_int("DEMF_BNRED_GRID", repl ? 1024 : 256);
     if (grid > cap) grid = cap;
     if (grid < 1) grid = 1;
