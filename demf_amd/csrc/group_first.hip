@@ -325,8 +325,10 @@ extern "C" int demf_group_first_fwd(int B, int N, int M, int ns, int C1, float r
   const int lpr = C1 / 4, gpb = 512 / lpr;
   const long long chunks = (rows + lpr - 1) / lpr;
   long long blocks = (chunks + gpb - 1) / gpb;
-  static const int fcap = getenv("DEMF_GF_FWD_BLOCKS") ? atoi(getenv("DEMF_GF_FWD_BLOCKS")) : 512;
-  if (blocks > fcap) blocks = fcap;  // one fp64 atomic per column per block: keep the tail short
+  // (one fp64 add per column per block; with the statistics in replicated accumulators the tail no longer argues for
+  //  few blocks - resident step 256 / 512 / 1024 blocks: 4.44 / 4.42 / 4.39 ms)
+  static const int fcap = getenv("DEMF_GF_FWD_BLOCKS") ? atoi(getenv("DEMF_GF_FWD_BLOCKS")) : 1024;
+  if (blocks > fcap) blocks = fcap;
   const dim3 grid((unsigned)blocks);
   // train-mode BatchNorm bookkeeping (demf_bn_finalize's arguments): by the launch's last workgroup when a counter set
   // and an accumulator block are to be had, as a launch behind this one otherwise
