@@ -816,9 +816,23 @@ class _LinearRows(Function):
             # grad_value); it is masked in place rather than cloned (152 MB at the bench size)
             g.masked_fill_(ctx.saved_tensors[2].unsqueeze(-1), 0.0)
         gx = gw = gb = None
+        # An output width that is not a multiple of 4 (the vote module's 3 + 256 = 259 columns on 8 192 seeds) leaves the
+        # gradient rows unaligned: both backward products then stage their operands element by element (33 + 44 us, and
+        # 23 us for the column sums).  The gradient and the weight are copied once into zero-padded buffers of 4-aligned
+        # width instead (two small copies): the products run on the vectorised staging and the bias gradient rides in
+        # the weight-gradient launch; what is returned are the leading rows of the padded results.
+        Np, gq, wq = N, g, weight
+        if N % 4 != 0 and R >= 4096 and len(ctx.saved_tensors) == 2:
+            Np = (N + 3) // 4 * 4
+            gq = zeros((R, Np), g.device)
+            gq[:, :N].copy_(g)
+            wq = zeros((Np, K), g.device)
+            wq[:N].copy_(weight)
         if ctx.needs_input_grad[0]:
             gx = torch.empty((R, K), dtype=torch.float32, device=g.device)
-            if _LinearRows._rows_ok(R, N, K, g):
+            if Np != N:
+                fused.gemm(R, K, Np, _p(gq), (Np, 1), _p(wq), (1, K), _p(gx), K)
+            elif _LinearRows._rows_ok(R, N, K, g):
                 planes = 1 if get_compute_dtype() == "bf16" else 3
                 rows_gemm(g, split_planes(weight.detach().t().contiguous(), planes), None, gx)
             else:
@@ -826,10 +840,17 @@ class _LinearRows(Function):
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] or want_b:
             # one zero-filled workspace for dW | db (split-K atomics, column sums)
-            ws = zeros(N * K + N, g.device)
-            gw = ws[:N * K].view(N, K)
-            gb = ws[N * K:] if ctx.has_bias else None
+            ws = zeros(Np * K + Np, g.device)
+            gw = ws[:Np * K].view(Np, K)
+            gb = ws[Np * K:] if ctx.has_bias else None
             in_gemm = False
+            if Np != N:
+                in_gemm = gb is not None
+                fused.gemm(Np, K, R, _p(gq), (1, Np), _p(x), (1, x.stride(0)), _p(gw), K,
+                           splitk=fused._splitk(R), asum=_p(gb) if in_gemm else None)
+                if gb is not None and not in_gemm:
+                    _ffi.call("demf_colsum_f32", R, Np, Np, _p(gq), _p(gb), _stream())
+                return gx, gw[:N], (gb[:N] if gb is not None else None), None
             if R >= 32768 and N % 4 == 0 and K % 4 == 0 and x.is_contiguous():
                 # long reduction (the value projection: 149 k tokens -> 256x256): the slab-split
                 # dW kernel of the shared-MLP path, run with an identity dY prologue

@@ -238,3 +238,25 @@ def test_replicated_accumulator_ring_wraps_cleanly():
             assert torch.allclose(dgamma.double(), want_g, rtol=1e-5, atol=1e-3), it
     torch.cuda.synchronize()
     assert float(g12.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,K,N", [(8192, 256, 259), (4096, 128, 7), (1024, 256, 259)])
+def test_linear_backward_with_an_unaligned_output_width(R, K, N):
+    """ops.linear whose output width is not a multiple of 4 (the vote module's conv_out: 3 + 256 columns): from 4 096
+    rows on, the backward pads the gradient and the weight to a 4-aligned width instead of staging them element by
+    element; input, weight and bias gradients against fp64 autograd, with and without the padding."""
+    from demf_amd import ops
+    torch.manual_seed(R + N)
+    x = torch.randn(R, K, dtype=torch.float64)
+    w = torch.randn(N, K, dtype=torch.float64) / K ** 0.5
+    b = torch.randn(N, dtype=torch.float64)
+    go = torch.randn(R, N, dtype=torch.float64)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    torch.nn.functional.linear(xr, wr, br).backward(go)
+    xg, wg, bg = (t.float().cuda().requires_grad_() for t in (x, w, b))
+    y = ops.linear(xg, wg, bg)
+    y.backward(go.float().cuda())
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    assert rel(y.detach(), torch.nn.functional.linear(x, w, b)) <= 2e-6
+    assert rel(xg.grad, xr.grad) <= 2e-6 and rel(wg.grad, wr.grad) <= 2e-6 and rel(bg.grad, br.grad) <= 2e-6
+    assert wg.grad.shape == (N, K) and bg.grad.shape == (N,)
